@@ -1,0 +1,31 @@
+"""pytest configuration: registers the `gpu` marker; puts the repo root on sys.path."""
+
+import json
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    """fixtures produced by the REAL reference (tests/golden/gen_golden.py)"""
+    return json.loads((ROOT / "tests" / "golden" / "golden.json").read_text())
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """the plain-C CPU restatement (test infrastructure)"""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle as _oracle  # noqa: PLC0415
+
+    _oracle.build()
+    return _oracle
