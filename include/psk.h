@@ -1,0 +1,187 @@
+/*
+ * psk.h -- C ABI of the MI355X-native probabilistic-sketch engine (libpsk_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of barrust/pyprobables (v0.7.0): bulk
+ * insert / lookup of BloomFilter, CountingBloomFilter and CountMinSketch with the
+ * default_fnv_1a hash family.  The reference is pure Python and has no FFI of its
+ * own; each entry point below names the reference method(s) whose per-key loop it
+ * replaces (paths relative to the reference checkout).  INTEGRATION.md shows the
+ * ctypes stub a pyprobables maintainer would add to bind them.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns a psk status code
+ *     (PSK_OK == 0, negative on error; text via psk_last_error()); no exceptions
+ *     cross the boundary.
+ *   - `where` says where the caller's buffers (keys, offsets, weights, outputs) live:
+ *     PSK_HOST  -> pageable/pinned host memory; the call stages through device
+ *                  scratch and returns after the result is back on the host.
+ *     PSK_DEVICE-> device memory of the sketch's GPU; the call only enqueues work on
+ *                  `stream` (a hipStream_t passed as void*, NULL = default stream)
+ *                  and returns immediately.
+ *   - a sketch handle is externally synchronised: one in-flight batch per handle.
+ *   - key batches come in four layouts (`layout` argument):
+ *       PSK_KEYS_FIXED    data = uint8[n][key_len]            equal-length byte keys
+ *       PSK_KEYS_VARLEN8  data = uint8 blob, offsets=uint64[n+1]   bytes / latin-1 str keys
+ *       PSK_KEYS_VARLEN32 data = uint32 code points, offsets=uint64[n+1]  str keys with
+ *                         code points > 255 (hashes.py:98 hashes ord(c), not UTF-8 bytes)
+ *       PSK_KEYS_HASHES   data = uint64[n][key_len] pre-computed hashes (key_len = hashes
+ *                         per key, >= k); the add_alt/check_alt path and the route for a
+ *                         user-supplied hash_function (hashes.py:10-15 HashFuncT)
+ *     For the three key layouts the engine computes default_fnv_1a(key, k)
+ *     (hashes.py:71-103) inside the kernel.
+ */
+#ifndef PSK_H
+#define PSK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct psk_sketch psk_sketch; /* opaque handle: owns (or borrows) one device-resident table */
+
+enum psk_status {
+    PSK_OK = 0,
+    PSK_EINVAL = -1,    /* bad argument */
+    PSK_ENODEV = -2,    /* no usable HIP device */
+    PSK_ENOMEM = -3,    /* device allocation failed */
+    PSK_EHIP = -4,      /* a HIP runtime call failed (see psk_last_error) */
+    PSK_ECONTRACT = -5  /* batch-stream contract violated (see psk_get_counters) */
+};
+
+enum psk_where { PSK_HOST = 0, PSK_DEVICE = 1 };
+
+enum psk_layout { PSK_KEYS_FIXED = 0, PSK_KEYS_VARLEN8 = 1, PSK_KEYS_VARLEN32 = 2, PSK_KEYS_HASHES = 3 };
+
+enum psk_query { PSK_Q_MIN = 0, PSK_Q_MEAN = 1, PSK_Q_MEANMIN = 2 }; /* countminsketch.py:429-453 */
+
+enum psk_kind { PSK_KIND_BLOOM = 0, PSK_KIND_CBF = 1, PSK_KIND_CMS = 2 };
+
+/* ordered-update opcode source (psk_*_update_ordered) */
+enum psk_opmode { PSK_OP_ADD = 0, PSK_OP_REMOVE = 1, PSK_OP_SIGNED = 2 /* w>=0 add(w), w<0 remove(-w) */ };
+
+/* counters kept on the device per sketch (psk_get_counters) */
+enum psk_counter {
+    PSK_CTR_ADDED = 0,      /* sum of weights applied by add batches */
+    PSK_CTR_REMOVED = 1,    /* sum of weights actually removed (CBF: to_remove, countingbloom.py:203-207) */
+    PSK_CTR_VIOLATIONS = 2, /* unordered batch ops whose result depended on order (CBF partial/underflowing remove) */
+    PSK_CTR_SATURATED = 3,  /* counter updates that hit a rail (UINT32_MAX / INT32_MAX / INT32_MIN) */
+    PSK_CTR_ABS_BOUND = 4,  /* upper bound on |any counter| (selects the wrap-free fast path) */
+    PSK_CTR_COUNT = 8
+};
+
+/* ------------------------------------------------------------------ misc */
+const char *psk_last_error(void);         /* thread-local text of the last failure */
+int psk_version(void);
+int psk_device_count(int *count);
+
+/* -------------------------------------------------------------- lifecycle
+ * ext_table: NULL -> the library hipMallocs (and zeroes) the table;
+ *            else -> device pointer to caller-owned, zero-initialised memory of at least
+ *                    psk_table_bytes(...) bytes (lets the caller keep the table in a tensor it
+ *                    can hand to RCCL).
+ * Replaces the array allocation of bloom.py:105, countingbloom.py:78, countminsketch.py:115. */
+uint64_t psk_bloom_table_bytes(uint64_t m_bits);            /* ceil(m/8) rounded up to 16 B */
+uint64_t psk_cbf_table_bytes(uint64_t m);                   /* 4*m rounded up to 16 B */
+uint64_t psk_cms_table_bytes(uint64_t width, uint32_t depth); /* 4*width*depth rounded up to 16 B */
+int psk_bloom_create(uint64_t m_bits, uint32_t k, int device, void *ext_table, psk_sketch **out);
+int psk_cbf_create(uint64_t m, uint32_t k, int device, void *ext_table, psk_sketch **out);
+int psk_cms_create(uint64_t width, uint32_t depth, int device, void *ext_table, psk_sketch **out);
+int psk_destroy(psk_sketch *s);
+int psk_clear(psk_sketch *s, void *stream);                 /* bloom.py:217-221, countminsketch.py:240-244 */
+int psk_synchronize(psk_sketch *s, void *stream);
+/* device pointer + padded size + logical size (the reference's array byte length) */
+int psk_table_info(psk_sketch *s, void **dev_ptr, uint64_t *padded_bytes, uint64_t *logical_bytes);
+/* copy the first nbytes of the table to / from host memory in the reference's byte layout
+ * (array('B') LSB-first bits, array('I') uint32 LE, array('i') int32 LE row-major by depth):
+ * what export()/bytes()/frombytes() read and write (bloom.py:287-304,548-550; countminsketch.py:342-354,417-427) */
+int psk_read_table(psk_sketch *s, void *dst_host, uint64_t nbytes, void *stream);
+int psk_write_table(psk_sketch *s, const void *src_host, uint64_t nbytes, void *stream);
+int psk_get_counters(psk_sketch *s, int64_t out[PSK_CTR_COUNT], void *stream); /* synchronises */
+int psk_reset_counters(psk_sketch *s, void *stream);
+/* recompute PSK_CTR_ABS_BOUND = max |counter| after the table was modified from outside the engine
+ * (e.g. the RCCL all-reduce of the multi-GPU merge wrote into it) */
+int psk_rescan_bound(psk_sketch *s, void *stream);
+
+/* ------------------------------------------------------------- BloomFilter
+ * add:   for each key: for i<k: bit = h_i % m; table |= bit      (bloom.py:234-250 add/add_alt)
+ * check: for each key: out = AND_i bit(h_i % m)                  (bloom.py:252-272 check/check_alt)
+ * check_bits: same result ballot-packed, bit (i & 63) of out_bits[i >> 6]; *hits += popcount */
+int psk_bloom_add(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                  uint32_t key_len, int where, void *stream);
+int psk_bloom_check(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                    uint32_t key_len, int where, uint8_t *out, void *stream);
+int psk_bloom_check_bits(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                         uint32_t key_len, int where, uint64_t *out_bits, uint64_t *hits, void *stream);
+
+/* ----------------------------------------------------- CountingBloomFilter
+ * Unordered batches (weights: uint32[n] or NULL = all 1).  Bit-exact with the reference for
+ * well-formed streams (no counter saturates; every remove targets a key with >= num_els live
+ * inserts); anything else is counted in PSK_CTR_VIOLATIONS / PSK_CTR_SATURATED.
+ * add:    counters[h_i % m] = min(c + w, 2^32-1) for i<k        (countingbloom.py:125-155)
+ * remove: conditional decrement                                 (countingbloom.py:176-208)
+ * check:  out = min_i counters[h_i % m]                         (countingbloom.py:157-174) */
+int psk_cbf_add(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                uint32_t key_len, const uint32_t *weights, int where, void *stream);
+int psk_cbf_remove(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                   uint32_t key_len, const uint32_t *weights, int where, void *stream);
+int psk_cbf_check(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                  uint32_t key_len, int where, uint32_t *out, void *stream);
+/* Ordered (one-at-a-time, in sequence) execution of the reference semantics on the GPU, including
+ * each op's return value: exact for ANY stream.  weights int64[n] or NULL (=1); opmode psk_opmode. */
+int psk_cbf_update_ordered(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                           uint32_t key_len, const int64_t *weights, int opmode, int where, uint32_t *out,
+                           void *stream);
+
+/* ---------------------------------------------------------- CountMinSketch
+ * bins row-major by depth: bin = (h_i % width) + i*width, i < depth (countminsketch.py:275)
+ * add:    saturating at INT32_MAX    (countminsketch.py:257-288)
+ * remove: saturating at INT32_MIN    (countminsketch.py:290-321)
+ * check:  min | mean (int32 out);  mean-min needs elements_added (int64 out)  (countminsketch.py:323-340,429-453)
+ * Unordered batches are bit-exact with the reference whenever the final table does not depend on
+ * order (same-sign weights, or no bin touching a rail). */
+int psk_cms_add(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                uint32_t key_len, const int32_t *weights, int where, void *stream);
+int psk_cms_remove(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                   uint32_t key_len, const int32_t *weights, int where, void *stream);
+int psk_cms_check(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                  uint32_t key_len, int where, int query /* MIN or MEAN */, int32_t *out, void *stream);
+int psk_cms_check_meanmin(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                          uint32_t key_len, int where, int64_t elements_added, int64_t *out, void *stream);
+int psk_cms_update_ordered(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                           uint32_t key_len, const int64_t *weights, int opmode, int query,
+                           int64_t elements_added_in, int where, int64_t *out, void *stream);
+
+/* ------------------------------------------------------------------ hashing
+ * out[i*depth + j] = fnv_1a(key_i, seed=j)  (hashes.py:71-103); layout != PSK_KEYS_HASHES */
+int psk_fnv1a_hash(int layout, const void *data, const uint64_t *offsets, uint64_t n, uint32_t key_len,
+                   uint32_t depth, int where, uint64_t *out, int device, void *stream);
+
+/* ------------------------------------------------------ table algebra (device pointers)
+ * Streaming kernels over whole tables; also the local half of the multi-GPU merge.
+ * or/and: bloom.py:371-428 union/intersection;  popcount: bloom.py:552-557;
+ * add_sat_i32: countminsketch.py:380-391 join;  add_u32: countingbloom.py:296-298 union;
+ * or_reduce: dst[w] = OR_j src[j*slice_words + w] (the reduce step of allreduce(OR): RCCL has no OR op) */
+int psk_table_or(void *dst, const void *src, uint64_t nwords32, int device, void *stream);
+int psk_table_and(void *dst, const void *src, uint64_t nwords32, int device, void *stream);
+int psk_table_popcount(const void *tab, uint64_t nwords32, uint64_t *out_host, int device, void *stream);
+int psk_table_nonzero_u32(const void *tab, uint64_t nwords32, uint64_t *out_host, int device, void *stream);
+int psk_table_add_sat_i32(void *dst, const void *src, uint64_t n, int device, void *stream);
+int psk_table_add_u32(void *dst, const void *src, uint64_t n, uint64_t *overflowed_host, int device, void *stream);
+int psk_or_reduce_slices(void *dst, const void *src, uint32_t nslices, uint64_t slice_words32, int device,
+                         void *stream);
+
+/* --------------------------------------------- synthetic streams (bench / tests)
+ * key_i = LE64(sm(seed+2i)) || LE64(sm(seed+2i+1)); w_i = 1 + sm((seed^0xC0FFEE)+i) % 7 */
+int psk_gen_keys16(void *dst_dev, uint64_t start, uint64_t n, uint64_t seed, int device, void *stream);
+int psk_gen_weights(void *dst_dev, uint64_t start, uint64_t n, uint64_t seed, int device, void *stream);
+/* GUPS-style ceiling: n uniformly random 4-byte atomic ORs (op=0), atomic adds (op=1) or loads (op=2)
+ * into a table of nwords32 words; the denominator of the "random-access roofline" */
+int psk_gups(void *table_dev, uint64_t nwords32, uint64_t n, int op, uint64_t seed, uint64_t *sink_dev,
+             int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSK_H */

@@ -1,0 +1,181 @@
+"""Device-side plumbing shared by the three sketches: one C-ABI handle + the HBM-resident table.
+
+The table lives in a torch tensor (so it can be handed to RCCL through ``torch.distributed`` without a
+copy) and is *borrowed* by the engine (``ext_table`` of ``psk_*_create``).  All work is enqueued on
+torch's current HIP stream for that device.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .exceptions import NativeLibraryError
+from .keys import KeyBatch
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _resolve_device(device) -> int:
+    if device is None:
+        if torch is not None and torch.cuda.is_available():
+            return torch.cuda.current_device()
+        return 0
+    if torch is not None and isinstance(device, torch.device):
+        return device.index or 0
+    if isinstance(device, str):
+        return int(device.split(":")[1]) if ":" in device else 0
+    return int(device)
+
+
+class DeviceTable:
+    """owns the psk handle and the table tensor"""
+
+    def __init__(self, kind: str, m: int, k: int, device=None):
+        L = N.lib()  # raises NativeLibraryError when the engine is missing
+        self.kind, self.m, self.k = kind, int(m), int(k)
+        self.device = _resolve_device(device)
+        if N.device_count() == 0:
+            raise NativeLibraryError(
+                "no HIP device available: the sketch table lives in GPU memory and there is no CPU fallback"
+            )
+        if kind == "bloom":
+            padded, create = L.psk_bloom_table_bytes(self.m), L.psk_bloom_create
+            self.logical_bytes = (self.m + 7) // 8
+        elif kind == "cbf":
+            padded, create = L.psk_cbf_table_bytes(self.m), L.psk_cbf_create
+            self.logical_bytes = 4 * self.m
+        else:
+            padded, create = L.psk_cms_table_bytes(self.m, self.k), L.psk_cms_create
+            self.logical_bytes = 4 * self.m * self.k
+        self.padded_bytes = int(padded)
+        self.tensor = None
+        ext = None
+        if torch is not None and torch.cuda.is_available():
+            self.tensor = torch.zeros(self.padded_bytes // 4, dtype=torch.int32, device=f"cuda:{self.device}")
+            torch.cuda.current_stream(self.device).synchronize()
+            ext = self.tensor.data_ptr()
+        h = C.c_void_p()
+        N.check(create(self.m, self.k, self.device, ext, C.byref(h)))
+        self.handle = h
+
+    # -- lifetime
+    def close(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                N.lib().psk_destroy(h)
+            except Exception:  # interpreter shutdown
+                pass
+
+    def __del__(self):
+        self.close()
+
+    # -- helpers
+    @property
+    def stream(self):
+        if torch is not None and torch.cuda.is_available():
+            return torch.cuda.current_stream(self.device).cuda_stream or None
+        return None
+
+    @property
+    def ptr(self) -> int:
+        p = C.c_void_p()
+        N.check(N.lib().psk_table_info(self.handle, C.byref(p), None, None))
+        return p.value
+
+    @property
+    def nwords(self) -> int:
+        return self.padded_bytes // 4
+
+    def check_batch(self, b: KeyBatch):
+        if b.where == N.DEVICE and b.device is not None and b.device != self.device:
+            raise ValueError(f"key batch lives on cuda:{b.device}, the sketch on cuda:{self.device}")
+
+    def clear(self):
+        N.check(N.lib().psk_clear(self.handle, self.stream))
+
+    def read(self) -> np.ndarray:
+        """the table in the reference's byte layout (uint8[logical_bytes])"""
+        out = np.empty(self.logical_bytes, dtype=np.uint8)
+        if out.size:
+            N.check(N.lib().psk_read_table(self.handle, out.ctypes.data, out.size, self.stream))
+        return out
+
+    def write(self, raw: bytes | np.ndarray):
+        a = np.frombuffer(bytes(raw), dtype=np.uint8) if not isinstance(raw, np.ndarray) else np.ascontiguousarray(raw).view(np.uint8)
+        if a.size != self.logical_bytes:
+            raise ValueError(f"table image has {a.size} bytes, expected {self.logical_bytes}")
+        N.check(N.lib().psk_write_table(self.handle, a.ctypes.data, a.size, self.stream))
+
+    def counters(self) -> list[int]:
+        buf = (C.c_int64 * N.CTR_COUNT)()
+        N.check(N.lib().psk_get_counters(self.handle, buf, self.stream))
+        return list(buf)
+
+    def reset_counters(self):
+        N.check(N.lib().psk_reset_counters(self.handle, self.stream))
+
+    def synchronize(self):
+        N.check(N.lib().psk_synchronize(self.handle, self.stream))
+
+    def popcount(self) -> int:
+        out = C.c_uint64(0)
+        N.check(N.lib().psk_table_popcount(self.ptr, self.nwords, C.byref(out), self.device, self.stream))
+        return out.value
+
+    def nonzero(self) -> int:
+        out = C.c_uint64(0)
+        N.check(N.lib().psk_table_nonzero_u32(self.ptr, self.nwords, C.byref(out), self.device, self.stream))
+        return out.value
+
+    # -- output buffers matching where the batch lives
+    def out_buffer(self, b: KeyBatch, n_items: int, np_dtype, torch_dtype):
+        """-> (address, finalize() -> result)"""
+        if b.where == N.DEVICE:
+            t = torch.empty(n_items, dtype=torch_dtype, device=f"cuda:{self.device}")
+            return t.data_ptr(), (lambda: t)
+        a = np.empty(n_items, dtype=np_dtype)
+        return (a.ctypes.data if a.size else 0), (lambda: a)
+
+
+def weights_arg(w, n: int, np_dtype, where: int, keep: list, lo: int, hi: int):
+    """per-key weights -> (address or None, host_sum or None).  Scalars are broadcast on the host."""
+    if w is None:
+        return None, n
+    if torch is not None and isinstance(w, torch.Tensor):
+        if w.is_cuda:
+            if where != N.DEVICE:
+                raise ValueError("device weights need a device key batch")
+            want = torch.int32 if np_dtype in (np.int32, np.uint32) else torch.int64
+            t = w.to(want).contiguous()
+            if t.numel() != n:
+                raise ValueError("weights length differs from the number of keys")
+            keep.append(t)
+            return t.data_ptr(), None
+        w = w.numpy()
+    if np.isscalar(w) or isinstance(w, int):
+        if int(w) == 1:
+            return None, n
+        if not lo <= int(w) <= hi:
+            raise OverflowError(f"num_els {w} outside [{lo}, {hi}]")
+        a = np.full(n, int(w), dtype=np_dtype)
+    else:
+        src = np.asarray(w)
+        if src.size != n:
+            raise ValueError("weights length differs from the number of keys")
+        if src.size and (int(src.min()) < lo or int(src.max()) > hi):
+            raise OverflowError(f"num_els outside [{lo}, {hi}]")
+        a = np.ascontiguousarray(src, dtype=np_dtype)
+    total = int(a.astype(np.int64).sum()) if a.size else 0
+    if where == N.DEVICE:
+        t = torch.from_numpy(a.view(np.int32 if a.dtype.itemsize == 4 else np.int64)).cuda()
+        keep.append(t)
+        return t.data_ptr(), total
+    keep.append(a)
+    return (a.ctypes.data if a.size else None), total

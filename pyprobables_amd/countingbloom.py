@@ -1,0 +1,229 @@
+"""CountingBloomFilter: uint32 counters in HBM, add / remove / check as HIP kernels.
+
+Drop-in for the hot path of ``probables.CountingBloomFilter`` (``probables/blooms/countingbloom.py``).
+
+Two execution modes
+  * single-key ``add`` / ``remove`` (and ``update_ordered``): the reference semantics executed literally,
+    in order, on the GPU -- exact for any stream, including the per-op return value;
+  * ``add_many`` / ``remove_many``: unordered batches with k atomics per key.  Bit-exact with the
+    reference for well-formed streams (no counter saturates; every remove targets a key with at least
+    ``num_els`` live inserts), which makes the result independent of the order inside the batch.
+    Anything else is reported through :meth:`batch_diagnostics`.
+"""
+
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+from . import _native as N
+from ._base import weights_arg
+from .bloom import BloomFilter, _torch_dtype
+from .exceptions import SimilarityError
+from .hashes import HashResultsT, KeyT
+from .keys import KeyBatch, pack_hashes
+
+_U32_MAX = 2**32 - 1
+_U64_MAX = 2**64 - 1
+
+
+class CountingBloomFilter(BloomFilter):
+    """Counting Bloom filter on the GPU (constructor identical to the reference, countingbloom.py:48-55)."""
+
+    _TYPE = "counting"
+    _KIND = "cbf"
+    _ELEM = struct.Struct("I")
+    _MISMATCH = "The parameter second must be of type CountingBloomFilter"
+
+    @staticmethod
+    def _insufficient_msg() -> str:
+        return "Insufecient parameters to set up the Counting Bloom Filter"  # (sic) countingbloom.py:73
+
+    def _table_len(self, n_bits: int) -> int:
+        return int(n_bits)  # one uint32 per position (countingbloom.py:77)
+
+    # -------------------------------------------------------------- elements_added bookkeeping
+    # adds/removes with device-side weights are tallied on the device; fold them in lazily
+    def _fold_counters(self) -> None:
+        if self._tab is None or not getattr(self, "_dirty", False):
+            return
+        c = self._tab.counters()
+        self._els_added = min(self._els_added + c[N.CTR_ADDED], _U64_MAX) - c[N.CTR_REMOVED]
+        self._diag = [a + b for a, b in zip(getattr(self, "_diag", [0, 0]), (c[N.CTR_VIOLATIONS], c[N.CTR_SATURATED]))]
+        self._tab.reset_counters()
+        self._dirty = False
+
+    @property
+    def elements_added(self) -> int:
+        self._fold_counters()
+        return self._els_added
+
+    @elements_added.setter
+    def elements_added(self, val: int):
+        self._fold_counters()
+        self._els_added = val
+
+    def batch_diagnostics(self) -> dict:
+        """order-dependence report of the unordered batches so far: ``violations`` (partial / underflowing
+        removes) and ``saturated`` (counter updates that hit 2^32-1)"""
+        self._dirty = True
+        self._fold_counters()
+        v, s = getattr(self, "_diag", [0, 0])
+        return {"violations": v, "saturated": s}
+
+    def clear(self) -> None:
+        super().clear()
+        self._dirty, self._diag = False, [0, 0]
+
+    # -------------------------------------------------------------- single-key ops (ordered kernel)
+    def _ordered(self, b: KeyBatch, num_els, opmode: int) -> np.ndarray:
+        if b.where != N.HOST:
+            raise ValueError("ordered updates take host batches")
+        w = np.ascontiguousarray(np.broadcast_to(np.asarray(num_els, dtype=np.int64), (b.n,)))
+        out = np.empty(b.n, dtype=np.uint32)
+        N.check(N.lib().psk_cbf_update_ordered(self._tab.handle, *b.args(), w.ctypes.data if b.n else None, opmode,
+                                               b.where, out.ctypes.data if b.n else None, self._tab.stream))
+        self._dirty = True
+        return out
+
+    def add(self, key: KeyT, num_els: int = 1) -> int:
+        """countingbloom.py:125-133"""
+        return int(self._ordered(self._batch(key), num_els, N.OP_ADD)[0])
+
+    def add_alt(self, hashes: HashResultsT, num_els: int = 1) -> int:
+        """countingbloom.py:135-155"""
+        return int(self._ordered(pack_hashes(hashes, self._number_hashes), num_els, N.OP_ADD)[0])
+
+    def remove(self, key: KeyT, num_els: int = 1) -> int:
+        """countingbloom.py:176-184"""
+        return int(self._ordered(self._batch(key), num_els, N.OP_REMOVE)[0])
+
+    def remove_alt(self, hashes: HashResultsT, num_els: int = 1) -> int:
+        """countingbloom.py:186-208"""
+        return int(self._ordered(pack_hashes(hashes, self._number_hashes), num_els, N.OP_REMOVE)[0])
+
+    def update_ordered(self, keys, signed_num_els) -> np.ndarray:
+        """execute a mixed stream strictly in order on the device: ``w >= 0`` adds ``w``, ``w < 0`` removes
+        ``-w``; returns every op's reference return value (uint32[n])"""
+        return self._ordered(self._batch(keys), signed_num_els, N.OP_SIGNED)
+
+    def check(self, key: KeyT) -> int:  # type: ignore[override]
+        """countingbloom.py:157-164"""
+        return int(self._check_batch(self._batch(key))[0])
+
+    def check_alt(self, hashes: HashResultsT) -> int:  # type: ignore[override]
+        """countingbloom.py:166-174 (min over ALL supplied hashes)"""
+        return int(self._check_batch(pack_hashes(hashes, 1))[0])
+
+    # -------------------------------------------------------------- batch ops (unordered kernels)
+    def _check_batch(self, b: KeyBatch):
+        addr, fin = self._tab.out_buffer(b, b.n, np.uint32, _torch_dtype("int32"))
+        N.check(N.lib().psk_cbf_check(self._tab.handle, *b.args(), b.where, addr, self._tab.stream))
+        return fin()
+
+    def _update_batch(self, fn, b: KeyBatch, num_els) -> None:
+        keep: list = []
+        w_addr, _ = weights_arg(num_els, b.n, np.uint32, b.where, keep, 0, _U32_MAX)
+        N.check(fn(self._tab.handle, *b.args(), w_addr, b.where, self._tab.stream))
+        self._dirty = True
+
+    def _add_batch(self, b: KeyBatch, num_els=None) -> None:  # type: ignore[override]
+        self._update_batch(N.lib().psk_cbf_add, b, num_els)
+
+    def add_many(self, keys, num_els=None) -> None:  # type: ignore[override]
+        """``num_els``: None (=1), an int, or one count per key"""
+        self._add_batch(self._batch(keys), num_els)
+
+    def add_alt_many(self, hashes, num_els=None) -> None:  # type: ignore[override]
+        self._add_batch(pack_hashes(hashes, self._number_hashes), num_els)
+
+    def remove_many(self, keys, num_els=None) -> None:
+        self._update_batch(N.lib().psk_cbf_remove, self._batch(keys), num_els)
+
+    def remove_alt_many(self, hashes, num_els=None) -> None:
+        self._update_batch(N.lib().psk_cbf_remove, pack_hashes(hashes, self._number_hashes), num_els)
+
+    def check_many(self, keys):
+        """uint32[n] numpy (host input) / int32-bits torch tensor (device input): min counter per key"""
+        return self._check_batch(self._batch(keys))
+
+    def check_alt_many(self, hashes):
+        return self._check_batch(pack_hashes(hashes, 1))
+
+    def check_many_bits(self, keys):
+        raise NotImplementedError("ballot bitmaps are a BloomFilter feature")
+
+    # -------------------------------------------------------------- statistics / algebra
+    def _cnt_number_bits_set(self) -> int:
+        return self._tab.nonzero()  # countingbloom.py:302-304
+
+    def __str__(self) -> str:
+        """countingbloom.py:99-123 (host statistics over a snapshot of the counters)"""
+        tab = self._tab.read().view(np.uint32)
+        total = int(tab.astype(np.uint64).sum())
+        largest = int(tab.max()) if tab.size else 0
+        largest_idx = int(tab.argmax()) if tab.size else 0
+        fullness = total / self.number_bits
+        return (
+            "CountingBloom:\n"
+            f"\tbits: {self.number_bits}\n"
+            f"\testimated elements: {self.estimated_elements}\n"
+            f"\tnumber hashes: {self.number_hashes}\n"
+            f"\tmax false positive rate: {self.false_positive_rate:.6f}\n"
+            f"\telements added: {self.elements_added}\n"
+            f"\tcurrent false positive rate: {self.current_false_positive_rate():.6f}\n"
+            "\tis on disk: no\n"
+            f"\tindex fullness: {fullness:.6}\n"
+            f"\tmax index usage: {largest}\n"
+            f"\tmax index id: {largest_idx}\n"
+            f"\tcalculated elements: {total // self.number_hashes}\n"
+        )
+
+    def _require_similar(self, second, msg="Counting Bloom Filters are not similar enough to calculate similarity"):
+        if not isinstance(second, CountingBloomFilter):
+            raise TypeError(self._MISMATCH)
+        if self._verify_bloom_similarity(second) is False:
+            raise SimilarityError(msg)
+        if second._tab.device != self._tab.device:
+            raise ValueError("set operations need both filters on the same device")
+
+    def union(self, second):
+        """element-wise sum (countingbloom.py:271-300)"""
+        import ctypes as C  # noqa: PLC0415
+
+        self._require_similar(second)
+        res = CountingBloomFilter(self.estimated_elements, self.false_positive_rate, hash_function=self.hash_function,
+                                  device=self._tab.device)
+        L, t = N.lib(), res._tab
+        ov = C.c_uint64(0)
+        N.check(L.psk_table_add_u32(t.ptr, self._tab.ptr, self.number_bits, C.byref(ov), t.device, t.stream))
+        N.check(L.psk_table_add_u32(t.ptr, second._tab.ptr, self.number_bits, C.byref(ov), t.device, t.stream))
+        if ov.value:  # the reference's array('I') store raises here
+            raise OverflowError("unsigned int is greater than maximum")
+        res.elements_added = res.estimate_elements()
+        return res
+
+    def intersection(self, second):
+        """countingbloom.py:210-240: sum where both are non-zero (host-side, table-sized, once)"""
+        self._require_similar(second)
+        a = self._tab.read().view(np.uint32).astype(np.uint64)
+        b = second._tab.read().view(np.uint32).astype(np.uint64)
+        s = np.where((a > 0) & (b > 0), a + b, 0)
+        if s.size and int(s.max()) > _U32_MAX:
+            raise OverflowError("unsigned int is greater than maximum")
+        res = CountingBloomFilter(self.estimated_elements, self.false_positive_rate, hash_function=self.hash_function,
+                                  device=self._tab.device)
+        res._tab.write(s.astype(np.uint32))
+        res.elements_added = res.estimate_elements()
+        return res
+
+    def jaccard_index(self, second) -> float:
+        """countingbloom.py:242-269 on the sets of non-zero positions"""
+        self._require_similar(second)
+        a = self._tab.read().view(np.uint32) > 0
+        b = second._tab.read().view(np.uint32) > 0
+        cu = int((a | b).sum())
+        if cu == 0:
+            return 1.0
+        return int((a & b).sum()) / cu

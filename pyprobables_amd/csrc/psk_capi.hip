@@ -1,0 +1,854 @@
+// psk_capi.hip -- the extern "C" boundary (include/psk.h) over the gfx950 kernels in psk_device.hpp.
+// Host side: handle bookkeeping, host<->device staging for PSK_HOST buffers, launch geometry.
+#include "psk_device.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/psk.h"
+
+using namespace psk;
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail(e__ == hipErrorOutOfMemory ? PSK_ENOMEM : PSK_EHIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e__), __FILE__, __LINE__);                                    \
+    } while (0)
+
+#define PSK_TRY(expr)            \
+    do {                         \
+        int rc__ = (expr);       \
+        if (rc__ != PSK_OK)      \
+            return rc__;         \
+    } while (0)
+
+extern "C" const char *psk_last_error(void) { return g_err; }
+extern "C" int psk_version(void) { return 100; }
+
+extern "C" int psk_device_count(int *count)
+{
+    if (!count) return fail(PSK_EINVAL, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(PSK_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return PSK_OK;
+}
+
+// ------------------------------------------------------------------ handle
+struct DevBuf {
+    void *p = nullptr;
+    uint64_t cap = 0;
+};
+
+struct psk_sketch {
+    int kind;
+    int device;
+    uint64_t m;        // bits (bloom), counters (cbf), width (cms)
+    uint32_t k;        // hashes (bloom/cbf), depth (cms)
+    Mod md;
+    bool pow2;
+    void *table;
+    bool owns_table;
+    uint64_t padded_bytes, logical_bytes;
+    long long *ctr;    // device int64[PSK_CTR_COUNT]
+    DevBuf s_keys, s_offs, s_w, s_out, s_aux;  // staging for PSK_HOST buffers
+};
+
+static uint64_t round16(uint64_t b) { return (b + 15) & ~15ULL; }
+extern "C" uint64_t psk_bloom_table_bytes(uint64_t m_bits) { return round16((m_bits + 7) / 8); }
+extern "C" uint64_t psk_cbf_table_bytes(uint64_t m) { return round16(4 * m); }
+extern "C" uint64_t psk_cms_table_bytes(uint64_t width, uint32_t depth) { return round16(4 * width * (uint64_t)depth); }
+
+static Mod make_mod(uint64_t m, bool *pow2)
+{
+    Mod md;
+    md.m = m;
+    *pow2 = (m & (m - 1)) == 0;
+    md.mask = m - 1;
+    md.magic = *pow2 ? 0 : (uint64_t)((((unsigned __int128)1) << 64) / m);
+    return md;
+}
+
+static int ensure(DevBuf &b, uint64_t bytes)
+{
+    if (bytes <= b.cap) return PSK_OK;
+    if (b.p) HIP_TRY(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    uint64_t cap = bytes + bytes / 4 + 256;
+    HIP_TRY(hipMalloc(&b.p, cap));
+    b.cap = cap;
+    return PSK_OK;
+}
+
+static int grid_for(uint64_t n)
+{
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    const uint64_t cap = 256ULL * 16;  // 256 CUs x 16 blocks: grid-stride beyond that
+    if (g > cap) g = cap;
+    if (g == 0) g = 1;
+    return (int)g;
+}
+
+static int create_common(int kind, uint64_t m, uint32_t k, uint64_t padded, uint64_t logical, int device,
+                         void *ext_table, psk_sketch **out)
+{
+    if (!out) return fail(PSK_EINVAL, "out handle pointer is NULL");
+    *out = nullptr;
+    if (m == 0 || k == 0) return fail(PSK_EINVAL, "table dimensions must be > 0 (m=%llu k=%u)", (unsigned long long)m, k);
+    if (m >> 62) return fail(PSK_EINVAL, "table too large");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(PSK_ENODEV, "no HIP device available (%s)", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(PSK_EINVAL, "device %d out of range [0,%d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    psk_sketch *s = new (std::nothrow) psk_sketch();
+    if (!s) return fail(PSK_ENOMEM, "host allocation failed");
+    s->kind = kind;
+    s->device = device;
+    s->m = m;
+    s->k = k;
+    s->md = make_mod(m, &s->pow2);
+    s->padded_bytes = padded;
+    s->logical_bytes = logical;
+    s->owns_table = ext_table == nullptr;
+    s->table = ext_table;
+    s->ctr = nullptr;
+    if (s->owns_table) {
+        hipError_t e2 = hipMalloc(&s->table, padded);
+        if (e2 != hipSuccess) {
+            delete s;
+            return fail(PSK_ENOMEM, "hipMalloc(%llu bytes) for the table failed: %s", (unsigned long long)padded,
+                        hipGetErrorString(e2));
+        }
+        e2 = hipMemset(s->table, 0, padded);
+        if (e2 != hipSuccess) {
+            hipFree(s->table);
+            delete s;
+            return fail(PSK_EHIP, "hipMemset failed: %s", hipGetErrorString(e2));
+        }
+    }
+    hipError_t e3 = hipMalloc((void **)&s->ctr, sizeof(long long) * PSK_CTR_COUNT);
+    if (e3 == hipSuccess) e3 = hipMemset(s->ctr, 0, sizeof(long long) * PSK_CTR_COUNT);
+    if (e3 != hipSuccess) {
+        if (s->owns_table) hipFree(s->table);
+        delete s;
+        return fail(PSK_ENOMEM, "counter allocation failed: %s", hipGetErrorString(e3));
+    }
+    *out = s;
+    return PSK_OK;
+}
+
+extern "C" int psk_bloom_create(uint64_t m_bits, uint32_t k, int device, void *ext_table, psk_sketch **out)
+{
+    return create_common(PSK_KIND_BLOOM, m_bits, k, psk_bloom_table_bytes(m_bits), (m_bits + 7) / 8, device, ext_table, out);
+}
+
+extern "C" int psk_cbf_create(uint64_t m, uint32_t k, int device, void *ext_table, psk_sketch **out)
+{
+    return create_common(PSK_KIND_CBF, m, k, psk_cbf_table_bytes(m), 4 * m, device, ext_table, out);
+}
+
+extern "C" int psk_cms_create(uint64_t width, uint32_t depth, int device, void *ext_table, psk_sketch **out)
+{
+    return create_common(PSK_KIND_CMS, width, depth, psk_cms_table_bytes(width, depth), 4 * width * (uint64_t)depth,
+                         device, ext_table, out);
+}
+
+extern "C" int psk_destroy(psk_sketch *s)
+{
+    if (!s) return PSK_OK;
+    hipSetDevice(s->device);
+    if (s->owns_table && s->table) hipFree(s->table);
+    if (s->ctr) hipFree(s->ctr);
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux})
+        if (b->p) hipFree(b->p);
+    delete s;
+    return PSK_OK;
+}
+
+#define CHECK_HANDLE(s, want_kind)                                                       \
+    do {                                                                                 \
+        if (!(s)) return fail(PSK_EINVAL, "sketch handle is NULL");                      \
+        if ((want_kind) >= 0 && (s)->kind != (want_kind))                                \
+            return fail(PSK_EINVAL, "wrong sketch kind %d for this call", (s)->kind);    \
+        HIP_TRY(hipSetDevice((s)->device));                                              \
+    } while (0)
+
+extern "C" int psk_clear(psk_sketch *s, void *stream)
+{
+    CHECK_HANDLE(s, -1);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(s->table, 0, s->padded_bytes, st));
+    HIP_TRY(hipMemsetAsync(s->ctr, 0, sizeof(long long) * PSK_CTR_COUNT, st));
+    return PSK_OK;
+}
+
+extern "C" int psk_synchronize(psk_sketch *s, void *stream)
+{
+    CHECK_HANDLE(s, -1);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return PSK_OK;
+}
+
+extern "C" int psk_table_info(psk_sketch *s, void **dev_ptr, uint64_t *padded_bytes, uint64_t *logical_bytes)
+{
+    if (!s) return fail(PSK_EINVAL, "sketch handle is NULL");
+    if (dev_ptr) *dev_ptr = s->table;
+    if (padded_bytes) *padded_bytes = s->padded_bytes;
+    if (logical_bytes) *logical_bytes = s->logical_bytes;
+    return PSK_OK;
+}
+
+extern "C" int psk_read_table(psk_sketch *s, void *dst_host, uint64_t nbytes, void *stream)
+{
+    CHECK_HANDLE(s, -1);
+    if (!dst_host || nbytes > s->padded_bytes) return fail(PSK_EINVAL, "bad read_table arguments");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(dst_host, s->table, nbytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PSK_OK;
+}
+
+extern "C" int psk_write_table(psk_sketch *s, const void *src_host, uint64_t nbytes, void *stream)
+{
+    CHECK_HANDLE(s, -1);
+    if (!src_host || nbytes > s->padded_bytes) return fail(PSK_EINVAL, "bad write_table arguments");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(s->table, 0, s->padded_bytes, st));
+    HIP_TRY(hipMemcpyAsync(s->table, src_host, nbytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(s->ctr, 0, sizeof(long long) * PSK_CTR_COUNT, st));
+    if (s->kind != PSK_KIND_BLOOM) {
+        // re-seed the wrap-free bound from the loaded counters
+        const uint64_t nel = s->logical_bytes / 4;
+        hipLaunchKernelGGL(k_absmax, dim3(grid_for(nel)), dim3(kBlock), 0, st, (const uint32_t *)s->table, nel,
+                           s->kind == PSK_KIND_CMS ? 1 : 0, s->ctr);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return PSK_OK;
+}
+
+extern "C" int psk_rescan_bound(psk_sketch *s, void *stream)
+{
+    CHECK_HANDLE(s, -1);
+    if (s->kind == PSK_KIND_BLOOM) return PSK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(s->ctr + PSK_CTR_ABS_BOUND, 0, sizeof(long long), st));
+    const uint64_t nel = s->logical_bytes / 4;
+    hipLaunchKernelGGL(k_absmax, dim3(grid_for(nel)), dim3(kBlock), 0, st, (const uint32_t *)s->table, nel,
+                       s->kind == PSK_KIND_CMS ? 1 : 0, s->ctr);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
+extern "C" int psk_get_counters(psk_sketch *s, int64_t out[PSK_CTR_COUNT], void *stream)
+{
+    CHECK_HANDLE(s, -1);
+    if (!out) return fail(PSK_EINVAL, "out is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(out, s->ctr, sizeof(long long) * PSK_CTR_COUNT, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PSK_OK;
+}
+
+extern "C" int psk_reset_counters(psk_sketch *s, void *stream)
+{
+    CHECK_HANDLE(s, -1);
+    // keep the wrap-free bound: it describes the table, not the batch history
+    HIP_TRY(hipMemsetAsync(s->ctr, 0, sizeof(long long) * PSK_CTR_ABS_BOUND, (hipStream_t)stream));
+    return PSK_OK;
+}
+
+// ---------------------------------------------------------- key batches
+struct Batch {  // device-resident view of one key batch
+    int layout;
+    const void *data;
+    const uint64_t *offs;
+    uint64_t n;
+    uint32_t key_len;
+};
+
+static int elem_bytes(int layout) { return layout == PSK_KEYS_VARLEN32 ? 4 : (layout == PSK_KEYS_HASHES ? 8 : 1); }
+
+// Validate, and for PSK_HOST stage the batch into the handle's device scratch.
+static int stage_batch(DevBuf &kbuf, DevBuf &obuf, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                       uint32_t key_len, int where, hipStream_t st, Batch *b)
+{
+    if (layout < PSK_KEYS_FIXED || layout > PSK_KEYS_HASHES) return fail(PSK_EINVAL, "unknown key layout %d", layout);
+    if (where != PSK_HOST && where != PSK_DEVICE) return fail(PSK_EINVAL, "`where` must be PSK_HOST or PSK_DEVICE");
+    const bool varlen = layout == PSK_KEYS_VARLEN8 || layout == PSK_KEYS_VARLEN32;
+    if (n && !data && !(layout == PSK_KEYS_FIXED && key_len == 0)) return fail(PSK_EINVAL, "key data pointer is NULL");
+    if (n && varlen && !offsets) return fail(PSK_EINVAL, "variable-length layout needs offsets[n+1]");
+    b->layout = layout;
+    b->n = n;
+    b->key_len = key_len;
+    b->data = data;
+    b->offs = offsets;
+    if (where == PSK_DEVICE || n == 0) return PSK_OK;
+    uint64_t nbytes;
+    if (varlen) {
+        const uint64_t total = offsets[n] - offsets[0];
+        if (offsets[0] != 0) return fail(PSK_EINVAL, "host offsets must start at 0");
+        nbytes = total * (uint64_t)elem_bytes(layout);
+        PSK_TRY(ensure(obuf, (n + 1) * 8));
+        HIP_TRY(hipMemcpyAsync(obuf.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
+        b->offs = (const uint64_t *)obuf.p;
+    } else {
+        nbytes = n * (uint64_t)key_len * (uint64_t)elem_bytes(layout);
+    }
+    PSK_TRY(ensure(kbuf, nbytes ? nbytes : 16));
+    if (nbytes) HIP_TRY(hipMemcpyAsync(kbuf.p, data, nbytes, hipMemcpyHostToDevice, st));
+    b->data = kbuf.p;
+    return PSK_OK;
+}
+
+// Dispatch a functor over the concrete key-source type of a batch.
+template <class F>
+static int with_source(const Batch &b, F &&f)
+{
+    switch (b.layout) {
+        case PSK_KEYS_FIXED:
+            if (b.key_len == 16 && ((uintptr_t)b.data & 15) == 0) return f(KeysFixed16{(const uint4 *)b.data});
+            if (b.key_len % 4 == 0 && ((uintptr_t)b.data & 3) == 0) return f(KeysFixed<true>{(const uint8_t *)b.data, b.key_len});
+            return f(KeysFixed<false>{(const uint8_t *)b.data, b.key_len});
+        case PSK_KEYS_VARLEN8: return f(KeysVarlen<uint8_t>{(const uint8_t *)b.data, b.offs});
+        case PSK_KEYS_VARLEN32: return f(KeysVarlen<uint32_t>{(const uint32_t *)b.data, b.offs});
+        case PSK_KEYS_HASHES: return f(KeysHashes{(const uint64_t *)b.data, b.key_len});
+    }
+    return fail(PSK_EINVAL, "unknown key layout");
+}
+
+template <class Src, class Op>
+static int launch_apply(const Src &src, const Op &op, uint64_t n, hipStream_t st)
+{
+    if (n == 0) return PSK_OK;
+    hipLaunchKernelGGL((k_apply<Src, Op>), dim3(grid_for(n)), dim3(kBlock), 0, st, src, op, n);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
+static int check_hashes_width(const psk_sketch *s, int layout, uint32_t key_len)
+{
+    if (layout == PSK_KEYS_HASHES && key_len < s->k)
+        return fail(PSK_EINVAL, "pre-hashed batch carries %u hashes per key, the sketch needs %u", key_len, s->k);
+    return PSK_OK;
+}
+
+// stage an optional per-key vector (weights); returns device pointer or nullptr
+template <class T>
+static int stage_vec(DevBuf &buf, const T *v, uint64_t n, int where, hipStream_t st, const T **dev)
+{
+    *dev = v;
+    if (!v || where == PSK_DEVICE || n == 0) return PSK_OK;
+    PSK_TRY(ensure(buf, n * sizeof(T)));
+    HIP_TRY(hipMemcpyAsync(buf.p, v, n * sizeof(T), hipMemcpyHostToDevice, st));
+    *dev = (const T *)buf.p;
+    return PSK_OK;
+}
+
+// output buffer: device pointer to write into (+ copy-back for PSK_HOST)
+struct OutBuf {
+    void *dev = nullptr;
+    void *host = nullptr;
+    uint64_t bytes = 0;
+};
+
+static int stage_out(DevBuf &buf, void *out, uint64_t bytes, int where, OutBuf *o)
+{
+    o->bytes = bytes;
+    if (where == PSK_DEVICE || bytes == 0) {
+        o->dev = out;
+        return PSK_OK;
+    }
+    PSK_TRY(ensure(buf, bytes));
+    o->dev = buf.p;
+    o->host = out;
+    return PSK_OK;
+}
+
+static int finish(int where, const OutBuf *o, hipStream_t st)
+{
+    if (where == PSK_HOST) {
+        if (o && o->host && o->bytes) HIP_TRY(hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return PSK_OK;
+}
+
+// ------------------------------------------------------------- BloomFilter
+extern "C" int psk_bloom_add(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                             uint32_t key_len, int where, void *stream)
+{
+    CHECK_HANDLE(s, PSK_KIND_BLOOM);
+    PSK_TRY(check_hashes_width(s, layout, key_len));
+    hipStream_t st = (hipStream_t)stream;
+    Batch b;
+    PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+    PSK_TRY(with_source(b, [&](auto src) {
+        if (s->pow2) return launch_apply(src, BloomAdd<true>{(uint32_t *)s->table, s->md, s->k}, n, st);
+        return launch_apply(src, BloomAdd<false>{(uint32_t *)s->table, s->md, s->k}, n, st);
+    }));
+    return finish(where, nullptr, st);
+}
+
+extern "C" int psk_bloom_check(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                               uint32_t key_len, int where, uint8_t *out, void *stream)
+{
+    CHECK_HANDLE(s, PSK_KIND_BLOOM);
+    PSK_TRY(check_hashes_width(s, layout, key_len));
+    if (n && !out) return fail(PSK_EINVAL, "out is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    Batch b;
+    PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+    OutBuf o;
+    PSK_TRY(stage_out(s->s_out, out, n, where, &o));
+    PSK_TRY(with_source(b, [&](auto src) {
+        if (s->pow2) return launch_apply(src, BloomCheck<true>{(const uint32_t *)s->table, s->md, s->k, (uint8_t *)o.dev}, n, st);
+        return launch_apply(src, BloomCheck<false>{(const uint32_t *)s->table, s->md, s->k, (uint8_t *)o.dev}, n, st);
+    }));
+    return finish(where, &o, st);
+}
+
+extern "C" int psk_bloom_check_bits(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                                    uint32_t key_len, int where, uint64_t *out_bits, uint64_t *hits, void *stream)
+{
+    CHECK_HANDLE(s, PSK_KIND_BLOOM);
+    PSK_TRY(check_hashes_width(s, layout, key_len));
+    if (n && (!out_bits || !hits)) return fail(PSK_EINVAL, "out_bits / hits is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    Batch b;
+    PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+    const uint64_t nwords = (n + 63) / 64;
+    OutBuf o;
+    PSK_TRY(stage_out(s->s_out, out_bits, nwords * 8, where, &o));
+    unsigned long long *hits_dev = (unsigned long long *)hits;
+    if (where == PSK_HOST) {
+        PSK_TRY(ensure(s->s_aux, 8));
+        hits_dev = (unsigned long long *)s->s_aux.p;
+        HIP_TRY(hipMemcpyAsync(hits_dev, hits, 8, hipMemcpyHostToDevice, st));
+    }
+    if (n) {
+        PSK_TRY(with_source(b, [&](auto src) {
+            using Src = decltype(src);
+            if (s->pow2)
+                hipLaunchKernelGGL((k_bloom_check_bits<Src, true>), dim3(grid_for(n)), dim3(kBlock), 0, st, src,
+                                   (const uint32_t *)s->table, s->md, s->k, n, (unsigned long long *)o.dev, hits_dev);
+            else
+                hipLaunchKernelGGL((k_bloom_check_bits<Src, false>), dim3(grid_for(n)), dim3(kBlock), 0, st, src,
+                                   (const uint32_t *)s->table, s->md, s->k, n, (unsigned long long *)o.dev, hits_dev);
+            HIP_TRY(hipGetLastError());
+            return (int)PSK_OK;
+        }));
+    }
+    if (where == PSK_HOST) HIP_TRY(hipMemcpyAsync(hits, hits_dev, 8, hipMemcpyDeviceToHost, st));
+    return finish(where, &o, st);
+}
+
+// ------------------------------------------------------ counters / weights
+template <class W>
+static int account_weights(psk_sketch *s, const W *w_dev, uint64_t n, int which, long long bound_mult, hipStream_t st)
+{
+    if (n == 0) return PSK_OK;
+    if (w_dev) {
+        hipLaunchKernelGGL((k_weight_sum<W>), dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(kBlock), 0, st, w_dev, n,
+                           s->ctr, which, bound_mult);
+    } else {
+        hipLaunchKernelGGL(k_ctr_add, dim3(1), dim3(1), 0, st, s->ctr, which, (long long)n, (long long)n * bound_mult);
+    }
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
+// ----------------------------------------------------- CountingBloomFilter
+extern "C" int psk_cbf_add(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                           uint32_t key_len, const uint32_t *weights, int where, void *stream)
+{
+    CHECK_HANDLE(s, PSK_KIND_CBF);
+    PSK_TRY(check_hashes_width(s, layout, key_len));
+    hipStream_t st = (hipStream_t)stream;
+    Batch b;
+    PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+    const uint32_t *w;
+    PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
+    PSK_TRY(account_weights(s, w, n, PSK_CTR_ADDED, (long long)s->k, st));
+    unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
+    PSK_TRY(with_source(b, [&](auto src) {
+        if (s->pow2) return launch_apply(src, CbfAdd<true>{(uint32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st);
+        return launch_apply(src, CbfAdd<false>{(uint32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st);
+    }));
+    return finish(where, nullptr, st);
+}
+
+extern "C" int psk_cbf_remove(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                              uint32_t key_len, const uint32_t *weights, int where, void *stream)
+{
+    CHECK_HANDLE(s, PSK_KIND_CBF);
+    PSK_TRY(check_hashes_width(s, layout, key_len));
+    hipStream_t st = (hipStream_t)stream;
+    Batch b;
+    PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+    const uint32_t *w;
+    PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
+    if (n) {
+        PSK_TRY(with_source(b, [&](auto src) {
+            using Src = decltype(src);
+            if (s->pow2)
+                hipLaunchKernelGGL((k_cbf_remove<Src, true>), dim3(grid_for(n)), dim3(kBlock), 0, st, src,
+                                   (uint32_t *)s->table, s->md, s->k, w, n, (unsigned long long *)s->ctr);
+            else
+                hipLaunchKernelGGL((k_cbf_remove<Src, false>), dim3(grid_for(n)), dim3(kBlock), 0, st, src,
+                                   (uint32_t *)s->table, s->md, s->k, w, n, (unsigned long long *)s->ctr);
+            HIP_TRY(hipGetLastError());
+            return (int)PSK_OK;
+        }));
+    }
+    return finish(where, nullptr, st);
+}
+
+extern "C" int psk_cbf_check(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                             uint32_t key_len, int where, uint32_t *out, void *stream)
+{
+    CHECK_HANDLE(s, PSK_KIND_CBF);
+    if (n && !out) return fail(PSK_EINVAL, "out is NULL");
+    if (layout == PSK_KEYS_HASHES && key_len == 0) return fail(PSK_EINVAL, "check needs at least one hash per key");
+    hipStream_t st = (hipStream_t)stream;
+    Batch b;
+    PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+    OutBuf o;
+    PSK_TRY(stage_out(s->s_out, out, n * 4, where, &o));
+    // countingbloom.py:174 takes the min over ALL supplied hashes (not just the first k)
+    const uint32_t kk = layout == PSK_KEYS_HASHES ? key_len : s->k;
+    PSK_TRY(with_source(b, [&](auto src) {
+        if (s->pow2) return launch_apply(src, CbfCheck<true>{(const uint32_t *)s->table, s->md, kk, (uint32_t *)o.dev}, n, st);
+        return launch_apply(src, CbfCheck<false>{(const uint32_t *)s->table, s->md, kk, (uint32_t *)o.dev}, n, st);
+    }));
+    return finish(where, &o, st);
+}
+
+extern "C" int psk_cbf_update_ordered(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                                      uint32_t key_len, const int64_t *weights, int opmode, int where, uint32_t *out,
+                                      void *stream)
+{
+    CHECK_HANDLE(s, PSK_KIND_CBF);
+    PSK_TRY(check_hashes_width(s, layout, key_len));
+    if (s->k > (uint32_t)kMaxKOrdered) return fail(PSK_EINVAL, "ordered updates support k <= %d", kMaxKOrdered);
+    if (opmode < PSK_OP_ADD || opmode > PSK_OP_SIGNED) return fail(PSK_EINVAL, "bad opmode %d", opmode);
+    hipStream_t st = (hipStream_t)stream;
+    Batch b;
+    PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+    const int64_t *w;
+    PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
+    OutBuf o;
+    PSK_TRY(stage_out(s->s_out, out, out ? n * 4 : 0, where, &o));
+    if (n) {
+        PSK_TRY(with_source(b, [&](auto src) {
+            using Src = decltype(src);
+            if (s->pow2)
+                hipLaunchKernelGGL((k_cbf_ordered<Src, true>), dim3(1), dim3(64), 0, st, src, (uint32_t *)s->table, s->md,
+                                   s->k, w, opmode, n, (uint32_t *)(out ? o.dev : nullptr), (unsigned long long *)s->ctr);
+            else
+                hipLaunchKernelGGL((k_cbf_ordered<Src, false>), dim3(1), dim3(64), 0, st, src, (uint32_t *)s->table, s->md,
+                                   s->k, w, opmode, n, (uint32_t *)(out ? o.dev : nullptr), (unsigned long long *)s->ctr);
+            HIP_TRY(hipGetLastError());
+            return (int)PSK_OK;
+        }));
+    }
+    return finish(where, &o, st);
+}
+
+// ---------------------------------------------------------- CountMinSketch
+template <bool NEG>
+static int cms_update(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n, uint32_t key_len,
+                      const int32_t *weights, int where, void *stream)
+{
+    CHECK_HANDLE(s, PSK_KIND_CMS);
+    PSK_TRY(check_hashes_width(s, layout, key_len));
+    hipStream_t st = (hipStream_t)stream;
+    Batch b;
+    PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+    const int32_t *w;
+    PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
+    PSK_TRY(account_weights(s, w, n, NEG ? PSK_CTR_REMOVED : PSK_CTR_ADDED, 1LL, st));
+    unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
+    PSK_TRY(with_source(b, [&](auto src) {
+        if (s->pow2)
+            return launch_apply(src, CmsAdd<true, NEG>{(int32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st);
+        return launch_apply(src, CmsAdd<false, NEG>{(int32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st);
+    }));
+    return finish(where, nullptr, st);
+}
+
+extern "C" int psk_cms_add(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                           uint32_t key_len, const int32_t *weights, int where, void *stream)
+{
+    return cms_update<false>(s, layout, data, offsets, n, key_len, weights, where, stream);
+}
+
+extern "C" int psk_cms_remove(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                              uint32_t key_len, const int32_t *weights, int where, void *stream)
+{
+    return cms_update<true>(s, layout, data, offsets, n, key_len, weights, where, stream);
+}
+
+extern "C" int psk_cms_check(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                             uint32_t key_len, int where, int query, int32_t *out, void *stream)
+{
+    CHECK_HANDLE(s, PSK_KIND_CMS);
+    PSK_TRY(check_hashes_width(s, layout, key_len));
+    if (query != PSK_Q_MIN && query != PSK_Q_MEAN) return fail(PSK_EINVAL, "psk_cms_check handles MIN and MEAN queries");
+    if (n && !out) return fail(PSK_EINVAL, "out is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    Batch b;
+    PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+    OutBuf o;
+    PSK_TRY(stage_out(s->s_out, out, n * 4, where, &o));
+    const bool mean = query == PSK_Q_MEAN;
+    PSK_TRY(with_source(b, [&](auto src) {
+        if (s->pow2) return launch_apply(src, CmsCheck<true>{(const int32_t *)s->table, s->md, s->k, (int32_t *)o.dev, mean}, n, st);
+        return launch_apply(src, CmsCheck<false>{(const int32_t *)s->table, s->md, s->k, (int32_t *)o.dev, mean}, n, st);
+    }));
+    return finish(where, &o, st);
+}
+
+extern "C" int psk_cms_check_meanmin(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                                     uint32_t key_len, int where, int64_t elements_added, int64_t *out, void *stream)
+{
+    CHECK_HANDLE(s, PSK_KIND_CMS);
+    PSK_TRY(check_hashes_width(s, layout, key_len));
+    if (s->k > (uint32_t)kMaxDepthMeanMin) return fail(PSK_EINVAL, "mean-min query supports depth <= %d", kMaxDepthMeanMin);
+    if (s->m < 2) return fail(PSK_EINVAL, "mean-min query needs width >= 2 (divides by width-1)");
+    if (n && !out) return fail(PSK_EINVAL, "out is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    Batch b;
+    PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+    OutBuf o;
+    PSK_TRY(stage_out(s->s_out, out, n * 8, where, &o));
+    PSK_TRY(with_source(b, [&](auto src) {
+        if (s->pow2)
+            return launch_apply(src, CmsCheckMeanMin<true>{(const int32_t *)s->table, s->md, s->k, elements_added, (int64_t *)o.dev}, n, st);
+        return launch_apply(src, CmsCheckMeanMin<false>{(const int32_t *)s->table, s->md, s->k, elements_added, (int64_t *)o.dev}, n, st);
+    }));
+    return finish(where, &o, st);
+}
+
+extern "C" int psk_cms_update_ordered(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                                      uint32_t key_len, const int64_t *weights, int opmode, int query,
+                                      int64_t elements_added_in, int where, int64_t *out, void *stream)
+{
+    CHECK_HANDLE(s, PSK_KIND_CMS);
+    PSK_TRY(check_hashes_width(s, layout, key_len));
+    if (s->k > (uint32_t)kMaxDepthMeanMin) return fail(PSK_EINVAL, "ordered updates support depth <= %d", kMaxDepthMeanMin);
+    if (opmode < PSK_OP_ADD || opmode > PSK_OP_SIGNED) return fail(PSK_EINVAL, "bad opmode %d", opmode);
+    if (query < PSK_Q_MIN || query > PSK_Q_MEANMIN) return fail(PSK_EINVAL, "bad query %d", query);
+    if (query == PSK_Q_MEANMIN && s->m < 2) return fail(PSK_EINVAL, "mean-min query needs width >= 2");
+    hipStream_t st = (hipStream_t)stream;
+    Batch b;
+    PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+    const int64_t *w;
+    PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
+    OutBuf o;
+    PSK_TRY(stage_out(s->s_out, out, out ? n * 8 : 0, where, &o));
+    PSK_TRY(with_source(b, [&](auto src) {
+        using Src = decltype(src);
+        if (s->pow2)
+            hipLaunchKernelGGL((k_cms_ordered<Src, true>), dim3(1), dim3(64), 0, st, src, (int32_t *)s->table, s->md, s->k, w,
+                               opmode, query, elements_added_in, n, (int64_t *)(out ? o.dev : nullptr), s->ctr);
+        else
+            hipLaunchKernelGGL((k_cms_ordered<Src, false>), dim3(1), dim3(64), 0, st, src, (int32_t *)s->table, s->md, s->k, w,
+                               opmode, query, elements_added_in, n, (int64_t *)(out ? o.dev : nullptr), s->ctr);
+        HIP_TRY(hipGetLastError());
+        return (int)PSK_OK;
+    }));
+    return finish(where, &o, st);
+}
+
+// ------------------------------------------------------------------ hashing
+static thread_local DevBuf g_hkeys, g_hoffs, g_hout;  // staging for the handle-less calls
+
+extern "C" int psk_fnv1a_hash(int layout, const void *data, const uint64_t *offsets, uint64_t n, uint32_t key_len,
+                              uint32_t depth, int where, uint64_t *out, int device, void *stream)
+{
+    if (layout == PSK_KEYS_HASHES) return fail(PSK_EINVAL, "psk_fnv1a_hash needs a key layout");
+    if (n && depth && !out) return fail(PSK_EINVAL, "out is NULL");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    Batch b;
+    PSK_TRY(stage_batch(g_hkeys, g_hoffs, layout, data, offsets, n, key_len, where, st, &b));
+    OutBuf o;
+    PSK_TRY(stage_out(g_hout, out, n * depth * 8, where, &o));
+    if (n && depth) {
+        PSK_TRY(with_source(b, [&](auto src) {
+            using Src = decltype(src);
+            hipLaunchKernelGGL((k_hash<Src>), dim3(grid_for(n)), dim3(kBlock), 0, st, src, (uint64_t *)o.dev, depth, n);
+            HIP_TRY(hipGetLastError());
+            return (int)PSK_OK;
+        }));
+    }
+    return finish(where, &o, st);
+}
+
+// ------------------------------------------------------------ table algebra
+static int check_vec(const void *a, const void *b, uint64_t nwords32)
+{
+    if (!a || !b) return fail(PSK_EINVAL, "table pointer is NULL");
+    if (nwords32 % 4 || ((uintptr_t)a & 15) || ((uintptr_t)b & 15))
+        return fail(PSK_EINVAL, "tables must be 16-byte aligned and a multiple of 16 bytes long");
+    return PSK_OK;
+}
+
+extern "C" int psk_table_or(void *dst, const void *src, uint64_t nwords32, int device, void *stream)
+{
+    PSK_TRY(check_vec(dst, src, nwords32));
+    HIP_TRY(hipSetDevice(device));
+    if (!nwords32) return PSK_OK;
+    hipLaunchKernelGGL((k_table_binop<OpOr>), dim3(grid_for(nwords32 / 4)), dim3(kBlock), 0, (hipStream_t)stream, (uint4 *)dst,
+                       (const uint4 *)src, nwords32 / 4, OpOr{});
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
+extern "C" int psk_table_and(void *dst, const void *src, uint64_t nwords32, int device, void *stream)
+{
+    PSK_TRY(check_vec(dst, src, nwords32));
+    HIP_TRY(hipSetDevice(device));
+    if (!nwords32) return PSK_OK;
+    hipLaunchKernelGGL((k_table_binop<OpAnd>), dim3(grid_for(nwords32 / 4)), dim3(kBlock), 0, (hipStream_t)stream, (uint4 *)dst,
+                       (const uint4 *)src, nwords32 / 4, OpAnd{});
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
+static int table_count(const void *tab, uint64_t nwords32, int mode, uint64_t *out_host, int device, void *stream)
+{
+    PSK_TRY(check_vec(tab, tab, nwords32));
+    if (!out_host) return fail(PSK_EINVAL, "out is NULL");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 8));
+    hipError_t e = hipMemsetAsync(d, 0, 8, st);
+    if (e == hipSuccess && nwords32) {
+        hipLaunchKernelGGL(k_table_count, dim3(grid_for(nwords32 / 4)), dim3(kBlock), 0, st, (const uint4 *)tab, nwords32 / 4, mode, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_host, d, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d);
+    if (e != hipSuccess) return fail(PSK_EHIP, "table count failed: %s", hipGetErrorString(e));
+    return PSK_OK;
+}
+
+extern "C" int psk_table_popcount(const void *tab, uint64_t nwords32, uint64_t *out_host, int device, void *stream)
+{
+    return table_count(tab, nwords32, 0, out_host, device, stream);
+}
+
+extern "C" int psk_table_nonzero_u32(const void *tab, uint64_t nwords32, uint64_t *out_host, int device, void *stream)
+{
+    return table_count(tab, nwords32, 1, out_host, device, stream);
+}
+
+extern "C" int psk_table_add_sat_i32(void *dst, const void *src, uint64_t n, int device, void *stream)
+{
+    if (!dst || !src) return fail(PSK_EINVAL, "table pointer is NULL");
+    HIP_TRY(hipSetDevice(device));
+    if (!n) return PSK_OK;
+    hipLaunchKernelGGL(k_add_sat_i32, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, (int32_t *)dst, (const int32_t *)src, n);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
+extern "C" int psk_table_add_u32(void *dst, const void *src, uint64_t n, uint64_t *overflowed_host, int device, void *stream)
+{
+    if (!dst || !src) return fail(PSK_EINVAL, "table pointer is NULL");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 8));
+    hipError_t e = hipMemsetAsync(d, 0, 8, st);
+    if (e == hipSuccess && n) {
+        hipLaunchKernelGGL(k_add_u32, dim3(grid_for(n)), dim3(kBlock), 0, st, (uint32_t *)dst, (const uint32_t *)src, n, d);
+        e = hipGetLastError();
+    }
+    uint64_t ov = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&ov, d, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d);
+    if (e != hipSuccess) return fail(PSK_EHIP, "table add failed: %s", hipGetErrorString(e));
+    if (overflowed_host) *overflowed_host = ov;
+    return PSK_OK;
+}
+
+extern "C" int psk_or_reduce_slices(void *dst, const void *src, uint32_t nslices, uint64_t slice_words32, int device, void *stream)
+{
+    PSK_TRY(check_vec(dst, src, slice_words32));
+    if (nslices == 0) return fail(PSK_EINVAL, "nslices must be > 0");
+    HIP_TRY(hipSetDevice(device));
+    if (!slice_words32) return PSK_OK;
+    hipLaunchKernelGGL(k_or_reduce, dim3(grid_for(slice_words32 / 4)), dim3(kBlock), 0, (hipStream_t)stream, (uint4 *)dst,
+                       (const uint4 *)src, nslices, slice_words32 / 4);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
+// ------------------------------------------------------- synthetic streams
+extern "C" int psk_gen_keys16(void *dst_dev, uint64_t start, uint64_t n, uint64_t seed, int device, void *stream)
+{
+    if (n && (!dst_dev || ((uintptr_t)dst_dev & 15))) return fail(PSK_EINVAL, "dst must be a 16-byte aligned device pointer");
+    HIP_TRY(hipSetDevice(device));
+    if (!n) return PSK_OK;
+    hipLaunchKernelGGL(k_gen_keys16, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, (ulonglong2 *)dst_dev, start, n, seed);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
+extern "C" int psk_gen_weights(void *dst_dev, uint64_t start, uint64_t n, uint64_t seed, int device, void *stream)
+{
+    if (n && !dst_dev) return fail(PSK_EINVAL, "dst is NULL");
+    HIP_TRY(hipSetDevice(device));
+    if (!n) return PSK_OK;
+    hipLaunchKernelGGL(k_gen_weights, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, (int32_t *)dst_dev, start, n, seed);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
+extern "C" int psk_gups(void *table_dev, uint64_t nwords32, uint64_t n, int op, uint64_t seed, uint64_t *sink_dev, int device,
+                        void *stream)
+{
+    if (!table_dev || !nwords32) return fail(PSK_EINVAL, "bad table");
+    if (op == 2 && !sink_dev) return fail(PSK_EINVAL, "load mode needs a sink");
+    HIP_TRY(hipSetDevice(device));
+    if (!n) return PSK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g(grid_for(n)), blk(kBlock);
+    if (op == 0) hipLaunchKernelGGL((k_gups<0>), g, blk, 0, st, (uint32_t *)table_dev, nwords32, n, seed, (unsigned long long *)sink_dev);
+    else if (op == 1) hipLaunchKernelGGL((k_gups<1>), g, blk, 0, st, (uint32_t *)table_dev, nwords32, n, seed, (unsigned long long *)sink_dev);
+    else if (op == 2) hipLaunchKernelGGL((k_gups<2>), g, blk, 0, st, (uint32_t *)table_dev, nwords32, n, seed, (unsigned long long *)sink_dev);
+    else return fail(PSK_EINVAL, "bad gups op %d", op);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}

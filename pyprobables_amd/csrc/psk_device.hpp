@@ -1,0 +1,781 @@
+// psk_device.hpp -- gfx950 (CDNA4) device code of the sketch engine.
+//
+// Everything here is integer hashing + random 4-byte read/modify/write on an HBM-resident table:
+// HBM/atomic bound, no MFMA.  One lane owns one key: it streams the key in (16 B/lane coalesced for
+// the fixed-16 layout), runs the k independent FNV-1a chains interleaved for ILP, reduces each
+// 64-bit hash mod m (mask for power-of-two m, exact Barrett otherwise) and issues the k table
+// accesses back-to-back (fire-and-forget atomics for updates, k loads in flight for lookups).
+//
+// Reference semantics (pyprobables v0.7.0) are cited per function as file:line.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace psk {
+
+constexpr uint64_t kFnvBasis = 14695981039346656037ULL;  // hashes.py:96
+constexpr uint64_t kFnvPrime = 1099511628211ULL;         // hashes.py:97  (2^40 + 0x1B3)
+constexpr int kBlock = 256;                              // 4 wavefronts of 64
+constexpr int kGroup = 8;                                // hash chains interleaved per pass
+
+// ------------------------------------------------------------------ hashing
+// hashes.py:99-102  hval ^= e; hval *= prime (mod 2^64)
+__device__ __forceinline__ uint64_t fnv_step(uint64_t h, uint32_t e) { return (h ^ (uint64_t)e) * kFnvPrime; }
+
+// hashes.py:96  seeded offset basis
+__device__ __forceinline__ uint64_t fnv_seed(uint32_t seed) { return kFnvBasis + 31ULL * (uint64_t)seed; }
+
+template <int G>
+__device__ __forceinline__ void fnv_init(uint64_t (&h)[G], uint32_t s0)
+{
+#pragma unroll
+    for (int g = 0; g < G; ++g) h[g] = fnv_seed(s0 + g);
+}
+
+template <int G>
+__device__ __forceinline__ void fnv_word(uint64_t (&h)[G], uint32_t w)
+{
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t e = (w >> (8 * b)) & 0xFFu;
+#pragma unroll
+        for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e);
+    }
+}
+
+// ------------------------------------------------------------ key sources
+// A source turns key i into `G` hashes for seeds s0..s0+G-1 (hashes.py:71-83 default_fnv_1a).
+
+struct KeysFixed16 {  // uint8[n][16], 16-byte aligned: one global_load_dwordx4 per lane
+    const uint4 *p;
+    struct Key { uint4 w; };
+    __device__ __forceinline__ Key load(uint64_t i) const { return Key{p[i]}; }
+    template <int G>
+    __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
+    {
+        fnv_init<G>(h, s0);
+        fnv_word<G>(h, k.w.x);
+        fnv_word<G>(h, k.w.y);
+        fnv_word<G>(h, k.w.z);
+        fnv_word<G>(h, k.w.w);
+    }
+};
+
+template <bool DWORDS>
+struct KeysFixed {  // uint8[n][L]; DWORDS: L % 4 == 0 and base 4-byte aligned
+    const uint8_t *p;
+    uint32_t L;
+    struct Key { const uint8_t *q; };
+    __device__ __forceinline__ Key load(uint64_t i) const { return Key{p + i * (uint64_t)L}; }
+    template <int G>
+    __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
+    {
+        fnv_init<G>(h, s0);
+        if (DWORDS) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(k.q);
+            for (uint32_t j = 0; j < L / 4; ++j) fnv_word<G>(h, q[j]);
+        } else {
+            for (uint32_t j = 0; j < L; ++j) {
+                const uint32_t e = k.q[j];
+#pragma unroll
+                for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e);
+            }
+        }
+    }
+};
+
+template <class T>
+struct KeysVarlen {  // elements T (uint8 bytes, or uint32 code points for str keys: hashes.py:98)
+    const T *p;
+    const uint64_t *off;
+    struct Key { const T *q; uint64_t len; };
+    __device__ __forceinline__ Key load(uint64_t i) const
+    {
+        const uint64_t a = off[i], b = off[i + 1];
+        return Key{p + a, b - a};
+    }
+    template <int G>
+    __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
+    {
+        fnv_init<G>(h, s0);
+        for (uint64_t j = 0; j < k.len; ++j) {
+            const uint32_t e = (uint32_t)k.q[j];
+#pragma unroll
+            for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e);
+        }
+    }
+};
+
+struct KeysHashes {  // uint64[n][stride] pre-computed hashes (add_alt / check_alt, custom hash_function)
+    const uint64_t *p;
+    uint32_t stride;
+    struct Key { const uint64_t *q; };
+    __device__ __forceinline__ Key load(uint64_t i) const { return Key{p + i * (uint64_t)stride}; }
+    template <int G>
+    __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
+    {
+#pragma unroll
+        for (int g = 0; g < G; ++g) h[g] = k.q[s0 + g];
+    }
+};
+
+// ------------------------------------------------------------------ h % m
+// bloom.py:247 / countingbloom.py:145 / countminsketch.py:275 use an exact 64-bit modulo.
+struct Mod {
+    uint64_t m;      // divisor, 1 <= m < 2^63
+    uint64_t magic;  // floor(2^64 / m) (non power-of-two m)
+    uint64_t mask;   // m - 1 (power-of-two m)
+};
+
+template <bool POW2>
+__device__ __forceinline__ uint64_t reduce(const Mod &md, uint64_t h)
+{
+    if (POW2) return h & md.mask;
+    // q in {floor(h/m) - 1, floor(h/m)}  =>  one conditional correction makes it exact
+    const uint64_t q = __umul64hi(h, md.magic);
+    const uint64_t r = h - q * md.m;
+    return r >= md.m ? r - md.m : r;
+}
+
+// ------------------------------------------------------- the generic kernel
+// for_each_hash: f(j, hash_j) for j < k, hashing kGroup seeds at a time so the independent
+// xor-multiply chains interleave (ILP) and the k table accesses issue back-to-back (MLP).
+template <int G, class Src, class F>
+__device__ __forceinline__ void hash_group(const Src &src, const typename Src::Key &key, uint64_t i, uint32_t s0, F &f)
+{
+    uint64_t h[G];
+    src.template hash<G>(key, i, s0, h);
+#pragma unroll
+    for (int g = 0; g < G; ++g) f(s0 + g, h[g]);
+}
+
+template <class Src, class F>
+__device__ __forceinline__ void for_each_hash(const Src &src, const typename Src::Key &key, uint64_t i, uint32_t k, F f)
+{
+    uint32_t s = 0;
+    for (; s + kGroup <= k; s += kGroup) hash_group<kGroup>(src, key, i, s, f);
+    switch (k - s) {  // wave-uniform
+        case 7: hash_group<7>(src, key, i, s, f); break;
+        case 6: hash_group<6>(src, key, i, s, f); break;
+        case 5: hash_group<5>(src, key, i, s, f); break;
+        case 4: hash_group<4>(src, key, i, s, f); break;
+        case 3: hash_group<3>(src, key, i, s, f); break;
+        case 2: hash_group<2>(src, key, i, s, f); break;
+        case 1: hash_group<1>(src, key, i, s, f); break;
+        default: break;
+    }
+}
+
+// Op interface:  uint32_t k;  void prepare();  State begin(i);  void apply(State&, j, hash);  void end(State&, i)
+template <class Src, class Op>
+__global__ __launch_bounds__(kBlock) void k_apply(Src src, Op op, uint64_t n)
+{
+    op.prepare();
+    const uint32_t k = op.k;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const typename Src::Key key = src.load(i);
+        typename Op::State st = op.begin(i);
+        for_each_hash(src, key, i, k, [&](uint32_t j, uint64_t h) { op.apply(st, j, h); });
+        op.end(st, i);
+    }
+}
+
+// ---------------------------------------------------------------- Bloom ops
+struct Empty {};
+
+template <bool POW2>
+struct BloomAdd {  // bloom.py:241-250 add_alt: bloom[k//8] |= 1 << (k%8)  == uint32 word k>>5, bit k&31 (LE)
+    uint32_t *tab;
+    Mod md;
+    uint32_t k;
+    using State = Empty;
+    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ State begin(uint64_t) const { return {}; }
+    __device__ __forceinline__ void apply(State &, uint32_t, uint64_t h) const
+    {
+        const uint64_t b = reduce<POW2>(md, h);
+        atomicOr(tab + (b >> 5), 1u << (uint32_t)(b & 31));  // result unused -> no-return global_atomic_or
+    }
+    __device__ __forceinline__ void end(State &, uint64_t) const {}
+};
+
+template <bool POW2>
+struct BloomCheck {  // bloom.py:261-272 check_alt (AND of the k bits; early exit does not change the result)
+    const uint32_t *tab;
+    Mod md;
+    uint32_t k;
+    uint8_t *out;
+    struct State { uint32_t ok; };
+    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ State begin(uint64_t) const { return State{1u}; }
+    __device__ __forceinline__ void apply(State &st, uint32_t, uint64_t h) const
+    {
+        const uint64_t b = reduce<POW2>(md, h);
+        st.ok &= (tab[b >> 5] >> (uint32_t)(b & 31)) & 1u;
+    }
+    __device__ __forceinline__ void end(State &st, uint64_t i) const { out[i] = (uint8_t)st.ok; }
+};
+
+// membership as a ballot bitmap + popcount of hits: one uint64 store per wavefront of 64 keys
+template <class Src, bool POW2>
+__global__ __launch_bounds__(kBlock) void k_bloom_check_bits(Src src, const uint32_t *tab, Mod md, uint32_t k,
+                                                             uint64_t n, unsigned long long *out_bits,
+                                                             unsigned long long *hits)
+{
+    BloomCheck<POW2> op{tab, md, k, nullptr};
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t nround = (n + 63) & ~63ULL;  // wave-uniform trip count
+    unsigned long long my_hits = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nround; i += stride) {
+        uint32_t ok = 0;
+        if (i < n) {
+            const typename Src::Key key = src.load(i);
+            typename BloomCheck<POW2>::State st = op.begin(i);
+            for_each_hash(src, key, i, k, [&](uint32_t j, uint64_t h) { op.apply(st, j, h); });
+            ok = st.ok;
+        }
+        const unsigned long long bal = __ballot(ok != 0);
+        if ((threadIdx.x & 63) == 0) {
+            out_bits[i >> 6] = bal;
+            my_hits += (unsigned long long)__popcll(bal);
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && my_hits) atomicAdd(hits, my_hits);
+}
+
+// ------------------------------------------------------------------ CMS ops
+// saturating signed add through CAS (only taken when the wrap-free bound does not hold)
+__device__ __forceinline__ void cms_sat_add(int32_t *p, int64_t w, unsigned long long *sat_ctr)
+{
+    int32_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        int64_t v = (int64_t)old + w;
+        bool sat = false;
+        if (v > INT32_MAX) { v = INT32_MAX; sat = true; }   // countminsketch.py:280-282
+        if (v < INT32_MIN) { v = INT32_MIN; sat = true; }   // countminsketch.py:314-316
+        if (__hip_atomic_compare_exchange_strong(p, &old, (int32_t)v, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)) {
+            if (sat) atomicAdd(sat_ctr, 1ULL);
+            return;
+        }
+    }
+}
+
+template <bool POW2, bool NEG>
+struct CmsAdd {  // countminsketch.py:267-288 add_alt / :300-321 remove_alt (NEG): bin = h%width + i*width
+    int32_t *bins;
+    Mod md;  // m = width
+    uint32_t k;  // depth
+    const int32_t *weights;  // nullptr -> 1
+    const long long *ctr;    // device counters; ctr[PSK_CTR_ABS_BOUND] chooses the path
+    unsigned long long *sat_ctr;
+    bool fast;
+    struct State { int32_t w; };
+    __device__ __forceinline__ void prepare() { fast = ctr[4] <= (long long)INT32_MAX; }
+    __device__ __forceinline__ State begin(uint64_t i) const
+    {
+        int32_t w = weights ? weights[i] : 1;
+        return State{w};
+    }
+    __device__ __forceinline__ void apply(State &st, uint32_t j, uint64_t h) const
+    {
+        const uint64_t bin = reduce<POW2>(md, h) + (uint64_t)j * md.m;
+        if (fast) {
+            // |bin| can never reach a rail: plain wrap-free atomic add, order-free, fire-and-forget
+            atomicAdd(bins + bin, NEG ? (int32_t)(0u - (uint32_t)st.w) : st.w);
+        } else {
+            cms_sat_add(bins + bin, NEG ? -(int64_t)st.w : (int64_t)st.w, sat_ctr);
+        }
+    }
+    __device__ __forceinline__ void end(State &, uint64_t) const {}
+};
+
+__device__ __forceinline__ void sort_small(int64_t *v, uint32_t n)
+{
+    for (uint32_t a = 1; a < n; ++a) {
+        const int64_t x = v[a];
+        uint32_t b = a;
+        while (b > 0 && v[b - 1] > x) { v[b] = v[b - 1]; --b; }
+        v[b] = x;
+    }
+}
+
+__device__ __forceinline__ int64_t floordiv(int64_t a, int64_t b)  // Python's //
+{
+    int64_t q = a / b;
+    const int64_t r = a % b;
+    if (r != 0 && ((r < 0) != (b < 0))) --q;
+    return q;
+}
+
+template <bool POW2>
+struct CmsCheck {  // countminsketch.py:332-340 check_alt with the min (:429-432) or mean (:434-436) query
+    const int32_t *bins;
+    Mod md;
+    uint32_t k;
+    int32_t *out;
+    bool mean;
+    struct State { int32_t mn; int64_t sum; };
+    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ State begin(uint64_t) const { return State{INT32_MAX, 0}; }
+    __device__ __forceinline__ void apply(State &st, uint32_t j, uint64_t h) const
+    {
+        const int32_t v = bins[reduce<POW2>(md, h) + (uint64_t)j * md.m];
+        st.mn = v < st.mn ? v : st.mn;
+        st.sum += v;
+    }
+    __device__ __forceinline__ void end(State &st, uint64_t i) const
+    {
+        out[i] = mean ? (int32_t)floordiv(st.sum, (int64_t)k) : st.mn;
+    }
+};
+
+constexpr int kMaxDepthMeanMin = 64;
+
+template <bool POW2>
+struct CmsCheckMeanMin {  // countminsketch.py:438-453 mean-min query
+    const int32_t *bins;
+    Mod md;
+    uint32_t k;
+    int64_t els_added;
+    int64_t *out;
+    struct State { int64_t v[kMaxDepthMeanMin]; };
+    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ State begin(uint64_t) const { return State{}; }
+    __device__ __forceinline__ void apply(State &st, uint32_t j, uint64_t h) const
+    {
+        st.v[j] = bins[reduce<POW2>(md, h) + (uint64_t)j * md.m];
+    }
+    __device__ __forceinline__ void end(State &st, uint64_t i) const
+    {
+        bool all_zero = true;
+        for (uint32_t j = 0; j < k; ++j) all_zero &= (st.v[j] == 0);
+        if (all_zero) { out[i] = 0; return; }  // :440-441 (sorted: first and last zero <=> all zero)
+        for (uint32_t j = 0; j < k; ++j) {
+            const int64_t diff = els_added - st.v[j];
+            st.v[j] = st.v[j] - floordiv(diff, (int64_t)md.m - 1);
+        }
+        sort_small(st.v, k);
+        out[i] = (k % 2 == 0) ? floordiv(st.v[k / 2] + st.v[k / 2 - 1], 2) : st.v[k / 2];
+    }
+};
+
+// ------------------------------------------------------------------ CBF ops
+__device__ __forceinline__ void cbf_sat_add(uint32_t *p, uint32_t w, unsigned long long *sat_ctr)
+{
+    uint32_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        uint64_t v = (uint64_t)old + w;
+        const bool sat = v > 0xFFFFFFFFULL;  // countingbloom.py:149-151
+        if (sat) v = 0xFFFFFFFFULL;
+        if (__hip_atomic_compare_exchange_strong(p, &old, (uint32_t)v, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)) {
+            if (sat) atomicAdd(sat_ctr, 1ULL);
+            return;
+        }
+    }
+}
+
+template <bool POW2>
+struct CbfAdd {  // countingbloom.py:135-155 add_alt (k independent increments; duplicates add twice)
+    uint32_t *tab;
+    Mod md;
+    uint32_t k;
+    const uint32_t *weights;
+    const long long *ctr;
+    unsigned long long *sat_ctr;
+    bool fast;
+    struct State { uint32_t w; };
+    __device__ __forceinline__ void prepare() { fast = ctr[4] <= 0xFFFFFFFFLL; }
+    __device__ __forceinline__ State begin(uint64_t i) const { return State{weights ? weights[i] : 1u}; }
+    __device__ __forceinline__ void apply(State &st, uint32_t, uint64_t h) const
+    {
+        uint32_t *p = tab + reduce<POW2>(md, h);
+        if (fast) atomicAdd(p, st.w);
+        else cbf_sat_add(p, st.w, sat_ctr);
+    }
+    __device__ __forceinline__ void end(State &, uint64_t) const {}
+};
+
+template <bool POW2>
+struct CbfCheck {  // countingbloom.py:166-174 check_alt: min over the hashes
+    const uint32_t *tab;
+    Mod md;
+    uint32_t k;
+    uint32_t *out;
+    struct State { uint32_t mn; };
+    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ State begin(uint64_t) const { return State{0xFFFFFFFFu}; }
+    __device__ __forceinline__ void apply(State &st, uint32_t, uint64_t h) const
+    {
+        const uint32_t v = tab[reduce<POW2>(md, h)];
+        st.mn = v < st.mn ? v : st.mn;
+    }
+    __device__ __forceinline__ void end(State &st, uint64_t i) const { out[i] = st.mn; }
+};
+
+constexpr int kMaxKOrdered = 64;  // ordered kernels keep the k indices of one key in registers
+
+// countingbloom.py:186-208 remove_alt, unordered batch form.
+// Phase A (gather): min over the k counters.  Phase B: conditional decrement of every index.
+// Well-formed streams (every removed key has >= num_els live inserts, nothing saturated) make
+// min_val >= num_els at every interleaving, so to_remove == num_els and the result is order-free.
+// Anything else is tallied in ctr[VIOLATIONS]; underflowing decrements are rolled back.
+template <class Src, bool POW2>
+__global__ __launch_bounds__(kBlock) void k_cbf_remove(Src src, uint32_t *tab, Mod md, uint32_t k,
+                                                       const uint32_t *weights, uint64_t n,
+                                                       unsigned long long *ctr)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    unsigned long long removed = 0, viol = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const typename Src::Key key = src.load(i);
+        const uint32_t w = weights ? weights[i] : 1u;
+        uint32_t mn = 0xFFFFFFFFu;
+        for_each_hash(src, key, i, k, [&](uint32_t, uint64_t h) {
+            const uint32_t v = __hip_atomic_load(tab + reduce<POW2>(md, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mn = v < mn ? v : mn;
+        });
+        if (mn == 0xFFFFFFFFu || mn == 0) continue;          // :198-201 frozen / absent: no-op
+        const uint32_t to_remove = mn > w ? w : mn;          // :203
+        if (to_remove != w) ++viol;                          // partial removal: order-dependent
+        for_each_hash(src, key, i, k, [&](uint32_t, uint64_t h) {
+            uint32_t *p = tab + reduce<POW2>(md, h);
+            const uint32_t old = atomicSub(p, to_remove);
+            if (old == 0xFFFFFFFFu || old < to_remove) {     // :205 frozen counter, or underflow
+                atomicAdd(p, to_remove);                     // roll back
+                ++viol;
+            }
+        });
+        removed += to_remove;                                // :207
+    }
+    // wavefront reduction, one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) {
+        removed += __shfl_down(removed, o);
+        viol += __shfl_down(viol, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (removed) atomicAdd(ctr + 1, removed);
+        if (viol) atomicAdd(ctr + 2, viol);
+    }
+}
+
+// ------------------------------------------------- ordered (sequential) execution on the device
+// One lane walks the batch in order and applies the reference semantics literally, including every
+// op's return value: exact for ANY stream (ill-formed removes, saturation, mixed signs).
+template <class Src, bool POW2>
+__global__ void k_cbf_ordered(Src src, uint32_t *tab, Mod md, uint32_t k, const int64_t *weights, int opmode,
+                              uint64_t n, uint32_t *out, unsigned long long *ctr)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    unsigned long long added = 0, removed = 0, sat = 0, abs_sum = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const typename Src::Key key = src.load(i);
+        int64_t w = weights ? weights[i] : 1;
+        bool rem = opmode == 1;
+        if (opmode == 2 && w < 0) { rem = true; w = -w; }
+        abs_sum += (unsigned long long)(w < 0 ? -w : w);
+        uint64_t idx[kMaxKOrdered];
+        for (uint32_t s = 0; s < k; ++s) {
+            uint64_t h[1];
+            src.template hash<1>(key, i, s, h);
+            idx[s] = reduce<POW2>(md, h[0]);
+        }
+        uint32_t ret;
+        if (!rem) {  // countingbloom.py:135-155
+            uint64_t mn = ~0ULL;
+            uint64_t vals[kMaxKOrdered];
+            for (uint32_t s = 0; s < k; ++s) vals[s] = (uint64_t)tab[idx[s]] + (uint64_t)w;  // :146 pre-read
+            for (uint32_t s = 0; s < k; ++s) {
+                if (vals[s] > 0xFFFFFFFFULL) { tab[idx[s]] = 0xFFFFFFFFu; vals[s] = 0xFFFFFFFFULL; ++sat; }
+                else tab[idx[s]] += (uint32_t)w;                                            // :153
+                mn = vals[s] < mn ? vals[s] : mn;
+            }
+            added += (uint64_t)w;
+            ret = (uint32_t)mn;
+        } else {  // countingbloom.py:186-208
+            uint32_t mn = 0xFFFFFFFFu;
+            for (uint32_t s = 0; s < k; ++s) mn = tab[idx[s]] < mn ? tab[idx[s]] : mn;
+            if (mn == 0xFFFFFFFFu) ret = 0xFFFFFFFFu;
+            else if (mn == 0) ret = 0;
+            else {
+                const uint32_t tr = (uint64_t)mn > (uint64_t)w ? (uint32_t)w : mn;
+                for (uint32_t s = 0; s < k; ++s)
+                    if (tab[idx[s]] < 0xFFFFFFFFu) tab[idx[s]] -= tr;
+                removed += tr;
+                ret = mn - tr;
+            }
+        }
+        if (out) out[i] = ret;
+    }
+    ctr[0] += added;
+    ctr[1] += removed;
+    ctr[3] += sat;
+    // every op moved a counter by at most k*|w|: keep the wrap-free bound an upper bound
+    const unsigned long long nb = ctr[4] + abs_sum * (unsigned long long)k;
+    ctr[4] = (nb < ctr[4] || nb > (1ULL << 62)) ? (1ULL << 62) : nb;
+}
+
+template <class Src, bool POW2>
+__global__ void k_cms_ordered(Src src, int32_t *bins, Mod md, uint32_t depth, const int64_t *weights, int opmode,
+                              int query, int64_t els, uint64_t n, int64_t *out, long long *ctr)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    unsigned long long sat = 0, abs_sum = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const typename Src::Key key = src.load(i);
+        int64_t w = weights ? weights[i] : 1;
+        bool rem = opmode == 1;
+        if (opmode == 2 && w < 0) { rem = true; w = -w; }
+        abs_sum += (unsigned long long)(w < 0 ? -w : w);
+        int64_t vals[kMaxDepthMeanMin];
+        for (uint32_t s = 0; s < depth; ++s) {
+            uint64_t h[1];
+            src.template hash<1>(key, i, s, h);
+            int32_t *p = bins + reduce<POW2>(md, h[0]) + (uint64_t)s * md.m;
+            int64_t v = (int64_t)*p + (rem ? -w : w);   // :276 / :309
+            if (v > INT32_MAX) { v = INT32_MAX; ++sat; }
+            if (v < INT32_MIN) { v = INT32_MIN; ++sat; }
+            *p = (int32_t)v;
+            vals[s] = v;
+        }
+        // countminsketch.py:285-287 / :317-319  exact add then clamp at the int64 rails
+        long long e2;
+        if (__builtin_saddll_overflow((long long)els, (long long)(rem ? -w : w), &e2))
+            e2 = (rem ? -w : w) > 0 ? INT64_MAX : INT64_MIN;
+        els = e2;
+        int64_t r;
+        sort_small(vals, depth);
+        if (query == 1) {  // mean :434-436
+            int64_t sum = 0;
+            for (uint32_t s = 0; s < depth; ++s) sum += vals[s];
+            r = floordiv(sum, (int64_t)depth);
+        } else if (query == 2) {  // mean-min :438-453
+            if (vals[0] == 0 && vals[depth - 1] == 0) r = 0;
+            else {
+                for (uint32_t s = 0; s < depth; ++s)
+                    vals[s] = vals[s] - floordiv(els - vals[s], (int64_t)md.m - 1);
+                sort_small(vals, depth);
+                r = (depth % 2 == 0) ? floordiv(vals[depth / 2] + vals[depth / 2 - 1], 2) : vals[depth / 2];
+            }
+        } else r = vals[0];
+        if (out) out[i] = r;
+    }
+    ctr[5] = els;
+    ctr[3] += (long long)sat;
+    const unsigned long long nb = (unsigned long long)ctr[4] + abs_sum;
+    ctr[4] = (nb < (unsigned long long)ctr[4] || nb > (1ULL << 62)) ? (1LL << 62) : (long long)nb;
+}
+
+// ------------------------------------------------------------- hash only
+struct StoreHashes {  // hashes.py:71-83: out[i][j] = fnv_1a(key_i, j)
+    uint64_t *out;
+    uint32_t k;
+    using State = Empty;
+    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ State begin(uint64_t) const { return {}; }
+    __device__ __forceinline__ void apply(State &, uint32_t, uint64_t) const {}
+    __device__ __forceinline__ void end(State &, uint64_t) const {}
+};
+
+template <class Src>
+__global__ __launch_bounds__(kBlock) void k_hash(Src src, uint64_t *out, uint32_t depth, uint64_t n)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const typename Src::Key key = src.load(i);
+        uint32_t s = 0;
+        for (; s + kGroup <= depth; s += kGroup) {
+            uint64_t h[kGroup];
+            src.template hash<kGroup>(key, i, s, h);
+#pragma unroll
+            for (int g = 0; g < kGroup; ++g) out[i * depth + s + g] = h[g];
+        }
+        for (; s < depth; ++s) {
+            uint64_t h[1];
+            src.template hash<1>(key, i, s, h);
+            out[i * depth + s] = h[0];
+        }
+    }
+}
+
+// --------------------------------------------------------- counter helpers
+// sum of a weight vector into the per-sketch device counters (selects fast/saturating path, feeds
+// elements_added).  which: 0 = ADDED, 1 = REMOVED, -1 = neither;  bound_mult: k for CBF, 1 for CMS.
+template <class W>
+__global__ __launch_bounds__(kBlock) void k_weight_sum(const W *w, uint64_t n, long long *ctr, int which,
+                                                       long long bound_mult)
+{
+    long long s = 0;
+    unsigned long long a = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const long long v = (long long)w[i];
+        s += v;
+        a += (unsigned long long)(v < 0 ? -v : v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o);
+        a += __shfl_down(a, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (which >= 0 && s) atomicAdd((unsigned long long *)(ctr + which), (unsigned long long)s);
+        if (a) {
+            // saturating bound: never wraps back below the threshold
+            unsigned long long add = a * (unsigned long long)bound_mult;
+            unsigned long long old = atomicAdd((unsigned long long *)(ctr + 4), add);
+            if (old + add < old || (long long)(old + add) < 0) atomicExch((unsigned long long *)(ctr + 4), 1ULL << 62);
+        }
+    }
+}
+
+__global__ void k_ctr_add(long long *ctr, int which, long long v, long long bound_add)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (which >= 0) ctr[which] += v;
+        long long b = ctr[4] + bound_add;
+        ctr[4] = (b < 0 || b > (1LL << 62)) ? (1LL << 62) : b;
+    }
+}
+
+// max |counter| of a freshly loaded table re-seeds the wrap-free bound
+__global__ __launch_bounds__(kBlock) void k_absmax(const uint32_t *tab, uint64_t n, int is_signed, long long *ctr)
+{
+    unsigned long long mx = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t v = tab[i];
+        unsigned long long a;
+        if (is_signed) { const long long sv = (long long)(int32_t)v; a = (unsigned long long)(sv < 0 ? -sv : sv); }
+        else a = v;
+        mx = a > mx ? a : mx;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_down(mx, o);
+        mx = t > mx ? t : mx;
+    }
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax((unsigned long long *)(ctr + 4), mx);
+}
+
+// -------------------------------------------------------- table algebra
+// All tables are padded to 16 B, so whole-table passes run on uint4 (global_load/store_dwordx4).
+struct OpOr  { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a | b; } };
+struct OpAnd { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a & b; } };
+
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_table_binop(uint4 *dst, const uint4 *src, uint64_t nvec, F f)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+        uint4 a = dst[i];
+        const uint4 b = src[i];
+        a.x = f(a.x, b.x); a.y = f(a.y, b.y); a.z = f(a.z, b.z); a.w = f(a.w, b.w);
+        dst[i] = a;
+    }
+}
+
+// dst[w] = OR_j src[j*slice + w]: the reduce step of allreduce(OR) (bloom.py:425-426 union is a bytewise OR)
+__global__ __launch_bounds__(kBlock) void k_or_reduce(uint4 *dst, const uint4 *src, uint32_t nslices,
+                                                      uint64_t slice_vec)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < slice_vec; i += stride) {
+        uint4 a = src[i];
+        for (uint32_t j = 1; j < nslices; ++j) {
+            const uint4 b = src[(uint64_t)j * slice_vec + i];
+            a.x |= b.x; a.y |= b.y; a.z |= b.z; a.w |= b.w;
+        }
+        dst[i] = a;
+    }
+}
+
+// mode 0: popcount of bits (bloom.py:552-557); mode 1: number of non-zero uint32 (countingbloom.py:302-304)
+__global__ __launch_bounds__(kBlock) void k_table_count(const uint4 *tab, uint64_t nvec, int mode,
+                                                        unsigned long long *out)
+{
+    unsigned long long c = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+        const uint4 a = tab[i];
+        if (mode == 0) c += __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w);
+        else c += (a.x != 0) + (a.y != 0) + (a.z != 0) + (a.w != 0);
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// countminsketch.py:380-391 join: clamp-add, bins already on a rail stay frozen
+__global__ __launch_bounds__(kBlock) void k_add_sat_i32(int32_t *dst, const int32_t *src, uint64_t n)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const int32_t a = dst[i];
+        if (a == INT32_MIN || a == INT32_MAX) continue;
+        int64_t t = (int64_t)a + (int64_t)src[i];
+        t = t > INT32_MAX ? INT32_MAX : (t < INT32_MIN ? INT32_MIN : t);
+        dst[i] = (int32_t)t;
+    }
+}
+
+// countingbloom.py:296-298 union: plain element-wise sum (the reference raises on uint32 overflow;
+// here overflowing elements are clamped and counted)
+__global__ __launch_bounds__(kBlock) void k_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n,
+                                                    unsigned long long *overflowed)
+{
+    unsigned long long ov = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t t = (uint64_t)dst[i] + (uint64_t)src[i];
+        if (t > 0xFFFFFFFFULL) { dst[i] = 0xFFFFFFFFu; ++ov; }
+        else dst[i] = (uint32_t)t;
+    }
+    for (int o = 32; o > 0; o >>= 1) ov += __shfl_down(ov, o);
+    if ((threadIdx.x & 63) == 0 && ov) atomicAdd(overflowed, ov);
+}
+
+// --------------------------------------------------- synthetic streams
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(kBlock) void k_gen_keys16(ulonglong2 *dst, uint64_t start, uint64_t n, uint64_t seed)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        const uint64_t i = start + j;
+        dst[j] = make_ulonglong2(splitmix64(seed + 2 * i), splitmix64(seed + 2 * i + 1));
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_gen_weights(int32_t *dst, uint64_t start, uint64_t n, uint64_t seed)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride)
+        dst[j] = (int32_t)(1 + splitmix64((seed ^ 0xC0FFEEULL) + start + j) % 7);
+}
+
+// GUPS-style random-access ceiling: the same access shape as the sketch kernels (one random 4-byte
+// atomic / load per probe, 7 independent probes in flight per lane) with the hashing stripped away.
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_gups(uint32_t *tab, uint64_t nwords, uint64_t n, uint64_t seed,
+                                                 unsigned long long *sink)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    uint32_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t r = splitmix64(seed + i);
+        const uint64_t idx = __umul64hi(r, nwords);  // uniform in [0, nwords)
+        if (OP == 0) atomicOr(tab + idx, 1u << (uint32_t)(r & 31));
+        else if (OP == 1) atomicAdd(tab + idx, 1u);
+        else acc += tab[idx];
+    }
+    if (OP == 2 && acc == 0x12345678u) atomicAdd(sink, 1ULL);
+}
+
+}  // namespace psk

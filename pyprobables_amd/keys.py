@@ -1,0 +1,134 @@
+"""Packing of key batches into the four layouts of the C ABI (include/psk.h ``psk_layout``).
+
+The reference hashes one python object at a time (``fnv_1a`` walks ``list(key)`` for bytes-likes and
+``map(ord, key)`` for str, hashes.py:98).  A batch is turned into ONE contiguous buffer:
+
+* equal-length byte keys            -> PSK_KEYS_FIXED    uint8[n][L]
+* ragged byte / latin-1 str keys    -> PSK_KEYS_VARLEN8  uint8 blob + uint64 offsets[n+1]
+* any str with a code point > 255   -> PSK_KEYS_VARLEN32 uint32 code points + offsets (never UTF-8:
+  the reference XORs the whole code point into the state)
+* ``(n, L)`` uint8 numpy arrays / torch tensors are taken as-is (torch CUDA tensors zero-copy).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _native as N
+
+try:  # torch is plumbing: device buffers + streams
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+@dataclass
+class KeyBatch:
+    layout: int
+    data: int            # address (host or device)
+    offsets: int         # address or 0
+    n: int
+    key_len: int
+    where: int           # N.HOST / N.DEVICE
+    device: int | None = None
+    keep: list = field(default_factory=list)  # keeps the buffers alive for the duration of the call
+
+    def args(self):
+        return (self.layout, self.data or None, self.offsets or None, self.n, self.key_len)
+
+
+def _np_ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+def _is_key(obj) -> bool:
+    return isinstance(obj, (str, bytes, bytearray, memoryview))
+
+
+def _code_points(key) -> np.ndarray:
+    if isinstance(key, str):
+        return np.frombuffer(key.encode("utf-32-le", "surrogatepass"), dtype=np.uint32)
+    return np.frombuffer(bytes(key), dtype=np.uint8).astype(np.uint32)
+
+
+def pack_keys(keys) -> KeyBatch:
+    """one key, a sequence of keys, a (n, L) uint8 array or a (n, L) uint8 torch tensor -> KeyBatch"""
+    if _is_key(keys):
+        keys = [keys]
+    if torch is not None and isinstance(keys, torch.Tensor):
+        if keys.dtype != torch.uint8 or keys.dim() != 2:
+            raise TypeError("tensor key batches must be uint8 of shape (n, key_len)")
+        if keys.is_cuda:
+            t = keys.contiguous()
+            return KeyBatch(N.KEYS_FIXED, t.data_ptr(), 0, t.shape[0], t.shape[1], N.DEVICE, t.device.index, [t])
+        keys = keys.numpy()
+    if isinstance(keys, np.ndarray):
+        a = keys
+        if a.dtype.kind == "S":  # fixed-width byte strings: raw buffer, trailing NULs included
+            a = np.ascontiguousarray(a).view(np.uint8).reshape(a.shape[0], a.dtype.itemsize)
+        if a.dtype != np.uint8 or a.ndim != 2:
+            raise TypeError("array key batches must be uint8 of shape (n, key_len) or dtype 'S<L>'")
+        a = np.ascontiguousarray(a)
+        return KeyBatch(N.KEYS_FIXED, _np_ptr(a) if a.size else 0, 0, a.shape[0], a.shape[1], N.HOST, None, [a])
+
+    keys = list(keys)
+    n = len(keys)
+    if n == 0:
+        return KeyBatch(N.KEYS_FIXED, 0, 0, 0, 0, N.HOST)
+    raw = []
+    wide = False
+    for k in keys:
+        if isinstance(k, str):
+            try:
+                raw.append(k.encode("latin-1"))  # code points <= 255 == byte values
+            except UnicodeEncodeError:
+                wide = True
+                break
+        elif isinstance(k, (bytes, bytearray, memoryview)):
+            raw.append(bytes(k))
+        else:
+            raise TypeError(f"keys must be str or bytes-like, got {type(k).__name__}")
+    if wide:
+        parts = [_code_points(k) for k in keys]
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum([p.size for p in parts], out=offs[1:])
+        blob = np.concatenate(parts) if offs[-1] else np.zeros(1, dtype=np.uint32)
+        blob = np.ascontiguousarray(blob, dtype=np.uint32)
+        return KeyBatch(N.KEYS_VARLEN32, _np_ptr(blob), _np_ptr(offs), n, 0, N.HOST, None, [blob, offs])
+    first = len(raw[0])
+    if all(len(r) == first for r in raw):
+        a = np.frombuffer(b"".join(raw), dtype=np.uint8).reshape(n, first) if first else np.zeros((n, 0), dtype=np.uint8)
+        return KeyBatch(N.KEYS_FIXED, _np_ptr(a) if a.size else 0, 0, n, first, N.HOST, None, [a])
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum([len(r) for r in raw], out=offs[1:])
+    blob = np.frombuffer(b"".join(raw), dtype=np.uint8)
+    return KeyBatch(N.KEYS_VARLEN8, _np_ptr(blob), _np_ptr(offs), n, 0, N.HOST, None, [blob, offs])
+
+
+def pack_hashes(hashes, need: int) -> KeyBatch:
+    """pre-computed hashes -> PSK_KEYS_HASHES.  Accepts one list of ints (a single key, add_alt style),
+    a sequence of such lists, a (n, h) uint64 array or a (n, h) torch tensor (int64/uint64 bits)."""
+    if torch is not None and isinstance(hashes, torch.Tensor):
+        if hashes.dim() != 2 or hashes.element_size() != 8:
+            raise TypeError("hash tensors must be 2-D with 8-byte elements")
+        if hashes.is_cuda:
+            t = hashes.contiguous()
+            if t.shape[1] < need:
+                raise ValueError(f"need at least {need} hashes per key, got {t.shape[1]}")
+            return KeyBatch(N.KEYS_HASHES, t.data_ptr(), 0, t.shape[0], t.shape[1], N.DEVICE, t.device.index, [t])
+        hashes = hashes.numpy().view(np.uint64)
+    if not isinstance(hashes, np.ndarray):
+        hashes = list(hashes)
+        if hashes and not isinstance(hashes[0], (list, tuple, np.ndarray)):
+            hashes = [hashes]
+        if len({len(h) for h in hashes}) > 1:
+            raise ValueError("all keys of a pre-hashed batch must carry the same number of hashes")
+        hashes = np.array([[int(x) & 0xFFFFFFFFFFFFFFFF for x in h] for h in hashes], dtype=np.uint64).reshape(len(hashes), -1)
+    a = np.ascontiguousarray(hashes, dtype=np.uint64)
+    if a.ndim != 2:
+        raise TypeError("hash batches must be 2-D (n, hashes_per_key)")
+    if a.shape[0] and a.shape[1] < need:
+        raise ValueError(f"need at least {need} hashes per key, got {a.shape[1]}")
+    return KeyBatch(N.KEYS_HASHES, _np_ptr(a) if a.size else 0, 0, a.shape[0], a.shape[1], N.HOST, None, [a])

@@ -1,0 +1,136 @@
+"""Host-side logic of the drop-in surface (CPU only): sizing, validation messages, the hash plugin
+helpers, key packing.  Expected values come from the real reference (tests/golden/golden.json) and
+from the reference's own tests (cited)."""
+
+import numpy as np
+import pytest
+
+import pyprobables_amd as pa
+from pyprobables_amd import _native as N
+from pyprobables_amd import hashes as H
+from pyprobables_amd.keys import pack_hashes, pack_keys
+
+from _util import as_key
+
+
+def test_sizing_matches_reference(golden):
+    for s in golden["sizing"]:
+        if "error" in s:
+            with pytest.raises(pa.InitializationError) as ei:
+                pa.BloomFilter._get_optimized_params(s["n"], s["p"])
+            assert str(ei.value) == s["error"] == ei.value.message
+        elif "raises" in s:  # (10, 0.0): math.log(0) -> ValueError in the reference too
+            with pytest.raises(ValueError):
+                pa.BloomFilter._get_optimized_params(s["n"], s["p"])
+        else:
+            assert pa.BloomFilter._get_optimized_params(s["n"], s["p"]) == (s["fpr"], s["k"], s["m"]), s
+    # BASELINE parameter sets: exact powers of two
+    assert pa.BloomFilter._get_optimized_params(28005615, 0.01)[1:] == (7, 2**28)
+    assert pa.BloomFilter._get_optimized_params(224044920, 0.01)[1:] == (7, 2**31)
+
+
+def test_constructor_validation_messages():
+    # reference tests/bloom_test.py:395-473, countminsketch_test.py init tests
+    for cls, msg in ((pa.BloomFilter, "Insufecient parameters to set up the Bloom Filter"),
+                     (pa.CountingBloomFilter, "Insufecient parameters to set up the Counting Bloom Filter")):
+        with pytest.raises(pa.InitializationError) as ei:
+            cls()
+        assert str(ei.value) == msg
+        with pytest.raises(pa.InitializationError):
+            cls(est_elements=10)
+        with pytest.raises(pa.InitializationError) as ei:
+            cls(est_elements=0, false_positive_rate=0.1)
+        assert str(ei.value) == "Bloom: estimated elements must be greater than 0"
+        with pytest.raises(pa.InitializationError) as ei:
+            cls(est_elements=10, false_positive_rate=1.5)
+        assert str(ei.value) == "Bloom: false positive rate must be between 0.0 and 1.0"
+        with pytest.raises(pa.InitializationError) as ei:
+            cls(est_elements=50, false_positive_rate=0.99)
+        assert str(ei.value) == "Bloom: Number hashes is zero; unusable parameters provided"
+        with pytest.raises(pa.InitializationError):  # invalid hex -> falls through to params (bloom_test.py:318-321)
+            cls(hex_string="85f240623b6d9459000000000000000a000000000000000a3d4ccccQ")
+    with pytest.raises(pa.InitializationError) as ei:
+        pa.CountMinSketch(width=0, depth=5)
+    assert str(ei.value) == "CountMinSketch: width and depth must be greater than 0"
+    with pytest.raises(pa.InitializationError):
+        pa.CountMinSketch(confidence=-1, error_rate=0.1)
+    with pytest.raises(pa.InitializationError) as ei:
+        pa.CountMinSketch()
+    assert str(ei.value).startswith("Must provide one of the following to initialize the Count-Min Sketch:")
+    assert issubclass(pa.InitializationError, pa.ProbablesBaseException)
+
+
+def test_host_hash_helpers_match_reference(golden):
+    for case in golden["hashes"]:
+        assert H.default_fnv_1a(as_key(case), case["depth"]) == case["hashes"]
+    for case in golden["fnv_1a_seeded"]:
+        assert H.fnv_1a(case["key"], case["seed"]) == case["hash"]
+    # reference tests/hashes_test.py:57-62, :64-146
+    assert H.fnv_1a_32("this is a test", 0) == 2139996864
+    assert H.fnv_1a_32("this is also a test", 0) == 1462718619
+    assert H.default_md5("this is a test", 5) == [
+        12174049463882854484, 10455450501617390806, 3838261292881602234, 12102952520950148619, 12126605867972429202]
+    assert H.default_sha256("this is a test", 5)[0] == 10244166640140130606
+    assert H.default_md5(b"this is a test", 5) == H.default_md5("this is a test", 5)
+
+    @H.hash_with_depth_int
+    def my_hash(key, depth=1, encoding="utf-8"):
+        import hashlib
+        return int(hashlib.sha512(key.encode(encoding)).hexdigest(), 16)
+
+    assert len(my_hash("this is a test", 5)) == 5
+    assert my_hash("this is a test", 3) == my_hash("this is a test", 5)[:3]
+
+
+def test_pack_keys_layouts():
+    b = pack_keys([b"abcd", b"efgh"])
+    assert (b.layout, b.n, b.key_len, b.where) == (N.KEYS_FIXED, 2, 4, N.HOST)
+    b = pack_keys("a single key")
+    assert (b.layout, b.n, b.key_len) == (N.KEYS_FIXED, 1, 12)
+    b = pack_keys([b"a", b"bcd", b""])
+    assert (b.layout, b.n) == (N.KEYS_VARLEN8, 3)
+    offs = b.keep[1]
+    assert offs.tolist() == [0, 1, 4, 4] and bytes(b.keep[0]) == b"abcd"
+    b = pack_keys(["caf\xe9", "na\xefve"])  # latin-1 range: one byte per code point (NOT utf-8)
+    assert b.layout == N.KEYS_VARLEN8 and bytes(b.keep[0]) == "caf\xe9na\xefve".encode("latin-1")
+    b = pack_keys(["€1", b"ab", "x"])  # a code point > 255 widens the whole batch
+    assert b.layout == N.KEYS_VARLEN32
+    assert b.keep[0].tolist() == [0x20AC, ord("1"), ord("a"), ord("b"), ord("x")] and b.keep[1].tolist() == [0, 2, 4, 5]
+    a = np.arange(48, dtype=np.uint8).reshape(3, 16)
+    b = pack_keys(a)
+    assert (b.layout, b.n, b.key_len) == (N.KEYS_FIXED, 3, 16)
+    b = pack_keys(np.array([b"abc", b"de"], dtype="S3"))
+    assert (b.n, b.key_len) == (2, 3) and bytes(b.keep[0]) == b"abcde\x00"
+    b = pack_keys([])
+    assert b.n == 0
+    with pytest.raises(TypeError):
+        pack_keys([1, 2, 3])
+    with pytest.raises(TypeError):
+        pack_keys(np.zeros((3, 4), dtype=np.int32))
+
+
+def test_pack_hashes():
+    b = pack_hashes([1, 2, 3, 2**64 - 1], 4)
+    assert (b.layout, b.n, b.key_len) == (N.KEYS_HASHES, 1, 4) and b.keep[0].tolist() == [[1, 2, 3, 2**64 - 1]]
+    b = pack_hashes([[1, 2], [3, 4], [5, 6]], 2)
+    assert (b.n, b.key_len) == (3, 2)
+    b = pack_hashes(np.arange(12, dtype=np.uint64).reshape(4, 3), 3)
+    assert (b.n, b.key_len) == (4, 3)
+    with pytest.raises(ValueError):
+        pack_hashes([1, 2], 4)
+    with pytest.raises(ValueError):
+        pack_hashes([[1, 2], [3]], 1)
+
+
+def test_public_surface_names():
+    for name in ("BloomFilter", "CountingBloomFilter", "CountMinSketch", "CountMeanSketch", "CountMeanMinSketch",
+                 "InitializationError", "NotSupportedError", "ProbablesBaseException", "SimilarityError"):
+        assert hasattr(pa, name)
+    for meth in ("add", "check", "add_alt", "check_alt", "hashes", "export", "export_hex", "frombytes", "union",
+                 "intersection", "jaccard_index", "estimate_elements", "clear", "add_many", "check_many"):
+        assert hasattr(pa.BloomFilter, meth)
+    for meth in ("add", "remove", "check", "add_alt", "remove_alt", "check_alt", "join", "export", "frombytes",
+                 "add_many", "remove_many", "check_many"):
+        assert hasattr(pa.CountMinSketch, meth)
+    for meth in ("remove", "remove_alt", "remove_many"):
+        assert hasattr(pa.CountingBloomFilter, meth)
