@@ -75,6 +75,10 @@ enum psk_counter {
 const char *psk_last_error(void);         /* thread-local text of the last failure */
 int psk_version(void);
 int psk_device_count(int *count);
+/* process-wide tunables: "partition" (0 = direct kernels only, 1 = auto), "partition_min_keys" (batches with
+ * at least this many keys take the partitioned path), "partition_max_keys" (keys per partition round) */
+int psk_set_option(const char *name, int64_t value);
+int psk_get_option(const char *name, int64_t *value);
 
 /* -------------------------------------------------------------- lifecycle
  * ext_table: NULL -> the library hipMallocs (and zeroes) the table;

@@ -33,6 +33,8 @@ PROTOTYPES = {
     "psk_last_error": (C.c_char_p, []),
     "psk_version": (_int, []),
     "psk_device_count": (_int, [C.POINTER(_int)]),
+    "psk_set_option": (_int, [C.c_char_p, _i64]),
+    "psk_get_option": (_int, [C.c_char_p, C.POINTER(_i64)]),
     "psk_bloom_table_bytes": (_u64, [_u64]),
     "psk_cbf_table_bytes": (_u64, [_u64]),
     "psk_cms_table_bytes": (_u64, [_u64, _u32]),
@@ -139,6 +141,16 @@ def check(rc: int) -> None:
     if rc == PSK_ENOMEM:
         raise MemoryError(msg)
     raise NativeLibraryError(f"psk error {rc}: {msg}")
+
+
+def set_option(name: str, value: int) -> None:
+    check(lib().psk_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = _i64(0)
+    check(lib().psk_get_option(name.encode(), C.byref(v)))
+    return v.value
 
 
 def device_count() -> int:

@@ -1,6 +1,7 @@
 // psk_capi.hip -- the extern "C" boundary (include/psk.h) over the gfx950 kernels in psk_device.hpp.
 // Host side: handle bookkeeping, host<->device staging for PSK_HOST buffers, launch geometry.
 #include "psk_device.hpp"
+#include "psk_partition.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -8,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #include "../../include/psk.h"
 
@@ -74,6 +76,7 @@ struct psk_sketch {
     uint64_t padded_bytes, logical_bytes;
     long long *ctr;    // device int64[PSK_CTR_COUNT]
     DevBuf s_keys, s_offs, s_w, s_out, s_aux;  // staging for PSK_HOST buffers
+    DevBuf s_part, s_cnt;                      // partitioned path: bucket buffer + per-bucket fill counts
 };
 
 static uint64_t round16(uint64_t b) { return (b + 15) & ~15ULL; }
@@ -184,7 +187,7 @@ extern "C" int psk_destroy(psk_sketch *s)
     hipSetDevice(s->device);
     if (s->owns_table && s->table) hipFree(s->table);
     if (s->ctr) hipFree(s->ctr);
-    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux})
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt})
         if (b->p) hipFree(b->p);
     delete s;
     return PSK_OK;
@@ -399,6 +402,161 @@ static int finish(int where, const OutBuf *o, hipStream_t st)
     return PSK_OK;
 }
 
+// ------------------------------------------------- partitioned (large-batch) path
+// Tunables (psk_set_option): the partitioned path is taken when the batch has at least
+// g_part_min_keys keys and the table geometry allows it; g_part_mode 0 = never, 1 = auto.
+static int64_t g_part_mode = 1;
+static int64_t g_part_min_keys = 1 << 17;
+static int64_t g_part_max_keys = 1 << 25;   // keys per partition round (bounds the bucket buffer)
+
+extern "C" int psk_set_option(const char *name, int64_t value)
+{
+    if (!name) return fail(PSK_EINVAL, "option name is NULL");
+    if (!strcmp(name, "partition")) g_part_mode = value;
+    else if (!strcmp(name, "partition_min_keys")) g_part_min_keys = value;
+    else if (!strcmp(name, "partition_max_keys")) g_part_max_keys = value < 1024 ? 1024 : value;
+    else return fail(PSK_EINVAL, "unknown option %s", name);
+    return PSK_OK;
+}
+
+extern "C" int psk_get_option(const char *name, int64_t *value)
+{
+    if (!name || !value) return fail(PSK_EINVAL, "NULL argument");
+    if (!strcmp(name, "partition")) *value = g_part_mode;
+    else if (!strcmp(name, "partition_min_keys")) *value = g_part_min_keys;
+    else if (!strcmp(name, "partition_max_keys")) *value = g_part_max_keys;
+    else return fail(PSK_EINVAL, "unknown option %s", name);
+    return PSK_OK;
+}
+
+// geometry of the slices for a table of `cells` cells, `max_shift` = log2(cells one LDS slice may hold)
+static bool part_geometry(uint64_t cells, uint32_t max_shift, uint32_t min_shift, uint32_t k, uint64_t n, PartGeom *g)
+{
+    if (cells > (1ULL << 32) || cells < (1ULL << 16)) return false;
+    uint32_t lg = 63 - __builtin_clzll(cells);        // floor(log2 cells)
+    int shift = (int)lg - 8;                          // aim at 256..511 slices: one per CU
+    if (shift > (int)max_shift) shift = max_shift;
+    if (shift < (int)min_shift) shift = min_shift;
+    const uint64_t B = (cells + (1ULL << shift) - 1) >> shift;
+    if (B > (uint64_t)kPartMaxBuckets) return false;
+    g->nbuckets = (uint32_t)B;
+    g->shift = (uint32_t)shift;
+    g->k = k;
+    const uint64_t mean = (n * (uint64_t)k + B - 1) / B;
+    uint64_t cap = mean + mean / 16 + 2048;           // ~ +6 % and +2048: > 8 sigma for uniform hashes
+    cap = (cap + 3) & ~3ULL;
+    if (cap > 0xFFFFFFF0ULL) return false;
+    g->cap = (uint32_t)cap;
+    return true;
+}
+
+template <class K>
+static int set_dyn_lds(K kernel, size_t bytes)
+{
+    HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PSK_OK;
+}
+
+// launch pass 1 for one concrete (Src, IdxFn, Pay, Spill, KT)
+template <class Src, class IdxFn, class Pay, class Spill, int KT>
+static int launch_scatter(const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, const PartGeom &g,
+                          uint64_t n, uint32_t *gcount, uint32_t *buckets, hipStream_t st)
+{
+    using Tile = PartTile<Src, IdxFn, Pay, Spill, KT>;
+    const uint64_t ntiles = (n + Tile::TILE - 1) / Tile::TILE;
+    const size_t stage_words = (size_t)Tile::TILE * (g.k < (uint32_t)KT ? g.k : KT) * (Pay::has ? 2 : 1);
+    const size_t lds = (3 * (size_t)g.nbuckets + 8 + stage_words) * 4;
+    auto kern = k_part_scatter<Src, IdxFn, Pay, Spill, KT>;
+    PSK_TRY(set_dyn_lds(kern, lds));
+    const uint64_t per_cu = lds > 72 * 1024 ? 1 : 2;
+    uint64_t grid = 256 * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kPartThreads), lds, st, src, idxfn, pay, spill, g, n, gcount, buckets);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
+// compile-time hash count: exact for the common small k on the 16-byte fast layout, rounded up otherwise
+template <class Src, class F>
+static int with_kt(uint32_t k, F &&f)
+{
+    constexpr bool fast = std::is_same<Src, KeysFixed16>::value;
+    if (fast) {
+        switch (k) {
+            case 4: return f(std::integral_constant<int, 4>{});
+            case 5: return f(std::integral_constant<int, 5>{});
+            case 7: return f(std::integral_constant<int, 7>{});
+            default: break;
+        }
+    }
+    if (k <= 8) return f(std::integral_constant<int, 8>{});
+    return f(std::integral_constant<int, 16>{});
+}
+
+// sources the partitioned path is instantiated for (the rest use the direct kernels)
+template <class F>
+static int with_part_source(const Batch &b, bool *handled, F &&f)
+{
+    *handled = true;
+    switch (b.layout) {
+        case PSK_KEYS_FIXED:
+            if (b.key_len == 16 && ((uintptr_t)b.data & 15) == 0) return f(KeysFixed16{(const uint4 *)b.data});
+            if (b.key_len % 4 == 0 && ((uintptr_t)b.data & 3) == 0) return f(KeysFixed<true>{(const uint8_t *)b.data, b.key_len});
+            break;
+        case PSK_KEYS_VARLEN8: return f(KeysVarlen<uint8_t>{(const uint8_t *)b.data, b.offs});
+        case PSK_KEYS_HASHES: return f(KeysHashes{(const uint64_t *)b.data, b.key_len});
+        default: break;
+    }
+    *handled = false;
+    return PSK_OK;
+}
+
+static bool part_wanted(const psk_sketch *s, uint64_t n, uint32_t k)
+{
+    return g_part_mode != 0 && (int64_t)n >= g_part_min_keys && k <= 16 && n < (1ULL << 32);
+}
+
+// Bloom insert through the partitioned path; *done = false when this batch/table is not eligible
+static int bloom_add_partitioned(psk_sketch *s, const Batch &b, hipStream_t st, bool *done)
+{
+    *done = false;
+    if (!part_wanted(s, b.n, s->k)) return PSK_OK;
+    PartGeom g;
+    const uint64_t round_keys = (uint64_t)g_part_max_keys < b.n ? (uint64_t)g_part_max_keys : b.n;
+    if (!part_geometry(s->m, 20, 7, s->k, round_keys, &g)) return PSK_OK;
+    bool handled = false;
+    PSK_TRY(ensure(s->s_part, (uint64_t)g.nbuckets * g.cap * 4 + 256));
+    PSK_TRY(ensure(s->s_cnt, (uint64_t)g.nbuckets * 4));
+    for (uint64_t start = 0; start < b.n; start += round_keys) {
+        const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
+        Batch sub = b;
+        sub.n = cnt;
+        if (b.layout == PSK_KEYS_VARLEN8) sub.offs = b.offs + start;
+        else sub.data = (const uint8_t *)b.data + start * (uint64_t)b.key_len * (b.layout == PSK_KEYS_HASHES ? 8 : 1);
+        HIP_TRY(hipMemsetAsync(s->s_cnt.p, 0, (uint64_t)g.nbuckets * 4, st));
+        PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
+            using Src = decltype(src);
+            return with_kt<Src>(s->k, [&](auto kt) {
+                constexpr int KT = decltype(kt)::value;
+                SpillBloomOr spill{(uint32_t *)s->table};
+                if (s->pow2)
+                    return launch_scatter<Src, IdxBloom<true>, PayNone, SpillBloomOr, KT>(
+                        src, IdxBloom<true>{s->md}, PayNone{}, spill, g, cnt, (uint32_t *)s->s_cnt.p, (uint32_t *)s->s_part.p, st);
+                return launch_scatter<Src, IdxBloom<false>, PayNone, SpillBloomOr, KT>(
+                    src, IdxBloom<false>{s->md}, PayNone{}, spill, g, cnt, (uint32_t *)s->s_cnt.p, (uint32_t *)s->s_part.p, st);
+            });
+        }));
+        if (!handled) return PSK_OK;  // nothing was launched
+        const size_t lds = (size_t)1 << (g.shift - 3);
+        PSK_TRY(set_dyn_lds(k_bloom_apply, lds));
+        hipLaunchKernelGGL(k_bloom_apply, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table,
+                           s->padded_bytes / 4, g, (const uint32_t *)s->s_cnt.p, (const uint32_t *)s->s_part.p);
+        HIP_TRY(hipGetLastError());
+    }
+    *done = true;
+    return PSK_OK;
+}
+
 // ------------------------------------------------------------- BloomFilter
 extern "C" int psk_bloom_add(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
                              uint32_t key_len, int where, void *stream)
@@ -408,6 +566,9 @@ extern "C" int psk_bloom_add(psk_sketch *s, int layout, const void *data, const 
     hipStream_t st = (hipStream_t)stream;
     Batch b;
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+    bool done = false;
+    PSK_TRY(bloom_add_partitioned(s, b, st, &done));
+    if (done) return finish(where, nullptr, st);
     PSK_TRY(with_source(b, [&](auto src) {
         if (s->pow2) return launch_apply(src, BloomAdd<true>{(uint32_t *)s->table, s->md, s->k}, n, st);
         return launch_apply(src, BloomAdd<false>{(uint32_t *)s->table, s->md, s->k}, n, st);

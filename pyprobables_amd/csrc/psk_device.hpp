@@ -115,7 +115,7 @@ struct KeysHashes {  // uint64[n][stride] pre-computed hashes (add_alt / check_a
     __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
     {
 #pragma unroll
-        for (int g = 0; g < G; ++g) h[g] = k.q[s0 + g];
+        for (int g = 0; g < G; ++g) h[g] = (s0 + g < stride) ? k.q[s0 + g] : 0;  // callers may round G up past k
     }
 };
 

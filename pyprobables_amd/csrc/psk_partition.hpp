@@ -1,0 +1,370 @@
+// psk_partition.hpp -- the large-batch path: radix-partition the probes by table slice, then apply
+// each slice inside LDS.
+//
+// Why: the direct kernels issue one device-scope atomic (a 32 B fabric write, ~27 G/s chip-wide) or
+// one 64 B line fetch per 4-byte probe; rocprof shows 3-9x the algorithmic bytes crossing the fabric
+// and the kernels pinned to that transaction ceiling.  Here the table is cut into slices that fit
+// one CU's LDS (<= 128 KiB of the 160 KiB):
+//   pass 1  k_part_scatter : hash the keys, bin every probe by slice (LDS histogram + LDS counting
+//                            sort per tile of 2048 keys), write each bin as a coalesced run into
+//                            that slice's bucket in HBM (4 B / probe, +4 B payload when needed);
+//   pass 2  k_*_apply      : one workgroup per slice keeps the slice in LDS, streams its bucket in
+//                            (coalesced dwordx4), does the random bit/counter updates with LDS
+//                            atomics (ds_or / ds_add), and merges the slice back with one coalesced
+//                            read-modify-write.  No global atomics on the table, no random HBM access.
+// Bucket overflow (adversarial / duplicate-heavy batches) falls back to a direct atomic on the
+// table, so the result is always exact.
+#pragma once
+#include "psk_device.hpp"
+
+namespace psk {
+
+constexpr int kPartThreads = 512;      // 8 wavefronts per workgroup
+constexpr int kPartProbes = 32;        // probes held in registers per thread (= keys/thread * KT); 16 with payload
+constexpr int kPartMaxBuckets = 2048;
+constexpr int kPartScanPerThread = kPartMaxBuckets / kPartThreads;  // 4
+
+struct PartGeom {
+    uint32_t nbuckets;      // B = ceil(cells / 2^shift)
+    uint32_t shift;         // log2(cells per slice)
+    uint32_t cap;           // slots per bucket in the HBM bucket buffer (multiple of 4)
+    uint32_t k;             // hashes per key
+};
+
+// idx functors: which table cell does hash j of a key address?
+template <bool POW2>
+struct IdxBloom {  // bloom.py:247 / countingbloom.py:145:  h % m
+    Mod md;
+    __device__ __forceinline__ uint32_t operator()(uint32_t, uint64_t h) const { return (uint32_t)reduce<POW2>(md, h); }
+};
+template <bool POW2>
+struct IdxCms {  // countminsketch.py:275:  (h % width) + i*width
+    Mod md;
+    __device__ __forceinline__ uint32_t operator()(uint32_t j, uint64_t h) const
+    {
+        return (uint32_t)(reduce<POW2>(md, h) + (uint64_t)j * md.m);
+    }
+};
+
+// payload functors (second word of a probe)
+struct PayNone { static constexpr bool has = false; __device__ __forceinline__ uint32_t operator()(uint64_t) const { return 0; } };
+struct PayKeyId { static constexpr bool has = true; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return (uint32_t)i; } };
+struct PayWeight {
+    static constexpr bool has = true;
+    const uint32_t *w;  // int32 / uint32 bit patterns; never null here
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return w[i]; }
+};
+
+// fallback for a probe that did not fit its bucket: apply it straight to the table
+struct SpillBloomOr {
+    uint32_t *tab;
+    __device__ __forceinline__ void operator()(uint32_t idx, uint32_t) const { atomicOr(tab + (idx >> 5), 1u << (idx & 31)); }
+};
+struct SpillAddU32 {  // wrap-free counter add (CMS fast path / CBF fast path / unit weights)
+    uint32_t *tab;
+    bool unit;
+    __device__ __forceinline__ void operator()(uint32_t idx, uint32_t w) const { atomicAdd(tab + idx, unit ? 1u : w); }
+};
+struct SpillBloomTest {  // lookup probe that did not fit its bucket: test it directly (bloom.py:269-271)
+    const uint32_t *tab;
+    uint8_t *out;
+    __device__ __forceinline__ void operator()(uint32_t idx, uint32_t key) const
+    {
+        if (((tab[idx >> 5] >> (idx & 31)) & 1u) == 0) out[key] = 0;
+    }
+};
+
+// block-wide exclusive scan of one uint32 per thread (512 threads = 8 waves)
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot /*LDS[8]*/, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wave_tot[wid] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kPartThreads / 64; ++w) {
+        const uint32_t t = wave_tot[w];
+        if (w < wid) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------------ pass 1
+// KT = hashes computed per key (>= k, compile time so the probes stay in registers).
+// dynamic LDS: hist[B] | off[B] | delta[B] | wave_tot[8] | stage[tile_probes * (1 + has_payload)]
+template <class Src, class IdxFn, class Pay, class Spill, int KT>
+struct PartTile {
+    static constexpr int PP = Pay::has ? kPartProbes / 2 : kPartProbes;  // stage <= 64 KiB either way
+    static constexpr int KPT = PP / KT >= 1 ? PP / KT : 1;               // keys per thread per tile
+    static constexpr int TILE = kPartThreads * KPT;                      // keys per tile
+};
+
+template <class Src, class IdxFn, class Pay, class Spill, int KT>
+__global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn idxfn, Pay pay, Spill spill, PartGeom g,
+                                                               uint64_t n, uint32_t *gcount, uint32_t *buckets)
+{
+    constexpr int KPT = PartTile<Src, IdxFn, Pay, Spill, KT>::KPT;
+    constexpr int TILE = PartTile<Src, IdxFn, Pay, Spill, KT>::TILE;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t B = g.nbuckets;
+    uint32_t *hist = smem;
+    uint32_t *off = hist + B;
+    uint32_t *delta = off + B;
+    uint32_t *wave_tot = delta + B;
+    uint32_t *stage = wave_tot + 8;
+    const uint32_t k = g.k;
+    const uint64_t ntiles = (n + TILE - 1) / TILE;
+
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) hist[b] = 0;
+        __syncthreads();
+
+        // ---- hash + histogram: rank = my position among this tile's probes of the same bucket
+        uint32_t idx[KPT][KT], rank[KPT][KT], payload[KPT];
+        const uint64_t base = tile * TILE;
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) {
+            const uint64_t i = base + (uint64_t)q * kPartThreads + threadIdx.x;  // coalesced key loads
+            if (i < n) {
+                const typename Src::Key key = src.load(i);
+                uint64_t h[KT];
+                src.template hash<KT>(key, i, 0, h);
+                if (Pay::has) payload[q] = pay(i);
+#pragma unroll
+                for (int j = 0; j < KT; ++j) {
+                    if ((uint32_t)j < k) {
+                        idx[q][j] = idxfn((uint32_t)j, h[j]);
+                        rank[q][j] = atomicAdd(&hist[idx[q][j] >> g.shift], 1u);  // ds_add_rtn_u32
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- exclusive scan of the histogram + one global reservation per non-empty bucket
+        uint32_t mine[kPartScanPerThread], s = 0;
+#pragma unroll
+        for (int c = 0; c < kPartScanPerThread; ++c) {
+            const uint32_t b = threadIdx.x * kPartScanPerThread + c;
+            mine[c] = b < B ? hist[b] : 0;
+            s += mine[c];
+        }
+        uint32_t tile_probes;
+        uint32_t run = block_exclusive_scan(s, wave_tot, &tile_probes);
+#pragma unroll
+        for (int c = 0; c < kPartScanPerThread; ++c) {
+            const uint32_t b = threadIdx.x * kPartScanPerThread + c;
+            if (b < B) {
+                off[b] = run;
+                uint32_t gb = 0;
+                if (mine[c]) gb = atomicAdd(gcount + b, mine[c]);  // device-scope, returning
+                delta[b] = gb - run;                               // global slot = delta[b] + stage position
+                run += mine[c];
+            }
+        }
+        __syncthreads();
+
+        // ---- counting-sort the probes into the LDS stage
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) {
+            const uint64_t i = base + (uint64_t)q * kPartThreads + threadIdx.x;
+            if (i < n) {
+#pragma unroll
+                for (int j = 0; j < KT; ++j) {
+                    if ((uint32_t)j < k) {
+                        const uint32_t p = off[idx[q][j] >> g.shift] + rank[q][j];
+                        if (Pay::has) {
+                            stage[2 * p] = idx[q][j];
+                            stage[2 * p + 1] = payload[q];
+                        } else {
+                            stage[p] = idx[q][j];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- write out: consecutive lanes -> consecutive stage slots -> runs of consecutive bucket slots
+        for (uint32_t p = threadIdx.x; p < tile_probes; p += kPartThreads) {
+            uint32_t w0, w1 = 0;
+            if (Pay::has) {
+                const uint2 v = reinterpret_cast<const uint2 *>(stage)[p];
+                w0 = v.x;
+                w1 = v.y;
+            } else {
+                w0 = stage[p];
+            }
+            const uint32_t b = w0 >> g.shift;
+            const uint32_t slot = delta[b] + p;
+            if (slot < g.cap) {
+                if (Pay::has) reinterpret_cast<uint2 *>(buckets)[(uint64_t)b * g.cap + slot] = make_uint2(w0, w1);
+                else buckets[(uint64_t)b * g.cap + slot] = w0;
+            } else {
+                spill(w0, w1);  // bucket full: exact fallback
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------ pass 2
+constexpr int kApplyThreads = 1024;
+
+// Bloom insert: OR the bucket's bits into an LDS image of the slice, then OR the image into the table.
+// dynamic LDS: slice image, 2^shift bits
+__global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *tab, uint64_t tab_words, PartGeom g,
+                                                               const uint32_t *gcount, const uint32_t *buckets)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t b = blockIdx.x;
+    const uint32_t slice_words = 1u << (g.shift - 5);
+    const uint32_t mask = (1u << g.shift) - 1;
+    for (uint32_t w = threadIdx.x; w < slice_words; w += kApplyThreads) smem[w] = 0;
+    __syncthreads();
+    uint32_t cnt = gcount[b];
+    cnt = cnt < g.cap ? cnt : g.cap;
+    const uint32_t *src = buckets + (uint64_t)b * g.cap;
+    const uint32_t nvec = cnt >> 2;
+    for (uint32_t v = threadIdx.x; v < nvec; v += kApplyThreads) {
+        const uint4 q = reinterpret_cast<const uint4 *>(src)[v];
+        atomicOr(&smem[(q.x & mask) >> 5], 1u << (q.x & 31));  // ds_or_b32
+        atomicOr(&smem[(q.y & mask) >> 5], 1u << (q.y & 31));
+        atomicOr(&smem[(q.z & mask) >> 5], 1u << (q.z & 31));
+        atomicOr(&smem[(q.w & mask) >> 5], 1u << (q.w & 31));
+    }
+    for (uint32_t p = (nvec << 2) + threadIdx.x; p < cnt; p += kApplyThreads) {
+        const uint32_t x = src[p];
+        atomicOr(&smem[(x & mask) >> 5], 1u << (x & 31));
+    }
+    __syncthreads();
+    // merge: this workgroup is the only writer of its slice
+    const uint64_t w0 = (uint64_t)b * slice_words;
+    for (uint32_t w = threadIdx.x * 4; w < slice_words; w += kApplyThreads * 4) {
+        const uint64_t gw = w0 + w;
+        if (gw + 3 < tab_words) {
+            const uint4 add = *reinterpret_cast<const uint4 *>(smem + w);
+            if (add.x | add.y | add.z | add.w) {
+                uint4 t = *reinterpret_cast<uint4 *>(tab + gw);
+                t.x |= add.x; t.y |= add.y; t.z |= add.z; t.w |= add.w;
+                *reinterpret_cast<uint4 *>(tab + gw) = t;
+            }
+        } else {
+            for (uint32_t e = 0; e < 4; ++e)
+                if (gw + e < tab_words && smem[w + e]) tab[gw + e] |= smem[w + e];
+        }
+    }
+}
+
+// Bloom lookup: the slice is loaded into LDS; a probe whose bit is clear zeroes its key's result byte
+// (out[] is pre-set to 1; every writer stores the same 0, so plain stores suffice).
+__global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint32_t *tab, uint64_t tab_words, PartGeom g,
+                                                              const uint32_t *gcount, const uint32_t *buckets, uint8_t *out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t b = blockIdx.x;
+    const uint32_t slice_words = 1u << (g.shift - 5);
+    const uint32_t mask = (1u << g.shift) - 1;
+    const uint64_t w0 = (uint64_t)b * slice_words;
+    for (uint32_t w = threadIdx.x * 4; w < slice_words; w += kApplyThreads * 4) {
+        const uint64_t gw = w0 + w;
+        uint4 t = make_uint4(0, 0, 0, 0);
+        if (gw + 3 < tab_words) t = *reinterpret_cast<const uint4 *>(tab + gw);
+        else {
+            if (gw + 0 < tab_words) t.x = tab[gw + 0];
+            if (gw + 1 < tab_words) t.y = tab[gw + 1];
+            if (gw + 2 < tab_words) t.z = tab[gw + 2];
+        }
+        *reinterpret_cast<uint4 *>(smem + w) = t;
+    }
+    __syncthreads();
+    uint32_t cnt = gcount[b];
+    cnt = cnt < g.cap ? cnt : g.cap;
+    const uint2 *src = reinterpret_cast<const uint2 *>(buckets) + (uint64_t)b * g.cap;
+    const uint32_t nvec = cnt >> 1;
+    for (uint32_t v = threadIdx.x; v < nvec; v += kApplyThreads) {
+        const uint4 q = reinterpret_cast<const uint4 *>(src)[v];  // two (idx, key) probes
+        if (((smem[(q.x & mask) >> 5] >> (q.x & 31)) & 1u) == 0) out[q.y] = 0;
+        if (((smem[(q.z & mask) >> 5] >> (q.z & 31)) & 1u) == 0) out[q.w] = 0;
+    }
+    if ((cnt & 1) && threadIdx.x == 0) {
+        const uint2 q = src[cnt - 1];
+        if (((smem[(q.x & mask) >> 5] >> (q.x & 31)) & 1u) == 0) out[q.y] = 0;
+    }
+}
+
+// Counter add (CMS / CBF fast path): accumulate the bucket's weights into an LDS image of the slice with
+// ds_add, then fold the image into the table with the reference's saturating add.
+// SIGNED: int32 bins clamped at both rails (countminsketch.py:280-284 / :312-316);
+// else uint32 counters clamped at 2^32-1 (countingbloom.py:149-153).
+// Exact for any order as long as the per-slice partial sums do not wrap 32 bits -- the caller
+// guarantees sum|w| of the batch < 2^31.
+template <bool SIGNED, bool WEIGHTED, bool NEG>
+__global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, uint64_t tab_cells, PartGeom g,
+                                                                 const uint32_t *gcount, const uint32_t *buckets,
+                                                                 unsigned long long *sat_ctr)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t b = blockIdx.x;
+    const uint32_t slice_cells = 1u << g.shift;
+    const uint32_t mask = slice_cells - 1;
+    for (uint32_t w = threadIdx.x; w < slice_cells; w += kApplyThreads) smem[w] = 0;
+    __syncthreads();
+    uint32_t cnt = gcount[b];
+    cnt = cnt < g.cap ? cnt : g.cap;
+    if (WEIGHTED) {
+        const uint2 *src = reinterpret_cast<const uint2 *>(buckets) + (uint64_t)b * g.cap;
+        const uint32_t nvec = cnt >> 1;
+        for (uint32_t v = threadIdx.x; v < nvec; v += kApplyThreads) {
+            const uint4 q = reinterpret_cast<const uint4 *>(src)[v];
+            atomicAdd(&smem[q.x & mask], NEG ? 0u - q.y : q.y);  // ds_add_u32 (two's complement for int32)
+            atomicAdd(&smem[q.z & mask], NEG ? 0u - q.w : q.w);
+        }
+        if ((cnt & 1) && threadIdx.x == 0) {
+            const uint2 q = src[cnt - 1];
+            atomicAdd(&smem[q.x & mask], NEG ? 0u - q.y : q.y);
+        }
+    } else {
+        const uint32_t *src = buckets + (uint64_t)b * g.cap;
+        const uint32_t nvec = cnt >> 2;
+        const uint32_t one = NEG ? 0xFFFFFFFFu : 1u;
+        for (uint32_t v = threadIdx.x; v < nvec; v += kApplyThreads) {
+            const uint4 q = reinterpret_cast<const uint4 *>(src)[v];
+            atomicAdd(&smem[q.x & mask], one);
+            atomicAdd(&smem[q.y & mask], one);
+            atomicAdd(&smem[q.z & mask], one);
+            atomicAdd(&smem[q.w & mask], one);
+        }
+        for (uint32_t p = (nvec << 2) + threadIdx.x; p < cnt; p += kApplyThreads) atomicAdd(&smem[src[p] & mask], one);
+    }
+    __syncthreads();
+    const uint64_t c0 = (uint64_t)b * slice_cells;
+    unsigned long long sat = 0;
+    for (uint32_t w = threadIdx.x; w < slice_cells; w += kApplyThreads) {
+        const uint64_t gc = c0 + w;
+        const uint32_t d = smem[w];
+        if (gc < tab_cells && d) {
+            if (SIGNED) {
+                int64_t v = (int64_t)(int32_t)tab[gc] + (int64_t)(int32_t)d;
+                if (v > INT32_MAX) { v = INT32_MAX; ++sat; }
+                if (v < INT32_MIN) { v = INT32_MIN; ++sat; }
+                tab[gc] = (uint32_t)(int32_t)v;
+            } else {
+                uint64_t v = (uint64_t)tab[gc] + (uint64_t)d;
+                if (v > 0xFFFFFFFFULL) { v = 0xFFFFFFFFULL; ++sat; }
+                tab[gc] = (uint32_t)v;
+            }
+        }
+    }
+    if (sat) atomicAdd(sat_ctr, sat);
+}
+
+}  // namespace psk

@@ -1,0 +1,131 @@
+"""GPU parity of the partitioned (large-batch) path: radix-bin probes by table slice, apply in LDS.
+The path is forced on for small batches here (partition_min_keys = 1) and compared bit-for-bit with
+the oracle and the golden fixtures; the direct path is the cross-check."""
+
+import numpy as np
+import pytest
+
+from _util import sha, unpackbits
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def pa():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import pyprobables_amd
+
+    return pyprobables_amd
+
+
+@pytest.fixture()
+def force_partition():
+    from pyprobables_amd import _native as N
+
+    old = (N.get_option("partition"), N.get_option("partition_min_keys"), N.get_option("partition_max_keys"))
+    N.set_option("partition", 1)
+    N.set_option("partition_min_keys", 1)
+    yield N
+    N.set_option("partition", old[0])
+    N.set_option("partition_min_keys", old[1])
+    N.set_option("partition_max_keys", old[2])
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _table(f, dtype=np.uint8):
+    return np.frombuffer(bytes(f.bloom), dtype=dtype)
+
+
+def test_bloom_partitioned_golden_np2(pa, golden, oracle, force_partition):
+    g = golden["bloom_np2"]  # m = 958506: non power of two, partial last slice
+    blm = pa.BloomFilter(est_elements=g["est_elements"], false_positive_rate=g["fpr"])
+    blm.add_many(_dev(oracle.gen_keys16(0, g["n_keys"])))
+    assert sha(bytes(blm.bloom)) == g["sha256_table"]
+    assert blm._cnt_number_bits_set() == g["bits_set"]
+    lo, hi = g["check_range"]
+    res = blm.check_many(_dev(oracle.gen_keys16(lo, hi - lo))).cpu().numpy().astype(np.uint8)
+    assert np.array_equal(res, unpackbits(g["membership_bits"], hi - lo))
+
+
+@pytest.mark.parametrize("est,fpr,n", [
+    (28005615, 0.01, 1_000_000),   # headline geometry: m = 2^28, k = 7, 256 slices of 128 KiB
+    (5_000_000, 0.05, 300_000),    # k = 4
+    (2_000_000, 0.001, 200_000),   # k = 10 -> 16 hash chains per key
+    (300_000, 0.03, 150_000),      # k = 5, m ~ 2.2 Mbit: small slices
+    (1000, 0.001, 5000),           # m < 2^16: not eligible, must fall through to the direct kernels
+])
+def test_bloom_partitioned_vs_oracle(pa, oracle, force_partition, est, fpr, n):
+    keys = oracle.gen_keys16(11, n)
+    blm = pa.BloomFilter(est_elements=est, false_positive_rate=fpr)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    half = n // 2
+    blm.add_many(_dev(keys[:half]))
+    blm.add_many(_dev(keys[:half // 3]))  # second batch ORs into a non-empty table
+    ob.add_keys(keys[:half])
+    assert np.array_equal(_table(blm), ob.bloom)
+    assert blm.elements_added == half + half // 3
+    assert np.array_equal(blm.check_many(_dev(keys)).cpu().numpy().astype(np.uint8), ob.check_keys(keys))
+
+
+def test_bloom_partitioned_layouts_vs_oracle(pa, oracle, force_partition):
+    rng = np.random.default_rng(5)
+    blm_args = dict(est_elements=400_000, false_positive_rate=0.01)
+    # 12-byte keys (dword source), ragged byte keys, pre-hashed keys, host-staged 16-byte keys
+    k12 = rng.integers(0, 256, size=(60_000, 12), dtype=np.uint8)
+    blm = pa.BloomFilter(**blm_args)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    blm.add_many(_dev(k12))
+    ob.add_keys(k12)
+    assert np.array_equal(_table(blm), ob.bloom)
+    ragged = [bytes(rng.integers(0, 256, size=int(l), dtype=np.uint8)) for l in rng.integers(0, 40, size=30_000)]
+    blm.add_many(ragged)
+    ob.add_varlen(ragged)
+    assert np.array_equal(_table(blm), ob.bloom)
+    hs = rng.integers(0, 2**63, size=(50_000, 7), dtype=np.uint64) * 2 + 1
+    blm.add_alt_many(hs)
+    ob.add_hashes(hs)
+    assert np.array_equal(_table(blm), ob.bloom)
+    k16 = oracle.gen_keys16(0, 70_000)
+    blm.add_many(k16)  # host buffer -> staged
+    ob.add_keys(k16)
+    assert np.array_equal(_table(blm), ob.bloom)
+    assert np.array_equal(blm.check_many(k16).astype(np.uint8), ob.check_keys(k16))
+
+
+def test_bloom_partitioned_bucket_overflow_is_exact(pa, oracle, force_partition):
+    # every key identical: all probes land in <= k slices, far beyond the bucket capacity -> spill path
+    key = oracle.gen_keys16(3, 1)
+    keys = np.repeat(key, 200_000, axis=0)
+    keys[::1000] = oracle.gen_keys16(100, 200)  # a few distinct ones in between
+    blm = pa.BloomFilter(est_elements=2_000_000, false_positive_rate=0.01)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    blm.add_many(_dev(keys))
+    ob.add_keys(keys)
+    assert np.array_equal(_table(blm), ob.bloom)
+
+
+def test_bloom_partitioned_rounds(pa, oracle, force_partition):
+    force_partition.set_option("partition_max_keys", 4096)  # many partition rounds per batch
+    keys = oracle.gen_keys16(0, 50_001)
+    blm = pa.BloomFilter(est_elements=500_000, false_positive_rate=0.01)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    blm.add_many(_dev(keys))
+    ob.add_keys(keys)
+    assert np.array_equal(_table(blm), ob.bloom)
+
+
+def test_partitioned_equals_direct(pa, oracle, force_partition):
+    keys = _dev(oracle.gen_keys16(0, 400_000))
+    a = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    a.add_many(keys)
+    force_partition.set_option("partition", 0)
+    b = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    b.add_many(keys)
+    assert torch.equal(a.table_tensor, b.table_tensor)
+    assert a._cnt_number_bits_set() == b._cnt_number_bits_set() > 0
