@@ -408,6 +408,7 @@ static int finish(int where, const OutBuf *o, hipStream_t st)
 static int64_t g_part_mode = 1;
 static int64_t g_part_min_keys = 1 << 17;
 static int64_t g_part_max_keys = 1 << 25;   // keys per partition round (bounds the bucket buffer)
+static int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGeom::dbg); 0 in production
 
 extern "C" int psk_set_option(const char *name, int64_t value)
 {
@@ -415,6 +416,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     if (!strcmp(name, "partition")) g_part_mode = value;
     else if (!strcmp(name, "partition_min_keys")) g_part_min_keys = value;
     else if (!strcmp(name, "partition_max_keys")) g_part_max_keys = value < 1024 ? 1024 : value;
+    else if (!strcmp(name, "part_debug")) g_part_debug = value;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
 }
@@ -429,11 +431,11 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     return PSK_OK;
 }
 
-// geometry of the slices for a table of `cells` cells, `max_shift` = log2(cells one LDS slice may hold)
-static bool part_geometry(uint64_t cells, uint32_t max_shift, uint32_t min_shift, uint32_t k, uint64_t n, PartGeom *g)
+// slices of a table of `cells` cells; max_shift = log2(cells one LDS slice may hold)
+static bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_shift, PartGeom *g)
 {
     if (cells > (1ULL << 32) || cells < (1ULL << 16)) return false;
-    uint32_t lg = 63 - __builtin_clzll(cells);        // floor(log2 cells)
+    const uint32_t lg = 63 - __builtin_clzll(cells);  // floor(log2 cells)
     int shift = (int)lg - 8;                          // aim at 256..511 slices: one per CU
     if (shift > (int)max_shift) shift = max_shift;
     if (shift < (int)min_shift) shift = min_shift;
@@ -441,12 +443,7 @@ static bool part_geometry(uint64_t cells, uint32_t max_shift, uint32_t min_shift
     if (B > (uint64_t)kPartMaxBuckets) return false;
     g->nbuckets = (uint32_t)B;
     g->shift = (uint32_t)shift;
-    g->k = k;
-    const uint64_t mean = (n * (uint64_t)k + B - 1) / B;
-    uint64_t cap = mean + mean / 16 + 2048;           // ~ +6 % and +2048: > 8 sigma for uniform hashes
-    cap = (cap + 3) & ~3ULL;
-    if (cap > 0xFFFFFFF0ULL) return false;
-    g->cap = (uint32_t)cap;
+    g->dbg = (uint32_t)g_part_debug;
     return true;
 }
 
@@ -457,21 +454,32 @@ static int set_dyn_lds(K kernel, size_t bytes)
     return PSK_OK;
 }
 
-// launch pass 1 for one concrete (Src, IdxFn, Pay, Spill, KT)
+// Pass 1 for one concrete (Src, IdxFn, Pay, Spill, KT): sizes the (slice, workgroup) segments for `n` keys,
+// grows the handle's bucket buffer, launches.  g->nwg / g->segcap are filled in for pass 2.
 template <class Src, class IdxFn, class Pay, class Spill, int KT>
-static int launch_scatter(const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, const PartGeom &g,
-                          uint64_t n, uint32_t *gcount, uint32_t *buckets, hipStream_t st)
+static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, PartGeom *g,
+                          uint64_t n, hipStream_t st)
 {
-    using Tile = PartTile<Src, IdxFn, Pay, Spill, KT>;
+    using Tile = PartTile<Pay, KT>;
+    constexpr uint32_t WPP = Pay::has ? 2 : 1;
     const uint64_t ntiles = (n + Tile::TILE - 1) / Tile::TILE;
-    const size_t stage_words = (size_t)Tile::TILE * (g.k < (uint32_t)KT ? g.k : KT) * (Pay::has ? 2 : 1);
-    const size_t lds = (3 * (size_t)g.nbuckets + 8 + stage_words) * 4;
+    const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
+    const size_t lds = (4 * (size_t)g->nbuckets + 8 + (size_t)Tile::TILE * kk * WPP) * 4;
+    const uint64_t per_cu = lds > 76 * 1024 ? 1 : 2;
+    uint64_t nwg = 256 * per_cu;
+    if (nwg > ntiles) nwg = ntiles;
+    const uint64_t tiles_per_wg = (ntiles + nwg - 1) / nwg;
+    const double mean = (double)tiles_per_wg * Tile::TILE * kk / (double)g->nbuckets;
+    uint64_t segcap = (uint64_t)(mean + 8.0 * __builtin_sqrt(mean) + 32.0);  // > 8 sigma for uniform hashes
+    segcap = (segcap + 3) & ~3ULL;
+    g->nwg = (uint32_t)nwg;
+    g->segcap = (uint32_t)segcap;
+    PSK_TRY(ensure(s->s_part, (uint64_t)g->nbuckets * nwg * segcap * 4 * WPP + 256));
+    PSK_TRY(ensure(s->s_cnt, (uint64_t)g->nbuckets * nwg * 4));
     auto kern = k_part_scatter<Src, IdxFn, Pay, Spill, KT>;
     PSK_TRY(set_dyn_lds(kern, lds));
-    const uint64_t per_cu = lds > 72 * 1024 ? 1 : 2;
-    uint64_t grid = 256 * per_cu;
-    if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kPartThreads), lds, st, src, idxfn, pay, spill, g, n, gcount, buckets);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kPartThreads), lds, st, src, idxfn, pay, spill, *g, n,
+                       (uint32_t *)s->s_cnt.p, (uint32_t *)s->s_part.p);
     HIP_TRY(hipGetLastError());
     return PSK_OK;
 }
@@ -511,46 +519,144 @@ static int with_part_source(const Batch &b, bool *handled, F &&f)
     return PSK_OK;
 }
 
-static bool part_wanted(const psk_sketch *s, uint64_t n, uint32_t k)
+static bool part_wanted(uint64_t n, uint32_t k)
 {
-    return g_part_mode != 0 && (int64_t)n >= g_part_min_keys && k <= 16 && n < (1ULL << 32);
+    return g_part_mode != 0 && (int64_t)n >= g_part_min_keys && k <= 16;
+}
+
+// view of keys [start, start+cnt) of a device batch
+static Batch sub_batch(const Batch &b, uint64_t start, uint64_t cnt)
+{
+    Batch sub = b;
+    sub.n = cnt;
+    if (b.layout == PSK_KEYS_VARLEN8 || b.layout == PSK_KEYS_VARLEN32) sub.offs = b.offs + start;
+    else sub.data = (const uint8_t *)b.data + start * (uint64_t)b.key_len * (b.layout == PSK_KEYS_HASHES ? 8 : 1);
+    return sub;
 }
 
 // Bloom insert through the partitioned path; *done = false when this batch/table is not eligible
 static int bloom_add_partitioned(psk_sketch *s, const Batch &b, hipStream_t st, bool *done)
 {
     *done = false;
-    if (!part_wanted(s, b.n, s->k)) return PSK_OK;
+    if (!part_wanted(b.n, s->k)) return PSK_OK;
     PartGeom g;
+    if (!part_slices(s->m, 20, 7, &g)) return PSK_OK;
+    g.k = s->k;
     const uint64_t round_keys = (uint64_t)g_part_max_keys < b.n ? (uint64_t)g_part_max_keys : b.n;
-    if (!part_geometry(s->m, 20, 7, s->k, round_keys, &g)) return PSK_OK;
-    bool handled = false;
-    PSK_TRY(ensure(s->s_part, (uint64_t)g.nbuckets * g.cap * 4 + 256));
-    PSK_TRY(ensure(s->s_cnt, (uint64_t)g.nbuckets * 4));
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
-        Batch sub = b;
-        sub.n = cnt;
-        if (b.layout == PSK_KEYS_VARLEN8) sub.offs = b.offs + start;
-        else sub.data = (const uint8_t *)b.data + start * (uint64_t)b.key_len * (b.layout == PSK_KEYS_HASHES ? 8 : 1);
-        HIP_TRY(hipMemsetAsync(s->s_cnt.p, 0, (uint64_t)g.nbuckets * 4, st));
+        const Batch sub = sub_batch(b, start, cnt);
+        bool handled = false;
         PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
             using Src = decltype(src);
             return with_kt<Src>(s->k, [&](auto kt) {
                 constexpr int KT = decltype(kt)::value;
                 SpillBloomOr spill{(uint32_t *)s->table};
                 if (s->pow2)
-                    return launch_scatter<Src, IdxBloom<true>, PayNone, SpillBloomOr, KT>(
-                        src, IdxBloom<true>{s->md}, PayNone{}, spill, g, cnt, (uint32_t *)s->s_cnt.p, (uint32_t *)s->s_part.p, st);
-                return launch_scatter<Src, IdxBloom<false>, PayNone, SpillBloomOr, KT>(
-                    src, IdxBloom<false>{s->md}, PayNone{}, spill, g, cnt, (uint32_t *)s->s_cnt.p, (uint32_t *)s->s_part.p, st);
+                    return launch_scatter<Src, IdxBloom<true>, PayNone, SpillBloomOr, KT>(s, src, IdxBloom<true>{s->md}, PayNone{},
+                                                                                          spill, &g, cnt, st);
+                return launch_scatter<Src, IdxBloom<false>, PayNone, SpillBloomOr, KT>(s, src, IdxBloom<false>{s->md}, PayNone{},
+                                                                                       spill, &g, cnt, st);
             });
         }));
-        if (!handled) return PSK_OK;  // nothing was launched
+        if (!handled) return PSK_OK;  // layout without a partitioned instantiation: nothing was launched
         const size_t lds = (size_t)1 << (g.shift - 3);
         PSK_TRY(set_dyn_lds(k_bloom_apply, lds));
         hipLaunchKernelGGL(k_bloom_apply, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table,
                            s->padded_bytes / 4, g, (const uint32_t *)s->s_cnt.p, (const uint32_t *)s->s_part.p);
+        HIP_TRY(hipGetLastError());
+    }
+    *done = true;
+    return PSK_OK;
+}
+
+// Bloom lookup through the partitioned path: probes carry their key's index; out[] starts at 1 and
+// any probe that finds its bit clear stores a 0
+static int bloom_check_partitioned(psk_sketch *s, const Batch &b, uint8_t *out_dev, hipStream_t st, bool *done)
+{
+    *done = false;
+    if (!part_wanted(b.n, s->k)) return PSK_OK;
+    PartGeom g;
+    if (!part_slices(s->m, 20, 7, &g)) return PSK_OK;
+    g.k = s->k;
+    uint64_t round_keys = (uint64_t)g_part_max_keys < b.n ? (uint64_t)g_part_max_keys : b.n;
+    if (round_keys > 0xFFFFFFFFULL) round_keys = 0xFFFFFFFFULL;  // 32-bit key ids inside a round
+    for (uint64_t start = 0; start < b.n; start += round_keys) {
+        const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
+        const Batch sub = sub_batch(b, start, cnt);
+        uint8_t *out = out_dev + start;
+        bool handled = false;
+        PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
+            using Src = decltype(src);
+            return with_kt<Src>(s->k, [&](auto kt) {
+                constexpr int KT = decltype(kt)::value;
+                HIP_TRY(hipMemsetAsync(out, 1, cnt, st));
+                SpillBloomTest spill{(const uint32_t *)s->table, out};
+                if (s->pow2)
+                    return launch_scatter<Src, IdxBloom<true>, PayKeyId, SpillBloomTest, KT>(s, src, IdxBloom<true>{s->md},
+                                                                                             PayKeyId{}, spill, &g, cnt, st);
+                return launch_scatter<Src, IdxBloom<false>, PayKeyId, SpillBloomTest, KT>(s, src, IdxBloom<false>{s->md},
+                                                                                          PayKeyId{}, spill, &g, cnt, st);
+            });
+        }));
+        if (!handled) return PSK_OK;
+        const size_t lds = (size_t)1 << (g.shift - 3);
+        PSK_TRY(set_dyn_lds(k_bloom_test, lds));
+        hipLaunchKernelGGL(k_bloom_test, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (const uint32_t *)s->table,
+                           s->padded_bytes / 4, g, (const uint32_t *)s->s_cnt.p, (const uint32_t *)s->s_part.p, out);
+        HIP_TRY(hipGetLastError());
+    }
+    *done = true;
+    return PSK_OK;
+}
+
+// Counter add (CMS add / remove, CBF add) through the partitioned path.  IDX = IdxCms / IdxBloom;
+// w_dev = per-key weights (uint32 bit patterns) or nullptr for unit weights.  The caller has already run
+// account_weights(), so ctr[6] holds this batch's sum|w| for the wrap check inside pass 2.
+template <template <bool> class IDX, bool SIGNED, bool NEG>
+static int counter_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, uint64_t cells, hipStream_t st,
+                                   bool *done)
+{
+    *done = false;
+    if (!part_wanted(b.n, s->k)) return PSK_OK;
+    // unit-weight batches cannot wrap a 32-bit partial sum when n*k < 2^31 (weighted ones are checked on the device)
+    if (!w_dev && b.n * (uint64_t)s->k >= (1ULL << 31)) return PSK_OK;
+    PartGeom g;
+    if (!part_slices(cells, 15, 5, &g)) return PSK_OK;  // 2^15 counters = 128 KiB per slice
+    g.k = s->k;
+    const uint64_t round_keys = (uint64_t)g_part_max_keys < b.n ? (uint64_t)g_part_max_keys : b.n;
+    unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
+    for (uint64_t start = 0; start < b.n; start += round_keys) {
+        const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
+        const Batch sub = sub_batch(b, start, cnt);
+        bool handled = false;
+        PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
+            using Src = decltype(src);
+            return with_kt<Src>(s->k, [&](auto kt) {
+                constexpr int KT = decltype(kt)::value;
+                SpillAddU32 spill{(uint32_t *)s->table, w_dev == nullptr, NEG};
+                if (w_dev) {
+                    PayWeight pay{w_dev + start};
+                    if (s->pow2) return launch_scatter<Src, IDX<true>, PayWeight, SpillAddU32, KT>(s, src, IDX<true>{s->md}, pay, spill, &g, cnt, st);
+                    return launch_scatter<Src, IDX<false>, PayWeight, SpillAddU32, KT>(s, src, IDX<false>{s->md}, pay, spill, &g, cnt, st);
+                }
+                if (s->pow2) return launch_scatter<Src, IDX<true>, PayNone, SpillAddU32, KT>(s, src, IDX<true>{s->md}, PayNone{}, spill, &g, cnt, st);
+                return launch_scatter<Src, IDX<false>, PayNone, SpillAddU32, KT>(s, src, IDX<false>{s->md}, PayNone{}, spill, &g, cnt, st);
+            });
+        }));
+        if (!handled) return PSK_OK;
+        const size_t lds = (size_t)4 << g.shift;
+        if (w_dev) {
+            auto kern = k_counter_apply<SIGNED, true, NEG>;
+            PSK_TRY(set_dyn_lds(kern, lds));
+            hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g,
+                               (const uint32_t *)s->s_cnt.p, (const uint32_t *)s->s_part.p, (const long long *)s->ctr, sat);
+        } else {
+            auto kern = k_counter_apply<SIGNED, false, NEG>;
+            PSK_TRY(set_dyn_lds(kern, lds));
+            hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g,
+                               (const uint32_t *)s->s_cnt.p, (const uint32_t *)s->s_part.p, (const long long *)s->ctr, sat);
+        }
         HIP_TRY(hipGetLastError());
     }
     *done = true;
@@ -587,6 +693,11 @@ extern "C" int psk_bloom_check(psk_sketch *s, int layout, const void *data, cons
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
     OutBuf o;
     PSK_TRY(stage_out(s->s_out, out, n, where, &o));
+    {
+        bool done = false;
+        PSK_TRY(bloom_check_partitioned(s, b, (uint8_t *)o.dev, st, &done));
+        if (done) return finish(where, &o, st);
+    }
     PSK_TRY(with_source(b, [&](auto src) {
         if (s->pow2) return launch_apply(src, BloomCheck<true>{(const uint32_t *)s->table, s->md, s->k, (uint8_t *)o.dev}, n, st);
         return launch_apply(src, BloomCheck<false>{(const uint32_t *)s->table, s->md, s->k, (uint8_t *)o.dev}, n, st);
@@ -635,6 +746,7 @@ static int account_weights(psk_sketch *s, const W *w_dev, uint64_t n, int which,
 {
     if (n == 0) return PSK_OK;
     if (w_dev) {
+        HIP_TRY(hipMemsetAsync(s->ctr + 6, 0, sizeof(long long), st));  // per-batch sum|w| (partitioned path wrap check)
         hipLaunchKernelGGL((k_weight_sum<W>), dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(kBlock), 0, st, w_dev, n,
                            s->ctr, which, bound_mult);
     } else {
@@ -657,6 +769,11 @@ extern "C" int psk_cbf_add(psk_sketch *s, int layout, const void *data, const ui
     PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
     PSK_TRY(account_weights(s, w, n, PSK_CTR_ADDED, (long long)s->k, st));
     unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
+    {
+        bool done = false;
+        PSK_TRY((counter_add_partitioned<IdxBloom, false, false>(s, b, w, s->m, st, &done)));
+        if (done) return finish(where, nullptr, st);
+    }
     PSK_TRY(with_source(b, [&](auto src) {
         if (s->pow2) return launch_apply(src, CbfAdd<true>{(uint32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st);
         return launch_apply(src, CbfAdd<false>{(uint32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st);
@@ -755,6 +872,11 @@ static int cms_update(psk_sketch *s, int layout, const void *data, const uint64_
     PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
     PSK_TRY(account_weights(s, w, n, NEG ? PSK_CTR_REMOVED : PSK_CTR_ADDED, 1LL, st));
     unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
+    {
+        bool done = false;
+        PSK_TRY((counter_add_partitioned<IdxCms, true, NEG>(s, b, (const uint32_t *)w, s->m * (uint64_t)s->k, st, &done)));
+        if (done) return finish(where, nullptr, st);
+    }
     PSK_TRY(with_source(b, [&](auto src) {
         if (s->pow2)
             return launch_apply(src, CmsAdd<true, NEG>{(int32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st);

@@ -622,6 +622,7 @@ __global__ __launch_bounds__(kBlock) void k_weight_sum(const W *w, uint64_t n, l
     if ((threadIdx.x & 63) == 0) {
         if (which >= 0 && s) atomicAdd((unsigned long long *)(ctr + which), (unsigned long long)s);
         if (a) {
+            atomicAdd((unsigned long long *)(ctr + 6), a * (unsigned long long)bound_mult);  // this batch only (zeroed by the host before)
             // saturating bound: never wraps back below the threshold
             unsigned long long add = a * (unsigned long long)bound_mult;
             unsigned long long old = atomicAdd((unsigned long long *)(ctr + 4), add);

@@ -6,13 +6,17 @@
 // and the kernels pinned to that transaction ceiling.  Here the table is cut into slices that fit
 // one CU's LDS (<= 128 KiB of the 160 KiB):
 //   pass 1  k_part_scatter : hash the keys, bin every probe by slice (LDS histogram + LDS counting
-//                            sort per tile of 2048 keys), write each bin as a coalesced run into
-//                            that slice's bucket in HBM (4 B / probe, +4 B payload when needed);
-//   pass 2  k_*_apply      : one workgroup per slice keeps the slice in LDS, streams its bucket in
-//                            (coalesced dwordx4), does the random bit/counter updates with LDS
-//                            atomics (ds_or / ds_add), and merges the slice back with one coalesced
-//                            read-modify-write.  No global atomics on the table, no random HBM access.
-// Bucket overflow (adversarial / duplicate-heavy batches) falls back to a direct atomic on the
+//                            sort per tile of ~2048 keys) and append each bin as a coalesced run to the
+//                            (slice, workgroup) SEGMENT of the bucket buffer in HBM (4 B / probe,
+//                            +4 B payload when needed).  Segments are private to one workgroup, so the
+//                            append cursor lives in LDS: no global atomics, no cross-workgroup line sharing
+//                            (a first version reserved space with one returning device atomic per
+//                            (tile, slice): 1.25 M atomics = 300 of its 400 us).
+//   pass 2  k_*_apply      : one workgroup per slice keeps the slice in LDS, streams the slice's segments
+//                            in (one wave per segment, dwordx4), does the random bit / counter updates
+//                            with LDS atomics (ds_or / ds_add) and merges the slice back with one
+//                            coalesced read-modify-write.  No atomics on the table, no random HBM access.
+// Segment overflow (adversarial / duplicate-heavy batches) falls back to a direct atomic on the
 // table, so the result is always exact.
 #pragma once
 #include "psk_device.hpp"
@@ -23,12 +27,15 @@ constexpr int kPartThreads = 512;      // 8 wavefronts per workgroup
 constexpr int kPartProbes = 32;        // probes held in registers per thread (= keys/thread * KT); 16 with payload
 constexpr int kPartMaxBuckets = 2048;
 constexpr int kPartScanPerThread = kPartMaxBuckets / kPartThreads;  // 4
+constexpr int kPartMaxWg = 512;        // workgroups in pass 1 == segments per slice
 
 struct PartGeom {
-    uint32_t nbuckets;      // B = ceil(cells / 2^shift)
+    uint32_t nbuckets;      // B = ceil(cells / 2^shift) slices
     uint32_t shift;         // log2(cells per slice)
-    uint32_t cap;           // slots per bucket in the HBM bucket buffer (multiple of 4)
+    uint32_t nwg;           // workgroups of pass 1 (segments per slice)
+    uint32_t segcap;        // probe slots per (slice, workgroup) segment (multiple of 4)
     uint32_t k;             // hashes per key
+    uint32_t dbg;           // ablation bits (bench only): 1 skip stores, 4 skip hashing
 };
 
 // idx functors: which table cell does hash j of a key address?
@@ -55,17 +62,21 @@ struct PayWeight {
     __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return w[i]; }
 };
 
-// fallback for a probe that did not fit its bucket: apply it straight to the table
+// fallback for a probe that did not fit its segment: apply it straight to the table
 struct SpillBloomOr {
     uint32_t *tab;
     __device__ __forceinline__ void operator()(uint32_t idx, uint32_t) const { atomicOr(tab + (idx >> 5), 1u << (idx & 31)); }
 };
-struct SpillAddU32 {  // wrap-free counter add (CMS fast path / CBF fast path / unit weights)
+struct SpillAddU32 {  // wrap-free counter add (CMS / CBF fast path); neg: subtract (two's complement)
     uint32_t *tab;
-    bool unit;
-    __device__ __forceinline__ void operator()(uint32_t idx, uint32_t w) const { atomicAdd(tab + idx, unit ? 1u : w); }
+    bool unit, neg;
+    __device__ __forceinline__ void operator()(uint32_t idx, uint32_t w) const
+    {
+        const uint32_t v = unit ? 1u : w;
+        atomicAdd(tab + idx, neg ? 0u - v : v);
+    }
 };
-struct SpillBloomTest {  // lookup probe that did not fit its bucket: test it directly (bloom.py:269-271)
+struct SpillBloomTest {  // lookup probe that did not fit its segment: test it directly (bloom.py:269-271)
     const uint32_t *tab;
     uint8_t *out;
     __device__ __forceinline__ void operator()(uint32_t idx, uint32_t key) const
@@ -99,8 +110,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
 
 // ------------------------------------------------------------------------------------ pass 1
 // KT = hashes computed per key (>= k, compile time so the probes stay in registers).
-// dynamic LDS: hist[B] | off[B] | delta[B] | wave_tot[8] | stage[tile_probes * (1 + has_payload)]
-template <class Src, class IdxFn, class Pay, class Spill, int KT>
+// dynamic LDS: hist[B] | off[B] | delta[B] | cur[B] | wave_tot[8] | stage[tile_probes * (1 + has_payload)]
+template <class Pay, int KT>
 struct PartTile {
     static constexpr int PP = Pay::has ? kPartProbes / 2 : kPartProbes;  // stage <= 64 KiB either way
     static constexpr int KPT = PP / KT >= 1 ? PP / KT : 1;               // keys per thread per tile
@@ -109,25 +120,28 @@ struct PartTile {
 
 template <class Src, class IdxFn, class Pay, class Spill, int KT>
 __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn idxfn, Pay pay, Spill spill, PartGeom g,
-                                                               uint64_t n, uint32_t *gcount, uint32_t *buckets)
+                                                               uint64_t n, uint32_t *segcnt, uint32_t *buckets)
 {
-    constexpr int KPT = PartTile<Src, IdxFn, Pay, Spill, KT>::KPT;
-    constexpr int TILE = PartTile<Src, IdxFn, Pay, Spill, KT>::TILE;
+    constexpr int KPT = PartTile<Pay, KT>::KPT;
+    constexpr int TILE = PartTile<Pay, KT>::TILE;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t B = g.nbuckets;
     uint32_t *hist = smem;
     uint32_t *off = hist + B;
     uint32_t *delta = off + B;
-    uint32_t *wave_tot = delta + B;
+    uint32_t *cur = delta + B;  // fill of my segment of every slice, across all my tiles
+    uint32_t *wave_tot = cur + B;
     uint32_t *stage = wave_tot + 8;
     const uint32_t k = g.k;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
+
+    for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) cur[b] = 0;
 
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) hist[b] = 0;
         __syncthreads();
 
-        // ---- hash + histogram: rank = my position among this tile's probes of the same bucket
+        // ---- hash + histogram: rank = my position among this tile's probes of the same slice
         uint32_t idx[KPT][KT], rank[KPT][KT], payload[KPT];
         const uint64_t base = tile * TILE;
 #pragma unroll
@@ -136,7 +150,11 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
             if (i < n) {
                 const typename Src::Key key = src.load(i);
                 uint64_t h[KT];
-                src.template hash<KT>(key, i, 0, h);
+                if (g.dbg & 4) {
+                    for (int j = 0; j < KT; ++j) h[j] = ((uint64_t)(i * 2654435761u + j * 40503u) * 0x9E3779B97F4A7C15ULL) >> 13;
+                } else {
+                    src.template hash<KT>(key, i, 0, h);
+                }
                 if (Pay::has) payload[q] = pay(i);
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
@@ -149,7 +167,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
         }
         __syncthreads();
 
-        // ---- exclusive scan of the histogram + one global reservation per non-empty bucket
+        // ---- exclusive scan of the histogram; advance my segment cursors (LDS only)
         uint32_t mine[kPartScanPerThread], s = 0;
 #pragma unroll
         for (int c = 0; c < kPartScanPerThread; ++c) {
@@ -164,9 +182,9 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
             const uint32_t b = threadIdx.x * kPartScanPerThread + c;
             if (b < B) {
                 off[b] = run;
-                uint32_t gb = 0;
-                if (mine[c]) gb = atomicAdd(gcount + b, mine[c]);  // device-scope, returning
-                delta[b] = gb - run;                               // global slot = delta[b] + stage position
+                const uint32_t c0 = cur[b];
+                delta[b] = c0 - run;       // segment slot = delta[b] + stage position
+                cur[b] = c0 + mine[c];
                 run += mine[c];
             }
         }
@@ -182,8 +200,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
                     if ((uint32_t)j < k) {
                         const uint32_t p = off[idx[q][j] >> g.shift] + rank[q][j];
                         if (Pay::has) {
-                            stage[2 * p] = idx[q][j];
-                            stage[2 * p + 1] = payload[q];
+                            reinterpret_cast<uint2 *>(stage)[p] = make_uint2(idx[q][j], payload[q]);
                         } else {
                             stage[p] = idx[q][j];
                         }
@@ -193,36 +210,86 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
         }
         __syncthreads();
 
-        // ---- write out: consecutive lanes -> consecutive stage slots -> runs of consecutive bucket slots
-        for (uint32_t p = threadIdx.x; p < tile_probes; p += kPartThreads) {
-            uint32_t w0, w1 = 0;
-            if (Pay::has) {
-                const uint2 v = reinterpret_cast<const uint2 *>(stage)[p];
-                w0 = v.x;
-                w1 = v.y;
-            } else {
-                w0 = stage[p];
-            }
-            const uint32_t b = w0 >> g.shift;
-            const uint32_t slot = delta[b] + p;
-            if (slot < g.cap) {
-                if (Pay::has) reinterpret_cast<uint2 *>(buckets)[(uint64_t)b * g.cap + slot] = make_uint2(w0, w1);
-                else buckets[(uint64_t)b * g.cap + slot] = w0;
-            } else {
-                spill(w0, w1);  // bucket full: exact fallback
+        // ---- write out: consecutive lanes -> consecutive stage slots -> runs of consecutive segment slots
+        if (!(g.dbg & 1)) {
+            for (uint32_t p = threadIdx.x; p < tile_probes; p += kPartThreads) {
+                uint32_t w0, w1 = 0;
+                if (Pay::has) {
+                    const uint2 v = reinterpret_cast<const uint2 *>(stage)[p];
+                    w0 = v.x;
+                    w1 = v.y;
+                } else {
+                    w0 = stage[p];
+                }
+                const uint32_t b = w0 >> g.shift;
+                const uint32_t slot = delta[b] + p;
+                if (slot < g.segcap) {
+                    const uint64_t at = ((uint64_t)b * g.nwg + blockIdx.x) * g.segcap + slot;
+                    if (Pay::has) reinterpret_cast<uint2 *>(buckets)[at] = make_uint2(w0, w1);
+                    else buckets[at] = w0;
+                } else {
+                    spill(w0, w1);  // segment full: exact fallback
+                }
             }
         }
         __syncthreads();
+    }
+    // publish how much of each of my segments is valid (kernel boundary orders it before pass 2)
+    for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
+        const uint32_t c = cur[b];
+        segcnt[(uint64_t)b * g.nwg + blockIdx.x] = c < g.segcap ? c : g.segcap;
     }
 }
 
 // ------------------------------------------------------------------------------------ pass 2
 constexpr int kApplyThreads = 1024;
+constexpr int kApplyWaves = kApplyThreads / 64;
 
-// Bloom insert: OR the bucket's bits into an LDS image of the slice, then OR the image into the table.
+// Walk the segments of slice `b`: wave w takes segments w, w+16, ...; f4(uint4) for aligned groups of 4 words,
+// f1(pointer to a probe) for the tail.  WPP = words per probe (1 or 2).
+template <int WPP, class F4, class F1>
+__device__ __forceinline__ void for_each_segment_word(const uint32_t *buckets, const uint32_t *segcnt, const PartGeom &g,
+                                                      uint32_t b, F4 f4, F1 f1)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Segments are short (a few hundred probes), so a naive walk is a chain of dependent HBM latencies
+    // (count -> data -> next count ...).  Instead: fetch all of this wave's segment counts with ONE load,
+    // then keep U segments x R dwordx4 per lane in flight before touching LDS.
+    const uint32_t nseg = g.nwg > wave ? (g.nwg - wave + kApplyWaves - 1) / kApplyWaves : 0;  // <= 32
+    uint32_t mycnt = 0;
+    if (lane < nseg) mycnt = segcnt[(uint64_t)b * g.nwg + wave + kApplyWaves * lane];
+    constexpr int U = 4, R = 3;
+    for (uint32_t s0 = 0; s0 < nseg; s0 += U) {
+        uint4 q[U][R];
+        uint32_t words[U], nvec[U];
+        const uint32_t *src[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t sl = s0 + u;
+            words[u] = sl < nseg ? (uint32_t)__shfl((int)mycnt, (int)sl) * WPP : 0;
+            nvec[u] = words[u] >> 2;
+            src[u] = buckets + ((uint64_t)b * g.nwg + wave + kApplyWaves * sl) * g.segcap * WPP;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t v = lane + 64 * r;
+                if (v < nvec[u]) q[u][r] = reinterpret_cast<const uint4 *>(src[u])[v];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (lane + 64 * r < nvec[u]) f4(q[u][r]);
+            for (uint32_t v = lane + 64 * R; v < nvec[u]; v += 64) f4(reinterpret_cast<const uint4 *>(src[u])[v]);
+            for (uint32_t p = (nvec[u] << 2) + lane * WPP; p < words[u]; p += 64 * WPP) f1(src[u] + p);
+        }
+    }
+}
+
+// Bloom insert: OR the slice's probes into an LDS image of the slice, then OR the image into the table.
 // dynamic LDS: slice image, 2^shift bits
 __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *tab, uint64_t tab_words, PartGeom g,
-                                                               const uint32_t *gcount, const uint32_t *buckets)
+                                                               const uint32_t *segcnt, const uint32_t *buckets)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = blockIdx.x;
@@ -230,21 +297,10 @@ __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *tab, ui
     const uint32_t mask = (1u << g.shift) - 1;
     for (uint32_t w = threadIdx.x; w < slice_words; w += kApplyThreads) smem[w] = 0;
     __syncthreads();
-    uint32_t cnt = gcount[b];
-    cnt = cnt < g.cap ? cnt : g.cap;
-    const uint32_t *src = buckets + (uint64_t)b * g.cap;
-    const uint32_t nvec = cnt >> 2;
-    for (uint32_t v = threadIdx.x; v < nvec; v += kApplyThreads) {
-        const uint4 q = reinterpret_cast<const uint4 *>(src)[v];
-        atomicOr(&smem[(q.x & mask) >> 5], 1u << (q.x & 31));  // ds_or_b32
-        atomicOr(&smem[(q.y & mask) >> 5], 1u << (q.y & 31));
-        atomicOr(&smem[(q.z & mask) >> 5], 1u << (q.z & 31));
-        atomicOr(&smem[(q.w & mask) >> 5], 1u << (q.w & 31));
-    }
-    for (uint32_t p = (nvec << 2) + threadIdx.x; p < cnt; p += kApplyThreads) {
-        const uint32_t x = src[p];
-        atomicOr(&smem[(x & mask) >> 5], 1u << (x & 31));
-    }
+    auto set = [&](uint32_t x) { atomicOr(&smem[(x & mask) >> 5], 1u << (x & 31)); };  // ds_or_b32
+    for_each_segment_word<1>(
+        buckets, segcnt, g, b, [&](const uint4 q) { set(q.x); set(q.y); set(q.z); set(q.w); },
+        [&](const uint32_t *p) { set(*p); });
     __syncthreads();
     // merge: this workgroup is the only writer of its slice
     const uint64_t w0 = (uint64_t)b * slice_words;
@@ -265,9 +321,9 @@ __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *tab, ui
 }
 
 // Bloom lookup: the slice is loaded into LDS; a probe whose bit is clear zeroes its key's result byte
-// (out[] is pre-set to 1; every writer stores the same 0, so plain stores suffice).
+// (out[] is pre-set to 1; every writer stores the same 0, so plain byte stores suffice).
 __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint32_t *tab, uint64_t tab_words, PartGeom g,
-                                                              const uint32_t *gcount, const uint32_t *buckets, uint8_t *out)
+                                                              const uint32_t *segcnt, const uint32_t *buckets, uint8_t *out)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = blockIdx.x;
@@ -286,64 +342,62 @@ __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint32_t *ta
         *reinterpret_cast<uint4 *>(smem + w) = t;
     }
     __syncthreads();
-    uint32_t cnt = gcount[b];
-    cnt = cnt < g.cap ? cnt : g.cap;
-    const uint2 *src = reinterpret_cast<const uint2 *>(buckets) + (uint64_t)b * g.cap;
-    const uint32_t nvec = cnt >> 1;
-    for (uint32_t v = threadIdx.x; v < nvec; v += kApplyThreads) {
-        const uint4 q = reinterpret_cast<const uint4 *>(src)[v];  // two (idx, key) probes
-        if (((smem[(q.x & mask) >> 5] >> (q.x & 31)) & 1u) == 0) out[q.y] = 0;
-        if (((smem[(q.z & mask) >> 5] >> (q.z & 31)) & 1u) == 0) out[q.w] = 0;
-    }
-    if ((cnt & 1) && threadIdx.x == 0) {
-        const uint2 q = src[cnt - 1];
-        if (((smem[(q.x & mask) >> 5] >> (q.x & 31)) & 1u) == 0) out[q.y] = 0;
-    }
+    auto test = [&](uint32_t x, uint32_t key) {
+        if (((smem[(x & mask) >> 5] >> (x & 31)) & 1u) == 0) out[key] = 0;
+    };
+    for_each_segment_word<2>(
+        buckets, segcnt, g, b, [&](const uint4 q) { test(q.x, q.y); test(q.z, q.w); },
+        [&](const uint32_t *p) { test(p[0], p[1]); });
 }
 
-// Counter add (CMS / CBF fast path): accumulate the bucket's weights into an LDS image of the slice with
-// ds_add, then fold the image into the table with the reference's saturating add.
+// Counter add (CMS / CBF fast path): accumulate the slice's weights into an LDS image with ds_add, then
+// fold the image into the table with the reference's saturating add.
 // SIGNED: int32 bins clamped at both rails (countminsketch.py:280-284 / :312-316);
 // else uint32 counters clamped at 2^32-1 (countingbloom.py:149-153).
-// Exact for any order as long as the per-slice partial sums do not wrap 32 bits -- the caller
+// Exact for any order as long as the per-cell partial sums do not wrap 32 bits -- the caller
 // guarantees sum|w| of the batch < 2^31.
 template <bool SIGNED, bool WEIGHTED, bool NEG>
 __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, uint64_t tab_cells, PartGeom g,
-                                                                 const uint32_t *gcount, const uint32_t *buckets,
-                                                                 unsigned long long *sat_ctr)
+                                                                 const uint32_t *segcnt, const uint32_t *buckets,
+                                                                 const long long *ctr, unsigned long long *sat_ctr)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = blockIdx.x;
     const uint32_t slice_cells = 1u << g.shift;
     const uint32_t mask = slice_cells - 1;
+    if (WEIGHTED && ctr[6] >= (1LL << 31)) {
+        // sum|w| of this batch could wrap a 32-bit partial sum: apply every probe with the saturating
+        // CAS instead (this workgroup still owns the slice; rare, exact, slow)
+        for_each_segment_word<2>(
+            buckets, segcnt, g, b,
+            [&](const uint4 q) {
+                if (SIGNED) {
+                    cms_sat_add((int32_t *)tab + q.x, NEG ? -(int64_t)(int32_t)q.y : (int64_t)(int32_t)q.y, sat_ctr);
+                    cms_sat_add((int32_t *)tab + q.z, NEG ? -(int64_t)(int32_t)q.w : (int64_t)(int32_t)q.w, sat_ctr);
+                } else {
+                    cbf_sat_add(tab + q.x, q.y, sat_ctr);
+                    cbf_sat_add(tab + q.z, q.w, sat_ctr);
+                }
+            },
+            [&](const uint32_t *p) {
+                if (SIGNED) cms_sat_add((int32_t *)tab + p[0], NEG ? -(int64_t)(int32_t)p[1] : (int64_t)(int32_t)p[1], sat_ctr);
+                else cbf_sat_add(tab + p[0], p[1], sat_ctr);
+            });
+        return;
+    }
     for (uint32_t w = threadIdx.x; w < slice_cells; w += kApplyThreads) smem[w] = 0;
     __syncthreads();
-    uint32_t cnt = gcount[b];
-    cnt = cnt < g.cap ? cnt : g.cap;
     if (WEIGHTED) {
-        const uint2 *src = reinterpret_cast<const uint2 *>(buckets) + (uint64_t)b * g.cap;
-        const uint32_t nvec = cnt >> 1;
-        for (uint32_t v = threadIdx.x; v < nvec; v += kApplyThreads) {
-            const uint4 q = reinterpret_cast<const uint4 *>(src)[v];
-            atomicAdd(&smem[q.x & mask], NEG ? 0u - q.y : q.y);  // ds_add_u32 (two's complement for int32)
-            atomicAdd(&smem[q.z & mask], NEG ? 0u - q.w : q.w);
-        }
-        if ((cnt & 1) && threadIdx.x == 0) {
-            const uint2 q = src[cnt - 1];
-            atomicAdd(&smem[q.x & mask], NEG ? 0u - q.y : q.y);
-        }
+        auto add = [&](uint32_t x, uint32_t w) { atomicAdd(&smem[x & mask], NEG ? 0u - w : w); };  // ds_add_u32
+        for_each_segment_word<2>(
+            buckets, segcnt, g, b, [&](const uint4 q) { add(q.x, q.y); add(q.z, q.w); },
+            [&](const uint32_t *p) { add(p[0], p[1]); });
     } else {
-        const uint32_t *src = buckets + (uint64_t)b * g.cap;
-        const uint32_t nvec = cnt >> 2;
         const uint32_t one = NEG ? 0xFFFFFFFFu : 1u;
-        for (uint32_t v = threadIdx.x; v < nvec; v += kApplyThreads) {
-            const uint4 q = reinterpret_cast<const uint4 *>(src)[v];
-            atomicAdd(&smem[q.x & mask], one);
-            atomicAdd(&smem[q.y & mask], one);
-            atomicAdd(&smem[q.z & mask], one);
-            atomicAdd(&smem[q.w & mask], one);
-        }
-        for (uint32_t p = (nvec << 2) + threadIdx.x; p < cnt; p += kApplyThreads) atomicAdd(&smem[src[p] & mask], one);
+        auto add = [&](uint32_t x) { atomicAdd(&smem[x & mask], one); };
+        for_each_segment_word<1>(
+            buckets, segcnt, g, b, [&](const uint4 q) { add(q.x); add(q.y); add(q.z); add(q.w); },
+            [&](const uint32_t *p) { add(*p); });
     }
     __syncthreads();
     const uint64_t c0 = (uint64_t)b * slice_cells;

@@ -29,3 +29,16 @@ def oracle():
 
     _oracle.build()
     return _oracle
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _engine_options_from_env():
+    """PSK_PARTITION_MIN_KEYS=1 pytest -m gpu ...  re-runs the whole GPU suite through the partitioned path"""
+    import os
+
+    val = os.environ.get("PSK_PARTITION_MIN_KEYS")
+    if val is not None:
+        from pyprobables_amd import _native as N
+
+        N.set_option("partition_min_keys", int(val))
+    yield

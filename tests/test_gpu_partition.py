@@ -129,3 +129,108 @@ def test_partitioned_equals_direct(pa, oracle, force_partition):
     b.add_many(keys)
     assert torch.equal(a.table_tensor, b.table_tensor)
     assert a._cnt_number_bits_set() == b._cnt_number_bits_set() > 0
+
+
+# ------------------------------------------------------------------ lookups through the partitioned path
+def test_bloom_check_partitioned_vs_oracle(pa, oracle, force_partition):
+    keys = oracle.gen_keys16(0, 300_000)
+    blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    blm.add_many(_dev(keys[:150_000]))
+    ob.add_keys(keys[:150_000])
+    got = blm.check_many(_dev(keys)).cpu().numpy().astype(np.uint8)
+    assert np.array_equal(got, ob.check_keys(keys))
+    assert got[:150_000].all() and not got[150_000:].all()
+    # a dense small filter: many false positives, non power-of-two m, k = 5
+    blm = pa.BloomFilter(est_elements=300_000, false_positive_rate=0.03)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    blm.add_many(keys[:250_000])
+    ob.add_keys(keys[:250_000])
+    got = blm.check_many(keys).astype(np.uint8)  # host-staged
+    exp = ob.check_keys(keys)
+    assert np.array_equal(got, exp) and 0 < int(exp[250_000:].sum()) < 50_000
+    # bitmap variant still goes through the direct kernel and must agree
+    bits, hits = blm.check_many_bits(keys)
+    assert hits == int(exp.sum())
+
+
+def test_bloom_check_partitioned_overflow_and_rounds(pa, oracle, force_partition):
+    key = oracle.gen_keys16(3, 1)
+    keys = np.repeat(key, 100_000, axis=0)
+    keys[::7] = oracle.gen_keys16(100, len(keys[::7]))
+    blm = pa.BloomFilter(est_elements=2_000_000, false_positive_rate=0.01)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    blm.add_many(_dev(keys[:50_000]))
+    ob.add_keys(keys[:50_000])
+    assert np.array_equal(blm.check_many(_dev(keys)).cpu().numpy().astype(np.uint8), ob.check_keys(keys))
+    force_partition.set_option("partition_max_keys", 8192)
+    assert np.array_equal(blm.check_many(_dev(keys)).cpu().numpy().astype(np.uint8), ob.check_keys(keys))
+
+
+# ------------------------------------------------------------------ counters through the partitioned path
+@pytest.mark.parametrize("width,depth", [(2**20, 5), (100_003, 4), (2**16, 9)])
+def test_cms_add_partitioned_vs_oracle(pa, oracle, force_partition, width, depth):
+    n = 300_000
+    keys = oracle.gen_keys16(0, n // 3)
+    stream = keys[np.arange(n) % (n // 3)]
+    w = oracle.gen_weights(0, n)
+    cms = pa.CountMinSketch(width=width, depth=depth)
+    oc = oracle.OracleCMS(width, depth)
+    cms.add_many(_dev(stream), _dev(w))        # weighted probes (8 B)
+    cms.add_many(_dev(stream[:100_000]))        # unit weights (4 B probes)
+    oc.add_keys(stream, w)
+    oc.add_keys(stream[:100_000])
+    assert np.array_equal(np.frombuffer(bytes(cms._bins), dtype=np.int32), oc.bins)
+    assert cms.elements_added == oc.els_added
+    cms.remove_many(_dev(stream[:50_000]), _dev(w[:50_000]))
+    cms.remove_many(stream[50_000:60_000])
+    oc.remove_keys(stream[:50_000], w[:50_000])
+    oc.remove_keys(stream[50_000:60_000])
+    assert np.array_equal(np.frombuffer(bytes(cms._bins), dtype=np.int32), oc.bins)
+    assert cms.elements_added == oc.els_added
+    assert np.array_equal(cms.check_many(_dev(keys)).cpu().numpy(), oc.check_keys(keys).astype(np.int32))
+
+
+def test_cms_partitioned_saturation_paths(pa, oracle, force_partition):
+    keys = oracle.gen_keys16(0, 4096)
+    # (a) partial sums fit 32 bits, table clamps at INT32_MAX in the fold step
+    w = np.full(4096, 2**18, dtype=np.int32)
+    cms = pa.CountMinSketch(width=2**16, depth=2)
+    oc = oracle.OracleCMS(2**16, 2)
+    for _ in range(17):  # 2^30 per batch (< 2^31: LDS partial sums are wrap-free), 2^27 per key per batch
+        cms.add_many(_dev(np.repeat(keys[:8], 512, axis=0)), _dev(w))
+        oc.add_keys(np.repeat(keys[:8], 512, axis=0), w)
+    assert int(oc.bins.max()) == 2**31 - 1
+    assert np.array_equal(np.frombuffer(bytes(cms._bins), dtype=np.int32), oc.bins)
+    # (b) batch sum|w| >= 2^31: pass 2 must take its CAS fallback and still be exact
+    w = np.full(4096, 2**30, dtype=np.int32)
+    cms = pa.CountMinSketch(width=2**16, depth=2)
+    oc = oracle.OracleCMS(2**16, 2)
+    cms.add_many(_dev(keys), _dev(w))
+    oc.add_keys(keys, w)
+    assert np.array_equal(np.frombuffer(bytes(cms._bins), dtype=np.int32), oc.bins)
+    assert cms.elements_added == oc.els_added
+
+
+def test_cbf_add_partitioned_vs_oracle(pa, oracle, force_partition, golden):
+    g = golden["cbf_stream"]  # the well-formed add/remove stream: adds partitioned, removes direct
+    B = g["B"]
+    cbf = pa.CountingBloomFilter(est_elements=g["est_elements"], false_positive_rate=g["fpr"])
+    for bt in range(4):
+        cbf.add_many(_dev(oracle.gen_keys16(bt * B, B)))
+        if bt >= 1:
+            cbf.remove_many(_dev(oracle.gen_keys16((bt - 1) * B, B // 2)))
+    assert sha(bytes(cbf.bloom)) == g["sha256_table"]
+    assert cbf.elements_added == g["elements_added"]
+    assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+    # weighted, larger table (2^22 counters), duplicates inside the batch
+    n = 200_000
+    keys = oracle.gen_keys16(5, n // 2)
+    stream = keys[np.arange(n) % (n // 2)]
+    w = oracle.gen_weights(1, n).astype(np.uint32)
+    cbf = pa.CountingBloomFilter(est_elements=437_000, false_positive_rate=0.01)
+    oc = oracle.OracleCBF(cbf.number_bits, cbf.number_hashes)
+    cbf.add_many(_dev(stream), w)
+    oc.update_keys(stream, w.astype(np.int64))
+    assert np.array_equal(np.frombuffer(bytes(cbf.bloom), dtype=np.uint32), oc.bloom)
+    assert cbf.elements_added == oc.els_added
