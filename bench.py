@@ -243,7 +243,8 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_apply<KeysFixed16, BloomAdd<pow2>> (Bloom insert)",
+            "kernel": "Bloom insert = k_part_scatter<KeysFixed16,IdxBloom<pow2>,PayNone,SpillBloomOr,7> + k_bloom_apply "
+                      "(one insert launch = both kernels; avg_kernel_ms is their sum between two HIP events)",
             "achieved": ach,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

@@ -191,7 +191,7 @@ class BloomFilter:
         addr, fin = self._tab.out_buffer(b, b.n, np.uint8, _torch_dtype("uint8"))
         N.check(N.lib().psk_bloom_check(self._tab.handle, *b.args(), b.where, addr, self._tab.stream))
         res = fin()
-        return res.view(np.bool_) if isinstance(res, np.ndarray) else res.bool()
+        return res.view(np.bool_) if isinstance(res, np.ndarray) else res.view(_torch_dtype("bool"))
 
     def add(self, key: KeyT) -> None:
         """bloom.py:234-239 (a batch of one)"""

@@ -1035,7 +1035,8 @@ static int table_count(const void *tab, uint64_t nwords32, int mode, uint64_t *o
     HIP_TRY(hipMalloc((void **)&d, 8));
     hipError_t e = hipMemsetAsync(d, 0, 8, st);
     if (e == hipSuccess && nwords32) {
-        hipLaunchKernelGGL(k_table_count, dim3(grid_for(nwords32 / 4)), dim3(kBlock), 0, st, (const uint4 *)tab, nwords32 / 4, mode, d);
+        const int g = grid_for(nwords32 / 4) > 1024 ? 1024 : grid_for(nwords32 / 4);
+        hipLaunchKernelGGL(k_table_count, dim3(g), dim3(kBlock), 0, st, (const uint4 *)tab, nwords32 / 4, mode, d);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out_host, d, 8, hipMemcpyDeviceToHost, st);

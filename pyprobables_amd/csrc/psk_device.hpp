@@ -703,7 +703,15 @@ __global__ __launch_bounds__(kBlock) void k_table_count(const uint4 *tab, uint64
         else c += (a.x != 0) + (a.y != 0) + (a.z != 0) + (a.w != 0);
     }
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+    // one atomic per workgroup (same-address device atomics serialise at ~11 ns each)
+    __shared__ unsigned long long part[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kBlock / 64; ++w) t += part[w];
+        if (t) atomicAdd(out, t);
+    }
 }
 
 // countminsketch.py:380-391 join: clamp-add, bins already on a rail stay frozen

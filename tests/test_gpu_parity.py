@@ -518,3 +518,22 @@ def test_ragged_batch_sizes_all_structures(pa, oracle, n):
     assert np.array_equal(_table(cbf, np.uint32), ocb.bloom)
     assert np.array_equal(cbf.check_many(_dev(probe)).cpu().numpy().view(np.uint32), ocb.check_keys(probe))
     assert cbf.elements_added == ocb.els_added and cms.elements_added == oc.els_added
+
+
+# ------------------------------------------------------------------ merge kernels (local half of the multi-GPU merge)
+def test_or_reduce_slices_kernel_and_single_rank_merge(pa):
+    import ctypes as C
+
+    from pyprobables_amd import _native as N
+    from pyprobables_amd import parallel
+
+    rng = np.random.default_rng(1)
+    for nslices, words in [(2, 4), (8, 1 << 16), (3, 1000), (5, 12)]:
+        src = rng.integers(-2**31, 2**31 - 1, size=(nslices, words), dtype=np.int64).astype(np.int32)
+        d_src = _dev(src.reshape(-1))
+        d_dst = torch.zeros(words, dtype=torch.int32, device="cuda")
+        parallel.hip_or_reduce(d_dst, d_src, nslices, words)
+        assert np.array_equal(d_dst.cpu().numpy(), np.bitwise_or.reduce(src, axis=0))
+    with pytest.raises(ValueError):  # slices must be 16-byte multiples
+        N.check(N.lib().psk_or_reduce_slices(d_dst.data_ptr(), d_src.data_ptr(), 2, 3, 0, None))
+    _ = C

@@ -1,0 +1,117 @@
+"""Multi-process (world_size 2 and 3, gloo, CPU) tests of the sharded-insert + merge composition in
+pyprobables_amd/parallel.py: key-range partition, allreduce(OR) = all_to_all + OR-reduce + all_gather,
+SUM all-reduce for counters.  The per-rank replicas are produced by the plain-C oracle (there is no GPU
+here); the OR-reduce step is injected as a torch op because the product's reduce step is a HIP kernel."""
+
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _torch_or_reduce(dst, src, nslices, slice_words):
+    acc = src[:slice_words].clone()
+    for j in range(1, nslices):
+        acc |= src[j * slice_words:(j + 1) * slice_words]
+    dst.copy_(acc)
+
+
+class _FakeSketch:
+    """what merge_* touch on a sketch, backed by CPU tensors"""
+
+    def __init__(self, table, els):
+        self.table_tensor = table
+        self._els_added = els
+        self._tab = None
+
+    @property
+    def elements_added(self):
+        return self._els_added
+
+    @elements_added.setter
+    def elements_added(self, v):
+        self._els_added = v
+
+
+def _worker(rank, world, port, n_total, m_bits, out_dir):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+
+    from pyprobables_amd import parallel
+
+    lo, hi = parallel.shard_range(n_total, rank, world)
+    keys = oracle.gen_keys16(lo, hi - lo)
+
+    # ---- Bloom: per-rank replica -> allreduce(OR)
+    ob = oracle.OracleBloom(m_bits, 7)
+    ob.add_keys(keys)
+    padded = (ob.bloom.size + 15) & ~15
+    raw = np.zeros(padded, dtype=np.uint8)
+    raw[: ob.bloom.size] = ob.bloom
+    blm = _FakeSketch(torch.from_numpy(raw.view(np.int32).copy()), hi - lo)
+    parallel.merge_bloom(blm, or_reduce=_torch_or_reduce)
+
+    # ---- CMS: per-rank replica -> allreduce(SUM)
+    w = oracle.gen_weights(lo, hi - lo)
+    oc = oracle.OracleCMS(1009, 4)
+    oc.add_keys(keys, w)
+    cms = _FakeSketch(torch.from_numpy(oc.bins.copy()), oc.els_added)
+    parallel.merge_counters(cms)
+
+    np.save(Path(out_dir) / f"bloom_{rank}.npy", blm.table_tensor.numpy().view(np.uint8)[: ob.bloom.size])
+    np.save(Path(out_dir) / f"cms_{rank}.npy", cms.table_tensor.numpy())
+    (Path(out_dir) / f"els_{rank}.txt").write_text(f"{blm.elements_added} {cms.elements_added}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,m_bits", [(2, 958506), (3, 958506), (2, 2**20)])
+def test_sharded_insert_and_merge_equals_single_stream(tmp_path, oracle, world, m_bits):
+    n_total = 20001  # not divisible by the world size
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_total, m_bits, str(tmp_path)), nprocs=world, join=True)
+    keys = oracle.gen_keys16(0, n_total)
+    ob = oracle.OracleBloom(m_bits, 7)
+    ob.add_keys(keys)
+    oc = oracle.OracleCMS(1009, 4)
+    oc.add_keys(keys, oracle.gen_weights(0, n_total))
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"bloom_{r}.npy"), ob.bloom), f"rank {r} bloom"
+        assert np.array_equal(np.load(tmp_path / f"cms_{r}.npy"), oc.bins), f"rank {r} cms"
+        els_b, els_c = map(int, (tmp_path / f"els_{r}.txt").read_text().split())
+        assert els_b == n_total and els_c == oc.els_added
+
+
+def test_shard_range_covers_stream():
+    from pyprobables_amd.parallel import shard_range
+
+    for n, w in [(10, 1), (10, 3), (7, 8), (1_000_000_000, 8), (0, 4)]:
+        pieces = [shard_range(n, r, w) for r in range(w)]
+        assert pieces[0][0] == 0 and pieces[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+        sizes = [hi - lo for lo, hi in pieces]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_hip_or_reduce_refuses_cpu_tensors():
+    from pyprobables_amd.parallel import hip_or_reduce
+
+    with pytest.raises(RuntimeError):
+        hip_or_reduce(torch.zeros(4, dtype=torch.int32), torch.zeros(8, dtype=torch.int32), 2, 4)
