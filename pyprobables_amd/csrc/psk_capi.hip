@@ -634,14 +634,14 @@ static int counter_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t
             using Src = decltype(src);
             return with_kt<Src>(s->k, [&](auto kt) {
                 constexpr int KT = decltype(kt)::value;
-                SpillAddU32 spill{(uint32_t *)s->table, w_dev == nullptr, NEG};
+                SpillCounter<SIGNED> spill{(uint32_t *)s->table, w_dev == nullptr, NEG, sat};
                 if (w_dev) {
                     PayWeight pay{w_dev + start};
-                    if (s->pow2) return launch_scatter<Src, IDX<true>, PayWeight, SpillAddU32, KT>(s, src, IDX<true>{s->md}, pay, spill, &g, cnt, st);
-                    return launch_scatter<Src, IDX<false>, PayWeight, SpillAddU32, KT>(s, src, IDX<false>{s->md}, pay, spill, &g, cnt, st);
+                    if (s->pow2) return launch_scatter<Src, IDX<true>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<true>{s->md}, pay, spill, &g, cnt, st);
+                    return launch_scatter<Src, IDX<false>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<false>{s->md}, pay, spill, &g, cnt, st);
                 }
-                if (s->pow2) return launch_scatter<Src, IDX<true>, PayNone, SpillAddU32, KT>(s, src, IDX<true>{s->md}, PayNone{}, spill, &g, cnt, st);
-                return launch_scatter<Src, IDX<false>, PayNone, SpillAddU32, KT>(s, src, IDX<false>{s->md}, PayNone{}, spill, &g, cnt, st);
+                if (s->pow2) return launch_scatter<Src, IDX<true>, PayNone, SpillCounter<SIGNED>, KT>(s, src, IDX<true>{s->md}, PayNone{}, spill, &g, cnt, st);
+                return launch_scatter<Src, IDX<false>, PayNone, SpillCounter<SIGNED>, KT>(s, src, IDX<false>{s->md}, PayNone{}, spill, &g, cnt, st);
             });
         }));
         if (!handled) return PSK_OK;
@@ -747,7 +747,7 @@ static int account_weights(psk_sketch *s, const W *w_dev, uint64_t n, int which,
     if (n == 0) return PSK_OK;
     if (w_dev) {
         HIP_TRY(hipMemsetAsync(s->ctr + 6, 0, sizeof(long long), st));  // per-batch sum|w| (partitioned path wrap check)
-        hipLaunchKernelGGL((k_weight_sum<W>), dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(kBlock), 0, st, w_dev, n,
+        hipLaunchKernelGGL((k_weight_sum<W>), dim3(grid_for(n) > 512 ? 512 : grid_for(n)), dim3(kBlock), 0, st, w_dev, n,
                            s->ctr, which, bound_mult);
     } else {
         hipLaunchKernelGGL(k_ctr_add, dim3(1), dim3(1), 0, st, s->ctr, which, (long long)n, (long long)n * bound_mult);

@@ -619,7 +619,14 @@ __global__ __launch_bounds__(kBlock) void k_weight_sum(const W *w, uint64_t n, l
         s += __shfl_down(s, o);
         a += __shfl_down(a, o);
     }
-    if ((threadIdx.x & 63) == 0) {
+    // one set of atomics per workgroup: same-address device atomics serialise (~11 ns each)
+    __shared__ long long ps[kBlock / 64];
+    __shared__ unsigned long long pa[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) { ps[threadIdx.x >> 6] = s; pa[threadIdx.x >> 6] = a; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = 0; a = 0;
+        for (int w = 0; w < kBlock / 64; ++w) { s += ps[w]; a += pa[w]; }
         if (which >= 0 && s) atomicAdd((unsigned long long *)(ctr + which), (unsigned long long)s);
         if (a) {
             atomicAdd((unsigned long long *)(ctr + 6), a * (unsigned long long)bound_mult);  // this batch only (zeroed by the host before)

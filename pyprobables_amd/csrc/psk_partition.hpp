@@ -67,13 +67,16 @@ struct SpillBloomOr {
     uint32_t *tab;
     __device__ __forceinline__ void operator()(uint32_t idx, uint32_t) const { atomicOr(tab + (idx >> 5), 1u << (idx & 31)); }
 };
-struct SpillAddU32 {  // wrap-free counter add (CMS / CBF fast path); neg: subtract (two's complement)
+template <bool SIGNED>
+struct SpillCounter {  // counter probe that did not fit its segment: saturating CAS add straight on the table
     uint32_t *tab;
     bool unit, neg;
+    unsigned long long *sat_ctr;
     __device__ __forceinline__ void operator()(uint32_t idx, uint32_t w) const
     {
         const uint32_t v = unit ? 1u : w;
-        atomicAdd(tab + idx, neg ? 0u - v : v);
+        if (SIGNED) cms_sat_add((int32_t *)tab + idx, neg ? -(int64_t)(int32_t)v : (int64_t)(int32_t)v, sat_ctr);
+        else cbf_sat_add(tab + idx, v, sat_ctr);
     }
 };
 struct SpillBloomTest {  // lookup probe that did not fit its segment: test it directly (bloom.py:269-271)
