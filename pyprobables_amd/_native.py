@@ -23,7 +23,8 @@ Q_MIN, Q_MEAN, Q_MEANMIN = 0, 1, 2
 OP_ADD, OP_REMOVE, OP_SIGNED = 0, 1, 2
 CTR_ADDED, CTR_REMOVED, CTR_VIOLATIONS, CTR_SATURATED, CTR_ABS_BOUND, CTR_ELS_OUT, CTR_COUNT = 0, 1, 2, 3, 4, 5, 8
 
-LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libpsk_hip.so"
+# PSK_LIB_PATH lets a bench A/B two builds of the engine inside one process launch each (same GPU box)
+LIB_PATH = Path(os.environ.get("PSK_LIB_PATH") or (Path(__file__).resolve().parent / "csrc" / "libpsk_hip.so"))
 
 _vp, _u64, _u32, _i64, _int = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int64, C.c_int
 _KEYS = [_int, _vp, _vp, _u64, _u32]  # layout, data, offsets, n, key_len
@@ -35,6 +36,7 @@ PROTOTYPES = {
     "psk_device_count": (_int, [C.POINTER(_int)]),
     "psk_set_option": (_int, [C.c_char_p, _i64]),
     "psk_get_option": (_int, [C.c_char_p, C.POINTER(_i64)]),
+    "psk_debug_phase_profile": (_int, [_vp, _u32, _u32, C.POINTER(_u64)]),
     "psk_bloom_table_bytes": (_u64, [_u64]),
     "psk_cbf_table_bytes": (_u64, [_u64]),
     "psk_cms_table_bytes": (_u64, [_u64, _u32]),

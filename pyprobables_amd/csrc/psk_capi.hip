@@ -421,6 +421,18 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     return PSK_OK;
 }
 
+// bench-only: phase cycle totals of the last pass-1 launch (valid when part_debug & 32); zeroes them afterwards
+extern "C" int psk_debug_phase_profile(psk_sketch *s, uint32_t nbuckets, uint32_t nwg, uint64_t out[6])
+{
+    if (!s || !s->s_cnt.p) return fail(PSK_EINVAL, "no partition scratch yet");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    char *p = (char *)s->s_cnt.p + (size_t)nbuckets * nwg * 4;
+    HIP_TRY(hipMemcpy(out, p, 48, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(p, 0, 48));
+    return PSK_OK;
+}
+
 extern "C" int psk_get_option(const char *name, int64_t *value)
 {
     if (!name || !value) return fail(PSK_EINVAL, "NULL argument");
@@ -434,7 +446,7 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
 // slices of a table of `cells` cells; max_shift = log2(cells one LDS slice may hold)
 static bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_shift, PartGeom *g)
 {
-    if (cells > (1ULL << 32) || cells < (1ULL << 16)) return false;
+    if (cells >= (1ULL << 32) || cells < (1ULL << 16)) return false;  // cell index 0xFFFFFFFF is the pad marker
     const uint32_t lg = 63 - __builtin_clzll(cells);  // floor(log2 cells)
     int shift = (int)lg - 8;                          // aim at 256..511 slices: one per CU
     if (shift > (int)max_shift) shift = max_shift;
@@ -464,18 +476,20 @@ static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, con
     constexpr uint32_t WPP = Pay::has ? 2 : 1;
     const uint64_t ntiles = (n + Tile::TILE - 1) / Tile::TILE;
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
-    const size_t lds = (4 * (size_t)g->nbuckets + 8 + (size_t)Tile::TILE * kk * WPP) * 4;
-    const uint64_t per_cu = lds > 76 * 1024 ? 1 : 2;
+    const size_t lds = (4 * (size_t)g->nbuckets + 8 + ((size_t)Tile::TILE * kk + 3 * (size_t)g->nbuckets) * WPP) * 4;
+    uint64_t per_cu = lds > 76 * 1024 ? 1 : (lds > 50 * 1024 ? 2 : (lds > 38 * 1024 ? 3 : 4));
+    if (g->dbg & 8) per_cu = 1;  // ablation: one workgroup per CU
     uint64_t nwg = 256 * per_cu;
     if (nwg > ntiles) nwg = ntiles;
     const uint64_t tiles_per_wg = (ntiles + nwg - 1) / nwg;
     const double mean = (double)tiles_per_wg * Tile::TILE * kk / (double)g->nbuckets;
-    uint64_t segcap = (uint64_t)(mean + 8.0 * __builtin_sqrt(mean) + 32.0);  // > 8 sigma for uniform hashes
+    // + 1.5 pad probes per (tile, slice) run on average, + 8 sigma for uniform hashes
+    uint64_t segcap = (uint64_t)(mean + 1.5 * (double)tiles_per_wg + 8.0 * __builtin_sqrt(mean) + 32.0);
     segcap = (segcap + 3) & ~3ULL;
     g->nwg = (uint32_t)nwg;
     g->segcap = (uint32_t)segcap;
     PSK_TRY(ensure(s->s_part, (uint64_t)g->nbuckets * nwg * segcap * 4 * WPP + 256));
-    PSK_TRY(ensure(s->s_cnt, (uint64_t)g->nbuckets * nwg * 4));
+    PSK_TRY(ensure(s->s_cnt, (uint64_t)g->nbuckets * nwg * 4 + 64));  // + 6 x u64 of phase profile (dbg & 32)
     auto kern = k_part_scatter<Src, IdxFn, Pay, Spill, KT>;
     PSK_TRY(set_dyn_lds(kern, lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kPartThreads), lds, st, src, idxfn, pay, spill, *g, n,

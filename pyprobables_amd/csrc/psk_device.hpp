@@ -43,6 +43,32 @@ __device__ __forceinline__ void fnv_word(uint64_t (&h)[G], uint32_t w)
     }
 }
 
+// Low 32 bits only.  prime = 2^40 + 0x1B3, so bits 0..31 of every state depend only on bits 0..31 of the
+// previous one: when the table index is h mod 2^p with p <= 32 the upper halves are dead.
+// (scripts/ubench/alu.hip: v_mul_lo_u32, v_lshl_add_u32 and SDWA forms all issue at 4 cycles per wave64, plain
+// VOP2 v_xor_b32 at 2 -- so one multiply beats a 3-instruction shift-add chain, and the byte is extracted once
+// per key byte (shared by the k chains) instead of through an SDWA operand on every xor.)
+__device__ __forceinline__ uint32_t fnv_step32(uint32_t h, uint32_t e) { return (h ^ e) * 0x1B3u; }
+
+template <int G>
+__device__ __forceinline__ void fnv_init32(uint32_t (&h)[G], uint32_t s0)
+{
+#pragma unroll
+    for (int g = 0; g < G; ++g) h[g] = (uint32_t)fnv_seed(s0 + g);
+}
+
+template <int G>
+__device__ __forceinline__ void fnv_word32(uint32_t (&h)[G], uint32_t w)
+{
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        uint32_t e = (w >> (8 * b)) & 0xFFu;
+        asm volatile("" : "+v"(e));  // keep the extracted byte in a VGPR (no per-chain SDWA byte select)
+#pragma unroll
+        for (int g = 0; g < G; ++g) h[g] = fnv_step32(h[g], e);
+    }
+}
+
 // ------------------------------------------------------------ key sources
 // A source turns key i into `G` hashes for seeds s0..s0+G-1 (hashes.py:71-83 default_fnv_1a).
 
@@ -50,6 +76,8 @@ struct KeysFixed16 {  // uint8[n][16], 16-byte aligned: one global_load_dwordx4 
     const uint4 *p;
     struct Key { uint4 w; };
     __device__ __forceinline__ Key load(uint64_t i) const { return Key{p[i]}; }
+    // force the load to have landed here (lets a caller drain it BEFORE it issues unrelated stores)
+    static __device__ __forceinline__ void pin(Key &k) { asm volatile("" : "+v"(k.w.x), "+v"(k.w.y), "+v"(k.w.z), "+v"(k.w.w)); }
     template <int G>
     __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
     {
@@ -59,6 +87,15 @@ struct KeysFixed16 {  // uint8[n][16], 16-byte aligned: one global_load_dwordx4 
         fnv_word<G>(h, k.w.z);
         fnv_word<G>(h, k.w.w);
     }
+    template <int G>
+    __device__ __forceinline__ void hash32(const Key &k, uint64_t, uint32_t s0, uint32_t (&h)[G]) const
+    {
+        fnv_init32<G>(h, s0);
+        fnv_word32<G>(h, k.w.x);
+        fnv_word32<G>(h, k.w.y);
+        fnv_word32<G>(h, k.w.z);
+        fnv_word32<G>(h, k.w.w);
+    }
 };
 
 template <bool DWORDS>
@@ -67,6 +104,7 @@ struct KeysFixed {  // uint8[n][L]; DWORDS: L % 4 == 0 and base 4-byte aligned
     uint32_t L;
     struct Key { const uint8_t *q; };
     __device__ __forceinline__ Key load(uint64_t i) const { return Key{p + i * (uint64_t)L}; }
+    static __device__ __forceinline__ void pin(Key &) {}
     template <int G>
     __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
     {
@@ -82,6 +120,21 @@ struct KeysFixed {  // uint8[n][L]; DWORDS: L % 4 == 0 and base 4-byte aligned
             }
         }
     }
+    template <int G>
+    __device__ __forceinline__ void hash32(const Key &k, uint64_t, uint32_t s0, uint32_t (&h)[G]) const
+    {
+        fnv_init32<G>(h, s0);
+        if (DWORDS) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(k.q);
+            for (uint32_t j = 0; j < L / 4; ++j) fnv_word32<G>(h, q[j]);
+        } else {
+            for (uint32_t j = 0; j < L; ++j) {
+                const uint32_t e = k.q[j];
+#pragma unroll
+                for (int g = 0; g < G; ++g) h[g] = fnv_step32(h[g], e);
+            }
+        }
+    }
 };
 
 template <class T>
@@ -94,6 +147,7 @@ struct KeysVarlen {  // elements T (uint8 bytes, or uint32 code points for str k
         const uint64_t a = off[i], b = off[i + 1];
         return Key{p + a, b - a};
     }
+    static __device__ __forceinline__ void pin(Key &) {}
     template <int G>
     __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
     {
@@ -104,6 +158,16 @@ struct KeysVarlen {  // elements T (uint8 bytes, or uint32 code points for str k
             for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e);
         }
     }
+    template <int G>
+    __device__ __forceinline__ void hash32(const Key &k, uint64_t, uint32_t s0, uint32_t (&h)[G]) const
+    {
+        fnv_init32<G>(h, s0);
+        for (uint64_t j = 0; j < k.len; ++j) {
+            const uint32_t e = (uint32_t)k.q[j];  // code points > 255 XOR whole into the low word as well
+#pragma unroll
+            for (int g = 0; g < G; ++g) h[g] = fnv_step32(h[g], e);
+        }
+    }
 };
 
 struct KeysHashes {  // uint64[n][stride] pre-computed hashes (add_alt / check_alt, custom hash_function)
@@ -111,11 +175,18 @@ struct KeysHashes {  // uint64[n][stride] pre-computed hashes (add_alt / check_a
     uint32_t stride;
     struct Key { const uint64_t *q; };
     __device__ __forceinline__ Key load(uint64_t i) const { return Key{p + i * (uint64_t)stride}; }
+    static __device__ __forceinline__ void pin(Key &) {}
     template <int G>
     __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
     {
 #pragma unroll
         for (int g = 0; g < G; ++g) h[g] = (s0 + g < stride) ? k.q[s0 + g] : 0;  // callers may round G up past k
+    }
+    template <int G>
+    __device__ __forceinline__ void hash32(const Key &k, uint64_t, uint32_t s0, uint32_t (&h)[G]) const
+    {
+#pragma unroll
+        for (int g = 0; g < G; ++g) h[g] = (s0 + g < stride) ? (uint32_t)k.q[s0 + g] : 0;
     }
 };
 

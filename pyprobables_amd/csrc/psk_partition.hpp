@@ -28,6 +28,9 @@ constexpr int kPartProbes = 32;        // probes held in registers per thread (=
 constexpr int kPartMaxBuckets = 2048;
 constexpr int kPartScanPerThread = kPartMaxBuckets / kPartThreads;  // 4
 constexpr int kPartMaxWg = 512;        // workgroups in pass 1 == segments per slice
+constexpr bool kPartPipeline = true;   // prefetch the next tile's keys under the current tile (see k_part_scatter)
+constexpr bool kPartHash32 = true;     // explicit 32-bit FNV chains for power-of-two tables
+constexpr uint32_t kPadProbe = 0xFFFFFFFFu;  // filler that pads every run to 4 probes; pass 2 skips it
 
 struct PartGeom {
     uint32_t nbuckets;      // B = ceil(cells / 2^shift) slices
@@ -39,17 +42,25 @@ struct PartGeom {
 };
 
 // idx functors: which table cell does hash j of a key address?
+// lo32: the index needs only the low 32 bits of the hash (power-of-two modulus <= 2^32)
 template <bool POW2>
 struct IdxBloom {  // bloom.py:247 / countingbloom.py:145:  h % m
+    static constexpr bool lo32 = POW2 && kPartHash32;
     Mod md;
     __device__ __forceinline__ uint32_t operator()(uint32_t, uint64_t h) const { return (uint32_t)reduce<POW2>(md, h); }
+    __device__ __forceinline__ uint32_t from32(uint32_t, uint32_t h) const { return h & (uint32_t)md.mask; }
 };
 template <bool POW2>
 struct IdxCms {  // countminsketch.py:275:  (h % width) + i*width
+    static constexpr bool lo32 = POW2 && kPartHash32;
     Mod md;
     __device__ __forceinline__ uint32_t operator()(uint32_t j, uint64_t h) const
     {
         return (uint32_t)(reduce<POW2>(md, h) + (uint64_t)j * md.m);
+    }
+    __device__ __forceinline__ uint32_t from32(uint32_t j, uint32_t h) const
+    {
+        return (h & (uint32_t)md.mask) + j * (uint32_t)md.m;
     }
 };
 
@@ -88,6 +99,11 @@ struct SpillBloomTest {  // lookup probe that did not fit its segment: test it d
     }
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a fence, for which hipcc emits
+// s_waitcnt vmcnt(0): every barrier of pass 1 would then drain the key prefetch (a full HBM latency per tile)
+// and the previous tile's write-out stores.  Pass 1 exchanges data between waves through LDS only.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // block-wide exclusive scan of one uint32 per thread (512 threads = 8 waves)
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot /*LDS[8]*/, uint32_t *total)
 {
@@ -99,7 +115,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
         if (lane >= o) inc += t;
     }
     if (lane == 63) wave_tot[wid] = inc;
-    __syncthreads();
+    lds_barrier();
     uint32_t base = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < kPartThreads / 64; ++w) {
@@ -139,59 +155,135 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
     const uint64_t ntiles = (n + TILE - 1) / TILE;
 
     for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) cur[b] = 0;
+    // Software pipeline over tiles: the NEXT tile's keys are loaded right after this tile's hash phase and
+    // pinned before this tile's write-out stores are issued.  vmcnt counts loads and stores in order on
+    // CDNA4, so a key load waited for AFTER the stores would also wait for ~300 KB of stores to drain
+    // (measured: 40 us of a 165 us kernel).  Now the stores drain underneath the next tile's hashing.
+    typename Src::Key kcur[KPT];
+    if (kPartPipeline) {
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) {
+            const uint64_t i = (uint64_t)blockIdx.x * TILE + (uint64_t)q * kPartThreads + threadIdx.x;
+            kcur[q] = src.load(i < n ? i : n - 1);  // coalesced; clamped, never branched around (a conditional load
+        }                                           // makes hipcc wait vmcnt(0) per element: 4 serial round trips)
+    }
 
+    // phase profile (dbg & 32): lane 0 of wave 0 accumulates s_memtime deltas per phase; bench-only
+    unsigned long long t_prev = 0, t_acc[6] = {0, 0, 0, 0, 0, 0};
+#define PSK_TICK(ph)                                                                   \
+    if ((g.dbg & 32) && threadIdx.x == 0) {                                            \
+        const unsigned long long t_now = __builtin_readcyclecounter();                 \
+        t_acc[ph] += t_now - t_prev;                                                   \
+        t_prev = t_now;                                                                \
+    }
+    if ((g.dbg & 32) && threadIdx.x == 0) t_prev = __builtin_readcyclecounter();
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) hist[b] = 0;
-        __syncthreads();
+        lds_barrier();
+        PSK_TICK(1);
 
         // ---- hash + histogram: rank = my position among this tile's probes of the same slice
         uint32_t idx[KPT][KT], rank[KPT][KT], payload[KPT];
         const uint64_t base = tile * TILE;
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
-            const uint64_t i = base + (uint64_t)q * kPartThreads + threadIdx.x;  // coalesced key loads
+            const uint64_t i = base + (uint64_t)q * kPartThreads + threadIdx.x;
             if (i < n) {
-                const typename Src::Key key = src.load(i);
-                uint64_t h[KT];
-                if (g.dbg & 4) {
-                    for (int j = 0; j < KT; ++j) h[j] = ((uint64_t)(i * 2654435761u + j * 40503u) * 0x9E3779B97F4A7C15ULL) >> 13;
-                } else {
-                    src.template hash<KT>(key, i, 0, h);
-                }
+                const typename Src::Key key = kPartPipeline ? kcur[q] : src.load(i);
                 if (Pay::has) payload[q] = pay(i);
+                if constexpr (IdxFn::lo32) {  // 32-bit chains (power-of-two table: the upper hash halves are dead)
+                    uint32_t h[KT];
+                    if (g.dbg & 4) {
+                        for (int j = 0; j < KT; ++j) h[j] = (uint32_t)(((uint64_t)(i * 2654435761u + j * 40503u) * 0x9E3779B97F4A7C15ULL) >> 13);
+                    } else {
+                        src.template hash32<KT>(key, i, 0, h);
+                    }
 #pragma unroll
-                for (int j = 0; j < KT; ++j) {
-                    if ((uint32_t)j < k) {
-                        idx[q][j] = idxfn((uint32_t)j, h[j]);
-                        rank[q][j] = atomicAdd(&hist[idx[q][j] >> g.shift], 1u);  // ds_add_rtn_u32
+                    for (int j = 0; j < KT; ++j) {
+                        if ((uint32_t)j < k) {
+                            idx[q][j] = idxfn.from32((uint32_t)j, h[j]);
+                            rank[q][j] = atomicAdd(&hist[idx[q][j] >> g.shift], 1u);  // ds_add_rtn_u32
+                        }
+                    }
+                } else {
+                    uint64_t h[KT];
+                    if (g.dbg & 4) {
+                        for (int j = 0; j < KT; ++j) h[j] = ((uint64_t)(i * 2654435761u + j * 40503u) * 0x9E3779B97F4A7C15ULL) >> 13;
+                    } else {
+                        src.template hash<KT>(key, i, 0, h);
+                    }
+#pragma unroll
+                    for (int j = 0; j < KT; ++j) {
+                        if ((uint32_t)j < k) {
+                            idx[q][j] = idxfn((uint32_t)j, h[j]);
+                            rank[q][j] = atomicAdd(&hist[idx[q][j] >> g.shift], 1u);  // ds_add_rtn_u32
+                        }
                     }
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        PSK_TICK(2);
 
-        // ---- exclusive scan of the histogram; advance my segment cursors (LDS only)
+        // ---- prefetch the next tile's keys (consumed -- pinned -- before the write-out below)
+        if (kPartPipeline) {
+            const uint64_t nbase = (tile + gridDim.x) * TILE;
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                const uint64_t i = nbase + (uint64_t)q * kPartThreads + threadIdx.x;
+                kcur[q] = src.load(i < n ? i : n - 1);  // unconditional (clamped) on purpose, see above
+            }
+        }
+
+        // ---- exclusive scan of the histogram; advance my segment cursors (LDS only).
+        // Every run is padded to a multiple of 4 probes with kPadProbe words, so stage positions and
+        // segment slots are both 16-byte aligned and the write-out moves dwordx4 per lane (dword stores
+        // were store-issue bound: 73 of 183 us).
         uint32_t mine[kPartScanPerThread], s = 0;
 #pragma unroll
         for (int c = 0; c < kPartScanPerThread; ++c) {
             const uint32_t b = threadIdx.x * kPartScanPerThread + c;
             mine[c] = b < B ? hist[b] : 0;
-            s += mine[c];
+            s += (mine[c] + 3) & ~3u;
         }
-        uint32_t tile_probes;
-        uint32_t run = block_exclusive_scan(s, wave_tot, &tile_probes);
+        uint32_t tile_probes;  // padded
+        uint32_t run;
+        if (B <= 64 * kPartScanPerThread) {
+            // all slices live in wave 0 (4 per lane): a wave scan, no cross-wave step, one barrier less
+            if (threadIdx.x < 64) {
+                uint32_t inc = s;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = __shfl_up(inc, o);
+                    if ((int)threadIdx.x >= o) inc += t;
+                }
+                run = inc - s;
+                if (threadIdx.x == 63) wave_tot[0] = inc;
+            } else {
+                run = 0;
+            }
+        } else {
+            run = block_exclusive_scan(s, wave_tot, &tile_probes);
+        }
 #pragma unroll
         for (int c = 0; c < kPartScanPerThread; ++c) {
             const uint32_t b = threadIdx.x * kPartScanPerThread + c;
             if (b < B) {
+                const uint32_t padded = (mine[c] + 3) & ~3u;
                 off[b] = run;
                 const uint32_t c0 = cur[b];
-                delta[b] = c0 - run;       // segment slot = delta[b] + stage position
-                cur[b] = c0 + mine[c];
-                run += mine[c];
+                delta[b] = c0 - run;       // segment slot = delta[b] + stage position (both multiples of 4)
+                cur[b] = c0 + padded;
+                for (uint32_t e = mine[c]; e < padded; ++e) {
+                    if (Pay::has) reinterpret_cast<uint2 *>(stage)[run + e] = make_uint2(kPadProbe, 0u);
+                    else stage[run + e] = kPadProbe;
+                }
+                run += padded;
             }
         }
-        __syncthreads();
+        lds_barrier();
+        if (B <= 64 * kPartScanPerThread) tile_probes = wave_tot[0];
+        PSK_TICK(3);
 
         // ---- counting-sort the probes into the LDS stage
 #pragma unroll
@@ -211,33 +303,62 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        PSK_TICK(4);
 
         // ---- write out: consecutive lanes -> consecutive stage slots -> runs of consecutive segment slots
+#pragma unroll
+        for (int q = 0; q < KPT; ++q)
+            if (kPartPipeline) Src::pin(kcur[q]);  // next tile's keys have landed: nothing to wait for later
         if (!(g.dbg & 1)) {
-            for (uint32_t p = threadIdx.x; p < tile_probes; p += kPartThreads) {
-                uint32_t w0, w1 = 0;
+            // one group = 4 consecutive probes of ONE run (runs are multiples of 4); its first probe is
+            // always a real one (pads trail), so it names the slice
+            for (uint32_t p4 = threadIdx.x; p4 < (tile_probes >> 2); p4 += kPartThreads) {
+                const uint32_t p = p4 << 2;
                 if (Pay::has) {
-                    const uint2 v = reinterpret_cast<const uint2 *>(stage)[p];
-                    w0 = v.x;
-                    w1 = v.y;
+                    const uint4 q0 = reinterpret_cast<const uint4 *>(stage)[2 * p4];      // idx0 pay0 idx1 pay1
+                    const uint4 q1 = reinterpret_cast<const uint4 *>(stage)[2 * p4 + 1];  // idx2 pay2 idx3 pay3
+                    const uint32_t b = q0.x >> g.shift;
+                    const uint32_t slot = delta[b] + p;
+                    if (slot + 4 <= g.segcap) {
+                        uint4 *dst = reinterpret_cast<uint4 *>(buckets + (((uint64_t)b * g.nwg + blockIdx.x) * g.segcap + slot) * 2);
+                        dst[0] = q0;
+                        dst[1] = q1;
+                    } else {  // segment full: exact fallback, probe by probe
+                        if (q0.x != kPadProbe) spill(q0.x, q0.y);
+                        if (q0.z != kPadProbe) spill(q0.z, q0.w);
+                        if (q1.x != kPadProbe) spill(q1.x, q1.y);
+                        if (q1.z != kPadProbe) spill(q1.z, q1.w);
+                    }
                 } else {
-                    w0 = stage[p];
-                }
-                const uint32_t b = w0 >> g.shift;
-                const uint32_t slot = delta[b] + p;
-                if (slot < g.segcap) {
-                    const uint64_t at = ((uint64_t)b * g.nwg + blockIdx.x) * g.segcap + slot;
-                    if (Pay::has) reinterpret_cast<uint2 *>(buckets)[at] = make_uint2(w0, w1);
-                    else buckets[at] = w0;
-                } else {
-                    spill(w0, w1);  // segment full: exact fallback
+                    const uint4 q = reinterpret_cast<const uint4 *>(stage)[p4];
+                    const uint32_t b = q.x >> g.shift;
+                    const uint32_t slot = delta[b] + p;
+                    if (slot + 4 <= g.segcap) {
+                        *reinterpret_cast<uint4 *>(buckets + ((uint64_t)b * g.nwg + blockIdx.x) * g.segcap + slot) = q;
+                    } else {
+                        if (q.x != kPadProbe) spill(q.x, 0u);
+                        if (q.y != kPadProbe) spill(q.y, 0u);
+                        if (q.z != kPadProbe) spill(q.z, 0u);
+                        if (q.w != kPadProbe) spill(q.w, 0u);
+                    }
                 }
             }
         }
-        __syncthreads();
+        // (pipelined form) no barrier needed here: the next iteration touches only hist (last read two barriers
+        // ago) before its own barriers, and writes stage only after the barrier that follows its hash phase
+        if (!kPartPipeline) lds_barrier();
+        PSK_TICK(5);
     }
-    // publish how much of each of my segments is valid (kernel boundary orders it before pass 2)
+    lds_barrier();
+    if ((g.dbg & 32) && threadIdx.x == 0) {  // counts land behind the segment counts (host reserves the room)
+        unsigned long long *prof = reinterpret_cast<unsigned long long *>(segcnt + (size_t)g.nbuckets * g.nwg);
+        for (int ph = 1; ph < 6; ++ph) atomicAdd(prof + ph, t_acc[ph]);
+        atomicAdd(prof, 1ULL);
+    }
+#undef PSK_TICK
+    // publish how much of each of my segments is valid (kernel boundary orders it before pass 2);
+    // cur and segcap are multiples of 4, so the clipped count matches the group-wise store above
     for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
         const uint32_t c = cur[b];
         segcnt[(uint64_t)b * g.nwg + blockIdx.x] = c < g.segcap ? c : g.segcap;
@@ -300,7 +421,9 @@ __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *tab, ui
     const uint32_t mask = (1u << g.shift) - 1;
     for (uint32_t w = threadIdx.x; w < slice_words; w += kApplyThreads) smem[w] = 0;
     __syncthreads();
-    auto set = [&](uint32_t x) { atomicOr(&smem[(x & mask) >> 5], 1u << (x & 31)); };  // ds_or_b32
+    auto set = [&](uint32_t x) {
+        if (x != kPadProbe) atomicOr(&smem[(x & mask) >> 5], 1u << (x & 31));  // ds_or_b32
+    };
     for_each_segment_word<1>(
         buckets, segcnt, g, b, [&](const uint4 q) { set(q.x); set(q.y); set(q.z); set(q.w); },
         [&](const uint32_t *p) { set(*p); });
@@ -346,7 +469,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint32_t *ta
     }
     __syncthreads();
     auto test = [&](uint32_t x, uint32_t key) {
-        if (((smem[(x & mask) >> 5] >> (x & 31)) & 1u) == 0) out[key] = 0;
+        if (x != kPadProbe && ((smem[(x & mask) >> 5] >> (x & 31)) & 1u) == 0) out[key] = 0;
     };
     for_each_segment_word<2>(
         buckets, segcnt, g, b, [&](const uint4 q) { test(q.x, q.y); test(q.z, q.w); },
@@ -375,14 +498,15 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, 
             buckets, segcnt, g, b,
             [&](const uint4 q) {
                 if (SIGNED) {
-                    cms_sat_add((int32_t *)tab + q.x, NEG ? -(int64_t)(int32_t)q.y : (int64_t)(int32_t)q.y, sat_ctr);
-                    cms_sat_add((int32_t *)tab + q.z, NEG ? -(int64_t)(int32_t)q.w : (int64_t)(int32_t)q.w, sat_ctr);
+                    if (q.x != kPadProbe) cms_sat_add((int32_t *)tab + q.x, NEG ? -(int64_t)(int32_t)q.y : (int64_t)(int32_t)q.y, sat_ctr);
+                    if (q.z != kPadProbe) cms_sat_add((int32_t *)tab + q.z, NEG ? -(int64_t)(int32_t)q.w : (int64_t)(int32_t)q.w, sat_ctr);
                 } else {
-                    cbf_sat_add(tab + q.x, q.y, sat_ctr);
-                    cbf_sat_add(tab + q.z, q.w, sat_ctr);
+                    if (q.x != kPadProbe) cbf_sat_add(tab + q.x, q.y, sat_ctr);
+                    if (q.z != kPadProbe) cbf_sat_add(tab + q.z, q.w, sat_ctr);
                 }
             },
             [&](const uint32_t *p) {
+                if (p[0] == kPadProbe) return;
                 if (SIGNED) cms_sat_add((int32_t *)tab + p[0], NEG ? -(int64_t)(int32_t)p[1] : (int64_t)(int32_t)p[1], sat_ctr);
                 else cbf_sat_add(tab + p[0], p[1], sat_ctr);
             });
@@ -391,13 +515,17 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, 
     for (uint32_t w = threadIdx.x; w < slice_cells; w += kApplyThreads) smem[w] = 0;
     __syncthreads();
     if (WEIGHTED) {
-        auto add = [&](uint32_t x, uint32_t w) { atomicAdd(&smem[x & mask], NEG ? 0u - w : w); };  // ds_add_u32
+        auto add = [&](uint32_t x, uint32_t w) {
+            if (x != kPadProbe) atomicAdd(&smem[x & mask], NEG ? 0u - w : w);  // ds_add_u32
+        };
         for_each_segment_word<2>(
             buckets, segcnt, g, b, [&](const uint4 q) { add(q.x, q.y); add(q.z, q.w); },
             [&](const uint32_t *p) { add(p[0], p[1]); });
     } else {
         const uint32_t one = NEG ? 0xFFFFFFFFu : 1u;
-        auto add = [&](uint32_t x) { atomicAdd(&smem[x & mask], one); };
+        auto add = [&](uint32_t x) {
+            if (x != kPadProbe) atomicAdd(&smem[x & mask], one);
+        };
         for_each_segment_word<1>(
             buckets, segcnt, g, b, [&](const uint4 q) { add(q.x); add(q.y); add(q.z); add(q.w); },
             [&](const uint32_t *p) { add(*p); });

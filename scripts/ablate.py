@@ -13,8 +13,24 @@ from pyprobables_amd import _native as N
 n = 10_000_000
 keys = bench.gen_keys(n, 0, 0)
 blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01, device=0)
-for dbg, label in [(0, "full"), (1, "no stores"), (2, "no reservation atomics"), (3, "no stores, no atomics"), (4, "no hashing"), (7, "skeleton only")]:
+for dbg, label in [(0, "full"), (1, "no stores"), (4, "no hashing"), (5, "skeleton only"), (8, "1 WG/CU"), (16, "de-phased WGs")]:
     N.set_option("part_debug", dbg)
     ms = bench.timed_loop(lambda: blm.add_many(keys), 10, warm=3)
     print(f"dbg={dbg} {label:28s} insert {ms*1e3:8.1f} us  -> {n/ms/1e3:9.0f} Mkeys/s", flush=True)
+N.set_option("part_debug", 0)
+
+# phase profile of pass 1 (s_memtime ticks of lane 0 per workgroup, summed over workgroups)
+import ctypes as C
+N.set_option("part_debug", 32)
+blm.add_many(keys); torch.cuda.synchronize()
+buf = (C.c_uint64 * 6)()
+N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 512, buf))   # clear whatever warm-up left
+for _ in range(3):
+    blm.add_many(keys)
+torch.cuda.synchronize()
+N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 512, buf))
+names = ["(wgs)", "zero+bar", "hash+hist+bar", "scan+bar", "sort+bar", "writeout(+bar)"]
+tot = sum(buf[1:6])
+for i in range(1, 6):
+    print(f"phase {names[i]:16s} {buf[i]/buf[0]/3:10.0f} ticks per WG per launch  ({100.0*buf[i]/tot:5.1f} %)")
 N.set_option("part_debug", 0)

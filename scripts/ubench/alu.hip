@@ -1,0 +1,79 @@
+// micro-benchmark: issue cost (cycles per wave64 instruction per SIMD) of the integer ops the FNV chain can be built from
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#define REP 4096
+template <int OP>
+__global__ void k(uint32_t *out, uint32_t seed)
+{
+    uint32_t a[8];
+    for (int i = 0; i < 8; ++i) a[i] = seed + threadIdx.x * 7 + i;
+    uint32_t e = seed * 3 + 1;
+    for (int r = 0; r < REP; ++r) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (OP == 0) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 1) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 2) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 3) asm volatile("v_xor_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(a[i]) : "v"(e));
+            if (OP == 4) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 5) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a[i]) : "v"(e));
+            if (OP == 6) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 7) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 8) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(a[i]));
+        }
+    }
+    uint32_t s = 0;
+    for (int i = 0; i < 8; ++i) s += a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int OP>
+__global__ void k64(uint64_t *out, uint32_t seed)
+{
+    uint64_t a[8];
+    for (int i = 0; i < 8; ++i) a[i] = seed + threadIdx.x * 7 + i;
+    uint32_t e = seed * 3 + 1;
+    for (int r = 0; r < REP; ++r) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (OP == 0) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[i]) : "v"(e), "v"((uint32_t)a[i]) : "vcc");
+            if (OP == 1) asm volatile("v_lshl_add_u64 %0, %0, 3, %0" : "+v"(a[i]));
+        }
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < 8; ++i) s += a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <class F>
+static void run(const char *name, F launch, int waves_per_simd)
+{
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    launch(); hipDeviceSynchronize();
+    hipEventRecord(a); launch(); hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    // per SIMD: waves_per_simd waves * REP * 8 instructions
+    double instr = (double)waves_per_simd * REP * 8;
+    printf("%-22s waves/SIMD=%d  %8.3f ms  -> %6.2f ns per wave-instruction per SIMD (x clock GHz = cycles)\n", name, waves_per_simd, ms,
+           ms * 1e6 / instr);
+}
+int main()
+{
+    uint32_t *o; hipMalloc(&o, 256 * 4 * 8 * 1024 * 8);
+    const char *names[] = {"v_mul_lo_u32", "v_xor_b32", "v_lshl_add_u32", "v_xor_b32_sdwa", "v_mul_u32_u24", "v_mad_u32_u24", "v_add_u32", "v_mul_hi_u32", "v_bfe_u32"};
+    for (int wps : {1, 4}) {
+        dim3 grid(256 * wps), block(256);  // 256 CUs x wps blocks of 4 waves = wps waves per SIMD
+        run(names[0], [&] { k<0><<<grid, block>>>(o, 1); }, wps);
+        run(names[1], [&] { k<1><<<grid, block>>>(o, 1); }, wps);
+        run(names[2], [&] { k<2><<<grid, block>>>(o, 1); }, wps);
+        run(names[3], [&] { k<3><<<grid, block>>>(o, 1); }, wps);
+        run(names[4], [&] { k<4><<<grid, block>>>(o, 1); }, wps);
+        run(names[5], [&] { k<5><<<grid, block>>>(o, 1); }, wps);
+        run(names[6], [&] { k<6><<<grid, block>>>(o, 1); }, wps);
+        run(names[7], [&] { k<7><<<grid, block>>>(o, 1); }, wps);
+        run(names[8], [&] { k<8><<<grid, block>>>(o, 1); }, wps);
+        run("v_mad_u64_u32", [&] { k64<0><<<grid, block>>>((uint64_t *)o, 1); }, wps);
+        run("v_lshl_add_u64", [&] { k64<1><<<grid, block>>>((uint64_t *)o, 1); }, wps);
+    }
+    return 0;
+}
