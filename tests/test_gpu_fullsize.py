@@ -1,0 +1,134 @@
+"""BASELINE.json configurations at (or near) full size on one MI355X, bit-exact against the C oracle where the
+oracle finishes in seconds, plus size-independent properties over the whole stream.
+
+cfg 2  BloomFilter m = 2^28, k = 7: insert 10M keys, check them + 10M fresh keys       (full compare)
+cfg 3  CountMinSketch 2^20 x 5: 100M weighted adds                                       (full compare)
+cfg 4  CountingBloomFilter m = 2^28 (1 GiB): 50M-op add/remove stream in 1M batches      (10 batches compared, all 50 by properties)
+cfg 5  BloomFilter m = 2^31: two rank-shards merged by OR == single-stream filter        (20M keys compared)
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+SEED = 0x5EED
+
+
+@pytest.fixture(scope="module")
+def pa():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import pyprobables_amd
+
+    return pyprobables_amd
+
+
+def dev_keys(start, n):
+    from pyprobables_amd import _native as N
+
+    t = torch.empty((n, 16), dtype=torch.uint8, device="cuda")
+    N.check(N.lib().psk_gen_keys16(t.data_ptr(), start, n, SEED, 0, torch.cuda.current_stream().cuda_stream or None))
+    return t
+
+
+def dev_weights(start, n):
+    from pyprobables_amd import _native as N
+
+    t = torch.empty(n, dtype=torch.int32, device="cuda")
+    N.check(N.lib().psk_gen_weights(t.data_ptr(), start, n, SEED, 0, torch.cuda.current_stream().cuda_stream or None))
+    return t
+
+
+def test_device_generators_match_oracle(pa, oracle, golden):
+    k = dev_keys(123_456, 100_000).cpu().numpy()
+    assert np.array_equal(k, oracle.gen_keys16(123_456, 100_000))
+    assert bytes(dev_keys(0, 1).cpu().numpy()[0]).hex() == golden["keygen"]["key0"]
+    w = dev_weights(77, 100_000).cpu().numpy()
+    assert np.array_equal(w, oracle.gen_weights(77, 100_000))
+
+
+def test_cfg2_bloom_2p28_10M_full(pa, oracle):
+    n = 10_000_000
+    blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    assert (blm.number_bits, blm.number_hashes) == (2**28, 7)
+    keys = dev_keys(0, n)
+    blm.add_many(keys)
+    ob = oracle.OracleBloom(2**28, 7)
+    ob.add_keys(oracle.gen_keys16(0, n))
+    tab = blm.table_tensor.cpu().numpy().view(np.uint8)[: ob.bloom.size]
+    assert np.array_equal(tab, ob.bloom)                      # all 32 MiB, bit for bit
+    assert blm.elements_added == n
+    assert blm._cnt_number_bits_set() == ob.bits_set()
+    assert bool(blm.check_many(keys).all())                   # every inserted key is found
+    fresh = blm.check_many(dev_keys(n, n)).cpu().numpy().view(np.uint8)
+    exp = ob.check_keys(oracle.gen_keys16(n, n))
+    assert np.array_equal(fresh, exp)                         # 10M membership answers incl. the false positives
+    assert 0 < int(exp.sum()) < n // 1000                     # fpr at 36 % load is far below the design 1 %
+    t0 = blm.table_tensor.clone()
+    blm.add_many(keys)                                        # idempotence at full size
+    assert torch.equal(t0, blm.table_tensor)
+
+
+def test_cfg3_cms_100M_weighted_full(pa, oracle):
+    d, passes = 10_000_000, 10
+    cms = pa.CountMinSketch(width=2**20, depth=5)
+    oc = oracle.OracleCMS(2**20, 5)
+    keys_h = oracle.gen_keys16(0, d)
+    keys = dev_keys(0, d)
+    for p in range(passes):  # update i uses key (i mod 10M) and weight w(i)
+        cms.add_many(keys, dev_weights(p * d, d))
+        oc.add_keys(keys_h, oracle.gen_weights(p * d, d))
+    bins = cms.table_tensor.cpu().numpy()[: oc.bins.size]
+    assert np.array_equal(bins, oc.bins)                       # all 5,242,880 counters
+    assert cms.elements_added == oc.els_added
+    assert int(bins.astype(np.int64).sum()) == 5 * oc.els_added  # every update lands once per row
+    assert cms.batch_diagnostics()["saturated"] == 0
+    got = cms.check_many(keys[:1_000_000]).cpu().numpy()
+    assert np.array_equal(got, oc.check_keys(keys_h[:1_000_000]).astype(np.int32))
+
+
+def test_cfg4_cbf_1GiB_mixed_stream(pa, oracle):
+    B, nb, nb_oracle = 1_000_000, 50, 10
+    cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    assert (cbf.number_bits, cbf.number_hashes) == (2**28, 7)
+    oc = oracle.OracleCBF(2**28, 7)
+    for b in range(nb):
+        cbf.add_many(dev_keys(b * B, B))
+        if b >= 1:
+            cbf.remove_many(dev_keys((b - 1) * B, B // 2))   # each key removed at most once: well-formed stream
+        if b < nb_oracle:
+            oc.update_keys(oracle.gen_keys16(b * B, B))
+            if b >= 1:
+                oc.update_keys(oracle.gen_keys16((b - 1) * B, B // 2), -np.ones(B // 2, dtype=np.int64))
+        if b == nb_oracle - 1:
+            tab = cbf.table_tensor.cpu().numpy().view(np.uint32)
+            assert np.array_equal(tab, oc.bloom)               # the whole 1 GiB table after 10 batches
+            assert cbf.elements_added == oc.els_added
+    expect = nb * B - (nb - 1) * (B // 2)
+    assert cbf.elements_added == expect
+    assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+    total = int(cbf.table_tensor.view(torch.int32).to(torch.int64).sum().item())
+    assert total == 7 * expect                                 # k increments per live insert, nothing lost
+    last = cbf.check_many(dev_keys((nb - 1) * B, B)).cpu().numpy().view(np.uint32)
+    assert int(last.min()) >= 1                                # the last batch was never removed
+
+
+def test_cfg5_bloom_2p31_two_shards_or_merge(pa, oracle):
+    from pyprobables_amd import _native as N
+
+    n = 10_000_000  # per shard
+    a = pa.BloomFilter(est_elements=224044920, false_positive_rate=0.01)
+    b = pa.BloomFilter(est_elements=224044920, false_positive_rate=0.01)
+    assert (a.number_bits, a.number_hashes) == (2**31, 7)
+    a.add_many(dev_keys(0, n))       # "rank 0" replica
+    b.add_many(dev_keys(n, n))       # "rank 1" replica
+    t = a._tab
+    N.check(N.lib().psk_table_or(t.ptr, b._tab.ptr, t.nwords, t.device, t.stream))   # local form of allreduce(OR)
+    ob = oracle.OracleBloom(2**31, 7)
+    ob.add_keys(oracle.gen_keys16(0, 2 * n))
+    tab = a.table_tensor.cpu().numpy().view(np.uint8)[: ob.bloom.size]
+    assert np.array_equal(tab, ob.bloom)                       # 256 MiB, merged == single-stream
+    assert bool(a.check_many(dev_keys(n // 2, n)).all())
