@@ -473,27 +473,27 @@ static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, con
                           uint64_t n, hipStream_t st)
 {
     using Tile = PartTile<Pay, KT>;
-    constexpr uint32_t WPP = Pay::has ? 2 : 1;
     const uint64_t ntiles = (n + Tile::TILE - 1) / Tile::TILE;
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
-    const size_t lds = (4 * (size_t)g->nbuckets + 8 + ((size_t)Tile::TILE * kk + 3 * (size_t)g->nbuckets) * WPP) * 4;
-    uint64_t per_cu = lds > 76 * 1024 ? 1 : (lds > 50 * 1024 ? 2 : (lds > 38 * 1024 ? 3 : 4));
+    const size_t stage_words = ((size_t)Tile::TILE * kk + (size_t)(Tile::GS - 1) * g->nbuckets) * (Tile::pair ? 2 : 1);
+    const size_t lds = (4 * (size_t)g->nbuckets + 8 + stage_words) * 4;
+    uint64_t per_cu = lds > 76 * 1024 ? 1 : 2;
     if (g->dbg & 8) per_cu = 1;  // ablation: one workgroup per CU
     uint64_t nwg = 256 * per_cu;
     if (nwg > ntiles) nwg = ntiles;
     const uint64_t tiles_per_wg = (ntiles + nwg - 1) / nwg;
-    const double mean = (double)tiles_per_wg * Tile::TILE * kk / (double)g->nbuckets;
-    // + 1.5 pad probes per (tile, slice) run on average, + 8 sigma for uniform hashes
-    uint64_t segcap = (uint64_t)(mean + 1.5 * (double)tiles_per_wg + 8.0 * __builtin_sqrt(mean) + 32.0);
-    segcap = (segcap + 3) & ~3ULL;
+    const double mean = (double)tiles_per_wg * Tile::TILE * kk / (double)g->nbuckets;  // probes per segment
+    // 16-byte groups per segment: mean/GS, + ~half a group of padding per (tile, slice) run, + 8 sigma
+    const uint64_t segcap = (uint64_t)(mean / Tile::GS + 0.5 * (double)tiles_per_wg + 8.0 * __builtin_sqrt(mean) / Tile::GS + 16.0);
     g->nwg = (uint32_t)nwg;
     g->segcap = (uint32_t)segcap;
-    PSK_TRY(ensure(s->s_part, (uint64_t)g->nbuckets * nwg * segcap * 4 * WPP + 256));
+    g->tile = (uint32_t)Tile::TILE;
+    PSK_TRY(ensure(s->s_part, (uint64_t)g->nbuckets * nwg * segcap * 16 + 256));
     PSK_TRY(ensure(s->s_cnt, (uint64_t)g->nbuckets * nwg * 4 + 64));  // + 6 x u64 of phase profile (dbg & 32)
     auto kern = k_part_scatter<Src, IdxFn, Pay, Spill, KT>;
     PSK_TRY(set_dyn_lds(kern, lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kPartThreads), lds, st, src, idxfn, pay, spill, *g, n,
-                       (uint32_t *)s->s_cnt.p, (uint32_t *)s->s_part.p);
+                       (uint32_t *)s->s_cnt.p, (uint4 *)s->s_part.p);
     HIP_TRY(hipGetLastError());
     return PSK_OK;
 }
@@ -577,7 +577,7 @@ static int bloom_add_partitioned(psk_sketch *s, const Batch &b, hipStream_t st, 
         const size_t lds = (size_t)1 << (g.shift - 3);
         PSK_TRY(set_dyn_lds(k_bloom_apply, lds));
         hipLaunchKernelGGL(k_bloom_apply, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table,
-                           s->padded_bytes / 4, g, (const uint32_t *)s->s_cnt.p, (const uint32_t *)s->s_part.p);
+                           s->padded_bytes / 4, g, (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p);
         HIP_TRY(hipGetLastError());
     }
     *done = true;
@@ -617,7 +617,7 @@ static int bloom_check_partitioned(psk_sketch *s, const Batch &b, uint8_t *out_d
         const size_t lds = (size_t)1 << (g.shift - 3);
         PSK_TRY(set_dyn_lds(k_bloom_test, lds));
         hipLaunchKernelGGL(k_bloom_test, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (const uint32_t *)s->table,
-                           s->padded_bytes / 4, g, (const uint32_t *)s->s_cnt.p, (const uint32_t *)s->s_part.p, out);
+                           s->padded_bytes / 4, g, (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, out);
         HIP_TRY(hipGetLastError());
     }
     *done = true;
@@ -664,12 +664,12 @@ static int counter_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t
             auto kern = k_counter_apply<SIGNED, true, NEG>;
             PSK_TRY(set_dyn_lds(kern, lds));
             hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g,
-                               (const uint32_t *)s->s_cnt.p, (const uint32_t *)s->s_part.p, (const long long *)s->ctr, sat);
+                               (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (const long long *)s->ctr, sat);
         } else {
             auto kern = k_counter_apply<SIGNED, false, NEG>;
             PSK_TRY(set_dyn_lds(kern, lds));
             hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g,
-                               (const uint32_t *)s->s_cnt.p, (const uint32_t *)s->s_part.p, (const long long *)s->ctr, sat);
+                               (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (const long long *)s->ctr, sat);
         }
         HIP_TRY(hipGetLastError());
     }

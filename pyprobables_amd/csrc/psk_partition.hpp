@@ -6,18 +6,22 @@
 // and the kernels pinned to that transaction ceiling.  Here the table is cut into slices that fit
 // one CU's LDS (<= 128 KiB of the 160 KiB):
 //   pass 1  k_part_scatter : hash the keys, bin every probe by slice (LDS histogram + LDS counting
-//                            sort per tile of ~2048 keys) and append each bin as a coalesced run to the
-//                            (slice, workgroup) SEGMENT of the bucket buffer in HBM (4 B / probe,
-//                            +4 B payload when needed).  Segments are private to one workgroup, so the
-//                            append cursor lives in LDS: no global atomics, no cross-workgroup line sharing
-//                            (a first version reserved space with one returning device atomic per
-//                            (tile, slice): 1.25 M atomics = 300 of its 400 us).
+//                            sort per tile of 1024..2048 keys) and append each bin as a coalesced run of
+//                            16-byte GROUPS to the (slice, workgroup) SEGMENT of the bucket buffer in HBM.
+//                            Segments are private to one workgroup, so the append cursor lives in LDS: no
+//                            global atomics, no cross-workgroup line sharing (a first version reserved
+//                            space with one returning device atomic per (tile, slice): 1.25 M atomics =
+//                            300 of its 400 us).
 //   pass 2  k_*_apply      : one workgroup per slice keeps the slice in LDS, streams the slice's segments
 //                            in (one wave per segment, dwordx4), does the random bit / counter updates
 //                            with LDS atomics (ds_or / ds_add) and merges the slice back with one
 //                            coalesced read-modify-write.  No atomics on the table, no random HBM access.
-// Segment overflow (adversarial / duplicate-heavy batches) falls back to a direct atomic on the
-// table, so the result is always exact.
+// Probe encodings (one uint4 group each, pads = 0xFFFFFFFF):
+//   plain   4 x cell index                                   Bloom insert, unit-weight counter adds
+//   inline  4 x (weight << shift | cell index within slice)  weighted counter adds, weight < 2^(31-shift)
+//   keyed   tile id, 3 x (key index within tile << shift | bit index within slice)      Bloom lookups
+// Anything that does not fit (segment overflow on adversarial / duplicate-heavy batches, weights too
+// large to inline) falls back to an exact direct atomic on the table, so the result is always exact.
 #pragma once
 #include "psk_device.hpp"
 
@@ -30,16 +34,24 @@ constexpr int kPartScanPerThread = kPartMaxBuckets / kPartThreads;  // 4
 constexpr int kPartMaxWg = 512;        // workgroups in pass 1 == segments per slice
 constexpr bool kPartPipeline = true;   // prefetch the next tile's keys under the current tile (see k_part_scatter)
 constexpr bool kPartHash32 = true;     // explicit 32-bit FNV chains for power-of-two tables
-constexpr uint32_t kPadProbe = 0xFFFFFFFFu;  // filler that pads every run to 4 probes; pass 2 skips it
+constexpr uint32_t kPadProbe = 0xFFFFFFFFu;  // filler that pads every run to whole groups; pass 2 skips it
+
+enum PartMode { kModePlain = 0, kModeInline = 1, kModeKeyed = 2 };
 
 struct PartGeom {
     uint32_t nbuckets;      // B = ceil(cells / 2^shift) slices
     uint32_t shift;         // log2(cells per slice)
     uint32_t nwg;           // workgroups of pass 1 (segments per slice)
-    uint32_t segcap;        // probe slots per (slice, workgroup) segment (multiple of 4)
+    uint32_t segcap;        // 16-byte groups per (slice, workgroup) segment
     uint32_t k;             // hashes per key
-    uint32_t dbg;           // ablation bits (bench only): 1 skip stores, 4 skip hashing
+    uint32_t tile;          // keys per pass-1 tile (keyed probes: key = tile id * tile + local index)
+    uint32_t dbg;           // bench-only bits: 1 skip stores, 4 skip hashing, 8 one workgroup per CU, 32 phase profile
 };
+
+// Where segment (slice b, workgroup wg) lives in the bucket buffer.  Workgroup-major: the B runs a workgroup
+// emits per tile go to B neighbouring segments (a few KiB apart) instead of nwg * segcap * 16 B apart
+// (a multiple of 8 KiB).  Measured neutral on MI355X (197.8 vs 196 us); kept because it is the safer layout.
+__device__ __forceinline__ uint64_t seg_index(const PartGeom &g, uint32_t b, uint32_t wg) { return (uint64_t)wg * g.nbuckets + b; }
 
 // idx functors: which table cell does hash j of a key address?
 // lo32: the index needs only the low 32 bits of the hash (power-of-two modulus <= 2^32)
@@ -64,22 +76,28 @@ struct IdxCms {  // countminsketch.py:275:  (h % width) + i*width
     }
 };
 
-// payload functors (second word of a probe)
-struct PayNone { static constexpr bool has = false; __device__ __forceinline__ uint32_t operator()(uint64_t) const { return 0; } };
-struct PayKeyId { static constexpr bool has = true; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return (uint32_t)i; } };
+// payload functors: the second word a probe carries through the LDS sort (key i of a tile starting at base)
+struct PayNone {
+    static constexpr int mode = kModePlain;
+    __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
+};
 struct PayWeight {
-    static constexpr bool has = true;
+    static constexpr int mode = kModeInline;
     const uint32_t *w;  // int32 / uint32 bit patterns; never null here
-    __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return w[i]; }
+    __device__ __forceinline__ uint32_t operator()(uint64_t i, uint64_t) const { return w[i]; }
+};
+struct PayKeyId {
+    static constexpr int mode = kModeKeyed;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i, uint64_t base) const { return (uint32_t)(i - base); }
 };
 
-// fallback for a probe that did not fit its segment: apply it straight to the table
+// fallback for a probe that cannot go through the bucket buffer: apply it straight to the table
 struct SpillBloomOr {
     uint32_t *tab;
     __device__ __forceinline__ void operator()(uint32_t idx, uint32_t) const { atomicOr(tab + (idx >> 5), 1u << (idx & 31)); }
 };
 template <bool SIGNED>
-struct SpillCounter {  // counter probe that did not fit its segment: saturating CAS add straight on the table
+struct SpillCounter {  // saturating CAS add (countminsketch.py:280-284,312-316 / countingbloom.py:149-153)
     uint32_t *tab;
     bool unit, neg;
     unsigned long long *sat_ctr;
@@ -90,7 +108,7 @@ struct SpillCounter {  // counter probe that did not fit its segment: saturating
         else cbf_sat_add(tab + idx, v, sat_ctr);
     }
 };
-struct SpillBloomTest {  // lookup probe that did not fit its segment: test it directly (bloom.py:269-271)
+struct SpillBloomTest {  // lookup probe: test it directly (bloom.py:269-271); `key` is the index inside this round
     const uint32_t *tab;
     uint8_t *out;
     __device__ __forceinline__ void operator()(uint32_t idx, uint32_t key) const
@@ -129,43 +147,47 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
 
 // ------------------------------------------------------------------------------------ pass 1
 // KT = hashes computed per key (>= k, compile time so the probes stay in registers).
-// dynamic LDS: hist[B] | off[B] | delta[B] | cur[B] | wave_tot[8] | stage[tile_probes * (1 + has_payload)]
+// dynamic LDS: hist[B] | off[B] | delta[B] | cur[B] | wave_tot[8] | stage (1 or 2 words per probe)
 template <class Pay, int KT>
 struct PartTile {
-    static constexpr int PP = Pay::has ? kPartProbes / 2 : kPartProbes;  // stage <= 64 KiB either way
-    static constexpr int KPT = PP / KT >= 1 ? PP / KT : 1;               // keys per thread per tile
-    static constexpr int TILE = kPartThreads * KPT;                      // keys per tile
+    static constexpr bool pair = Pay::mode != kModePlain;           // stage entry = (cell, payload)
+    static constexpr int GS = Pay::mode == kModeKeyed ? 3 : 4;      // probes per 16-byte output group
+    static constexpr int PP = kPartProbes / 2;                      // 16 probes per thread: <= 100 VGPRs, 2 workgroups per CU
+    static constexpr int KPT = PP / KT >= 1 ? PP / KT : 1;          // keys per thread per tile
+    static constexpr int TILE = kPartThreads * KPT;                 // keys per tile
 };
 
 template <class Src, class IdxFn, class Pay, class Spill, int KT>
 __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn idxfn, Pay pay, Spill spill, PartGeom g,
-                                                               uint64_t n, uint32_t *segcnt, uint32_t *buckets)
+                                                               uint64_t n, uint32_t *segcnt, uint4 *buckets)
 {
-    constexpr int KPT = PartTile<Pay, KT>::KPT;
-    constexpr int TILE = PartTile<Pay, KT>::TILE;
+    using T = PartTile<Pay, KT>;
+    constexpr int KPT = T::KPT, TILE = T::TILE, GS = T::GS;
+    constexpr bool PAIR = T::pair;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t B = g.nbuckets;
     uint32_t *hist = smem;
     uint32_t *off = hist + B;
     uint32_t *delta = off + B;
-    uint32_t *cur = delta + B;  // fill of my segment of every slice, across all my tiles
+    uint32_t *cur = delta + B;  // groups already appended to my segment of every slice, across all my tiles
     uint32_t *wave_tot = cur + B;
     uint32_t *stage = wave_tot + 8;
     const uint32_t k = g.k;
+    const uint32_t mask = (1u << g.shift) - 1;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
 
     for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) cur[b] = 0;
+
     // Software pipeline over tiles: the NEXT tile's keys are loaded right after this tile's hash phase and
-    // pinned before this tile's write-out stores are issued.  vmcnt counts loads and stores in order on
-    // CDNA4, so a key load waited for AFTER the stores would also wait for ~300 KB of stores to drain
-    // (measured: 40 us of a 165 us kernel).  Now the stores drain underneath the next tile's hashing.
+    // pinned before this tile's write-out stores are issued (vmcnt counts loads and stores in order on CDNA4:
+    // a key load waited for AFTER the stores would also wait for ~300 KB of stores to drain).
     typename Src::Key kcur[KPT];
     if (kPartPipeline) {
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
             const uint64_t i = (uint64_t)blockIdx.x * TILE + (uint64_t)q * kPartThreads + threadIdx.x;
             kcur[q] = src.load(i < n ? i : n - 1);  // coalesced; clamped, never branched around (a conditional load
-        }                                           // makes hipcc wait vmcnt(0) per element: 4 serial round trips)
+        }                                           // makes hipcc wait vmcnt(0) per element: serial round trips)
     }
 
     // phase profile (dbg & 32): lane 0 of wave 0 accumulates s_memtime deltas per phase; bench-only
@@ -177,6 +199,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
         t_prev = t_now;                                                                \
     }
     if ((g.dbg & 32) && threadIdx.x == 0) t_prev = __builtin_readcyclecounter();
+
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) hist[b] = 0;
         lds_barrier();
@@ -190,7 +213,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
             const uint64_t i = base + (uint64_t)q * kPartThreads + threadIdx.x;
             if (i < n) {
                 const typename Src::Key key = kPartPipeline ? kcur[q] : src.load(i);
-                if (Pay::has) payload[q] = pay(i);
+                if (PAIR) payload[q] = pay(i, base);
                 if constexpr (IdxFn::lo32) {  // 32-bit chains (power-of-two table: the upper hash halves are dead)
                     uint32_t h[KT];
                     if (g.dbg & 4) {
@@ -236,15 +259,14 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
         }
 
         // ---- exclusive scan of the histogram; advance my segment cursors (LDS only).
-        // Every run is padded to a multiple of 4 probes with kPadProbe words, so stage positions and
-        // segment slots are both 16-byte aligned and the write-out moves dwordx4 per lane (dword stores
-        // were store-issue bound: 73 of 183 us).
+        // Every run is padded to whole groups of GS probes with kPadProbe, so one lane moves one 16-byte
+        // group from an aligned stage position to an aligned segment slot (dword stores were store-issue bound).
         uint32_t mine[kPartScanPerThread], s = 0;
 #pragma unroll
         for (int c = 0; c < kPartScanPerThread; ++c) {
             const uint32_t b = threadIdx.x * kPartScanPerThread + c;
             mine[c] = b < B ? hist[b] : 0;
-            s += (mine[c] + 3) & ~3u;
+            s += (mine[c] + GS - 1) / GS * GS;
         }
         uint32_t tile_probes;  // padded
         uint32_t run;
@@ -269,13 +291,13 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
         for (int c = 0; c < kPartScanPerThread; ++c) {
             const uint32_t b = threadIdx.x * kPartScanPerThread + c;
             if (b < B) {
-                const uint32_t padded = (mine[c] + 3) & ~3u;
-                off[b] = run;
+                const uint32_t padded = (mine[c] + GS - 1) / GS * GS;
+                off[b] = run;               // stage position of the run, in probes (a multiple of GS)
                 const uint32_t c0 = cur[b];
-                delta[b] = c0 - run;       // segment slot = delta[b] + stage position (both multiples of 4)
-                cur[b] = c0 + padded;
+                delta[b] = c0 - run / GS;   // segment group = delta[b] + stage group
+                cur[b] = c0 + padded / GS;
                 for (uint32_t e = mine[c]; e < padded; ++e) {
-                    if (Pay::has) reinterpret_cast<uint2 *>(stage)[run + e] = make_uint2(kPadProbe, 0u);
+                    if (PAIR) reinterpret_cast<uint2 *>(stage)[run + e] = make_uint2(kPadProbe, 0u);
                     else stage[run + e] = kPadProbe;
                 }
                 run += padded;
@@ -294,11 +316,8 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
                 for (int j = 0; j < KT; ++j) {
                     if ((uint32_t)j < k) {
                         const uint32_t p = off[idx[q][j] >> g.shift] + rank[q][j];
-                        if (Pay::has) {
-                            reinterpret_cast<uint2 *>(stage)[p] = make_uint2(idx[q][j], payload[q]);
-                        } else {
-                            stage[p] = idx[q][j];
-                        }
+                        if (PAIR) reinterpret_cast<uint2 *>(stage)[p] = make_uint2(idx[q][j], payload[q]);
+                        else stage[p] = idx[q][j];
                     }
                 }
             }
@@ -306,41 +325,57 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
         lds_barrier();
         PSK_TICK(4);
 
-        // ---- write out: consecutive lanes -> consecutive stage slots -> runs of consecutive segment slots
+        // ---- write out: one lane = one group of GS probes of ONE run; its first probe is always real (pads
+        // trail), so it names the slice
 #pragma unroll
         for (int q = 0; q < KPT; ++q)
             if (kPartPipeline) Src::pin(kcur[q]);  // next tile's keys have landed: nothing to wait for later
         if (!(g.dbg & 1)) {
-            // one group = 4 consecutive probes of ONE run (runs are multiples of 4); its first probe is
-            // always a real one (pads trail), so it names the slice
-            for (uint32_t p4 = threadIdx.x; p4 < (tile_probes >> 2); p4 += kPartThreads) {
-                const uint32_t p = p4 << 2;
-                if (Pay::has) {
-                    const uint4 q0 = reinterpret_cast<const uint4 *>(stage)[2 * p4];      // idx0 pay0 idx1 pay1
-                    const uint4 q1 = reinterpret_cast<const uint4 *>(stage)[2 * p4 + 1];  // idx2 pay2 idx3 pay3
-                    const uint32_t b = q0.x >> g.shift;
-                    const uint32_t slot = delta[b] + p;
-                    if (slot + 4 <= g.segcap) {
-                        uint4 *dst = reinterpret_cast<uint4 *>(buckets + (((uint64_t)b * g.nwg + blockIdx.x) * g.segcap + slot) * 2);
-                        dst[0] = q0;
-                        dst[1] = q1;
-                    } else {  // segment full: exact fallback, probe by probe
-                        if (q0.x != kPadProbe) spill(q0.x, q0.y);
-                        if (q0.z != kPadProbe) spill(q0.z, q0.w);
-                        if (q1.x != kPadProbe) spill(q1.x, q1.y);
-                        if (q1.z != kPadProbe) spill(q1.z, q1.w);
-                    }
-                } else {
-                    const uint4 q = reinterpret_cast<const uint4 *>(stage)[p4];
+            const uint32_t ngroups = tile_probes / GS;
+            for (uint32_t gi = threadIdx.x; gi < ngroups; gi += kPartThreads) {
+                if constexpr (Pay::mode == kModePlain) {
+                    const uint4 q = reinterpret_cast<const uint4 *>(stage)[gi];
                     const uint32_t b = q.x >> g.shift;
-                    const uint32_t slot = delta[b] + p;
-                    if (slot + 4 <= g.segcap) {
-                        *reinterpret_cast<uint4 *>(buckets + ((uint64_t)b * g.nwg + blockIdx.x) * g.segcap + slot) = q;
-                    } else {
+                    const uint32_t slot = delta[b] + gi;
+                    if (slot < g.segcap) {
+                        buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = q;
+                    } else {  // segment full: exact fallback, probe by probe
                         if (q.x != kPadProbe) spill(q.x, 0u);
                         if (q.y != kPadProbe) spill(q.y, 0u);
                         if (q.z != kPadProbe) spill(q.z, 0u);
                         if (q.w != kPadProbe) spill(q.w, 0u);
+                    }
+                } else if constexpr (Pay::mode == kModeInline) {
+                    const uint4 e01 = reinterpret_cast<const uint4 *>(stage)[2 * gi];      // cell0 w0 cell1 w1
+                    const uint4 e23 = reinterpret_cast<const uint4 *>(stage)[2 * gi + 1];  // cell2 w2 cell3 w3
+                    const uint32_t b = e01.x >> g.shift;
+                    const uint32_t slot = delta[b] + gi;
+                    const bool room = slot < g.segcap;
+                    const uint32_t wmax = 1u << (31 - g.shift);  // weights below this ride inside the probe word
+                    auto enc = [&](uint32_t cell, uint32_t w) -> uint32_t {
+                        if (cell == kPadProbe) return kPadProbe;
+                        if (room && w < wmax) return (w << g.shift) | (cell & mask);
+                        spill(cell, w);  // big / negative weight, or segment full: exact saturating add on the table
+                        return kPadProbe;
+                    };
+                    const uint4 o = make_uint4(enc(e01.x, e01.y), enc(e01.z, e01.w), enc(e23.x, e23.y), enc(e23.z, e23.w));
+                    if (room) buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = o;
+                } else {  // keyed
+                    const uint2 e0 = reinterpret_cast<const uint2 *>(stage)[3 * gi];
+                    const uint2 e1 = reinterpret_cast<const uint2 *>(stage)[3 * gi + 1];
+                    const uint2 e2 = reinterpret_cast<const uint2 *>(stage)[3 * gi + 2];
+                    const uint32_t b = e0.x >> g.shift;
+                    const uint32_t slot = delta[b] + gi;
+                    if (slot < g.segcap) {
+                        auto enc = [&](uint2 e) -> uint32_t {
+                            return e.x == kPadProbe ? kPadProbe : ((e.y << g.shift) | (e.x & mask));
+                        };
+                        buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] =
+                            make_uint4((uint32_t)tile, enc(e0), enc(e1), enc(e2));
+                    } else {
+                        if (e0.x != kPadProbe) spill(e0.x, (uint32_t)base + e0.y);
+                        if (e1.x != kPadProbe) spill(e1.x, (uint32_t)base + e1.y);
+                        if (e2.x != kPadProbe) spill(e2.x, (uint32_t)base + e2.y);
                     }
                 }
             }
@@ -357,8 +392,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
         atomicAdd(prof, 1ULL);
     }
 #undef PSK_TICK
-    // publish how much of each of my segments is valid (kernel boundary orders it before pass 2);
-    // cur and segcap are multiples of 4, so the clipped count matches the group-wise store above
+    // publish how many groups of each of my segments are valid (the kernel boundary orders it before pass 2)
     for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
         const uint32_t c = cur[b];
         segcnt[(uint64_t)b * g.nwg + blockIdx.x] = c < g.segcap ? c : g.segcap;
@@ -369,34 +403,31 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
 constexpr int kApplyThreads = 1024;
 constexpr int kApplyWaves = kApplyThreads / 64;
 
-// Walk the segments of slice `b`: wave w takes segments w, w+16, ...; f4(uint4) for aligned groups of 4 words,
-// f1(pointer to a probe) for the tail.  WPP = words per probe (1 or 2).
-template <int WPP, class F4, class F1>
-__device__ __forceinline__ void for_each_segment_word(const uint32_t *buckets, const uint32_t *segcnt, const PartGeom &g,
-                                                      uint32_t b, F4 f4, F1 f1)
+// Walk the groups of slice `b`: wave w takes segments w, w+16, ...
+// Segments are short (a few hundred probes), so a naive walk is a chain of dependent HBM latencies
+// (count -> data -> next count ...).  Instead: fetch all of this wave's segment counts with ONE load, then
+// keep U segments x R dwordx4 per lane in flight before touching LDS.
+template <class F4>
+__device__ __forceinline__ void for_each_group(const uint4 *buckets, const uint32_t *segcnt, const PartGeom &g, uint32_t b, F4 f4)
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // Segments are short (a few hundred probes), so a naive walk is a chain of dependent HBM latencies
-    // (count -> data -> next count ...).  Instead: fetch all of this wave's segment counts with ONE load,
-    // then keep U segments x R dwordx4 per lane in flight before touching LDS.
     const uint32_t nseg = g.nwg > wave ? (g.nwg - wave + kApplyWaves - 1) / kApplyWaves : 0;  // <= 32
     uint32_t mycnt = 0;
     if (lane < nseg) mycnt = segcnt[(uint64_t)b * g.nwg + wave + kApplyWaves * lane];
     constexpr int U = 4, R = 3;
     for (uint32_t s0 = 0; s0 < nseg; s0 += U) {
         uint4 q[U][R];
-        uint32_t words[U], nvec[U];
-        const uint32_t *src[U];
+        uint32_t nvec[U];
+        const uint4 *src[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t sl = s0 + u;
-            words[u] = sl < nseg ? (uint32_t)__shfl((int)mycnt, (int)sl) * WPP : 0;
-            nvec[u] = words[u] >> 2;
-            src[u] = buckets + ((uint64_t)b * g.nwg + wave + kApplyWaves * sl) * g.segcap * WPP;
+            nvec[u] = sl < nseg ? (uint32_t)__shfl((int)mycnt, (int)sl) : 0;
+            src[u] = buckets + seg_index(g, b, wave + kApplyWaves * sl) * g.segcap;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t v = lane + 64 * r;
-                if (v < nvec[u]) q[u][r] = reinterpret_cast<const uint4 *>(src[u])[v];
+                if (v < nvec[u]) q[u][r] = src[u][v];
             }
         }
 #pragma unroll
@@ -404,8 +435,7 @@ __device__ __forceinline__ void for_each_segment_word(const uint32_t *buckets, c
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (lane + 64 * r < nvec[u]) f4(q[u][r]);
-            for (uint32_t v = lane + 64 * R; v < nvec[u]; v += 64) f4(reinterpret_cast<const uint4 *>(src[u])[v]);
-            for (uint32_t p = (nvec[u] << 2) + lane * WPP; p < words[u]; p += 64 * WPP) f1(src[u] + p);
+            for (uint32_t v = lane + 64 * R; v < nvec[u]; v += 64) f4(src[u][v]);
         }
     }
 }
@@ -413,7 +443,7 @@ __device__ __forceinline__ void for_each_segment_word(const uint32_t *buckets, c
 // Bloom insert: OR the slice's probes into an LDS image of the slice, then OR the image into the table.
 // dynamic LDS: slice image, 2^shift bits
 __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *tab, uint64_t tab_words, PartGeom g,
-                                                               const uint32_t *segcnt, const uint32_t *buckets)
+                                                               const uint32_t *segcnt, const uint4 *buckets)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = blockIdx.x;
@@ -424,9 +454,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *tab, ui
     auto set = [&](uint32_t x) {
         if (x != kPadProbe) atomicOr(&smem[(x & mask) >> 5], 1u << (x & 31));  // ds_or_b32
     };
-    for_each_segment_word<1>(
-        buckets, segcnt, g, b, [&](const uint4 q) { set(q.x); set(q.y); set(q.z); set(q.w); },
-        [&](const uint32_t *p) { set(*p); });
+    for_each_group(buckets, segcnt, g, b, [&](const uint4 q) { set(q.x); set(q.y); set(q.z); set(q.w); });
     __syncthreads();
     // merge: this workgroup is the only writer of its slice
     const uint64_t w0 = (uint64_t)b * slice_words;
@@ -448,8 +476,9 @@ __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *tab, ui
 
 // Bloom lookup: the slice is loaded into LDS; a probe whose bit is clear zeroes its key's result byte
 // (out[] is pre-set to 1; every writer stores the same 0, so plain byte stores suffice).
+// group = (tile id, 3 x (key index in tile << shift | bit index in slice))
 __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint32_t *tab, uint64_t tab_words, PartGeom g,
-                                                              const uint32_t *segcnt, const uint32_t *buckets, uint8_t *out)
+                                                              const uint32_t *segcnt, const uint4 *buckets, uint8_t *out)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = blockIdx.x;
@@ -468,70 +497,59 @@ __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint32_t *ta
         *reinterpret_cast<uint4 *>(smem + w) = t;
     }
     __syncthreads();
-    auto test = [&](uint32_t x, uint32_t key) {
-        if (x != kPadProbe && ((smem[(x & mask) >> 5] >> (x & 31)) & 1u) == 0) out[key] = 0;
-    };
-    for_each_segment_word<2>(
-        buckets, segcnt, g, b, [&](const uint4 q) { test(q.x, q.y); test(q.z, q.w); },
-        [&](const uint32_t *p) { test(p[0], p[1]); });
+    for_each_group(buckets, segcnt, g, b, [&](const uint4 q) {
+        const uint32_t kbase = q.x * g.tile;
+        auto test = [&](uint32_t x) {
+            if (x != kPadProbe && ((smem[(x & mask) >> 5] >> (x & 31)) & 1u) == 0) out[kbase + (x >> g.shift)] = 0;
+        };
+        test(q.y);
+        test(q.z);
+        test(q.w);
+    });
 }
 
 // Counter add (CMS / CBF fast path): accumulate the slice's weights into an LDS image with ds_add, then
 // fold the image into the table with the reference's saturating add.
 // SIGNED: int32 bins clamped at both rails (countminsketch.py:280-284 / :312-316);
 // else uint32 counters clamped at 2^32-1 (countingbloom.py:149-153).
-// Exact for any order as long as the per-cell partial sums do not wrap 32 bits -- the caller
-// guarantees sum|w| of the batch < 2^31.
+// Exact for any order as long as the per-cell partial sums do not wrap 32 bits: unit weights -- the host
+// checks n*k < 2^31; weighted -- ctr[6] = sum|w| of the batch, else every probe takes the saturating CAS.
 template <bool SIGNED, bool WEIGHTED, bool NEG>
 __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, uint64_t tab_cells, PartGeom g,
-                                                                 const uint32_t *segcnt, const uint32_t *buckets,
+                                                                 const uint32_t *segcnt, const uint4 *buckets,
                                                                  const long long *ctr, unsigned long long *sat_ctr)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = blockIdx.x;
     const uint32_t slice_cells = 1u << g.shift;
     const uint32_t mask = slice_cells - 1;
+    const uint64_t c0 = (uint64_t)b * slice_cells;
     if (WEIGHTED && ctr[6] >= (1LL << 31)) {
-        // sum|w| of this batch could wrap a 32-bit partial sum: apply every probe with the saturating
-        // CAS instead (this workgroup still owns the slice; rare, exact, slow)
-        for_each_segment_word<2>(
-            buckets, segcnt, g, b,
-            [&](const uint4 q) {
-                if (SIGNED) {
-                    if (q.x != kPadProbe) cms_sat_add((int32_t *)tab + q.x, NEG ? -(int64_t)(int32_t)q.y : (int64_t)(int32_t)q.y, sat_ctr);
-                    if (q.z != kPadProbe) cms_sat_add((int32_t *)tab + q.z, NEG ? -(int64_t)(int32_t)q.w : (int64_t)(int32_t)q.w, sat_ctr);
-                } else {
-                    if (q.x != kPadProbe) cbf_sat_add(tab + q.x, q.y, sat_ctr);
-                    if (q.z != kPadProbe) cbf_sat_add(tab + q.z, q.w, sat_ctr);
-                }
-            },
-            [&](const uint32_t *p) {
-                if (p[0] == kPadProbe) return;
-                if (SIGNED) cms_sat_add((int32_t *)tab + p[0], NEG ? -(int64_t)(int32_t)p[1] : (int64_t)(int32_t)p[1], sat_ctr);
-                else cbf_sat_add(tab + p[0], p[1], sat_ctr);
-            });
+        auto slow = [&](uint32_t x) {
+            if (x == kPadProbe) return;
+            const uint64_t cell = c0 + (x & mask);
+            const uint32_t w = x >> g.shift;
+            if (SIGNED) cms_sat_add((int32_t *)tab + cell, NEG ? -(int64_t)w : (int64_t)w, sat_ctr);
+            else cbf_sat_add(tab + cell, w, sat_ctr);
+        };
+        for_each_group(buckets, segcnt, g, b, [&](const uint4 q) { slow(q.x); slow(q.y); slow(q.z); slow(q.w); });
         return;
     }
     for (uint32_t w = threadIdx.x; w < slice_cells; w += kApplyThreads) smem[w] = 0;
     __syncthreads();
     if (WEIGHTED) {
-        auto add = [&](uint32_t x, uint32_t w) {
-            if (x != kPadProbe) atomicAdd(&smem[x & mask], NEG ? 0u - w : w);  // ds_add_u32
+        auto add = [&](uint32_t x) {
+            if (x != kPadProbe) atomicAdd(&smem[x & mask], NEG ? 0u - (x >> g.shift) : (x >> g.shift));  // ds_add_u32
         };
-        for_each_segment_word<2>(
-            buckets, segcnt, g, b, [&](const uint4 q) { add(q.x, q.y); add(q.z, q.w); },
-            [&](const uint32_t *p) { add(p[0], p[1]); });
+        for_each_group(buckets, segcnt, g, b, [&](const uint4 q) { add(q.x); add(q.y); add(q.z); add(q.w); });
     } else {
         const uint32_t one = NEG ? 0xFFFFFFFFu : 1u;
         auto add = [&](uint32_t x) {
             if (x != kPadProbe) atomicAdd(&smem[x & mask], one);
         };
-        for_each_segment_word<1>(
-            buckets, segcnt, g, b, [&](const uint4 q) { add(q.x); add(q.y); add(q.z); add(q.w); },
-            [&](const uint32_t *p) { add(*p); });
+        for_each_group(buckets, segcnt, g, b, [&](const uint4 q) { add(q.x); add(q.y); add(q.z); add(q.w); });
     }
     __syncthreads();
-    const uint64_t c0 = (uint64_t)b * slice_cells;
     unsigned long long sat = 0;
     for (uint32_t w = threadIdx.x; w < slice_cells; w += kApplyThreads) {
         const uint64_t gc = c0 + w;

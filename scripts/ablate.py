@@ -34,3 +34,16 @@ tot = sum(buf[1:6])
 for i in range(1, 6):
     print(f"phase {names[i]:16s} {buf[i]/buf[0]/3:10.0f} ticks per WG per launch  ({100.0*buf[i]/tot:5.1f} %)")
 N.set_option("part_debug", 0)
+
+# same phase profile for the lookup (keyed) variant
+N.set_option("part_debug", 32)
+blm.check_many(keys); torch.cuda.synchronize()
+N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 512, buf))
+for _ in range(3):
+    blm.check_many(keys)
+torch.cuda.synchronize()
+N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 512, buf))
+tot = sum(buf[1:6])
+for i in range(1, 6):
+    print(f"check phase {names[i]:16s} {buf[i]/buf[0]/3:10.0f} ticks per WG per launch  ({100.0*buf[i]/tot:5.1f} %)")
+N.set_option("part_debug", 0)
