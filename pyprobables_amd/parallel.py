@@ -17,6 +17,8 @@ replica equal to the table one filter fed the whole stream would hold (SURVEY.md
 
 from __future__ import annotations
 
+import os
+
 from . import _native as N
 
 try:
@@ -45,7 +47,7 @@ def hip_or_reduce(dst, src, nslices: int, slice_words: int) -> None:
 def allreduce_or_(table, group=None, or_reduce=hip_or_reduce):
     """in-place bitwise-OR all-reduce of a 1-D int32 tensor (all_to_all -> OR kernel -> all_gather)"""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not os.environ.get("PSK_FORCE_MERGE_PATH"):  # (the env knob lets a 1-GPU test drive RCCL)
         return table
     n = table.numel()
     slice_words = -(-n // world)
@@ -71,13 +73,15 @@ def _sum_int(value: int, device, group=None) -> int:
     return int(t.item())
 
 
-def merge_bloom(blm, group=None, or_reduce=hip_or_reduce) -> None:
+def merge_bloom(blm, group=None, or_reduce=hip_or_reduce, sync_elements: bool = True) -> None:
     """make every rank's BloomFilter the filter of the union of all ranks' inserts.
 
     ``elements_added`` becomes the SUM over ranks (one filter fed the whole stream counts every add,
-    bloom.py:250) -- not ``union()``'s estimate (bloom.py:427)."""
+    bloom.py:250) -- not ``union()``'s estimate (bloom.py:427).  That scalar all-reduce ends in a host
+    read; pass ``sync_elements=False`` inside a throughput loop and fix the counter up afterwards."""
     allreduce_or_(blm.table_tensor, group, or_reduce)
-    blm.elements_added = _sum_int(blm.elements_added, blm.table_tensor.device, group)
+    if sync_elements:
+        blm.elements_added = _sum_int(blm.elements_added, blm.table_tensor.device, group)
 
 
 def merge_counters(sk, group=None) -> None:

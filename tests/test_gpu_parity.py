@@ -537,3 +537,44 @@ def test_or_reduce_slices_kernel_and_single_rank_merge(pa):
     with pytest.raises(ValueError):  # slices must be 16-byte multiples
         N.check(N.lib().psk_or_reduce_slices(d_dst.data_ptr(), d_src.data_ptr(), 2, 3, 0, None))
     _ = C
+
+
+def test_merge_path_on_rccl_single_rank(pa, oracle, monkeypatch):
+    """drive the real collective composition (all_to_all_single / OR kernel / all_gather_into_tensor / all_reduce)
+    through RCCL on one GPU: catches dtype / API problems the gloo tests cannot see"""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from pyprobables_amd import parallel
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        monkeypatch.setenv("PSK_FORCE_MERGE_PATH", "1")
+        keys = oracle.gen_keys16(0, 50_000)
+        blm = pa.BloomFilter(est_elements=100000, false_positive_rate=0.01)  # 958506 bits: padded, not a multiple of R*16
+        blm.add_many(_dev(keys))
+        before = bytes(blm.bloom)
+        parallel.merge_bloom(blm)
+        assert bytes(blm.bloom) == before and blm.elements_added == 50_000
+        cms = pa.CountMinSketch(width=1009, depth=4)
+        cms.add_many(_dev(keys), _dev(oracle.gen_weights(0, 50_000)))
+        bins, els = bytes(cms._bins), cms.elements_added
+        parallel.merge_counters(cms)
+        assert bytes(cms._bins) == bins and cms.elements_added == els
+        cbf = pa.CountingBloomFilter(est_elements=20000, false_positive_rate=0.01)
+        cbf.add_many(_dev(keys))
+        tab = bytes(cbf.bloom)
+        parallel.merge_counters(cbf)
+        assert bytes(cbf.bloom) == tab and cbf.elements_added == 50_000
+        cbf.add_many(_dev(keys))  # the wrap-free bound was rescanned: adds still work
+        assert cbf.elements_added == 100_000
+    finally:
+        dist.destroy_process_group()
