@@ -1,7 +1,8 @@
 """Build the HIP engine in-tree: ``python -m pyprobables_amd.build`` -> ``csrc/libpsk_hip.so``.
 
-hipcc cross-compiles gfx950 without a GPU.  ``-no-hip-rt`` leaves the hip* symbols undefined so the
-library binds to the HIP runtime already loaded in the process (see ``_native.py``).
+hipcc cross-compiles gfx950 without a GPU.  The translation units (C ABI + direct kernels, and one per
+partitioned-path launcher family) are compiled in parallel, then linked with ``-no-hip-rt``: the hip* symbols stay
+undefined so the library binds to the HIP runtime already loaded in the process (see ``_native.py``).
 """
 
 from __future__ import annotations
@@ -10,12 +11,22 @@ import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
-SOURCES = ["psk_capi.hip"]
-HEADERS = ["psk_device.hpp", "../../include/psk.h"]
+SOURCES = [
+    "psk_capi.hip",
+    "psk_part_bloom_add.hip",
+    "psk_part_bloom_check.hip",
+    "psk_part_cms_add.hip",
+    "psk_part_cms_remove.hip",
+    "psk_part_cbf.hip",
+]
+HEADERS = ["psk_device.hpp", "psk_partition.hpp", "psk_host.hpp", "psk_part_counter.hpp", "../../include/psk.h"]
 OUT = CSRC / "libpsk_hip.so"
+OBJ = CSRC / "build"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fvisibility-inlines-hidden"]
 
 
 def hipcc() -> str:
@@ -25,20 +36,36 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+def _newest_header() -> float:
+    return max((CSRC / h).resolve().stat().st_mtime for h in HEADERS)
+
+
 def needs_build() -> bool:
     if not OUT.exists():
         return True
     t = OUT.stat().st_mtime
-    return any((CSRC / f).resolve().stat().st_mtime > t for f in SOURCES + HEADERS)
+    return _newest_header() > t or any((CSRC / f).stat().st_mtime > t for f in SOURCES)
+
+
+def _compile(src: str, force: bool, verbose: bool) -> Path:
+    obj = OBJ / (Path(src).stem + ".o")
+    dep = max((CSRC / src).stat().st_mtime, _newest_header())
+    if force or not obj.exists() or obj.stat().st_mtime < dep:
+        cmd = [hipcc(), *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=str(CSRC))
+    return obj
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
     if not force and not needs_build():
         return OUT
-    cmd = [
-        hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-no-hip-rt",
-        "-Wno-unused-value", "-o", str(OUT),
-    ] + [str(CSRC / s) for s in SOURCES]
+    OBJ.mkdir(exist_ok=True)
+    jobs = min(len(SOURCES), os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        objs = list(pool.map(lambda s: _compile(s, force, verbose), SOURCES))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-no-hip-rt", "-o", str(OUT), *map(str, objs)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=str(CSRC))

@@ -1,24 +1,11 @@
 // psk_capi.hip -- the extern "C" boundary (include/psk.h) over the gfx950 kernels in psk_device.hpp.
 // Host side: handle bookkeeping, host<->device staging for PSK_HOST buffers, launch geometry.
-#include "psk_device.hpp"
-#include "psk_partition.hpp"
-
-#include <hip/hip_runtime.h>
-
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <new>
-#include <type_traits>
-
-#include "../../include/psk.h"
-
-using namespace psk;
+#include "psk_host.hpp"
 
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char *fmt, ...)
+int fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -27,20 +14,6 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e__ = (expr);                                                                        \
-        if (e__ != hipSuccess)                                                                          \
-            return fail(e__ == hipErrorOutOfMemory ? PSK_ENOMEM : PSK_EHIP, "%s failed: %s (%s:%d)", #expr, \
-                        hipGetErrorString(e__), __FILE__, __LINE__);                                    \
-    } while (0)
-
-#define PSK_TRY(expr)            \
-    do {                         \
-        int rc__ = (expr);       \
-        if (rc__ != PSK_OK)      \
-            return rc__;         \
-    } while (0)
 
 extern "C" const char *psk_last_error(void) { return g_err; }
 extern "C" int psk_version(void) { return 100; }
@@ -58,27 +31,6 @@ extern "C" int psk_device_count(int *count)
     return PSK_OK;
 }
 
-// ------------------------------------------------------------------ handle
-struct DevBuf {
-    void *p = nullptr;
-    uint64_t cap = 0;
-};
-
-struct psk_sketch {
-    int kind;
-    int device;
-    uint64_t m;        // bits (bloom), counters (cbf), width (cms)
-    uint32_t k;        // hashes (bloom/cbf), depth (cms)
-    Mod md;
-    bool pow2;
-    void *table;
-    bool owns_table;
-    uint64_t padded_bytes, logical_bytes;
-    long long *ctr;    // device int64[PSK_CTR_COUNT]
-    DevBuf s_keys, s_offs, s_w, s_out, s_aux;  // staging for PSK_HOST buffers
-    DevBuf s_part, s_cnt;                      // partitioned path: bucket buffer + per-bucket fill counts
-};
-
 static uint64_t round16(uint64_t b) { return (b + 15) & ~15ULL; }
 extern "C" uint64_t psk_bloom_table_bytes(uint64_t m_bits) { return round16((m_bits + 7) / 8); }
 extern "C" uint64_t psk_cbf_table_bytes(uint64_t m) { return round16(4 * m); }
@@ -94,7 +46,7 @@ static Mod make_mod(uint64_t m, bool *pow2)
     return md;
 }
 
-static int ensure(DevBuf &b, uint64_t bytes)
+int ensure(DevBuf &b, uint64_t bytes)
 {
     if (bytes <= b.cap) return PSK_OK;
     if (b.p) HIP_TRY(hipFree(b.p));
@@ -105,6 +57,7 @@ static int ensure(DevBuf &b, uint64_t bytes)
     b.cap = cap;
     return PSK_OK;
 }
+
 
 static int grid_for(uint64_t n)
 {
@@ -287,14 +240,6 @@ extern "C" int psk_reset_counters(psk_sketch *s, void *stream)
 }
 
 // ---------------------------------------------------------- key batches
-struct Batch {  // device-resident view of one key batch
-    int layout;
-    const void *data;
-    const uint64_t *offs;
-    uint64_t n;
-    uint32_t key_len;
-};
-
 static int elem_bytes(int layout) { return layout == PSK_KEYS_VARLEN32 ? 4 : (layout == PSK_KEYS_HASHES ? 8 : 1); }
 
 // Validate, and for PSK_HOST stage the batch into the handle's device scratch.
@@ -402,13 +347,11 @@ static int finish(int where, const OutBuf *o, hipStream_t st)
     return PSK_OK;
 }
 
-// ------------------------------------------------- partitioned (large-batch) path
-// Tunables (psk_set_option): the partitioned path is taken when the batch has at least
-// g_part_min_keys keys and the table geometry allows it; g_part_mode 0 = never, 1 = auto.
-static int64_t g_part_mode = 1;
-static int64_t g_part_min_keys = 1 << 17;
-static int64_t g_part_max_keys = 1 << 25;   // keys per partition round (bounds the bucket buffer)
-static int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGeom::dbg); 0 in production
+// ------------------------------------------------- partitioned (large-batch) path: options
+int64_t g_part_mode = 1;
+int64_t g_part_min_keys = 1 << 17;
+int64_t g_part_max_keys = 1 << 25;   // keys per partition round (bounds the bucket buffer)
+int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGeom::dbg); 0 in production
 
 extern "C" int psk_set_option(const char *name, int64_t value)
 {
@@ -440,240 +383,6 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "partition_min_keys")) *value = g_part_min_keys;
     else if (!strcmp(name, "partition_max_keys")) *value = g_part_max_keys;
     else return fail(PSK_EINVAL, "unknown option %s", name);
-    return PSK_OK;
-}
-
-// slices of a table of `cells` cells; max_shift = log2(cells one LDS slice may hold)
-static bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_shift, PartGeom *g)
-{
-    if (cells >= (1ULL << 32) || cells < (1ULL << 16)) return false;  // cell index 0xFFFFFFFF is the pad marker
-    const uint32_t lg = 63 - __builtin_clzll(cells);  // floor(log2 cells)
-    int shift = (int)lg - 8;                          // aim at 256..511 slices: one per CU
-    if (shift > (int)max_shift) shift = max_shift;
-    if (shift < (int)min_shift) shift = min_shift;
-    const uint64_t B = (cells + (1ULL << shift) - 1) >> shift;
-    if (B > (uint64_t)kPartMaxBuckets) return false;
-    g->nbuckets = (uint32_t)B;
-    g->shift = (uint32_t)shift;
-    g->dbg = (uint32_t)g_part_debug;
-    return true;
-}
-
-template <class K>
-static int set_dyn_lds(K kernel, size_t bytes)
-{
-    HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return PSK_OK;
-}
-
-// Pass 1 for one concrete (Src, IdxFn, Pay, Spill, KT): sizes the (slice, workgroup) segments for `n` keys,
-// grows the handle's bucket buffer, launches.  g->nwg / g->segcap are filled in for pass 2.
-template <class Src, class IdxFn, class Pay, class Spill, int KT>
-static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, PartGeom *g,
-                          uint64_t n, hipStream_t st)
-{
-    using Tile = PartTile<Pay, KT>;
-    const uint64_t ntiles = (n + Tile::TILE - 1) / Tile::TILE;
-    const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
-    const size_t stage_words = ((size_t)Tile::TILE * kk + (size_t)(Tile::GS - 1) * g->nbuckets) * (Tile::pair ? 2 : 1);
-    const size_t lds = (4 * (size_t)g->nbuckets + 8 + stage_words) * 4;
-    uint64_t per_cu = lds > 76 * 1024 ? 1 : 2;
-    if (g->dbg & 8) per_cu = 1;  // ablation: one workgroup per CU
-    uint64_t nwg = 256 * per_cu;
-    if (nwg > ntiles) nwg = ntiles;
-    const uint64_t tiles_per_wg = (ntiles + nwg - 1) / nwg;
-    const double mean = (double)tiles_per_wg * Tile::TILE * kk / (double)g->nbuckets;  // probes per segment
-    // 16-byte groups per segment: mean/GS, + ~half a group of padding per (tile, slice) run, + 8 sigma
-    const uint64_t segcap = (uint64_t)(mean / Tile::GS + 0.5 * (double)tiles_per_wg + 8.0 * __builtin_sqrt(mean) / Tile::GS + 16.0);
-    g->nwg = (uint32_t)nwg;
-    g->segcap = (uint32_t)segcap;
-    g->tile = (uint32_t)Tile::TILE;
-    PSK_TRY(ensure(s->s_part, (uint64_t)g->nbuckets * nwg * segcap * 16 + 256));
-    PSK_TRY(ensure(s->s_cnt, (uint64_t)g->nbuckets * nwg * 4 + 64));  // + 6 x u64 of phase profile (dbg & 32)
-    auto kern = k_part_scatter<Src, IdxFn, Pay, Spill, KT>;
-    PSK_TRY(set_dyn_lds(kern, lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kPartThreads), lds, st, src, idxfn, pay, spill, *g, n,
-                       (uint32_t *)s->s_cnt.p, (uint4 *)s->s_part.p);
-    HIP_TRY(hipGetLastError());
-    return PSK_OK;
-}
-
-// compile-time hash count: exact for the common small k on the 16-byte fast layout, rounded up otherwise
-template <class Src, class F>
-static int with_kt(uint32_t k, F &&f)
-{
-    constexpr bool fast = std::is_same<Src, KeysFixed16>::value;
-    if (fast) {
-        switch (k) {
-            case 4: return f(std::integral_constant<int, 4>{});
-            case 5: return f(std::integral_constant<int, 5>{});
-            case 7: return f(std::integral_constant<int, 7>{});
-            default: break;
-        }
-    }
-    if (k <= 8) return f(std::integral_constant<int, 8>{});
-    return f(std::integral_constant<int, 16>{});
-}
-
-// sources the partitioned path is instantiated for (the rest use the direct kernels)
-template <class F>
-static int with_part_source(const Batch &b, bool *handled, F &&f)
-{
-    *handled = true;
-    switch (b.layout) {
-        case PSK_KEYS_FIXED:
-            if (b.key_len == 16 && ((uintptr_t)b.data & 15) == 0) return f(KeysFixed16{(const uint4 *)b.data});
-            if (b.key_len % 4 == 0 && ((uintptr_t)b.data & 3) == 0) return f(KeysFixed<true>{(const uint8_t *)b.data, b.key_len});
-            break;
-        case PSK_KEYS_VARLEN8: return f(KeysVarlen<uint8_t>{(const uint8_t *)b.data, b.offs});
-        case PSK_KEYS_HASHES: return f(KeysHashes{(const uint64_t *)b.data, b.key_len});
-        default: break;
-    }
-    *handled = false;
-    return PSK_OK;
-}
-
-static bool part_wanted(uint64_t n, uint32_t k)
-{
-    return g_part_mode != 0 && (int64_t)n >= g_part_min_keys && k <= 16;
-}
-
-// view of keys [start, start+cnt) of a device batch
-static Batch sub_batch(const Batch &b, uint64_t start, uint64_t cnt)
-{
-    Batch sub = b;
-    sub.n = cnt;
-    if (b.layout == PSK_KEYS_VARLEN8 || b.layout == PSK_KEYS_VARLEN32) sub.offs = b.offs + start;
-    else sub.data = (const uint8_t *)b.data + start * (uint64_t)b.key_len * (b.layout == PSK_KEYS_HASHES ? 8 : 1);
-    return sub;
-}
-
-// Bloom insert through the partitioned path; *done = false when this batch/table is not eligible
-static int bloom_add_partitioned(psk_sketch *s, const Batch &b, hipStream_t st, bool *done)
-{
-    *done = false;
-    if (!part_wanted(b.n, s->k)) return PSK_OK;
-    PartGeom g;
-    if (!part_slices(s->m, 20, 7, &g)) return PSK_OK;
-    g.k = s->k;
-    const uint64_t round_keys = (uint64_t)g_part_max_keys < b.n ? (uint64_t)g_part_max_keys : b.n;
-    for (uint64_t start = 0; start < b.n; start += round_keys) {
-        const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
-        const Batch sub = sub_batch(b, start, cnt);
-        bool handled = false;
-        PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
-            using Src = decltype(src);
-            return with_kt<Src>(s->k, [&](auto kt) {
-                constexpr int KT = decltype(kt)::value;
-                SpillBloomOr spill{(uint32_t *)s->table};
-                if (s->pow2)
-                    return launch_scatter<Src, IdxBloom<true>, PayNone, SpillBloomOr, KT>(s, src, IdxBloom<true>{s->md}, PayNone{},
-                                                                                          spill, &g, cnt, st);
-                return launch_scatter<Src, IdxBloom<false>, PayNone, SpillBloomOr, KT>(s, src, IdxBloom<false>{s->md}, PayNone{},
-                                                                                       spill, &g, cnt, st);
-            });
-        }));
-        if (!handled) return PSK_OK;  // layout without a partitioned instantiation: nothing was launched
-        const size_t lds = (size_t)1 << (g.shift - 3);
-        PSK_TRY(set_dyn_lds(k_bloom_apply, lds));
-        hipLaunchKernelGGL(k_bloom_apply, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table,
-                           s->padded_bytes / 4, g, (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p);
-        HIP_TRY(hipGetLastError());
-    }
-    *done = true;
-    return PSK_OK;
-}
-
-// Bloom lookup through the partitioned path: probes carry their key's index; out[] starts at 1 and
-// any probe that finds its bit clear stores a 0
-static int bloom_check_partitioned(psk_sketch *s, const Batch &b, uint8_t *out_dev, hipStream_t st, bool *done)
-{
-    *done = false;
-    if (!part_wanted(b.n, s->k)) return PSK_OK;
-    PartGeom g;
-    if (!part_slices(s->m, 20, 7, &g)) return PSK_OK;
-    g.k = s->k;
-    uint64_t round_keys = (uint64_t)g_part_max_keys < b.n ? (uint64_t)g_part_max_keys : b.n;
-    if (round_keys > 0xFFFFFFFFULL) round_keys = 0xFFFFFFFFULL;  // 32-bit key ids inside a round
-    for (uint64_t start = 0; start < b.n; start += round_keys) {
-        const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
-        const Batch sub = sub_batch(b, start, cnt);
-        uint8_t *out = out_dev + start;
-        bool handled = false;
-        PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
-            using Src = decltype(src);
-            return with_kt<Src>(s->k, [&](auto kt) {
-                constexpr int KT = decltype(kt)::value;
-                HIP_TRY(hipMemsetAsync(out, 1, cnt, st));
-                SpillBloomTest spill{(const uint32_t *)s->table, out};
-                if (s->pow2)
-                    return launch_scatter<Src, IdxBloom<true>, PayKeyId, SpillBloomTest, KT>(s, src, IdxBloom<true>{s->md},
-                                                                                             PayKeyId{}, spill, &g, cnt, st);
-                return launch_scatter<Src, IdxBloom<false>, PayKeyId, SpillBloomTest, KT>(s, src, IdxBloom<false>{s->md},
-                                                                                          PayKeyId{}, spill, &g, cnt, st);
-            });
-        }));
-        if (!handled) return PSK_OK;
-        const size_t lds = (size_t)1 << (g.shift - 3);
-        PSK_TRY(set_dyn_lds(k_bloom_test, lds));
-        hipLaunchKernelGGL(k_bloom_test, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (const uint32_t *)s->table,
-                           s->padded_bytes / 4, g, (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, out);
-        HIP_TRY(hipGetLastError());
-    }
-    *done = true;
-    return PSK_OK;
-}
-
-// Counter add (CMS add / remove, CBF add) through the partitioned path.  IDX = IdxCms / IdxBloom;
-// w_dev = per-key weights (uint32 bit patterns) or nullptr for unit weights.  The caller has already run
-// account_weights(), so ctr[6] holds this batch's sum|w| for the wrap check inside pass 2.
-template <template <bool> class IDX, bool SIGNED, bool NEG>
-static int counter_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, uint64_t cells, hipStream_t st,
-                                   bool *done)
-{
-    *done = false;
-    if (!part_wanted(b.n, s->k)) return PSK_OK;
-    // unit-weight batches cannot wrap a 32-bit partial sum when n*k < 2^31 (weighted ones are checked on the device)
-    if (!w_dev && b.n * (uint64_t)s->k >= (1ULL << 31)) return PSK_OK;
-    PartGeom g;
-    if (!part_slices(cells, 15, 5, &g)) return PSK_OK;  // 2^15 counters = 128 KiB per slice
-    g.k = s->k;
-    const uint64_t round_keys = (uint64_t)g_part_max_keys < b.n ? (uint64_t)g_part_max_keys : b.n;
-    unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
-    for (uint64_t start = 0; start < b.n; start += round_keys) {
-        const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
-        const Batch sub = sub_batch(b, start, cnt);
-        bool handled = false;
-        PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
-            using Src = decltype(src);
-            return with_kt<Src>(s->k, [&](auto kt) {
-                constexpr int KT = decltype(kt)::value;
-                SpillCounter<SIGNED> spill{(uint32_t *)s->table, w_dev == nullptr, NEG, sat};
-                if (w_dev) {
-                    PayWeight pay{w_dev + start};
-                    if (s->pow2) return launch_scatter<Src, IDX<true>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<true>{s->md}, pay, spill, &g, cnt, st);
-                    return launch_scatter<Src, IDX<false>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<false>{s->md}, pay, spill, &g, cnt, st);
-                }
-                if (s->pow2) return launch_scatter<Src, IDX<true>, PayNone, SpillCounter<SIGNED>, KT>(s, src, IDX<true>{s->md}, PayNone{}, spill, &g, cnt, st);
-                return launch_scatter<Src, IDX<false>, PayNone, SpillCounter<SIGNED>, KT>(s, src, IDX<false>{s->md}, PayNone{}, spill, &g, cnt, st);
-            });
-        }));
-        if (!handled) return PSK_OK;
-        const size_t lds = (size_t)4 << g.shift;
-        if (w_dev) {
-            auto kern = k_counter_apply<SIGNED, true, NEG>;
-            PSK_TRY(set_dyn_lds(kern, lds));
-            hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g,
-                               (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (const long long *)s->ctr, sat);
-        } else {
-            auto kern = k_counter_apply<SIGNED, false, NEG>;
-            PSK_TRY(set_dyn_lds(kern, lds));
-            hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g,
-                               (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (const long long *)s->ctr, sat);
-        }
-        HIP_TRY(hipGetLastError());
-    }
-    *done = true;
     return PSK_OK;
 }
 
@@ -785,7 +494,7 @@ extern "C" int psk_cbf_add(psk_sketch *s, int layout, const void *data, const ui
     unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
     {
         bool done = false;
-        PSK_TRY((counter_add_partitioned<IdxBloom, false, false>(s, b, w, s->m, st, &done)));
+        PSK_TRY(cbf_add_partitioned(s, b, w, st, &done));
         if (done) return finish(where, nullptr, st);
     }
     PSK_TRY(with_source(b, [&](auto src) {
@@ -888,7 +597,7 @@ static int cms_update(psk_sketch *s, int layout, const void *data, const uint64_
     unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
     {
         bool done = false;
-        PSK_TRY((counter_add_partitioned<IdxCms, true, NEG>(s, b, (const uint32_t *)w, s->m * (uint64_t)s->k, st, &done)));
+        PSK_TRY(NEG ? cms_remove_partitioned(s, b, (const uint32_t *)w, st, &done) : cms_add_partitioned(s, b, (const uint32_t *)w, st, &done));
         if (done) return finish(where, nullptr, st);
     }
     PSK_TRY(with_source(b, [&](auto src) {

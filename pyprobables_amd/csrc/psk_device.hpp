@@ -709,7 +709,7 @@ __global__ __launch_bounds__(kBlock) void k_weight_sum(const W *w, uint64_t n, l
     }
 }
 
-__global__ void k_ctr_add(long long *ctr, int which, long long v, long long bound_add)
+static __global__ void k_ctr_add(long long *ctr, int which, long long v, long long bound_add)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (which >= 0) ctr[which] += v;
@@ -719,7 +719,7 @@ __global__ void k_ctr_add(long long *ctr, int which, long long v, long long boun
 }
 
 // max |counter| of a freshly loaded table re-seeds the wrap-free bound
-__global__ __launch_bounds__(kBlock) void k_absmax(const uint32_t *tab, uint64_t n, int is_signed, long long *ctr)
+static __global__ __launch_bounds__(kBlock) void k_absmax(const uint32_t *tab, uint64_t n, int is_signed, long long *ctr)
 {
     unsigned long long mx = 0;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(kBlock) void k_table_binop(uint4 *dst, const uint4 
 }
 
 // dst[w] = OR_j src[j*slice + w]: the reduce step of allreduce(OR) (bloom.py:425-426 union is a bytewise OR)
-__global__ __launch_bounds__(kBlock) void k_or_reduce(uint4 *dst, const uint4 *src, uint32_t nslices,
+static __global__ __launch_bounds__(kBlock) void k_or_reduce(uint4 *dst, const uint4 *src, uint32_t nslices,
                                                       uint64_t slice_vec)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(kBlock) void k_or_reduce(uint4 *dst, const uint4 *s
 }
 
 // mode 0: popcount of bits (bloom.py:552-557); mode 1: number of non-zero uint32 (countingbloom.py:302-304)
-__global__ __launch_bounds__(kBlock) void k_table_count(const uint4 *tab, uint64_t nvec, int mode,
+static __global__ __launch_bounds__(kBlock) void k_table_count(const uint4 *tab, uint64_t nvec, int mode,
                                                         unsigned long long *out)
 {
     unsigned long long c = 0;
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(kBlock) void k_table_count(const uint4 *tab, uint64
 }
 
 // countminsketch.py:380-391 join: clamp-add, bins already on a rail stay frozen
-__global__ __launch_bounds__(kBlock) void k_add_sat_i32(int32_t *dst, const int32_t *src, uint64_t n)
+static __global__ __launch_bounds__(kBlock) void k_add_sat_i32(int32_t *dst, const int32_t *src, uint64_t n)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(kBlock) void k_add_sat_i32(int32_t *dst, const int3
 
 // countingbloom.py:296-298 union: plain element-wise sum (the reference raises on uint32 overflow;
 // here overflowing elements are clamped and counted)
-__global__ __launch_bounds__(kBlock) void k_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n,
+static __global__ __launch_bounds__(kBlock) void k_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n,
                                                     unsigned long long *overflowed)
 {
     unsigned long long ov = 0;
@@ -831,7 +831,7 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
     return z ^ (z >> 31);
 }
 
-__global__ __launch_bounds__(kBlock) void k_gen_keys16(ulonglong2 *dst, uint64_t start, uint64_t n, uint64_t seed)
+static __global__ __launch_bounds__(kBlock) void k_gen_keys16(ulonglong2 *dst, uint64_t start, uint64_t n, uint64_t seed)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(kBlock) void k_gen_keys16(ulonglong2 *dst, uint64_t
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_gen_weights(int32_t *dst, uint64_t start, uint64_t n, uint64_t seed)
+static __global__ __launch_bounds__(kBlock) void k_gen_weights(int32_t *dst, uint64_t start, uint64_t n, uint64_t seed)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride)

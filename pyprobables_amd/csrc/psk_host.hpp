@@ -1,0 +1,190 @@
+// psk_host.hpp -- host-side declarations shared by the translation units of libpsk_hip.so
+// (psk_capi.hip = C ABI + direct kernels; psk_part_*.hip = the partitioned-path launchers, split so that
+// hipcc can build the ~300 k_part_scatter instantiations in parallel).
+#pragma once
+#include "psk_device.hpp"
+#include "psk_partition.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <type_traits>
+
+#include "../../include/psk.h"
+
+using namespace psk;
+
+#define PSK_HIDDEN __attribute__((visibility("hidden")))
+
+// ------------------------------------------------------------------ errors
+PSK_HIDDEN int fail(int code, const char *fmt, ...);  // records the thread-local message, returns `code`
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail(e__ == hipErrorOutOfMemory ? PSK_ENOMEM : PSK_EHIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e__), __FILE__, __LINE__);                                    \
+    } while (0)
+
+#define PSK_TRY(expr)            \
+    do {                         \
+        int rc__ = (expr);       \
+        if (rc__ != PSK_OK)      \
+            return rc__;         \
+    } while (0)
+
+// ------------------------------------------------------------------ handle
+// ------------------------------------------------------------------ handle
+struct DevBuf {
+    void *p = nullptr;
+    uint64_t cap = 0;
+};
+
+struct psk_sketch {
+    int kind;
+    int device;
+    uint64_t m;        // bits (bloom), counters (cbf), width (cms)
+    uint32_t k;        // hashes (bloom/cbf), depth (cms)
+    Mod md;
+    bool pow2;
+    void *table;
+    bool owns_table;
+    uint64_t padded_bytes, logical_bytes;
+    long long *ctr;    // device int64[PSK_CTR_COUNT]
+    DevBuf s_keys, s_offs, s_w, s_out, s_aux;  // staging for PSK_HOST buffers
+    DevBuf s_part, s_cnt;                      // partitioned path: bucket buffer + per-bucket fill counts
+};
+
+PSK_HIDDEN int ensure(DevBuf &b, uint64_t bytes);  // grow a scratch buffer
+
+// ---------------------------------------------------------- key batches
+struct Batch {  // device-resident view of one key batch
+    int layout;
+    const void *data;
+    const uint64_t *offs;
+    uint64_t n;
+    uint32_t key_len;
+};
+
+// ------------------------------------------------- partitioned (large-batch) path
+// Tunables (psk_set_option): the partitioned path is taken when the batch has at least g_part_min_keys keys and
+// the table geometry allows it; g_part_mode 0 = never, 1 = auto.
+extern PSK_HIDDEN int64_t g_part_mode, g_part_min_keys, g_part_max_keys, g_part_debug;
+
+// slices of a table of `cells` cells; max_shift = log2(cells one LDS slice may hold)
+static inline bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_shift, PartGeom *g)
+{
+    if (cells >= (1ULL << 32) || cells < (1ULL << 16)) return false;  // cell index 0xFFFFFFFF is the pad marker
+    const uint32_t lg = 63 - __builtin_clzll(cells);  // floor(log2 cells)
+    int shift = (int)lg - 8;                          // aim at 256..511 slices: one per CU
+    if (shift > (int)max_shift) shift = max_shift;
+    if (shift < (int)min_shift) shift = min_shift;
+    const uint64_t B = (cells + (1ULL << shift) - 1) >> shift;
+    if (B > (uint64_t)kPartMaxBuckets) return false;
+    g->nbuckets = (uint32_t)B;
+    g->shift = (uint32_t)shift;
+    g->dbg = (uint32_t)g_part_debug;
+    return true;
+}
+
+template <class K>
+static int set_dyn_lds(K kernel, size_t bytes)
+{
+    HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PSK_OK;
+}
+
+// Pass 1 for one concrete (Src, IdxFn, Pay, Spill, KT): sizes the (slice, workgroup) segments for `n` keys,
+// grows the handle's bucket buffer, launches.  g->nwg / g->segcap are filled in for pass 2.
+template <class Src, class IdxFn, class Pay, class Spill, int KT>
+static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, PartGeom *g,
+                          uint64_t n, hipStream_t st)
+{
+    using Tile = PartTile<Pay, KT>;
+    const uint64_t ntiles = (n + Tile::TILE - 1) / Tile::TILE;
+    const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
+    const size_t stage_words = ((size_t)Tile::TILE * kk + (size_t)(Tile::GS - 1) * g->nbuckets) * (Tile::pair ? 2 : 1);
+    const size_t lds = (4 * (size_t)g->nbuckets + 8 + stage_words) * 4;
+    uint64_t per_cu = lds > 76 * 1024 ? 1 : 2;
+    if (g->dbg & 8) per_cu = 1;  // ablation: one workgroup per CU
+    uint64_t nwg = 256 * per_cu;
+    if (nwg > ntiles) nwg = ntiles;
+    const uint64_t tiles_per_wg = (ntiles + nwg - 1) / nwg;
+    const double mean = (double)tiles_per_wg * Tile::TILE * kk / (double)g->nbuckets;  // probes per segment
+    // 16-byte groups per segment: mean/GS, + ~half a group of padding per (tile, slice) run, + 8 sigma
+    const uint64_t segcap = (uint64_t)(mean / Tile::GS + 0.5 * (double)tiles_per_wg + 8.0 * __builtin_sqrt(mean) / Tile::GS + 16.0);
+    g->nwg = (uint32_t)nwg;
+    g->segcap = (uint32_t)segcap;
+    g->tile = (uint32_t)Tile::TILE;
+    PSK_TRY(ensure(s->s_part, (uint64_t)g->nbuckets * nwg * segcap * 16 + 256));
+    PSK_TRY(ensure(s->s_cnt, (uint64_t)g->nbuckets * nwg * 4 + 64));  // + 6 x u64 of phase profile (dbg & 32)
+    auto kern = k_part_scatter<Src, IdxFn, Pay, Spill, KT>;
+    PSK_TRY(set_dyn_lds(kern, lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kPartThreads), lds, st, src, idxfn, pay, spill, *g, n,
+                       (uint32_t *)s->s_cnt.p, (uint4 *)s->s_part.p);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
+// compile-time hash count: exact for the common small k on the 16-byte fast layout, rounded up otherwise
+template <class Src, class F>
+static int with_kt(uint32_t k, F &&f)
+{
+    constexpr bool fast = std::is_same<Src, KeysFixed16>::value;
+    if (fast) {
+        switch (k) {
+            case 4: return f(std::integral_constant<int, 4>{});
+            case 5: return f(std::integral_constant<int, 5>{});
+            case 7: return f(std::integral_constant<int, 7>{});
+            default: break;
+        }
+    }
+    if (k <= 8) return f(std::integral_constant<int, 8>{});
+    if (k <= 16) return f(std::integral_constant<int, 16>{});
+    return f(std::integral_constant<int, 32>{});
+}
+
+// sources the partitioned path is instantiated for (the rest use the direct kernels)
+template <class F>
+static int with_part_source(const Batch &b, bool *handled, F &&f)
+{
+    *handled = true;
+    switch (b.layout) {
+        case PSK_KEYS_FIXED:
+            if (b.key_len == 16 && ((uintptr_t)b.data & 15) == 0) return f(KeysFixed16{(const uint4 *)b.data});
+            if (b.key_len % 4 == 0 && ((uintptr_t)b.data & 3) == 0) return f(KeysFixed<true>{(const uint8_t *)b.data, b.key_len});
+            return f(KeysFixed<false>{(const uint8_t *)b.data, b.key_len});
+        case PSK_KEYS_VARLEN8: return f(KeysVarlen<uint8_t>{(const uint8_t *)b.data, b.offs});
+        case PSK_KEYS_VARLEN32: return f(KeysVarlen<uint32_t>{(const uint32_t *)b.data, b.offs});
+        case PSK_KEYS_HASHES: return f(KeysHashes{(const uint64_t *)b.data, b.key_len});
+        default: break;
+    }
+    *handled = false;
+    return PSK_OK;
+}
+
+static inline bool part_wanted(uint64_t n, uint32_t k)
+{
+    return g_part_mode != 0 && (int64_t)n >= g_part_min_keys && k <= 32;
+}
+
+// view of keys [start, start+cnt) of a device batch
+static inline Batch sub_batch(const Batch &b, uint64_t start, uint64_t cnt)
+{
+    Batch sub = b;
+    sub.n = cnt;
+    if (b.layout == PSK_KEYS_VARLEN8 || b.layout == PSK_KEYS_VARLEN32) sub.offs = b.offs + start;
+    else sub.data = (const uint8_t *)b.data + start * (uint64_t)b.key_len * (b.layout == PSK_KEYS_HASHES ? 8 : 1);
+    return sub;
+}
+
+// the launchers (one translation unit each); *done = false when the batch / table is not eligible
+PSK_HIDDEN int bloom_add_partitioned(psk_sketch *s, const Batch &b, hipStream_t st, bool *done);
+PSK_HIDDEN int bloom_check_partitioned(psk_sketch *s, const Batch &b, uint8_t *out_dev, hipStream_t st, bool *done);
+PSK_HIDDEN int cms_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);
+PSK_HIDDEN int cms_remove_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);
+PSK_HIDDEN int cbf_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);

@@ -1,0 +1,40 @@
+// partitioned Bloom insert launcher (own translation unit: parallel build)
+#include "psk_host.hpp"
+
+// Bloom insert through the partitioned path; *done = false when this batch/table is not eligible
+int bloom_add_partitioned(psk_sketch *s, const Batch &b, hipStream_t st, bool *done)
+{
+    *done = false;
+    if (!part_wanted(b.n, s->k)) return PSK_OK;
+    PartGeom g;
+    if (!part_slices(s->m, 20, 7, &g)) return PSK_OK;
+    g.k = s->k;
+    const uint64_t round_keys = (uint64_t)g_part_max_keys < b.n ? (uint64_t)g_part_max_keys : b.n;
+    for (uint64_t start = 0; start < b.n; start += round_keys) {
+        const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
+        const Batch sub = sub_batch(b, start, cnt);
+        bool handled = false;
+        PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
+            using Src = decltype(src);
+            return with_kt<Src>(s->k, [&](auto kt) {
+                constexpr int KT = decltype(kt)::value;
+                SpillBloomOr spill{(uint32_t *)s->table};
+                if (s->pow2)
+                    return launch_scatter<Src, IdxBloom<true>, PayNone, SpillBloomOr, KT>(s, src, IdxBloom<true>{s->md}, PayNone{},
+                                                                                          spill, &g, cnt, st);
+                return launch_scatter<Src, IdxBloom<false>, PayNone, SpillBloomOr, KT>(s, src, IdxBloom<false>{s->md}, PayNone{},
+                                                                                       spill, &g, cnt, st);
+            });
+        }));
+        if (!handled) return PSK_OK;  // layout without a partitioned instantiation: nothing was launched
+        const size_t lds = (size_t)1 << (g.shift - 3);
+        PSK_TRY(set_dyn_lds(k_bloom_apply, lds));
+        hipLaunchKernelGGL(k_bloom_apply, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table,
+                           s->padded_bytes / 4, g, (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p);
+        HIP_TRY(hipGetLastError());
+    }
+    *done = true;
+    return PSK_OK;
+}
+
+// Bloom lookup through the partitioned path: probes carry their key's index; out[] starts at 1 and

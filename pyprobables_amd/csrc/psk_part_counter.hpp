@@ -1,0 +1,54 @@
+// psk_part_counter.hpp -- launcher template of the partitioned counter adds (CMS add / remove, CBF add)
+#pragma once
+#include "psk_host.hpp"
+
+// account_weights(), so ctr[6] holds this batch's sum|w| for the wrap check inside pass 2.
+template <template <bool> class IDX, bool SIGNED, bool NEG>
+static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, uint64_t cells, hipStream_t st,
+                                   bool *done)
+{
+    *done = false;
+    if (!part_wanted(b.n, s->k)) return PSK_OK;
+    // unit-weight batches cannot wrap a 32-bit partial sum when n*k < 2^31 (weighted ones are checked on the device)
+    if (!w_dev && b.n * (uint64_t)s->k >= (1ULL << 31)) return PSK_OK;
+    PartGeom g;
+    if (!part_slices(cells, 15, 5, &g)) return PSK_OK;  // 2^15 counters = 128 KiB per slice
+    g.k = s->k;
+    const uint64_t round_keys = (uint64_t)g_part_max_keys < b.n ? (uint64_t)g_part_max_keys : b.n;
+    unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
+    for (uint64_t start = 0; start < b.n; start += round_keys) {
+        const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
+        const Batch sub = sub_batch(b, start, cnt);
+        bool handled = false;
+        PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
+            using Src = decltype(src);
+            return with_kt<Src>(s->k, [&](auto kt) {
+                constexpr int KT = decltype(kt)::value;
+                SpillCounter<SIGNED> spill{(uint32_t *)s->table, w_dev == nullptr, NEG, sat};
+                if (w_dev) {
+                    PayWeight pay{w_dev + start};
+                    if (s->pow2) return launch_scatter<Src, IDX<true>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<true>{s->md}, pay, spill, &g, cnt, st);
+                    return launch_scatter<Src, IDX<false>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<false>{s->md}, pay, spill, &g, cnt, st);
+                }
+                if (s->pow2) return launch_scatter<Src, IDX<true>, PayNone, SpillCounter<SIGNED>, KT>(s, src, IDX<true>{s->md}, PayNone{}, spill, &g, cnt, st);
+                return launch_scatter<Src, IDX<false>, PayNone, SpillCounter<SIGNED>, KT>(s, src, IDX<false>{s->md}, PayNone{}, spill, &g, cnt, st);
+            });
+        }));
+        if (!handled) return PSK_OK;
+        const size_t lds = (size_t)4 << g.shift;
+        if (w_dev) {
+            auto kern = k_counter_apply<SIGNED, true, NEG>;
+            PSK_TRY(set_dyn_lds(kern, lds));
+            hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g,
+                               (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (const long long *)s->ctr, sat);
+        } else {
+            auto kern = k_counter_apply<SIGNED, false, NEG>;
+            PSK_TRY(set_dyn_lds(kern, lds));
+            hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g,
+                               (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (const long long *)s->ctr, sat);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    *done = true;
+    return PSK_OK;
+}

@@ -442,7 +442,7 @@ __device__ __forceinline__ void for_each_group(const uint4 *buckets, const uint3
 
 // Bloom insert: OR the slice's probes into an LDS image of the slice, then OR the image into the table.
 // dynamic LDS: slice image, 2^shift bits
-__global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *tab, uint64_t tab_words, PartGeom g,
+static __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *tab, uint64_t tab_words, PartGeom g,
                                                                const uint32_t *segcnt, const uint4 *buckets)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *tab, ui
 // Bloom lookup: the slice is loaded into LDS; a probe whose bit is clear zeroes its key's result byte
 // (out[] is pre-set to 1; every writer stores the same 0, so plain byte stores suffice).
 // group = (tile id, 3 x (key index in tile << shift | bit index in slice))
-__global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint32_t *tab, uint64_t tab_words, PartGeom g,
+static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint32_t *tab, uint64_t tab_words, PartGeom g,
                                                               const uint32_t *segcnt, const uint4 *buckets, uint8_t *out)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Throughput matrix over table geometry / key layout (side evidence, not the headline): M keys/s per op."""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+import torch
+
+import bench
+import pyprobables_amd as pa
+
+n = 10_000_000
+keys16 = bench.gen_keys(n, 0, 0)
+w = bench.gen_weights(n, 0, 0)
+rows = []
+
+
+def t(fn, it=5):
+    return bench.timed_loop(fn, it, warm=2)
+
+
+def bloom_case(label, est, fpr, keys):
+    f = pa.BloomFilter(est_elements=est, false_positive_rate=fpr)
+    nn = keys.shape[0]
+    a = t(lambda: f.add_many(keys))
+    c = t(lambda: f.check_many(keys))
+    rows.append((label, f"m={f.number_bits} k={f.number_hashes}", nn / a / 1e3, nn / c / 1e3))
+    del f
+
+
+bloom_case("bloom pow2 2^28 (headline)", 28005615, 0.01, keys16)
+bloom_case("bloom non-pow2 ~96 Mbit", 10_000_000, 0.01, keys16)
+bloom_case("bloom non-pow2 ~1.9 Gbit", 200_000_000, 0.01, keys16)
+bloom_case("bloom pow2 2^31", 224044920, 0.01, keys16)
+bloom_case("bloom k=4 (fpr 0.05)", 40_000_000, 0.05, keys16)
+bloom_case("bloom k=10 (fpr 0.001)", 10_000_000, 0.001, keys16)
+bloom_case("bloom k=17 (fpr 1e-5)", 10_000_000, 1e-5, keys16)
+k8 = torch.randint(0, 256, (n, 8), dtype=torch.uint8, device="cuda")
+k32 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda")
+k13 = torch.randint(0, 256, (n, 13), dtype=torch.uint8, device="cuda")
+bloom_case("bloom 8-byte keys", 28005615, 0.01, k8)
+bloom_case("bloom 32-byte keys", 28005615, 0.01, k32)
+bloom_case("bloom 13-byte keys (unaligned)", 28005615, 0.01, k13)
+# host-staged (PCIe inclusive) 16-byte keys
+kh = keys16.cpu().numpy()
+f = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01)
+a = t(lambda: f.add_many(kh), 3)
+c = t(lambda: f.check_many(kh), 3)
+rows.append(("bloom host buffers (PCIe incl.)", "m=2^28 k=7", n / a / 1e3, n / c / 1e3))
+del f
+for label, width, depth in [("cms 2^20 x 5 (headline)", 2**20, 5), ("cms 1e6+3 x 5 (non-pow2)", 1_000_003, 5), ("cms 2^24 x 8", 2**24, 8)]:
+    cms = pa.CountMinSketch(width=width, depth=depth)
+    a = t(lambda: cms.add_many(keys16, w))
+    u = t(lambda: cms.add_many(keys16))
+    c = t(lambda: cms.check_many(keys16))
+    rows.append((label + " weighted add / check", f"{width}x{depth}", n / a / 1e3, n / c / 1e3))
+    rows.append((label + " unit add", f"{width}x{depth}", n / u / 1e3, float("nan")))
+    del cms
+for label, est in [("cbf 2^28 counters (1 GiB, cfg 4)", 28005615), ("cbf ~9.6e7 counters", 10_000_000), ("cbf 2^25 counters", 3_500_701)]:
+    cbf = pa.CountingBloomFilter(est_elements=est, false_positive_rate=0.01)
+    a = t(lambda: cbf.add_many(keys16), 3)
+    c = t(lambda: cbf.check_many(keys16), 3)
+    r = bench.timed_loop(lambda: cbf.remove_many(keys16), 1, warm=0)
+    rows.append((label + " add / check", f"m={cbf.number_bits}", n / a / 1e3, n / c / 1e3))
+    rows.append((label + " remove", f"m={cbf.number_bits}", n / r / 1e3, float("nan")))
+    del cbf
+print(f"{'case':48s} {'geometry':22s} {'update Mkeys/s':>15s} {'lookup Mkeys/s':>15s}")
+for r in rows:
+    print(f"{r[0]:48s} {r[1]:22s} {r[2]:15.0f} {r[3]:15.0f}")

@@ -234,3 +234,42 @@ def test_cbf_add_partitioned_vs_oracle(pa, oracle, force_partition, golden):
     oc.update_keys(stream, w.astype(np.int64))
     assert np.array_equal(np.frombuffer(bytes(cbf.bloom), dtype=np.uint32), oc.bloom)
     assert cbf.elements_added == oc.els_added
+
+
+def test_partitioned_more_layouts_and_big_k(pa, oracle, force_partition):
+    rng = np.random.default_rng(9)
+    # 13-byte keys (byte-granular source), device resident
+    k13 = rng.integers(0, 256, size=(80_000, 13), dtype=np.uint8)
+    blm = pa.BloomFilter(est_elements=500_000, false_positive_rate=0.01)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    blm.add_many(_dev(k13[:50_000]))
+    ob.add_keys(k13[:50_000])
+    assert np.array_equal(_table(blm), ob.bloom)
+    assert np.array_equal(blm.check_many(_dev(k13)).cpu().numpy().astype(np.uint8), ob.check_keys(k13))
+    # k = 17 and k = 27: 32 hash chains per key
+    for fpr in (1e-5, 1e-8):
+        blm = pa.BloomFilter(est_elements=100_000, false_positive_rate=fpr)
+        assert 16 < blm.number_hashes <= 32
+        keys = oracle.gen_keys16(0, 60_000)
+        ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+        blm.add_many(_dev(keys[:40_000]))
+        ob.add_keys(keys[:40_000])
+        assert np.array_equal(_table(blm), ob.bloom)
+        assert np.array_equal(blm.check_many(_dev(keys)).cpu().numpy().astype(np.uint8), ob.check_keys(keys))
+    # str keys with code points > 255 (uint32 code-point layout) through the partitioned kernels
+    words = [("ключ-%d-€" % i) * (1 + i % 3) for i in range(30_000)]
+    blm = pa.BloomFilter(est_elements=300_000, false_positive_rate=0.01)
+    blm.add_many(words[:20_000])
+    hs = np.array([oracle.default_fnv_1a(w, blm.number_hashes) for w in words], dtype=np.uint64)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    ob.add_hashes(hs[:20_000])
+    assert np.array_equal(_table(blm), ob.bloom)
+    assert np.array_equal(blm.check_many(words).astype(np.uint8), ob.check_hashes(hs))
+    # counters with the byte-granular source
+    cms = pa.CountMinSketch(width=2**18, depth=6)
+    oc = oracle.OracleCMS(2**18, 6)
+    w = rng.integers(1, 70_000, size=80_000).astype(np.int32)  # some weights too big to ride inline -> exact spill
+    cms.add_many(_dev(k13), _dev(w))
+    oc.add_keys(k13, w)
+    assert np.array_equal(np.frombuffer(bytes(cms._bins), dtype=np.int32), oc.bins)
+    assert cms.elements_added == oc.els_added
