@@ -222,6 +222,13 @@ def main():
     total_ops = 2 * n * world
     ins_ms, chk_ms = timer.mean_ms("insert"), timer.mean_ms("check")
     ach = n * BYTES["bloom_insert"] / (ins_ms * 1e-3) / 1e9
+    traffic = None  # HBM bytes per insert launch from the committed PMC profile (same workload, same kernels)
+    try:
+        pmc = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
+        if pmc["keys"] == n:
+            traffic = pmc["bloom_insert"]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     line = {
         "metric": "million keys/sec insert+lookup (Bloom m=2^28 k=7)",
         "value": total_ops / (elapsed / args.steps) / 1e6,
@@ -249,7 +256,9 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per insert launch)" if traffic else None,
+            "algorithmic_bytes_per_launch": n * BYTES["bloom_insert"],
             "algorithmic_bytes_per_key": BYTES["bloom_insert"],
             "avg_kernel_ms": ins_ms,
         },
