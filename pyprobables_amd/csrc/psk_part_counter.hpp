@@ -30,8 +30,8 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
                     if (s->pow2) return launch_scatter<Src, IDX<true>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<true>{s->md}, pay, spill, &g, cnt, st);
                     return launch_scatter<Src, IDX<false>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<false>{s->md}, pay, spill, &g, cnt, st);
                 }
-                if (s->pow2) return launch_scatter<Src, IDX<true>, PayNone, SpillCounter<SIGNED>, KT>(s, src, IDX<true>{s->md}, PayNone{}, spill, &g, cnt, st);
-                return launch_scatter<Src, IDX<false>, PayNone, SpillCounter<SIGNED>, KT>(s, src, IDX<false>{s->md}, PayNone{}, spill, &g, cnt, st);
+                if (s->pow2) return launch_scatter<Src, IDX<true>, PayUnit, SpillCounter<SIGNED>, KT>(s, src, IDX<true>{s->md}, PayUnit{}, spill, &g, cnt, st);
+                return launch_scatter<Src, IDX<false>, PayUnit, SpillCounter<SIGNED>, KT>(s, src, IDX<false>{s->md}, PayUnit{}, spill, &g, cnt, st);
             });
         }));
         if (!handled) return PSK_OK;

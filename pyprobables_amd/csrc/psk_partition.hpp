@@ -17,7 +17,8 @@
 //                            with LDS atomics (ds_or / ds_add) and merges the slice back with one
 //                            coalesced read-modify-write.  No atomics on the table, no random HBM access.
 // Probe encodings (one uint4 group each, pads = 0xFFFFFFFF):
-//   plain   4 x cell index                                   Bloom insert, unit-weight counter adds
+//   packed  6 x 20-bit bit-in-slice (+ 2 x 4-bit counts)     Bloom insert            (2.67 B / probe)
+//           8 x 16-bit cell-in-slice (0xFFFF = pad)          unit-weight counter adds (2 B / probe)
 //   inline  4 x (weight << shift | cell index within slice)  weighted counter adds, weight < 2^(31-shift)
 //   keyed   tile id, 3 x (key index within tile << shift | bit index within slice)      Bloom lookups
 // Anything that does not fit (segment overflow on adversarial / duplicate-heavy batches, weights too
@@ -77,16 +78,24 @@ struct IdxCms {  // countminsketch.py:275:  (h % width) + i*width
 };
 
 // payload functors: the second word a probe carries through the LDS sort (key i of a tile starting at base)
-struct PayNone {
+struct PayNone {   // Bloom insert: 6 probes per group, 20-bit slice-local bit indices
     static constexpr int mode = kModePlain;
+    static constexpr int group = 6;
+    __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
+};
+struct PayUnit {   // unit-weight counter adds: 8 probes per group, 16-bit slice-local cell indices (slices <= 2^15 cells)
+    static constexpr int mode = kModePlain;
+    static constexpr int group = 8;
     __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
 };
 struct PayWeight {
+    static constexpr int group = 4;
     static constexpr int mode = kModeInline;
     const uint32_t *w;  // int32 / uint32 bit patterns; never null here
     __device__ __forceinline__ uint32_t operator()(uint64_t i, uint64_t) const { return w[i]; }
 };
 struct PayKeyId {
+    static constexpr int group = 3;
     static constexpr int mode = kModeKeyed;
     __device__ __forceinline__ uint32_t operator()(uint64_t i, uint64_t base) const { return (uint32_t)(i - base); }
 };
@@ -151,7 +160,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
 template <class Pay, int KT>
 struct PartTile {
     static constexpr bool pair = Pay::mode != kModePlain;           // stage entry = (cell, payload)
-    static constexpr int GS = Pay::mode == kModeKeyed ? 3 : 4;      // probes per 16-byte output group
+    static constexpr int GS = Pay::group;                           // probes per 16-byte output group
     static constexpr int PP = kPartProbes / 2;                      // 16 probes per thread: <= 100 VGPRs, 2 workgroups per CU
     static constexpr int KPT = PP / KT >= 1 ? PP / KT : 1;          // keys per thread per tile
     static constexpr int TILE = kPartThreads * KPT;                 // keys per tile
@@ -334,16 +343,43 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
             const uint32_t ngroups = tile_probes / GS;
             for (uint32_t gi = threadIdx.x; gi < ngroups; gi += kPartThreads) {
                 if constexpr (Pay::mode == kModePlain) {
-                    const uint4 q = reinterpret_cast<const uint4 *>(stage)[gi];
-                    const uint32_t b = q.x >> g.shift;
+                    // the LDS stage holds full cell indices (the first one names the slice); HBM gets them packed
+                    uint32_t c[GS];
+                    if constexpr (GS == 6) {
+                        const uint2 a0 = reinterpret_cast<const uint2 *>(stage)[3 * gi];
+                        const uint2 a1 = reinterpret_cast<const uint2 *>(stage)[3 * gi + 1];
+                        const uint2 a2 = reinterpret_cast<const uint2 *>(stage)[3 * gi + 2];
+                        c[0] = a0.x; c[1] = a0.y; c[2] = a1.x; c[3] = a1.y; c[4] = a2.x; c[5] = a2.y;
+                    } else {
+                        const uint4 a0 = reinterpret_cast<const uint4 *>(stage)[2 * gi];
+                        const uint4 a1 = reinterpret_cast<const uint4 *>(stage)[2 * gi + 1];
+                        c[0] = a0.x; c[1] = a0.y; c[2] = a0.z; c[3] = a0.w; c[4] = a1.x; c[5] = a1.y; c[6] = a1.z; c[7] = a1.w;
+                    }
+                    const uint32_t b = c[0] >> g.shift;
                     const uint32_t slot = delta[b] + gi;
                     if (slot < g.segcap) {
-                        buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = q;
+                        uint4 o;
+                        if constexpr (GS == 6) {
+                            // two 64-bit halves: 3 x 20-bit local indices + the number of valid ones in bits 60..63
+                            uint32_t nv = 0;
+#pragma unroll
+                            for (int e = 0; e < 6; ++e) nv += c[e] != kPadProbe;  // pads trail
+                            const uint32_t n0 = nv < 3 ? nv : 3, n1 = nv - n0;
+                            const unsigned long long h0 = (unsigned long long)(c[0] & mask) | ((unsigned long long)(c[1] & mask) << 20) |
+                                                          ((unsigned long long)(c[2] & mask) << 40) | ((unsigned long long)n0 << 60);
+                            const unsigned long long h1 = (unsigned long long)(c[3] & mask) | ((unsigned long long)(c[4] & mask) << 20) |
+                                                          ((unsigned long long)(c[5] & mask) << 40) | ((unsigned long long)n1 << 60);
+                            o = make_uint4((uint32_t)h0, (uint32_t)(h0 >> 32), (uint32_t)h1, (uint32_t)(h1 >> 32));
+                        } else {
+                            auto h16 = [&](uint32_t x) -> uint32_t { return x == kPadProbe ? 0xFFFFu : (x & mask); };
+                            o = make_uint4(h16(c[0]) | (h16(c[1]) << 16), h16(c[2]) | (h16(c[3]) << 16),
+                                           h16(c[4]) | (h16(c[5]) << 16), h16(c[6]) | (h16(c[7]) << 16));
+                        }
+                        buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = o;
                     } else {  // segment full: exact fallback, probe by probe
-                        if (q.x != kPadProbe) spill(q.x, 0u);
-                        if (q.y != kPadProbe) spill(q.y, 0u);
-                        if (q.z != kPadProbe) spill(q.z, 0u);
-                        if (q.w != kPadProbe) spill(q.w, 0u);
+#pragma unroll
+                        for (int e = 0; e < GS; ++e)
+                            if (c[e] != kPadProbe) spill(c[e], 0u);
                     }
                 } else if constexpr (Pay::mode == kModeInline) {
                     const uint4 e01 = reinterpret_cast<const uint4 *>(stage)[2 * gi];      // cell0 w0 cell1 w1
@@ -451,10 +487,15 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *
     const uint32_t mask = (1u << g.shift) - 1;
     for (uint32_t w = threadIdx.x; w < slice_words; w += kApplyThreads) smem[w] = 0;
     __syncthreads();
-    auto set = [&](uint32_t x) {
-        if (x != kPadProbe) atomicOr(&smem[(x & mask) >> 5], 1u << (x & 31));  // ds_or_b32
+    // group = two 64-bit halves of 3 x 20-bit slice-local bit indices, valid count in bits 60..63
+    auto half = [&](uint32_t lo, uint32_t hi) {
+        const unsigned long long h = ((unsigned long long)hi << 32) | lo;
+        const uint32_t nv = hi >> 28;
+        if (nv > 0) { const uint32_t x = (uint32_t)h & 0xFFFFFu; atomicOr(&smem[x >> 5], 1u << (x & 31)); }  // ds_or_b32
+        if (nv > 1) { const uint32_t x = (uint32_t)(h >> 20) & 0xFFFFFu; atomicOr(&smem[x >> 5], 1u << (x & 31)); }
+        if (nv > 2) { const uint32_t x = (uint32_t)(h >> 40) & 0xFFFFFu; atomicOr(&smem[x >> 5], 1u << (x & 31)); }
     };
-    for_each_group(buckets, segcnt, g, b, [&](const uint4 q) { set(q.x); set(q.y); set(q.z); set(q.w); });
+    for_each_group(buckets, segcnt, g, b, [&](const uint4 q) { half(q.x, q.y); half(q.z, q.w); });
     __syncthreads();
     // merge: this workgroup is the only writer of its slice
     const uint64_t w0 = (uint64_t)b * slice_words;
@@ -544,10 +585,11 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, 
         for_each_group(buckets, segcnt, g, b, [&](const uint4 q) { add(q.x); add(q.y); add(q.z); add(q.w); });
     } else {
         const uint32_t one = NEG ? 0xFFFFFFFFu : 1u;
-        auto add = [&](uint32_t x) {
-            if (x != kPadProbe) atomicAdd(&smem[x & mask], one);
+        auto add2 = [&](uint32_t w) {  // two 16-bit slice-local cell indices, 0xFFFF = pad
+            if ((w & 0xFFFFu) != 0xFFFFu) atomicAdd(&smem[w & 0xFFFFu], one);
+            if ((w >> 16) != 0xFFFFu) atomicAdd(&smem[w >> 16], one);
         };
-        for_each_group(buckets, segcnt, g, b, [&](const uint4 q) { add(q.x); add(q.y); add(q.z); add(q.w); });
+        for_each_group(buckets, segcnt, g, b, [&](const uint4 q) { add2(q.x); add2(q.y); add2(q.z); add2(q.w); });
     }
     __syncthreads();
     unsigned long long sat = 0;
