@@ -97,6 +97,7 @@ int psk_cms_create(uint64_t width, uint32_t depth, int device, void *ext_table, 
 int psk_destroy(psk_sketch *s);
 int psk_clear(psk_sketch *s, void *stream);                 /* bloom.py:217-221, countminsketch.py:240-244 */
 int psk_synchronize(psk_sketch *s, void *stream);
+int psk_release_scratch(psk_sketch *s);                     /* free staging + partition buffers (regrow on demand) */
 /* device pointer + padded size + logical size (the reference's array byte length) */
 int psk_table_info(psk_sketch *s, void **dev_ptr, uint64_t *padded_bytes, uint64_t *logical_bytes);
 /* copy the first nbytes of the table to / from host memory in the reference's byte layout
@@ -175,6 +176,10 @@ int psk_table_popcount(const void *tab, uint64_t nwords32, uint64_t *out_host, i
 int psk_table_nonzero_u32(const void *tab, uint64_t nwords32, uint64_t *out_host, int device, void *stream);
 int psk_table_add_sat_i32(void *dst, const void *src, uint64_t n, int device, void *stream);
 int psk_table_add_u32(void *dst, const void *src, uint64_t n, uint64_t *overflowed_host, int device, void *stream);
+/* countingbloom.py:210-269: intersection (sum where both non-zero) and the two counts of jaccard_index */
+int psk_cbf_intersect(void *dst, const void *a, const void *b, uint64_t n, uint64_t *overflowed_host, int device, void *stream);
+int psk_cbf_jaccard_counts(const void *a, const void *b, uint64_t n, uint64_t out_host[2] /* union, intersection */,
+                           int device, void *stream);
 int psk_or_reduce_slices(void *dst, const void *src, uint32_t nslices, uint64_t slice_words32, int device,
                          void *stream);
 

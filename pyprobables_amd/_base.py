@@ -121,6 +121,10 @@ class DeviceTable:
     def reset_counters(self):
         N.check(N.lib().psk_reset_counters(self.handle, self.stream))
 
+    def release_scratch(self):
+        """free the engine's staging / partition buffers for this table (they regrow on the next large batch)"""
+        N.check(N.lib().psk_release_scratch(self.handle))
+
     def synchronize(self):
         N.check(N.lib().psk_synchronize(self.handle, self.stream))
 

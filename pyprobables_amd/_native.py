@@ -71,6 +71,9 @@ PROTOTYPES = {
     "psk_table_nonzero_u32": (_int, [_vp, _u64, C.POINTER(_u64), _int, _vp]),
     "psk_table_add_sat_i32": (_int, [_vp, _vp, _u64, _int, _vp]),
     "psk_table_add_u32": (_int, [_vp, _vp, _u64, C.POINTER(_u64), _int, _vp]),
+    "psk_cbf_intersect": (_int, [_vp, _vp, _vp, _u64, C.POINTER(_u64), _int, _vp]),
+    "psk_cbf_jaccard_counts": (_int, [_vp, _vp, _u64, C.POINTER(_u64), _int, _vp]),
+    "psk_release_scratch": (_int, [_vp]),
     "psk_or_reduce_slices": (_int, [_vp, _vp, _u32, _u64, _int, _vp]),
     "psk_gen_keys16": (_int, [_vp, _u64, _u64, _u64, _int, _vp]),
     "psk_gen_weights": (_int, [_vp, _u64, _u64, _u64, _int, _vp]),

@@ -205,25 +205,27 @@ class CountingBloomFilter(BloomFilter):
         return res
 
     def intersection(self, second):
-        """countingbloom.py:210-240: sum where both are non-zero (host-side, table-sized, once)"""
+        """countingbloom.py:210-240: sum where both are non-zero (one streaming kernel)"""
+        import ctypes as C  # noqa: PLC0415
+
         self._require_similar(second)
-        a = self._tab.read().view(np.uint32).astype(np.uint64)
-        b = second._tab.read().view(np.uint32).astype(np.uint64)
-        s = np.where((a > 0) & (b > 0), a + b, 0)
-        if s.size and int(s.max()) > _U32_MAX:
-            raise OverflowError("unsigned int is greater than maximum")
         res = CountingBloomFilter(self.estimated_elements, self.false_positive_rate, hash_function=self.hash_function,
                                   device=self._tab.device)
-        res._tab.write(s.astype(np.uint32))
+        t, ov = res._tab, C.c_uint64(0)
+        N.check(N.lib().psk_cbf_intersect(t.ptr, self._tab.ptr, second._tab.ptr, self.number_bits, C.byref(ov), t.device, t.stream))
+        if ov.value:  # the reference's array('I') store raises here
+            raise OverflowError("unsigned int is greater than maximum")
         res.elements_added = res.estimate_elements()
         return res
 
     def jaccard_index(self, second) -> float:
-        """countingbloom.py:242-269 on the sets of non-zero positions"""
+        """countingbloom.py:242-269 on the sets of non-zero positions (one streaming kernel)"""
+        import ctypes as C  # noqa: PLC0415
+
         self._require_similar(second)
-        a = self._tab.read().view(np.uint32) > 0
-        b = second._tab.read().view(np.uint32) > 0
-        cu = int((a | b).sum())
-        if cu == 0:
+        out = (C.c_uint64 * 2)()
+        t = self._tab
+        N.check(N.lib().psk_cbf_jaccard_counts(t.ptr, second._tab.ptr, self.number_bits, out, t.device, t.stream))
+        if out[0] == 0:
             return 1.0
-        return int((a & b).sum()) / cu
+        return out[1] / out[0]

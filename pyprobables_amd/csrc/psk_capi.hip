@@ -810,6 +810,62 @@ extern "C" int psk_table_add_u32(void *dst, const void *src, uint64_t n, uint64_
     return PSK_OK;
 }
 
+extern "C" int psk_cbf_intersect(void *dst, const void *a, const void *b, uint64_t n, uint64_t *overflowed_host, int device, void *stream)
+{
+    if (!dst || !a || !b) return fail(PSK_EINVAL, "table pointer is NULL");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 8));
+    hipError_t e = hipMemsetAsync(d, 0, 8, st);
+    if (e == hipSuccess && n) {
+        const int g = grid_for(n) > 2048 ? 2048 : grid_for(n);
+        hipLaunchKernelGGL(k_cbf_intersect, dim3(g), dim3(kBlock), 0, st, (uint32_t *)dst, (const uint32_t *)a, (const uint32_t *)b, n, d);
+        e = hipGetLastError();
+    }
+    uint64_t ov = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&ov, d, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d);
+    if (e != hipSuccess) return fail(PSK_EHIP, "cbf intersect failed: %s", hipGetErrorString(e));
+    if (overflowed_host) *overflowed_host = ov;
+    return PSK_OK;
+}
+
+extern "C" int psk_cbf_jaccard_counts(const void *a, const void *b, uint64_t n, uint64_t out_host[2], int device, void *stream)
+{
+    if (!a || !b || !out_host) return fail(PSK_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 16));
+    hipError_t e = hipMemsetAsync(d, 0, 16, st);
+    if (e == hipSuccess && n) {
+        const int g = grid_for(n) > 1024 ? 1024 : grid_for(n);
+        hipLaunchKernelGGL(k_cbf_jaccard, dim3(g), dim3(kBlock), 0, st, (const uint32_t *)a, (const uint32_t *)b, n, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_host, d, 16, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d);
+    if (e != hipSuccess) return fail(PSK_EHIP, "cbf jaccard failed: %s", hipGetErrorString(e));
+    return PSK_OK;
+}
+
+// release the partition / staging scratch of a handle (hundreds of MB after a large batch); it regrows on demand
+extern "C" int psk_release_scratch(psk_sketch *s)
+{
+    if (!s) return fail(PSK_EINVAL, "sketch handle is NULL");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt}) {
+        if (b->p) HIP_TRY(hipFree(b->p));
+        b->p = nullptr;
+        b->cap = 0;
+    }
+    return PSK_OK;
+}
+
 extern "C" int psk_or_reduce_slices(void *dst, const void *src, uint32_t nslices, uint64_t slice_words32, int device, void *stream)
 {
     PSK_TRY(check_vec(dst, src, slice_words32));

@@ -821,6 +821,48 @@ static __global__ __launch_bounds__(kBlock) void k_add_u32(uint32_t *dst, const 
     if ((threadIdx.x & 63) == 0 && ov) atomicAdd(overflowed, ov);
 }
 
+// countingbloom.py:235-238 intersection: dst[i] = (a[i] > 0 && b[i] > 0) ? a[i] + b[i] : 0  (overflow clamped + counted)
+static __global__ __launch_bounds__(kBlock) void k_cbf_intersect(uint32_t *dst, const uint32_t *a, const uint32_t *b, uint64_t n,
+                                                                unsigned long long *overflowed)
+{
+    unsigned long long ov = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t x = a[i], y = b[i];
+        uint64_t t = (x > 0 && y > 0) ? (uint64_t)x + (uint64_t)y : 0;
+        if (t > 0xFFFFFFFFULL) { t = 0xFFFFFFFFULL; ++ov; }
+        dst[i] = (uint32_t)t;
+    }
+    for (int o = 32; o > 0; o >>= 1) ov += __shfl_down(ov, o);
+    if ((threadIdx.x & 63) == 0 && ov) atomicAdd(overflowed, ov);
+}
+
+// countingbloom.py:262-266 jaccard: out[0] += #(a>0 || b>0), out[1] += #(a>0 && b>0)
+static __global__ __launch_bounds__(kBlock) void k_cbf_jaccard(const uint32_t *a, const uint32_t *b, uint64_t n,
+                                                              unsigned long long *out)
+{
+    unsigned long long cu = 0, ci = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const bool x = a[i] > 0, y = b[i] > 0;
+        cu += x || y;
+        ci += x && y;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        cu += __shfl_down(cu, o);
+        ci += __shfl_down(ci, o);
+    }
+    __shared__ unsigned long long pu[kBlock / 64], pi[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) { pu[threadIdx.x >> 6] = cu; pi[threadIdx.x >> 6] = ci; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cu = 0; ci = 0;
+        for (int w = 0; w < kBlock / 64; ++w) { cu += pu[w]; ci += pi[w]; }
+        if (cu) atomicAdd(out, cu);
+        if (ci) atomicAdd(out + 1, ci);
+    }
+}
+
 // --------------------------------------------------- synthetic streams
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 {

@@ -186,6 +186,10 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
     const uint64_t ntiles = (n + TILE - 1) / TILE;
 
     for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) cur[b] = 0;
+    if ((g.dbg & 16) && blockIdx.x >= gridDim.x / 2) {  // experiment: start the second co-resident workgroup half a tile late
+        __builtin_amdgcn_s_sleep(127);
+        if (g.dbg & 64) __builtin_amdgcn_s_sleep(127);
+    }
 
     // Software pipeline over tiles: the NEXT tile's keys are loaded right after this tile's hash phase and
     // pinned before this tile's write-out stores are issued (vmcnt counts loads and stores in order on CDNA4:
