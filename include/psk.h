@@ -75,8 +75,8 @@ enum psk_counter {
 const char *psk_last_error(void);         /* thread-local text of the last failure */
 int psk_version(void);
 int psk_device_count(int *count);
-/* process-wide tunables: "partition" (0 = direct kernels only, 1 = auto), "partition_min_keys" (batches with
- * at least this many keys take the partitioned path), "partition_max_keys" (keys per partition round) */
+/* process-wide tunables: "partition" (0 = direct kernels only, 1 = auto), "partition_min_keys" (Bloom inserts with
+ * at least this many keys -- 4x as many for lookups and counter adds -- take the partitioned path), "partition_max_keys" (keys per partition round) */
 int psk_set_option(const char *name, int64_t value);
 int psk_get_option(const char *name, int64_t *value);
 /* bench-only: s_memtime totals per phase of the last partition pass 1 (option part_debug & 32) */

@@ -349,7 +349,7 @@ static int finish(int where, const OutBuf *o, hipStream_t st)
 
 // ------------------------------------------------- partitioned (large-batch) path: options
 int64_t g_part_mode = 1;
-int64_t g_part_min_keys = 1 << 17;
+int64_t g_part_min_keys = 1 << 16;   // x1 for Bloom inserts, x4 for lookups / counter adds (part_wanted)
 int64_t g_part_max_keys = 1 << 25;   // keys per partition round (bounds the bucket buffer)
 int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGeom::dbg); 0 in production
 

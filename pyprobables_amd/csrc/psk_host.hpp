@@ -167,9 +167,11 @@ static int with_part_source(const Batch &b, bool *handled, F &&f)
     return PSK_OK;
 }
 
-static inline bool part_wanted(uint64_t n, uint32_t k)
+// `scale`: measured crossover vs the direct kernels (scripts/crossover.py, m = 2^28 / 2^20 x 5): Bloom insert wins
+// from ~64 K keys (scale 1), Bloom lookups and counter adds from ~256 K keys (scale 4)
+static inline bool part_wanted(uint64_t n, uint32_t k, int64_t scale = 1)
 {
-    return g_part_mode != 0 && (int64_t)n >= g_part_min_keys && k <= 32;
+    return g_part_mode != 0 && (int64_t)n >= g_part_min_keys * scale && k <= 32;
 }
 
 // view of keys [start, start+cnt) of a device batch

@@ -5,7 +5,7 @@
 int bloom_check_partitioned(psk_sketch *s, const Batch &b, uint8_t *out_dev, hipStream_t st, bool *done)
 {
     *done = false;
-    if (!part_wanted(b.n, s->k)) return PSK_OK;
+    if (!part_wanted(b.n, s->k, 4)) return PSK_OK;
     PartGeom g;
     if (!part_slices(s->m, 20, 7, &g)) return PSK_OK;
     g.k = s->k;

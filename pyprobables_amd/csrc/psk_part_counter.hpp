@@ -8,7 +8,7 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
                                    bool *done)
 {
     *done = false;
-    if (!part_wanted(b.n, s->k)) return PSK_OK;
+    if (!part_wanted(b.n, s->k, 4)) return PSK_OK;
     // unit-weight batches cannot wrap a 32-bit partial sum when n*k < 2^31 (weighted ones are checked on the device)
     if (!w_dev && b.n * (uint64_t)s->k >= (1ULL << 31)) return PSK_OK;
     PartGeom g;
