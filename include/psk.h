@@ -156,6 +156,7 @@ int psk_cms_check(psk_sketch *s, int layout, const void *data, const uint64_t *o
                   uint32_t key_len, int where, int query /* MIN or MEAN */, int32_t *out, void *stream);
 int psk_cms_check_meanmin(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
                           uint32_t key_len, int where, int64_t elements_added, int64_t *out, void *stream);
+/* out (optional): int64[n + 1] -- the n return values, then elements_added after the batch (exact int64 clamps) */
 int psk_cms_update_ordered(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
                            uint32_t key_len, const int64_t *weights, int opmode, int query,
                            int64_t elements_added_in, int where, int64_t *out, void *stream);

@@ -62,6 +62,7 @@ class BloomFilter:
                  hash_function: HashFuncT | None = None, device=None):
         self._dev_arg = device
         self._els_added = 0
+        self._pending: list = []
         self._tab: DeviceTable | None = None
         if _existing_file(filepath):
             self._load(Path(filepath).expanduser().resolve().read_bytes(), hash_function)
@@ -142,6 +143,7 @@ class BloomFilter:
     @property
     def bloom(self) -> array:
         """host SNAPSHOT of the table as the reference's ``array`` type (the live table is in HBM)"""
+        self._flush()
         return array(self._ELEM.format, self._tab.read().tobytes())
 
     @property
@@ -155,6 +157,7 @@ class BloomFilter:
     @property
     def table_tensor(self):
         """the torch int32 tensor backing the table (padded to 16 B); what the multi-GPU merge reduces"""
+        self._flush()
         return self._tab.tensor
 
     @property
@@ -164,8 +167,20 @@ class BloomFilter:
 
     # ------------------------------------------------------------------ working set (bloom.py:216-272)
     def clear(self) -> None:
+        self._pending = []
         self._els_added = 0
         self._tab.clear()
+
+    # Per-key ``add`` calls (the reference's only insert API, e.g. ``for w in words: blm.add(w)``) are write-combined
+    # on the host and reach the GPU as ONE batch: a Bloom insert returns nothing and commutes with every other
+    # insert, so deferring it is unobservable.  Everything that reads the table flushes first.
+    _PENDING_LIMIT = 1 << 16
+
+    def _flush(self) -> None:
+        if self._pending:
+            keys, self._pending = self._pending, []
+            b = self._batch(keys)
+            N.check(N.lib().psk_bloom_add(self._tab.handle, *b.args(), b.where, self._tab.stream))
 
     def hashes(self, key: KeyT, depth: int | None = None) -> HashResultsT:
         """the plugin call site (bloom.py:223-232)"""
@@ -188,14 +203,20 @@ class BloomFilter:
         self._els_added += b.n  # bloom.py:250, once per key
 
     def _check_batch(self, b: KeyBatch):
+        self._flush()
         addr, fin = self._tab.out_buffer(b, b.n, np.uint8, _torch_dtype("uint8"))
         N.check(N.lib().psk_bloom_check(self._tab.handle, *b.args(), b.where, addr, self._tab.stream))
         res = fin()
         return res.view(np.bool_) if isinstance(res, np.ndarray) else res.view(_torch_dtype("bool"))
 
     def add(self, key: KeyT) -> None:
-        """bloom.py:234-239 (a batch of one)"""
-        self._add_batch(self._batch(key))
+        """bloom.py:234-239; write-combined on the host (see ``_flush``)"""
+        if not isinstance(key, (str, bytes, bytearray, memoryview)):
+            raise TypeError(f"keys must be str or bytes-like, got {type(key).__name__}")
+        self._pending.append(bytes(key) if isinstance(key, (bytearray, memoryview)) else key)
+        self._els_added += 1  # bloom.py:250
+        if len(self._pending) >= self._PENDING_LIMIT:
+            self._flush()
 
     def add_alt(self, hashes: HashResultsT) -> None:
         """bloom.py:241-250: insert the element represented by its hashes"""
@@ -231,6 +252,7 @@ class BloomFilter:
 
     def check_many_bits(self, keys):
         """membership as a ballot bitmap (bit i&63 of word i>>6) plus the number of hits"""
+        self._flush()
         b = self._batch(keys)
         nwords = (b.n + 63) // 64
         if b.where == N.DEVICE:
@@ -247,6 +269,7 @@ class BloomFilter:
         return bits, int(hits[0])
 
     def synchronize(self) -> None:
+        self._flush()
         self._tab.synchronize()
 
     # ------------------------------------------------------------------ export / import (bloom.py:274-338, 504-550)
@@ -254,6 +277,7 @@ class BloomFilter:
         return st.pack(self.estimated_elements, self.elements_added, self.false_positive_rate)
 
     def _table_bytes(self) -> bytes:
+        self._flush()
         return self._tab.read().tobytes()
 
     def __bytes__(self) -> bytes:
@@ -291,6 +315,7 @@ class BloomFilter:
         inst = cls.__new__(cls)
         inst._dev_arg = device
         inst._els_added = 0
+        inst._pending = []
         inst._tab = None
         inst._load(bytes(b), hash_function)
         return inst
@@ -316,6 +341,7 @@ class BloomFilter:
 
     # ------------------------------------------------------------------ statistics (bloom.py:117-133, 340-369)
     def _cnt_number_bits_set(self) -> int:
+        self._flush()
         return self._tab.popcount()  # device popcount kernel
 
     def estimate_elements(self) -> int:
@@ -362,6 +388,8 @@ class BloomFilter:
             raise ValueError("set operations need both filters on the same device")
 
     def _combine(self, second, fn_name: str):
+        self._flush()
+        second._flush()
         res = type(self)(self.estimated_elements, self.false_positive_rate, hash_function=self.hash_function,
                          device=self._tab.device)
         L, t = N.lib(), res._tab

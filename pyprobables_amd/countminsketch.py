@@ -219,13 +219,12 @@ class CountMinSketch:
         if b.where != N.HOST:
             raise ValueError("ordered updates take host batches")
         w = np.ascontiguousarray(np.broadcast_to(np.asarray(num_els, dtype=np.int64), (b.n,)))
-        out = np.empty(b.n, dtype=np.int64)
+        out = np.empty(b.n + 1, dtype=np.int64)  # n return values + elements_added after the batch
         els_in = self.elements_added
         N.check(N.lib().psk_cms_update_ordered(self._tab.handle, *b.args(), w.ctypes.data if b.n else None, opmode,
-                                               _QUERIES[self._query], els_in, b.where,
-                                               out.ctypes.data if b.n else None, self._tab.stream))
-        self._els_added = self._tab.counters()[N.CTR_ELS_OUT]
-        return out
+                                               _QUERIES[self._query], els_in, b.where, out.ctypes.data, self._tab.stream))
+        self._els_added = int(out[b.n])
+        return out[: b.n]
 
     def add(self, key: KeyT, num_els: int = 1) -> int:
         """countminsketch.py:257-265"""

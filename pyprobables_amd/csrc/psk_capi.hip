@@ -140,8 +140,10 @@ extern "C" int psk_destroy(psk_sketch *s)
     hipSetDevice(s->device);
     if (s->owns_table && s->table) hipFree(s->table);
     if (s->ctr) hipFree(s->ctr);
-    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt})
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt}) {
         if (b->p) hipFree(b->p);
+        if (b->pin) hipHostFree(b->pin);
+    }
     delete s;
     return PSK_OK;
 }
@@ -239,6 +241,14 @@ extern "C" int psk_reset_counters(psk_sketch *s, void *stream)
     return PSK_OK;
 }
 
+// small-transfer fast path: lazily allocated pinned (host-coherent, device-visible) page per scratch buffer
+static int pinned(DevBuf &b, void **out)
+{
+    if (!b.pin) HIP_TRY(hipHostMalloc(&b.pin, kPinBytes, hipHostMallocDefault));
+    *out = b.pin;
+    return PSK_OK;
+}
+
 // ---------------------------------------------------------- key batches
 static int elem_bytes(int layout) { return layout == PSK_KEYS_VARLEN32 ? 4 : (layout == PSK_KEYS_HASHES ? 8 : 1); }
 
@@ -262,14 +272,28 @@ static int stage_batch(DevBuf &kbuf, DevBuf &obuf, int layout, const void *data,
         const uint64_t total = offsets[n] - offsets[0];
         if (offsets[0] != 0) return fail(PSK_EINVAL, "host offsets must start at 0");
         nbytes = total * (uint64_t)elem_bytes(layout);
-        PSK_TRY(ensure(obuf, (n + 1) * 8));
-        HIP_TRY(hipMemcpyAsync(obuf.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
-        b->offs = (const uint64_t *)obuf.p;
+        if ((n + 1) * 8 <= kPinBytes) {
+            void *pp;
+            PSK_TRY(pinned(obuf, &pp));
+            memcpy(pp, offsets, (n + 1) * 8);
+            b->offs = (const uint64_t *)pp;
+        } else {
+            PSK_TRY(ensure(obuf, (n + 1) * 8));
+            HIP_TRY(hipMemcpyAsync(obuf.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
+            b->offs = (const uint64_t *)obuf.p;
+        }
     } else {
         nbytes = n * (uint64_t)key_len * (uint64_t)elem_bytes(layout);
     }
-    PSK_TRY(ensure(kbuf, nbytes ? nbytes : 16));
-    if (nbytes) HIP_TRY(hipMemcpyAsync(kbuf.p, data, nbytes, hipMemcpyHostToDevice, st));
+    if (nbytes <= kPinBytes) {  // tiny batch (single-key API): the kernel reads the keys straight from pinned host memory
+        void *pp;
+        PSK_TRY(pinned(kbuf, &pp));
+        if (nbytes) memcpy(pp, data, nbytes);
+        b->data = pp;
+        return PSK_OK;
+    }
+    PSK_TRY(ensure(kbuf, nbytes));
+    HIP_TRY(hipMemcpyAsync(kbuf.p, data, nbytes, hipMemcpyHostToDevice, st));
     b->data = kbuf.p;
     return PSK_OK;
 }
@@ -312,6 +336,13 @@ static int stage_vec(DevBuf &buf, const T *v, uint64_t n, int where, hipStream_t
 {
     *dev = v;
     if (!v || where == PSK_DEVICE || n == 0) return PSK_OK;
+    if (n * sizeof(T) <= kPinBytes) {
+        void *pp;
+        PSK_TRY(pinned(buf, &pp));
+        memcpy(pp, v, n * sizeof(T));
+        *dev = (const T *)pp;
+        return PSK_OK;
+    }
     PSK_TRY(ensure(buf, n * sizeof(T)));
     HIP_TRY(hipMemcpyAsync(buf.p, v, n * sizeof(T), hipMemcpyHostToDevice, st));
     *dev = (const T *)buf.p;
@@ -323,6 +354,7 @@ struct OutBuf {
     void *dev = nullptr;
     void *host = nullptr;
     uint64_t bytes = 0;
+    bool is_pinned = false;  // dev is pinned host memory: no device-to-host copy, just a sync and a memcpy
 };
 
 static int stage_out(DevBuf &buf, void *out, uint64_t bytes, int where, OutBuf *o)
@@ -332,17 +364,24 @@ static int stage_out(DevBuf &buf, void *out, uint64_t bytes, int where, OutBuf *
         o->dev = out;
         return PSK_OK;
     }
+    o->host = out;
+    if (bytes <= kPinBytes) {
+        PSK_TRY(pinned(buf, &o->dev));
+        o->is_pinned = true;
+        return PSK_OK;
+    }
     PSK_TRY(ensure(buf, bytes));
     o->dev = buf.p;
-    o->host = out;
     return PSK_OK;
 }
 
 static int finish(int where, const OutBuf *o, hipStream_t st)
 {
     if (where == PSK_HOST) {
-        if (o && o->host && o->bytes) HIP_TRY(hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, st));
+        const bool copy = o && o->host && o->bytes;
+        if (copy && !o->is_pinned) HIP_TRY(hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (copy && o->is_pinned) memcpy(o->host, o->dev, o->bytes);
     }
     return PSK_OK;
 }
@@ -677,7 +716,7 @@ extern "C" int psk_cms_update_ordered(psk_sketch *s, int layout, const void *dat
     const int64_t *w;
     PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
     OutBuf o;
-    PSK_TRY(stage_out(s->s_out, out, out ? n * 8 : 0, where, &o));
+    PSK_TRY(stage_out(s->s_out, out, out ? (n + 1) * 8 : 0, where, &o));  // out[n] = elements_added after the batch
     PSK_TRY(with_source(b, [&](auto src) {
         using Src = decltype(src);
         if (s->pow2)

@@ -634,6 +634,7 @@ __global__ void k_cms_ordered(Src src, int32_t *bins, Mod md, uint32_t depth, co
         if (out) out[i] = r;
     }
     ctr[5] = els;
+    if (out) out[n] = els;  // out is int64[n + 1]: the caller gets elements_added with the results, no second read-back
     ctr[3] += (long long)sat;
     const unsigned long long nb = (unsigned long long)ctr[4] + abs_sum;
     ctr[4] = (nb < (unsigned long long)ctr[4] || nb > (1ULL << 62)) ? (1LL << 62) : (long long)nb;

@@ -40,9 +40,12 @@ PSK_HIDDEN int fail(int code, const char *fmt, ...);  // records the thread-loca
 // ------------------------------------------------------------------ handle
 // ------------------------------------------------------------------ handle
 struct DevBuf {
-    void *p = nullptr;
+    void *p = nullptr;    // device scratch, grown on demand
     uint64_t cap = 0;
+    void *pin = nullptr;  // kPinBytes of pinned, device-visible host memory for tiny PSK_HOST batches: the kernel reads /
+                          // writes it in place, so a single-key call is one launch + one stream sync, no staging copies
 };
+constexpr uint64_t kPinBytes = 4096;
 
 struct psk_sketch {
     int kind;

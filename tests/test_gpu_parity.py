@@ -578,3 +578,28 @@ def test_merge_path_on_rccl_single_rank(pa, oracle, monkeypatch):
         assert cbf.elements_added == 100_000
     finally:
         dist.destroy_process_group()
+
+
+def test_bloom_per_key_add_loop_is_write_combined(pa, oracle):
+    """the reference's usage pattern -- `for key in keys: blm.add(key)` -- reaches the GPU as batches; every read
+    (check / export / in / stats) sees all prior adds"""
+    keys = [bytes(k) for k in oracle.gen_keys16(0, 70_000)] + ["str key %d" % i for i in range(100)] + ["ключ-€"]
+    blm = pa.BloomFilter(est_elements=100_000, false_positive_rate=0.01)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    for i, k in enumerate(keys):
+        blm.add(k)
+        if i == 10:
+            assert blm.check(keys[3]) and (keys[10] in blm)       # a read in the middle flushes
+            assert blm.elements_added == 11
+    hs = np.array([oracle.default_fnv_1a(k, blm.number_hashes) for k in keys], dtype=np.uint64)
+    ob.add_hashes(hs)
+    assert blm.elements_added == len(keys)
+    assert np.array_equal(_table(blm), ob.bloom)                  # export path flushes the tail
+    assert blm.check(keys[-1]) and blm.check("str key 7")
+    blm.add("late key")
+    assert blm.estimate_elements() > 0 and "late key" in blm
+    blm.add("dropped by clear")
+    blm.clear()
+    assert blm.elements_added == 0 and blm._cnt_number_bits_set() == 0
+    with pytest.raises(TypeError):
+        blm.add(123)
