@@ -2,6 +2,10 @@
 // Host side: handle bookkeeping, host<->device staging for PSK_HOST buffers, launch geometry.
 #include "psk_host.hpp"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
 
@@ -238,6 +242,21 @@ extern "C" int psk_reset_counters(psk_sketch *s, void *stream)
     CHECK_HANDLE(s, -1);
     // keep the wrap-free bound: it describes the table, not the batch history
     HIP_TRY(hipMemsetAsync(s->ctr, 0, sizeof(long long) * PSK_CTR_ABS_BOUND, (hipStream_t)stream));
+    return PSK_OK;
+}
+
+int raise_dyn_lds(const void *kernel, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> granted;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = granted[{kernel, dev}];
+    if (bytes > have) {
+        HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
     return PSK_OK;
 }
 

@@ -94,11 +94,14 @@ static inline bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_
     return true;
 }
 
+// raise a kernel's dynamic-LDS limit (needed above 64 KiB); remembered per (kernel, device) so the driver call is
+// paid once, not on every launch
+PSK_HIDDEN int raise_dyn_lds(const void *kernel, size_t bytes);
+
 template <class K>
 static int set_dyn_lds(K kernel, size_t bytes)
 {
-    HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return PSK_OK;
+    return raise_dyn_lds((const void *)kernel, bytes);
 }
 
 // Pass 1 for one concrete (Src, IdxFn, Pay, Spill, KT): sizes the (slice, workgroup) segments for `n` keys,

@@ -32,7 +32,6 @@ constexpr int kPartThreads = 512;      // 8 wavefronts per workgroup
 constexpr int kPartProbes = 32;        // probes held in registers per thread (= keys/thread * KT); 16 with payload
 constexpr int kPartMaxBuckets = 2048;
 constexpr int kPartScanPerThread = kPartMaxBuckets / kPartThreads;  // 4
-constexpr int kPartMaxWg = 512;        // workgroups in pass 1 == segments per slice
 constexpr bool kPartPipeline = true;   // prefetch the next tile's keys under the current tile (see k_part_scatter)
 constexpr bool kPartHash32 = true;     // explicit 32-bit FNV chains for power-of-two tables
 constexpr uint32_t kPadProbe = 0xFFFFFFFFu;  // filler that pads every run to whole groups; pass 2 skips it
@@ -186,10 +185,6 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
     const uint64_t ntiles = (n + TILE - 1) / TILE;
 
     for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) cur[b] = 0;
-    if ((g.dbg & 16) && blockIdx.x >= gridDim.x / 2) {  // experiment: start the second co-resident workgroup half a tile late
-        __builtin_amdgcn_s_sleep(127);
-        if (g.dbg & 64) __builtin_amdgcn_s_sleep(127);
-    }
 
     // Software pipeline over tiles: the NEXT tile's keys are loaded right after this tile's hash phase and
     // pinned before this tile's write-out stores are issued (vmcnt counts loads and stores in order on CDNA4:

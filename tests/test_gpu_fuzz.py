@@ -1,0 +1,149 @@
+"""Seeded differential fuzzing of the HIP engine against the C oracle: random table geometries, key layouts,
+batch sizes and both kernel families (direct / partitioned).  Bit-exact or it fails."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def pa():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import pyprobables_amd
+
+    return pyprobables_amd
+
+
+@pytest.fixture()
+def engine_options():
+    from pyprobables_amd import _native as N
+
+    old = {k: N.get_option(k) for k in ("partition", "partition_min_keys", "partition_max_keys")}
+    yield N
+    for k, v in old.items():
+        N.set_option(k, v)
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _random_keys(rng, n):
+    """-> (what to hand to the engine, the same keys as a list of bytes for the oracle)"""
+    kind = rng.integers(0, 4)
+    if kind == 0:  # fixed length, device resident
+        L = int(rng.choice([1, 4, 5, 8, 11, 16, 16, 16, 24, 40]))
+        a = rng.integers(0, 256, size=(n, L), dtype=np.uint8)
+        return _dev(a), [bytes(r) for r in a]
+    if kind == 1:  # fixed length, host array
+        L = int(rng.choice([2, 8, 16, 31]))
+        a = rng.integers(0, 256, size=(n, L), dtype=np.uint8)
+        return a, [bytes(r) for r in a]
+    if kind == 2:  # ragged bytes (with duplicates and empties)
+        pool = [bytes(rng.integers(0, 256, size=int(l), dtype=np.uint8)) for l in rng.integers(0, 33, size=max(n // 3, 1))]
+        ks = [pool[i] for i in rng.integers(0, len(pool), size=n)]
+        return ks, ks
+    # latin-1 strings (one byte per code point)
+    ks = ["k%d-é%s" % (int(i), "x" * int(l)) for i, l in zip(rng.integers(0, n, size=n), rng.integers(0, 9, size=n))]
+    return ks, [k.encode("latin-1") for k in ks]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_bloom(pa, oracle, engine_options, seed):
+    rng = np.random.default_rng(1000 + seed)
+    engine_options.set_option("partition", int(rng.integers(0, 2)))
+    engine_options.set_option("partition_min_keys", int(rng.choice([1, 1, 4096])))
+    engine_options.set_option("partition_max_keys", int(rng.choice([2048, 1 << 25])))
+    est = int(rng.choice([50, 3000, 40_000, 200_000, 1_000_000]))
+    fpr = float(rng.choice([0.3, 0.05, 0.01, 0.001, 1e-6]))
+    blm = pa.BloomFilter(est_elements=est, false_positive_rate=fpr)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    for _ in range(int(rng.integers(1, 4))):
+        n = int(rng.choice([0, 1, 7, 100, 5000, 30_000]))
+        eng, ref = _random_keys(rng, n)
+        blm.add_many(eng)
+        if ref:
+            ob.add_varlen(ref)
+        probe_eng, probe_ref = _random_keys(rng, int(rng.choice([1, 64, 3000, 20_000])))
+        got = blm.check_many(probe_eng)
+        got = got.cpu().numpy() if hasattr(got, "cpu") else got
+        assert np.array_equal(got.astype(np.uint8), ob.check_varlen(probe_ref))
+        if ref:
+            again = blm.check_many(eng)
+            again = again.cpu().numpy() if hasattr(again, "cpu") else again
+            assert bool(again.all())
+    assert np.array_equal(np.frombuffer(bytes(blm.bloom), dtype=np.uint8), ob.bloom)
+    assert blm._cnt_number_bits_set() == ob.bits_set()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_cms(pa, oracle, engine_options, seed):
+    rng = np.random.default_rng(2000 + seed)
+    engine_options.set_option("partition", int(rng.integers(0, 2)))
+    engine_options.set_option("partition_min_keys", int(rng.choice([1, 1, 4096])))
+    width = int(rng.choice([7, 1000, 4096, 65_536, 100_003, 1 << 18]))
+    depth = int(rng.choice([1, 3, 5, 8, 11]))
+    cms = pa.CountMinSketch(width=width, depth=depth)
+    oc = oracle.OracleCMS(width, depth)
+    for _ in range(int(rng.integers(1, 4))):
+        n = int(rng.choice([1, 50, 4000, 25_000]))
+        keys = rng.integers(0, 256, size=(n, 16), dtype=np.uint8)
+        keys[n // 2:] = keys[: n - n // 2]  # duplicates inside the batch
+        wmax = int(rng.choice([1, 7, 1000, 100_000]))
+        w = rng.integers(1, wmax + 1, size=n).astype(np.int32)
+        if rng.integers(0, 3) == 0:
+            cms.add_many(_dev(keys))
+            oc.add_keys(keys)
+        else:
+            cms.add_many(_dev(keys), _dev(w))
+            oc.add_keys(keys, w)
+        if rng.integers(0, 2):
+            m = n // 3
+            cms.remove_many(keys[:m], w[:m])
+            oc.remove_keys(keys[:m], w[:m])
+        assert np.array_equal(np.frombuffer(bytes(cms._bins), dtype=np.int32), oc.bins)
+        assert cms.elements_added == oc.els_added
+        for q, oq in (("min", oracle.Q_MIN), ("mean", oracle.Q_MEAN), ("mean-min", oracle.Q_MEANMIN)):
+            if q == "mean-min" and width < 2:
+                continue
+            cms.query_type, oc.query = q, oq
+            got = cms.check_many(_dev(keys[:500])).cpu().numpy()
+            assert np.array_equal(got.astype(np.int64), oc.check_keys(keys[:500])), q
+        cms.query_type, oc.query = "min", oracle.Q_MIN
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_cbf(pa, oracle, engine_options, seed):
+    rng = np.random.default_rng(3000 + seed)
+    engine_options.set_option("partition", int(rng.integers(0, 2)))
+    engine_options.set_option("partition_min_keys", int(rng.choice([1, 4096])))
+    est = int(rng.choice([200, 5000, 30_000, 300_000]))
+    fpr = float(rng.choice([0.1, 0.01, 0.001]))
+    cbf = pa.CountingBloomFilter(est_elements=est, false_positive_rate=fpr)
+    oc = oracle.OracleCBF(cbf.number_bits, cbf.number_hashes)
+    live = []
+    for _ in range(int(rng.integers(2, 5))):
+        n = int(rng.choice([1, 300, 6000, 20_000]))
+        keys = rng.integers(0, 256, size=(n, 12), dtype=np.uint8)
+        w = rng.integers(1, 6, size=n).astype(np.uint32)
+        cbf.add_many(_dev(keys), w)
+        oc.update_keys(keys, w.astype(np.int64))
+        live.append((keys, w))
+        if rng.integers(0, 2) and live:  # well-formed removal: take back (part of) an earlier batch exactly once
+            k0, w0 = live.pop(int(rng.integers(0, len(live))))
+            m = len(k0) // 2
+            if m:
+                cbf.remove_many(_dev(k0[:m]), w0[:m])
+                oc.update_keys(k0[:m], -w0[:m].astype(np.int64))
+                if len(k0) - m:
+                    live.append((k0[m:], w0[m:]))
+        assert np.array_equal(np.frombuffer(bytes(cbf.bloom), dtype=np.uint32), oc.bloom)
+        assert cbf.elements_added == oc.els_added
+        probe = rng.integers(0, 256, size=(1000, 12), dtype=np.uint8)
+        probe[:500] = keys[:500] if n >= 500 else probe[:500]
+        assert np.array_equal(cbf.check_many(probe), oc.check_keys(probe))
+    assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
