@@ -114,7 +114,7 @@ static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, con
     const uint64_t ntiles = (n + Tile::TILE - 1) / Tile::TILE;
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
     const size_t stage_words = ((size_t)Tile::TILE * kk + (size_t)(Tile::GS - 1) * g->nbuckets) * (Tile::pair ? 2 : 1);
-    const size_t lds = (4 * (size_t)g->nbuckets + 8 + stage_words) * 4;
+    const size_t lds = (5 * (size_t)g->nbuckets + 8 + stage_words) * 4;
     uint64_t per_cu = lds > 76 * 1024 ? 1 : 2;
     if (g->dbg & 8) per_cu = 1;  // ablation: one workgroup per CU
     uint64_t nwg = 256 * per_cu;

@@ -130,16 +130,24 @@ struct SpillBloomTest {  // lookup probe: test it directly (bloom.py:269-271); `
 // and the previous tile's write-out stores.  Pass 1 exchanges data between waves through LDS only.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// wave64 inclusive prefix sum on the DPP network (row_shr 1/2/4/8 inside each row of 16, then row_bcast 15 / 31 across
+// rows): 6 dependent VALU adds instead of 6 ds_bpermute round trips through the LDS pipe
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 // block-wide exclusive scan of one uint32 per thread (512 threads = 8 waves)
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot /*LDS[8]*/, uint32_t *total)
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
+    const uint32_t inc = wave_inclusive_scan(v);
     if (lane == 63) wave_tot[wid] = inc;
     lds_barrier();
     uint32_t base = 0, tot = 0;
@@ -155,7 +163,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
 
 // ------------------------------------------------------------------------------------ pass 1
 // KT = hashes computed per key (>= k, compile time so the probes stay in registers).
-// dynamic LDS: hist[B] | off[B] | delta[B] | cur[B] | wave_tot[8] | stage (1 or 2 words per probe)
+// dynamic LDS: hist[2][B] | off[B] | delta[B] | cur[B] | wave_tot[8] | stage (1 or 2 words per probe)
 template <class Pay, int KT>
 struct PartTile {
     static constexpr bool pair = Pay::mode != kModePlain;           // stage entry = (cell, payload)
@@ -174,8 +182,8 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
     constexpr bool PAIR = T::pair;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t B = g.nbuckets;
-    uint32_t *hist = smem;
-    uint32_t *off = hist + B;
+    uint32_t *hist0 = smem;  // two copies: tile t counts in one while the scan phase of tile t zeroes the other
+    uint32_t *off = hist0 + 2 * B;
     uint32_t *delta = off + B;
     uint32_t *cur = delta + B;  // groups already appended to my segment of every slice, across all my tiles
     uint32_t *wave_tot = cur + B;
@@ -185,6 +193,9 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
     const uint64_t ntiles = (n + TILE - 1) / TILE;
 
     for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) cur[b] = 0;
+    for (uint32_t b = threadIdx.x; b < 2 * B; b += kPartThreads) hist0[b] = 0;
+    uint32_t parity = 0;
+    lds_barrier();
 
     // Software pipeline over tiles: the NEXT tile's keys are loaded right after this tile's hash phase and
     // pinned before this tile's write-out stores are issued (vmcnt counts loads and stores in order on CDNA4:
@@ -209,8 +220,9 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
     if ((g.dbg & 32) && threadIdx.x == 0) t_prev = __builtin_readcyclecounter();
 
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) hist[b] = 0;
-        lds_barrier();
+        uint32_t *hist = hist0 + (size_t)(parity ? B : 0);
+        uint32_t *hist_next = hist0 + (size_t)(parity ? 0 : B);
+        parity ^= 1u;
         PSK_TICK(1);
 
         // ---- hash + histogram: rank = my position among this tile's probes of the same slice
@@ -276,17 +288,13 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
             mine[c] = b < B ? hist[b] : 0;
             s += (mine[c] + GS - 1) / GS * GS;
         }
+        for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) hist_next[b] = 0;  // ready for the next tile
         uint32_t tile_probes;  // padded
         uint32_t run;
         if (B <= 64 * kPartScanPerThread) {
             // all slices live in wave 0 (4 per lane): a wave scan, no cross-wave step, one barrier less
             if (threadIdx.x < 64) {
-                uint32_t inc = s;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t t = __shfl_up(inc, o);
-                    if ((int)threadIdx.x >= o) inc += t;
-                }
+                const uint32_t inc = wave_inclusive_scan(s);
                 run = inc - s;
                 if (threadIdx.x == 63) wave_tot[0] = inc;
             } else {
