@@ -409,6 +409,7 @@ static int finish(int where, const OutBuf *o, hipStream_t st)
 int64_t g_part_mode = 1;
 int64_t g_part_min_keys = 1 << 16;   // x1 for Bloom inserts, x4 for lookups / counter adds (part_wanted)
 int64_t g_part_max_keys = 1 << 25;   // keys per partition round (bounds the bucket buffer)
+int64_t g_part_cache_bytes = 240 << 20;  // bucket-buffer budget per round: the part of the 256 MB MALL we count on
 int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGeom::dbg); 0 in production
 
 extern "C" int psk_set_option(const char *name, int64_t value)
@@ -417,6 +418,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     if (!strcmp(name, "partition")) g_part_mode = value;
     else if (!strcmp(name, "partition_min_keys")) g_part_min_keys = value;
     else if (!strcmp(name, "partition_max_keys")) g_part_max_keys = value < 1024 ? 1024 : value;
+    else if (!strcmp(name, "partition_cache_bytes")) g_part_cache_bytes = value;
     else if (!strcmp(name, "part_debug")) g_part_debug = value;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
@@ -440,6 +442,7 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     if (!strcmp(name, "partition")) *value = g_part_mode;
     else if (!strcmp(name, "partition_min_keys")) *value = g_part_min_keys;
     else if (!strcmp(name, "partition_max_keys")) *value = g_part_max_keys;
+    else if (!strcmp(name, "partition_cache_bytes")) *value = g_part_cache_bytes;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
 }

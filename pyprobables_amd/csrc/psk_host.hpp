@@ -76,7 +76,7 @@ struct Batch {  // device-resident view of one key batch
 // ------------------------------------------------- partitioned (large-batch) path
 // Tunables (psk_set_option): the partitioned path is taken when the batch has at least g_part_min_keys keys and
 // the table geometry allows it; g_part_mode 0 = never, 1 = auto.
-extern PSK_HIDDEN int64_t g_part_mode, g_part_min_keys, g_part_max_keys, g_part_debug;
+extern PSK_HIDDEN int64_t g_part_mode, g_part_min_keys, g_part_max_keys, g_part_cache_bytes, g_part_debug;
 
 // slices of a table of `cells` cells; max_shift = log2(cells one LDS slice may hold)
 static inline bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_shift, PartGeom *g)
@@ -178,6 +178,27 @@ static int with_part_source(const Batch &b, bool *handled, F &&f)
 static inline bool part_wanted(uint64_t n, uint32_t k, int64_t scale = 1)
 {
     return g_part_mode != 0 && (int64_t)n >= g_part_min_keys * scale && k <= 32;
+}
+
+// Keys per partition round.  Pass 2 reads back what pass 1 has just written: while a round's bucket buffer fits the
+// 256 MB Infinity Cache (MALL) most of that read never reaches HBM (measured, 10 M lookups: 475 MB in one round
+// 321 us, two rounds of 237 MB 271 us; inserts at 300 MB are still best in one round).  So a batch whose buffer
+// would exceed 1.5 x `partition_cache_bytes` is cut into equal rounds of at most that size.
+// group = probes per 16-byte group of the encoding in use.
+static inline uint64_t part_round_keys(uint64_t n, uint32_t k, int group)
+{
+    uint64_t rk = (uint64_t)g_part_max_keys < n ? (uint64_t)g_part_max_keys : n;
+    if (g_part_cache_bytes > 0 && n) {
+        const double per_key = (double)k * 16.0 / group * 1.3;  // + run padding and partly filled 64-byte lines
+        const double total = per_key * (double)n;
+        if (total > 1.5 * (double)g_part_cache_bytes) {
+            const uint64_t rounds = (uint64_t)(total / (double)g_part_cache_bytes) + 1;
+            uint64_t per = ((n + rounds - 1) / rounds + 4095) & ~4095ULL;
+            if (per < 1u << 20) per = 1u << 20;
+            if (per < rk) rk = per;
+        }
+    }
+    return rk ? rk : 1;
 }
 
 // view of keys [start, start+cnt) of a device batch

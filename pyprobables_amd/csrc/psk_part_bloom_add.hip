@@ -9,7 +9,7 @@ int bloom_add_partitioned(psk_sketch *s, const Batch &b, hipStream_t st, bool *d
     PartGeom g;
     if (!part_slices(s->m, 20, 7, &g)) return PSK_OK;
     g.k = s->k;
-    const uint64_t round_keys = (uint64_t)g_part_max_keys < b.n ? (uint64_t)g_part_max_keys : b.n;
+    const uint64_t round_keys = part_round_keys(b.n, s->k, PayNone::group);
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
         const Batch sub = sub_batch(b, start, cnt);

@@ -9,7 +9,7 @@ int bloom_check_partitioned(psk_sketch *s, const Batch &b, uint8_t *out_dev, hip
     PartGeom g;
     if (!part_slices(s->m, 20, 7, &g)) return PSK_OK;
     g.k = s->k;
-    uint64_t round_keys = (uint64_t)g_part_max_keys < b.n ? (uint64_t)g_part_max_keys : b.n;
+    uint64_t round_keys = part_round_keys(b.n, s->k, PayKeyId::group);
     if (round_keys > 0xFFFFFFFFULL) round_keys = 0xFFFFFFFFULL;  // 32-bit key ids inside a round
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;

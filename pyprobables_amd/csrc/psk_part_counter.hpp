@@ -14,7 +14,7 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
     PartGeom g;
     if (!part_slices(cells, 15, 5, &g)) return PSK_OK;  // 2^15 counters = 128 KiB per slice
     g.k = s->k;
-    const uint64_t round_keys = (uint64_t)g_part_max_keys < b.n ? (uint64_t)g_part_max_keys : b.n;
+    const uint64_t round_keys = part_round_keys(b.n, s->k, w_dev ? PayWeight::group : PayUnit::group);
     unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;

@@ -446,41 +446,67 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
 constexpr int kApplyThreads = 1024;
 constexpr int kApplyWaves = kApplyThreads / 64;
 
-// Walk the groups of slice `b`: wave w takes segments w, w+16, ...
-// Segments are short (a few hundred probes), so a naive walk is a chain of dependent HBM latencies
-// (count -> data -> next count ...).  Instead: fetch all of this wave's segment counts with ONE load, then
-// keep U segments x R dwordx4 per lane in flight before touching LDS.
-template <class F4>
-__device__ __forceinline__ void for_each_group(const uint4 *buckets, const uint32_t *segcnt, const PartGeom &g, uint32_t b, F4 f4)
+// Walk the groups of slice `b`: wave w takes segments w, w+16, ... (<= 32 of them: one count per lane).
+// A segment is a few hundred probes, so walking segment by segment is a chain of dependent HBM latencies
+// (count -> data -> next count ...) and leaves most loads of the last 64-group chunk of every segment empty.
+// Instead the wave's segments are cut into 64-group chunks, the chunks are numbered across segments (DPP prefix
+// sum of the per-segment chunk counts) and D chunks -- whichever segments they fall in -- are kept in flight per
+// lane before LDS is touched.  chunk -> (segment, offset) is scalar work: ballot + popcount + two readlanes.
+// `body` gets the D groups of a batch; absent ones hold `pad`.
+template <int D, class Body>
+__device__ __forceinline__ void for_each_batch(const uint4 *buckets, const uint32_t *segcnt, const PartGeom &g, uint32_t b,
+                                               const uint4 pad, Body body)
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nseg = g.nwg > wave ? (g.nwg - wave + kApplyWaves - 1) / kApplyWaves : 0;  // <= 32
     uint32_t mycnt = 0;
     if (lane < nseg) mycnt = segcnt[(uint64_t)b * g.nwg + wave + kApplyWaves * lane];
-    constexpr int U = 4, R = 3;
-    for (uint32_t s0 = 0; s0 < nseg; s0 += U) {
-        uint4 q[U][R];
-        uint32_t nvec[U];
-        const uint4 *src[U];
+    const uint32_t chunks = (mycnt + 63) >> 6;
+    const uint32_t incl = wave_inclusive_scan(chunks), excl = incl - chunks;
+    const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    for (uint32_t c0 = 0; c0 < C; c0 += D) {
+        uint4 q[D];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t sl = s0 + u;
-            nvec[u] = sl < nseg ? (uint32_t)__shfl((int)mycnt, (int)sl) : 0;
-            src[u] = buckets + seg_index(g, b, wave + kApplyWaves * sl) * g.segcap;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t v = lane + 64 * r;
-                if (v < nvec[u]) q[u][r] = src[u][v];
-            }
+        for (int d = 0; d < D; ++d) {
+            const uint32_t cc = c0 + d;
+            const uint32_t seg = (uint32_t)__builtin_popcountll(__ballot(incl <= cc));  // uniform; == 64 past the end
+            const uint32_t sl = seg < 64 ? seg : 63;
+            const uint32_t v = (cc - (uint32_t)__builtin_amdgcn_readlane((int)excl, sl)) * 64 + lane;
+            const uint32_t cnt = seg < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)mycnt, sl) : 0;
+            const uint4 *src = buckets + seg_index(g, b, wave + kApplyWaves * sl) * g.segcap;
+            q[d] = pad;
+            if (v < cnt) q[d] = src[v];
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (lane + 64 * r < nvec[u]) f4(q[u][r]);
-            for (uint32_t v = lane + 64 * R; v < nvec[u]; v += 64) f4(src[u][v]);
-        }
+        body(q);
     }
+}
+
+constexpr int kApplyDepth = 12;  // 16-byte loads in flight per lane
+
+// consumers that only issue LDS atomics: one callback per group
+template <class F4>
+__device__ __forceinline__ void for_each_group(const uint4 *buckets, const uint32_t *segcnt, const PartGeom &g, uint32_t b,
+                                               const uint4 pad, F4 f4)
+{
+    for_each_batch<kApplyDepth>(buckets, segcnt, g, b, pad, [&](const uint4 (&q)[kApplyDepth]) {
+#pragma unroll
+        for (int d = 0; d < kApplyDepth; ++d) f4(q[d]);
+    });
+}
+
+// consumers that READ LDS per probe: `pre` (the reads) runs on the whole batch before `post` (the tests), so the
+// reads carry no control dependence and issue back to back instead of one read -> wait -> branch trip per probe
+template <class Pre, class Post>
+__device__ __forceinline__ void for_each_group_padded(const uint4 *buckets, const uint32_t *segcnt, const PartGeom &g, uint32_t b,
+                                                      const uint4 pad, Pre pre, Post post)
+{
+    for_each_batch<kApplyDepth>(buckets, segcnt, g, b, pad, [&](const uint4 (&q)[kApplyDepth]) {
+        uint4 w[kApplyDepth];
+#pragma unroll
+        for (int d = 0; d < kApplyDepth; ++d) w[d] = pre(q[d]);
+#pragma unroll
+        for (int d = 0; d < kApplyDepth; ++d) post(q[d], w[d]);
+    });
 }
 
 // Bloom insert: OR the slice's probes into an LDS image of the slice, then OR the image into the table.
@@ -502,7 +528,7 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *
         if (nv > 1) { const uint32_t x = (uint32_t)(h >> 20) & 0xFFFFFu; atomicOr(&smem[x >> 5], 1u << (x & 31)); }
         if (nv > 2) { const uint32_t x = (uint32_t)(h >> 40) & 0xFFFFFu; atomicOr(&smem[x >> 5], 1u << (x & 31)); }
     };
-    for_each_group(buckets, segcnt, g, b, [&](const uint4 q) { half(q.x, q.y); half(q.z, q.w); });
+    for_each_group(buckets, segcnt, g, b, make_uint4(0, 0, 0, 0), [&](const uint4 q) { half(q.x, q.y); half(q.z, q.w); });
     __syncthreads();
     // merge: this workgroup is the only writer of its slice
     const uint64_t w0 = (uint64_t)b * slice_words;
@@ -533,7 +559,7 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint3
     const uint32_t slice_words = 1u << (g.shift - 5);
     const uint32_t mask = (1u << g.shift) - 1;
     const uint64_t w0 = (uint64_t)b * slice_words;
-    for (uint32_t w = threadIdx.x * 4; w < slice_words; w += kApplyThreads * 4) {
+    for (uint32_t w = threadIdx.x * 4; w < slice_words && !(g.dbg & 128); w += kApplyThreads * 4) {
         const uint64_t gw = w0 + w;
         uint4 t = make_uint4(0, 0, 0, 0);
         if (gw + 3 < tab_words) t = *reinterpret_cast<const uint4 *>(tab + gw);
@@ -545,14 +571,21 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint3
         *reinterpret_cast<uint4 *>(smem + w) = t;
     }
     __syncthreads();
-    for_each_group(buckets, segcnt, g, b, [&](const uint4 q) {
-        const uint32_t kbase = q.x * g.tile;
-        auto test = [&](uint32_t x) {
-            if (x != kPadProbe && ((smem[(x & mask) >> 5] >> (x & 31)) & 1u) == 0) out[kbase + (x >> g.shift)] = 0;
-        };
-        test(q.y);
-        test(q.z);
-        test(q.w);
+    for_each_group_padded(buckets, segcnt, g, b, make_uint4(kPadProbe, kPadProbe, kPadProbe, kPadProbe),
+      [&](const uint4 q) {  // a pad probe reads a harmless in-slice word
+        if (g.dbg & 64) return make_uint4(0, ~0u, ~0u, ~0u);
+        return make_uint4(0, smem[(q.y & mask) >> 5], smem[(q.z & mask) >> 5], smem[(q.w & mask) >> 5]);
+      },
+      [&](const uint4 q, const uint4 w) {  // the rare miss stores
+        const bool my = q.y != kPadProbe && ((w.y >> (q.y & 31)) & 1u) == 0;
+        const bool mz = q.z != kPadProbe && ((w.z >> (q.z & 31)) & 1u) == 0;
+        const bool mw = q.w != kPadProbe && ((w.w >> (q.w & 31)) & 1u) == 0;
+        if (my | mz | mw) {
+            const uint32_t kbase = q.x * g.tile;
+            if (my) out[kbase + (q.y >> g.shift)] = 0;
+            if (mz) out[kbase + (q.z >> g.shift)] = 0;
+            if (mw) out[kbase + (q.w >> g.shift)] = 0;
+        }
     });
 }
 
@@ -572,6 +605,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, 
     const uint32_t slice_cells = 1u << g.shift;
     const uint32_t mask = slice_cells - 1;
     const uint64_t c0 = (uint64_t)b * slice_cells;
+    const uint4 pad4 = make_uint4(kPadProbe, kPadProbe, kPadProbe, kPadProbe);  // (unit adds: 0xFFFF halves)
     if (WEIGHTED && ctr[6] >= (1LL << 31)) {
         auto slow = [&](uint32_t x) {
             if (x == kPadProbe) return;
@@ -580,7 +614,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, 
             if (SIGNED) cms_sat_add((int32_t *)tab + cell, NEG ? -(int64_t)w : (int64_t)w, sat_ctr);
             else cbf_sat_add(tab + cell, w, sat_ctr);
         };
-        for_each_group(buckets, segcnt, g, b, [&](const uint4 q) { slow(q.x); slow(q.y); slow(q.z); slow(q.w); });
+        for_each_group(buckets, segcnt, g, b, pad4, [&](const uint4 q) { slow(q.x); slow(q.y); slow(q.z); slow(q.w); });
         return;
     }
     for (uint32_t w = threadIdx.x; w < slice_cells; w += kApplyThreads) smem[w] = 0;
@@ -589,14 +623,14 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, 
         auto add = [&](uint32_t x) {
             if (x != kPadProbe) atomicAdd(&smem[x & mask], NEG ? 0u - (x >> g.shift) : (x >> g.shift));  // ds_add_u32
         };
-        for_each_group(buckets, segcnt, g, b, [&](const uint4 q) { add(q.x); add(q.y); add(q.z); add(q.w); });
+        for_each_group(buckets, segcnt, g, b, pad4, [&](const uint4 q) { add(q.x); add(q.y); add(q.z); add(q.w); });
     } else {
         const uint32_t one = NEG ? 0xFFFFFFFFu : 1u;
         auto add2 = [&](uint32_t w) {  // two 16-bit slice-local cell indices, 0xFFFF = pad
             if ((w & 0xFFFFu) != 0xFFFFu) atomicAdd(&smem[w & 0xFFFFu], one);
             if ((w >> 16) != 0xFFFFu) atomicAdd(&smem[w >> 16], one);
         };
-        for_each_group(buckets, segcnt, g, b, [&](const uint4 q) { add2(q.x); add2(q.y); add2(q.z); add2(q.w); });
+        for_each_group(buckets, segcnt, g, b, pad4, [&](const uint4 q) { add2(q.x); add2(q.y); add2(q.z); add2(q.w); });
     }
     __syncthreads();
     unsigned long long sat = 0;
