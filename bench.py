@@ -173,8 +173,16 @@ def main():
         raise SystemExit("launch N > 1 through torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # PSK_BENCH_FORCE_DIST=1 drives the whole N > 1 code path (RCCL init, merge, barriers) with a single rank
+    distributed = world > 1 or bool(os.environ.get("PSK_BENCH_FORCE_DIST"))
+    if distributed:
         import torch.distributed as dist
+
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ["PSK_FORCE_MERGE_PATH"] = "1"
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
@@ -193,7 +201,7 @@ def main():
         t = timer.time if record else (lambda _n, f: f())
         t("clear", blm.clear)
         t("insert", lambda: blm.add_many(keys))
-        if world > 1:
+        if distributed:
             t("merge", lambda: parallel.merge_bloom(blm, sync_elements=False))  # table merge only: no host sync
         state["res"] = t("check", lambda: blm.check_many(keys))
 
@@ -267,7 +275,7 @@ def main():
             "check_Mkeys_s": n / chk_ms / 1e3,
             "check_GBs": n * BYTES["bloom_check"] / chk_ms / 1e6,
             "clear_ms": timer.mean_ms("clear"),
-            "merge_ms": timer.mean_ms("merge") if world > 1 else None,
+            "merge_ms": timer.mean_ms("merge") if distributed else None,
             "all_inserted_found": ok,
             "bits_set": bits_set,
         },
