@@ -143,9 +143,12 @@ static int with_kt(uint32_t k, F &&f)
     constexpr bool fast = std::is_same<Src, KeysFixed16>::value;
     if (fast) {
         switch (k) {
+            case 3: return f(std::integral_constant<int, 3>{});
             case 4: return f(std::integral_constant<int, 4>{});
             case 5: return f(std::integral_constant<int, 5>{});
+            case 6: return f(std::integral_constant<int, 6>{});
             case 7: return f(std::integral_constant<int, 7>{});
+            case 10: return f(std::integral_constant<int, 10>{});
             default: break;
         }
     }

@@ -238,8 +238,16 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
                     uint32_t h[KT];
                     if (g.dbg & 4) {
                         for (int j = 0; j < KT; ++j) h[j] = (uint32_t)(((uint64_t)(i * 2654435761u + j * 40503u) * 0x9E3779B97F4A7C15ULL) >> 13);
-                    } else {
+                    } else if constexpr (KT <= 8 || KT % 4 != 0) {  // exact k: every chain is live
                         src.template hash32<KT>(key, i, 0, h);
+                    } else {  // KT is k rounded up: run the chains four at a time and skip the groups past k
+#pragma unroll
+                        for (int s0 = 0; s0 < KT; s0 += 4) {
+                            uint32_t hh[4] = {0, 0, 0, 0};
+                            if ((uint32_t)s0 < k) src.template hash32<4>(key, i, (uint32_t)s0, hh);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) h[s0 + e] = hh[e];
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < KT; ++j) {
@@ -252,8 +260,16 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
                     uint64_t h[KT];
                     if (g.dbg & 4) {
                         for (int j = 0; j < KT; ++j) h[j] = ((uint64_t)(i * 2654435761u + j * 40503u) * 0x9E3779B97F4A7C15ULL) >> 13;
-                    } else {
+                    } else if constexpr (KT <= 8 || KT % 4 != 0) {  // exact k: every chain is live
                         src.template hash<KT>(key, i, 0, h);
+                    } else {
+#pragma unroll
+                        for (int s0 = 0; s0 < KT; s0 += 4) {
+                            uint64_t hh[4] = {0, 0, 0, 0};
+                            if ((uint32_t)s0 < k) src.template hash<4>(key, i, (uint32_t)s0, hh);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) h[s0 + e] = hh[e];
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < KT; ++j) {

@@ -56,13 +56,25 @@ def test_bloom_partitioned_golden_np2(pa, golden, oracle, force_partition):
 @pytest.mark.parametrize("est,fpr,n", [
     (28005615, 0.01, 1_000_000),   # headline geometry: m = 2^28, k = 7, 256 slices of 128 KiB
     (5_000_000, 0.05, 300_000),    # k = 4
-    (2_000_000, 0.001, 200_000),   # k = 10 -> 16 hash chains per key
+    (2_000_000, 0.001, 200_000),   # k = 10 (exact instantiation)
+    (1_000_000, 0.1, 200_000),     # k = 3
+    (1_000_000, 0.02, 200_000),    # k = 6
+    (1_000_000, 0.0001, 150_000),  # k = 13 -> 16 chains in groups of four
+    (1_000_000, 0.00001, 150_000), # k = 17 -> KT = 32, five groups run
+    (500_000, 0.000001, 100_000),  # k = 20
+    # power-of-two m (32-bit hash chains) for the same k values
+    (1160981, 0.0009653916676755292, 150_000),   # k = 10, m = 2^24
+    (892544, 0.00011962950342528697, 150_000),   # k = 13, m = 2^24
+    (682063, 7.370214733371715e-06, 120_000),    # k = 17, m = 2^24
+    (967126, 0.12447325804747715, 150_000),      # k = 3,  m = 2^22
+    (967089, 0.015491121938168474, 150_000),     # k = 6,  m = 2^23
     (300_000, 0.03, 150_000),      # k = 5, m ~ 2.2 Mbit: small slices
     (1000, 0.001, 5000),           # m < 2^16: not eligible, must fall through to the direct kernels
 ])
 def test_bloom_partitioned_vs_oracle(pa, oracle, force_partition, est, fpr, n):
     keys = oracle.gen_keys16(11, n)
     blm = pa.BloomFilter(est_elements=est, false_positive_rate=fpr)
+    assert (blm.number_hashes, blm.number_bits) == oracle.bloom_params(est, fpr)[1:]
     ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
     half = n // 2
     blm.add_many(_dev(keys[:half]))
