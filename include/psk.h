@@ -186,6 +186,30 @@ int psk_cbf_jaccard_counts(const void *a, const void *b, uint64_t n, uint64_t ou
 int psk_or_reduce_slices(void *dst, const void *src, uint32_t nslices, uint64_t slice_words32, int device,
                          void *stream);
 
+/* --------------------------------------------- filters whose insert depends on a lookup
+ * ExpandingBloomFilter / RotatingBloomFilter (expandingbloom.py:140-170, :320-331): a key goes into the newest filter
+ * unless ANY filter of the stack already reports it.  All filters share (m, k, hash): hash once, then index kernels.
+ *   psk_bloom_indices        out_idx_dev[i*k + j] = hash_j(key_i) % m  (bloom.py:247; device buffer; m <= 2^32)
+ *   psk_idx_test             out[i] = all k bits set (bloom.py:269-271); accumulate != 0: out[i] |= ...  (the `any`
+ *                            over the filters of expandingbloom.py:147)
+ *   psk_idx_resolve_ordered  flag[i] = 1 iff the sequential loop "if key not in table: table.add(key)" over the ordered
+ *                            batch would insert key i (expandingbloom.py:166-170), else 0; present[i] != 0 marks keys
+ *                            another filter already holds (nullable); table_dev is NOT modified.  first_dev: uint32[m]
+ *                            scratch, all-ones on entry and again on exit; count_dev: uint64 scratch; *inserted_host
+ *                            receives the number of inserts (NULL: no host sync)
+ *   psk_idx_insert           table |= bits of the keys with flag[i] == 1 (flag NULL: all keys)  (bloom.py:247-249)
+ *   psk_bytes_or             dst[i] |= src[i] */
+int psk_bloom_indices(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n, uint32_t key_len,
+                      int where, uint32_t *out_idx_dev, void *stream);
+int psk_idx_test(const void *table_dev, const uint32_t *idx_dev, uint64_t n, uint32_t k, uint8_t *out_dev, int accumulate,
+                 int device, void *stream);
+int psk_idx_resolve_ordered(const void *table_dev, const uint32_t *idx_dev, const uint8_t *present_dev, uint64_t n, uint32_t k,
+                            uint32_t *first_dev, uint8_t *flag_dev, uint64_t *count_dev, uint64_t *inserted_host, int device,
+                            void *stream);
+int psk_idx_insert(void *table_dev, const uint32_t *idx_dev, const uint8_t *flag_dev, uint64_t n, uint32_t k, int device,
+                   void *stream);
+int psk_bytes_or(void *dst_dev, const void *src_dev, uint64_t n, int device, void *stream);
+
 /* --------------------------------------------- synthetic streams (bench / tests)
  * key_i = LE64(sm(seed+2i)) || LE64(sm(seed+2i+1)); w_i = 1 + sm((seed^0xC0FFEE)+i) % 7 */
 int psk_gen_keys16(void *dst_dev, uint64_t start, uint64_t n, uint64_t seed, int device, void *stream);

@@ -77,6 +77,10 @@ def lib():
         L.psk_o_bloom_check_hashes.restype = None
         L.psk_o_bloom_check_hashes.argtypes = [vp, u64, u32, vp, u64, u64, vp]
         L.psk_o_bloom_bits_set.restype = u64
+        L.psk_o_stack_add_varlen.restype = ci
+        L.psk_o_stack_add_varlen.argtypes = [vp, u64, u64, u64p, vp, u64, u32, u64, u64, vp, vp, u64, ci, u64p]
+        L.psk_o_stack_check_varlen.restype = None
+        L.psk_o_stack_check_varlen.argtypes = [vp, u64, u64, u64, u32, vp, vp, u64, vp]
         L.psk_o_bloom_bits_set.argtypes = [vp, u64]
         L.psk_o_cbf_add_alt.restype = u32
         L.psk_o_cbf_add_alt.argtypes = [vp, u64, u32, vp, u64, u64p]
@@ -227,6 +231,59 @@ class OracleBloom:
 
     def bits_set(self) -> int:
         return int(lib().psk_o_bloom_bits_set(_ptr(self.bloom), self.bloom.size))
+
+
+def splitmix64(x: int) -> int:
+    """the stream generator of SURVEY.md 8(d)"""
+    return int(lib().psk_o_splitmix64(C.c_uint64(x & 0xFFFFFFFFFFFFFFFF)))
+
+
+class OracleStack:
+    """sequential ExpandingBloomFilter (queue=0) / RotatingBloomFilter (queue>0): expandingbloom.py:140-184, :320-358"""
+
+    def __init__(self, est_elements: int, false_positive_rate: float, queue: int = 0, max_filters: int = 64):
+        self.est, self.fpr_given, self.queue = int(est_elements), false_positive_rate, int(queue)
+        self.fpr32, self.k, self.m = bloom_params(est_elements, false_positive_rate)
+        self.filter_bytes = (self.m + 7) // 8
+        self.max_filters = max_filters
+        self.stack = np.zeros((max_filters, self.filter_bytes), dtype=np.uint8)
+        self.counts = np.zeros(max_filters, dtype=np.uint64)
+        self._n = C.c_uint64(1)       # starts with one empty filter (expandingbloom.py:66-68)
+        self._added = C.c_uint64(0)
+
+    @property
+    def nfilters(self) -> int:
+        return self._n.value
+
+    @property
+    def els_added(self) -> int:
+        return self._added.value
+
+    def add_keys(self, keys, force: bool = False):
+        blob, offs = pack_varlen(keys)
+        rc = lib().psk_o_stack_add_varlen(_ptr(self.stack), self.filter_bytes, self.max_filters, C.byref(self._n),
+                                          _ptr(self.counts), self.m, self.k, self.est, self.queue, _ptr(blob), _ptr(offs),
+                                          len(keys), int(force), C.byref(self._added))
+        if rc != 0:
+            raise RuntimeError("OracleStack: max_filters exceeded")
+
+    def check_keys(self, keys) -> np.ndarray:
+        blob, offs = pack_varlen(keys)
+        out = np.empty(len(keys), dtype=np.uint8)
+        lib().psk_o_stack_check_varlen(_ptr(self.stack), self.filter_bytes, self.nfilters, self.m, self.k, _ptr(blob),
+                                       _ptr(offs), len(keys), _ptr(out))
+        return out
+
+    def export_bytes(self) -> bytes:
+        """expandingbloom.py:186-210: per filter uint64 elements_added + bit array, then the QQQf footer"""
+        import struct
+
+        parts = []
+        for f in range(self.nfilters):
+            parts.append(struct.pack("Q", int(self.counts[f])))
+            parts.append(self.stack[f].tobytes())
+        parts.append(struct.pack("QQQf", self.nfilters, self.est, self.els_added, self.fpr_given))
+        return b"".join(parts)
 
 
 class OracleCBF:

@@ -489,6 +489,23 @@ extern "C" int psk_bloom_check(psk_sketch *s, int layout, const void *data, cons
     return finish(where, &o, st);
 }
 
+extern "C" int psk_bloom_indices(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                                uint32_t key_len, int where, uint32_t *out_idx_dev, void *stream)
+{
+    CHECK_HANDLE(s, PSK_KIND_BLOOM);
+    PSK_TRY(check_hashes_width(s, layout, key_len));
+    if (n && !out_idx_dev) return fail(PSK_EINVAL, "out_idx_dev is NULL");
+    if (s->m > (1ULL << 32)) return fail(PSK_EINVAL, "bit indices are 32-bit: m must be <= 2^32");
+    hipStream_t st = (hipStream_t)stream;
+    Batch b;
+    PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+    PSK_TRY(with_source(b, [&](auto src) {
+        if (s->pow2) return launch_apply(src, BloomIndexOut<true>{out_idx_dev, s->md, s->k}, n, st);
+        return launch_apply(src, BloomIndexOut<false>{out_idx_dev, s->md, s->k}, n, st);
+    }));
+    return finish(where, nullptr, st);
+}
+
 extern "C" int psk_bloom_check_bits(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
                                     uint32_t key_len, int where, uint64_t *out_bits, uint64_t *hits, void *stream)
 {

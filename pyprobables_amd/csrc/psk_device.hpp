@@ -288,6 +288,19 @@ struct BloomCheck {  // bloom.py:261-272 check_alt (AND of the k bits; early exi
     __device__ __forceinline__ void end(State &st, uint64_t i) const { out[i] = (uint8_t)st.ok; }
 };
 
+// the k bit positions of every key, for index-only follow-up kernels (psk_index_ops.hip); m <= 2^32
+template <bool POW2>
+struct BloomIndexOut {
+    uint32_t *out;  // [n][k]
+    Mod md;
+    uint32_t k;
+    struct State { uint64_t base; };
+    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ State begin(uint64_t i) const { return State{i * (uint64_t)k}; }
+    __device__ __forceinline__ void apply(State &st, uint32_t j, uint64_t h) const { out[st.base + j] = (uint32_t)reduce<POW2>(md, h); }
+    __device__ __forceinline__ void end(State &, uint64_t) const {}
+};
+
 // membership as a ballot bitmap + popcount of hits: one uint64 store per wavefront of 64 keys
 template <class Src, bool POW2>
 __global__ __launch_bounds__(kBlock) void k_bloom_check_bits(Src src, const uint32_t *tab, Mod md, uint32_t k,

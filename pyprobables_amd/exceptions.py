@@ -28,6 +28,10 @@ class SimilarityError(ProbablesBaseException):
     """two filters cannot be combined (different size / hash family)"""
 
 
+class RotatingBloomFilterError(ProbablesBaseException):
+    """popping the last filter of a RotatingBloomFilter (reference exceptions.py:62-70)"""
+
+
 class CountMinSketchError(ProbablesBaseException):
     """mismatched count-min sketches in ``join``"""
 
