@@ -197,12 +197,27 @@ class ExpandingBloomFilter:
                 self._added_elements += take
                 s += take
                 continue
-            present = self._present(idx, s, rem)
+            if rem == 1:  # single-key call: one lookup, at most one insert, one host sync
+                if int(self._present(idx, s, 1)[0].item()):
+                    self._added_elements += 1
+                    return
+                if room == 0:
+                    self._grow()  # (a rotation may drop the oldest filter: the key is still absent afterwards)
+                    last = self._blooms[-1]
+                self._insert(last, idx, s, 1, None)
+                last._els_added += 1
+                self._added_elements += 1
+                return
+            # Look at a window of the remaining keys: the chunk ends at the room-th candidate anyway, so testing far
+            # beyond it against every filter would be wasted work (a window of repeats just yields a smaller chunk).
+            win = rem if room is None else min(rem, 2 * room + 65536)
+            present = self._present(idx, s, win)
             cand = present == 0
             ncand = int(cand.sum().item())
-            if ncand == 0:  # everything left is already reported: counted, not inserted
-                self._added_elements += rem
-                return
+            if ncand == 0:  # the whole window is already reported: counted, not inserted
+                self._added_elements += win
+                s += win
+                continue
             if room == 0:
                 # the newest filter is full: it is replaced when the first key that really has to be inserted comes
                 j = int(torch.argmax(cand.to(torch.uint8)).item())
@@ -211,7 +226,7 @@ class ExpandingBloomFilter:
                 self._grow()
                 continue
             if room is None or ncand <= room:
-                e = rem
+                e = win
             else:  # end the chunk right after the room-th candidate: no growth can happen inside it
                 csum = torch.cumsum(cand, 0)
                 e = int(torch.searchsorted(csum, torch.tensor([room], device=csum.device, dtype=csum.dtype)).item()) + 1
