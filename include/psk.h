@@ -82,7 +82,7 @@ int psk_device_count(int *count);
 int psk_set_option(const char *name, int64_t value);
 int psk_get_option(const char *name, int64_t *value);
 /* bench-only: s_memtime totals per phase of the last partition pass 1 (option part_debug & 32) */
-int psk_debug_phase_profile(psk_sketch *s, uint32_t nbuckets, uint32_t nwg, uint64_t out[6]);
+int psk_debug_phase_profile(psk_sketch *s, uint32_t nbuckets, uint32_t nwg, uint64_t out[12]);
 
 /* -------------------------------------------------------------- lifecycle
  * ext_table: NULL -> the library hipMallocs (and zeroes) the table;

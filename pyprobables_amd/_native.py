@@ -134,6 +134,9 @@ def lib():
                 raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from ex
             fn.restype, fn.argtypes = res, args
         _lib = L
+        for env, opt in (("PSK_PART_DEBUG", "part_debug"),):  # bench-only ablation bits, see PartGeom::dbg
+            if os.environ.get(env):
+                L.psk_set_option(opt.encode(), int(os.environ[env]))
     return _lib
 
 

@@ -425,14 +425,14 @@ extern "C" int psk_set_option(const char *name, int64_t value)
 }
 
 // bench-only: phase cycle totals of the last pass-1 launch (valid when part_debug & 32); zeroes them afterwards
-extern "C" int psk_debug_phase_profile(psk_sketch *s, uint32_t nbuckets, uint32_t nwg, uint64_t out[6])
+extern "C" int psk_debug_phase_profile(psk_sketch *s, uint32_t nbuckets, uint32_t nwg, uint64_t out[12])
 {
     if (!s || !s->s_cnt.p) return fail(PSK_EINVAL, "no partition scratch yet");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipDeviceSynchronize());
     char *p = (char *)s->s_cnt.p + (size_t)nbuckets * nwg * 4;
-    HIP_TRY(hipMemcpy(out, p, 48, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(p, 0, 48));
+    HIP_TRY(hipMemcpy(out, p, 96, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(p, 0, 96));
     return PSK_OK;
 }
 

@@ -114,7 +114,7 @@ static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, con
     const uint64_t ntiles = (n + Tile::TILE - 1) / Tile::TILE;
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
     const size_t stage_words = ((size_t)Tile::TILE * kk + (size_t)(Tile::GS - 1) * g->nbuckets) * (Tile::pair ? 2 : 1);
-    const size_t lds = (5 * (size_t)g->nbuckets + 8 + stage_words) * 4;
+    const size_t lds = (5 * (size_t)g->nbuckets + 8 + 24 + stage_words) * 4;
     uint64_t per_cu = lds > 76 * 1024 ? 1 : 2;
     if (g->dbg & 8) per_cu = 1;  // ablation: one workgroup per CU
     uint64_t nwg = 256 * per_cu;
@@ -127,7 +127,7 @@ static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, con
     g->segcap = (uint32_t)segcap;
     g->tile = (uint32_t)Tile::TILE;
     PSK_TRY(ensure(s->s_part, (uint64_t)g->nbuckets * nwg * segcap * 16 + 256));
-    PSK_TRY(ensure(s->s_cnt, (uint64_t)g->nbuckets * nwg * 4 + 64));  // + 6 x u64 of phase profile (dbg & 32)
+    PSK_TRY(ensure(s->s_cnt, (uint64_t)g->nbuckets * nwg * 4 + 128));  // + 12 x u64 of phase profile (dbg & 32)
     auto kern = k_part_scatter<Src, IdxFn, Pay, Spill, KT>;
     PSK_TRY(set_dyn_lds(kern, lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kPartThreads), lds, st, src, idxfn, pay, spill, *g, n,

@@ -163,7 +163,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
 
 // ------------------------------------------------------------------------------------ pass 1
 // KT = hashes computed per key (>= k, compile time so the probes stay in registers).
-// dynamic LDS: hist[2][B] | off[B] | delta[B] | cur[B] | wave_tot[8] | stage (1 or 2 words per probe)
+// dynamic LDS: hist[2][B] | off[B] | delta[B] | cur[B] | wave_tot[8] | profile[24] | stage (1 or 2 words per probe)
 template <class Pay, int KT>
 struct PartTile {
     static constexpr bool pair = Pay::mode != kModePlain;           // stage entry = (cell, payload)
@@ -173,8 +173,10 @@ struct PartTile {
     static constexpr int TILE = kPartThreads * KPT;                 // keys per tile
 };
 
+// (the second launch bound is hipcc's "min waves per SIMD": 4 = two workgroups per CU = at most 128 VGPRs; without it
+// small source changes tip the keyed instantiation to 133 VGPRs and one workgroup per CU, 15 % slower)
 template <class Src, class IdxFn, class Pay, class Spill, int KT>
-__global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn idxfn, Pay pay, Spill spill, PartGeom g,
+__global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatter(Src src, IdxFn idxfn, Pay pay, Spill spill, PartGeom g,
                                                                uint64_t n, uint32_t *segcnt, uint4 *buckets)
 {
     using T = PartTile<Pay, KT>;
@@ -187,7 +189,8 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
     uint32_t *delta = off + B;
     uint32_t *cur = delta + B;  // groups already appended to my segment of every slice, across all my tiles
     uint32_t *wave_tot = cur + B;
-    uint32_t *stage = wave_tot + 8;
+    unsigned long long *t_acc = reinterpret_cast<unsigned long long *>(wave_tot + 8);  // phase profile (dbg & 32), 12 slots
+    uint32_t *stage = wave_tot + 8 + 24;
     const uint32_t k = g.k;
     const uint32_t mask = (1u << g.shift) - 1;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
@@ -210,7 +213,8 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
     }
 
     // phase profile (dbg & 32): lane 0 of wave 0 accumulates s_memtime deltas per phase; bench-only
-    unsigned long long t_prev = 0, t_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = 0;  // (the accumulators live in LDS: 12 x 64-bit in registers cost 24 VGPRs on every lane)
+    if ((g.dbg & 32) && threadIdx.x < 12) t_acc[threadIdx.x] = 0;
 #define PSK_TICK(ph)                                                                   \
     if ((g.dbg & 32) && threadIdx.x == 0) {                                            \
         const unsigned long long t_now = __builtin_readcyclecounter();                 \
@@ -281,6 +285,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
                 }
             }
         }
+        PSK_TICK(9);
         lds_barrier();
         PSK_TICK(2);
 
@@ -305,6 +310,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
             s += (mine[c] + GS - 1) / GS * GS;
         }
         for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) hist_next[b] = 0;  // ready for the next tile
+        PSK_TICK(6);
         uint32_t tile_probes;  // padded
         uint32_t run;
         if (B <= 64 * kPartScanPerThread) {
@@ -319,6 +325,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
         } else {
             run = block_exclusive_scan(s, wave_tot, &tile_probes);
         }
+        PSK_TICK(7);
 #pragma unroll
         for (int c = 0; c < kPartScanPerThread; ++c) {
             const uint32_t b = threadIdx.x * kPartScanPerThread + c;
@@ -328,18 +335,16 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
                 const uint32_t c0 = cur[b];
                 delta[b] = c0 - run / GS;   // segment group = delta[b] + stage group
                 cur[b] = c0 + padded / GS;
-                for (uint32_t e = mine[c]; e < padded; ++e) {
-                    if (PAIR) reinterpret_cast<uint2 *>(stage)[run + e] = make_uint2(kPadProbe, 0u);
-                    else stage[run + e] = kPadProbe;
-                }
                 run += padded;
             }
         }
+        PSK_TICK(8);
         lds_barrier();
         if (B <= 64 * kPartScanPerThread) tile_probes = wave_tot[0];
         PSK_TICK(3);
 
-        // ---- counting-sort the probes into the LDS stage
+        // ---- counting-sort the probes into the LDS stage; one thread per slice also fills its run's trailing pads
+        // (in the scan phase that was 4 slices x up to GS-1 serial stores on the single scanning wave: 18 % of pass 1)
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
             const uint64_t i = base + (uint64_t)q * kPartThreads + threadIdx.x;
@@ -352,6 +357,14 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
                         else stage[p] = idx[q][j];
                     }
                 }
+            }
+        }
+        // (after the sort stores: idx / rank are dead by now, so this costs no registers)
+        for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
+            const uint32_t cnt = hist[b], padded = (cnt + GS - 1) / GS * GS, at = off[b];
+            for (uint32_t e = cnt; e < padded; ++e) {
+                if (PAIR) reinterpret_cast<uint2 *>(stage)[at + e] = make_uint2(kPadProbe, 0u);
+                else stage[at + e] = kPadProbe;
             }
         }
         lds_barrier();
@@ -447,7 +460,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Src src, IdxFn id
     lds_barrier();
     if ((g.dbg & 32) && threadIdx.x == 0) {  // counts land behind the segment counts (host reserves the room)
         unsigned long long *prof = reinterpret_cast<unsigned long long *>(segcnt + (size_t)g.nbuckets * g.nwg);
-        for (int ph = 1; ph < 6; ++ph) atomicAdd(prof + ph, t_acc[ph]);
+        for (int ph = 1; ph < 12; ++ph) atomicAdd(prof + ph, t_acc[ph]);
         atomicAdd(prof, 1ULL);
     }
 #undef PSK_TICK

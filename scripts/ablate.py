@@ -23,16 +23,18 @@ N.set_option("part_debug", 0)
 import ctypes as C
 N.set_option("part_debug", 32)
 blm.add_many(keys); torch.cuda.synchronize()
-buf = (C.c_uint64 * 6)()
+buf = (C.c_uint64 * 12)()
 N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 512, buf))   # clear whatever warm-up left
 for _ in range(3):
     blm.add_many(keys)
 torch.cuda.synchronize()
 N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 512, buf))
 names = ["(wgs)", "zero+bar", "hash+hist+bar", "scan+bar", "sort+bar", "writeout(+bar)"]
-tot = sum(buf[1:6])
-for i in range(1, 6):
-    print(f"phase {names[i]:16s} {buf[i]/buf[0]/3:10.0f} ticks per WG per launch  ({100.0*buf[i]/tot:5.1f} %)")
+tot = sum(buf[1:12])
+names += ["  scan: read hist+zero", "  scan: wave scan", "  scan: cursor+pads", "  hash+hist (own work)"]
+names[2], names[3] = "wait at barrier 1", "wait at barrier 2"
+for i in [1, 9, 2, 6, 7, 8, 3, 4, 5]:
+    print(f"phase {names[i]:24s} {buf[i]/buf[0]/3:10.0f} ticks per WG per launch  ({100.0*buf[i]/tot:5.1f} %)")
 N.set_option("part_debug", 0)
 
 # same phase profile for the lookup (keyed) variant
@@ -43,7 +45,7 @@ for _ in range(3):
     blm.check_many(keys)
 torch.cuda.synchronize()
 N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 512, buf))
-tot = sum(buf[1:6])
-for i in range(1, 6):
-    print(f"check phase {names[i]:16s} {buf[i]/buf[0]/3:10.0f} ticks per WG per launch  ({100.0*buf[i]/tot:5.1f} %)")
+tot = sum(buf[1:12])
+for i in [1, 9, 2, 6, 7, 8, 3, 4, 5]:
+    print(f"check phase {names[i]:24s} {buf[i]/buf[0]/3:10.0f} ticks per WG per launch  ({100.0*buf[i]/tot:5.1f} %)")
 N.set_option("part_debug", 0)
