@@ -173,6 +173,87 @@ struct PartTile {
     static constexpr int TILE = kPartThreads * KPT;                 // keys per tile
 };
 
+// Write-out of ONE 16-byte group of the sorted LDS stage: lane = group gi of the tile; its first probe is always
+// real (pads trail), so it names the slice.  delta[b] turns the stage group index into the slot of my segment.
+template <class Pay, class Spill>
+__device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t *delta, const PartGeom &g, uint32_t mask, uint32_t gi,
+                                           uint64_t tile, uint64_t base, const Spill &spill, uint4 *buckets)
+{
+    constexpr int GS = Pay::group;
+    if constexpr (Pay::mode == kModePlain) {
+        // the LDS stage holds full cell indices (the first one names the slice); HBM gets them packed
+        uint32_t c[GS];
+        if constexpr (GS == 6) {
+            const uint2 a0 = reinterpret_cast<const uint2 *>(stage)[3 * gi];
+            const uint2 a1 = reinterpret_cast<const uint2 *>(stage)[3 * gi + 1];
+            const uint2 a2 = reinterpret_cast<const uint2 *>(stage)[3 * gi + 2];
+            c[0] = a0.x; c[1] = a0.y; c[2] = a1.x; c[3] = a1.y; c[4] = a2.x; c[5] = a2.y;
+        } else {
+            const uint4 a0 = reinterpret_cast<const uint4 *>(stage)[2 * gi];
+            const uint4 a1 = reinterpret_cast<const uint4 *>(stage)[2 * gi + 1];
+            c[0] = a0.x; c[1] = a0.y; c[2] = a0.z; c[3] = a0.w; c[4] = a1.x; c[5] = a1.y; c[6] = a1.z; c[7] = a1.w;
+        }
+        const uint32_t b = c[0] >> g.shift;
+        const uint32_t slot = delta[b] + gi;
+        if (slot < g.segcap) {
+            uint4 o;
+            if constexpr (GS == 6) {
+                // two 64-bit halves: 3 x 20-bit local indices + the number of valid ones in bits 60..63
+                uint32_t nv = 0;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) nv += c[e] != kPadProbe;  // pads trail
+                const uint32_t n0 = nv < 3 ? nv : 3, n1 = nv - n0;
+                const unsigned long long h0 = (unsigned long long)(c[0] & mask) | ((unsigned long long)(c[1] & mask) << 20) |
+                                              ((unsigned long long)(c[2] & mask) << 40) | ((unsigned long long)n0 << 60);
+                const unsigned long long h1 = (unsigned long long)(c[3] & mask) | ((unsigned long long)(c[4] & mask) << 20) |
+                                              ((unsigned long long)(c[5] & mask) << 40) | ((unsigned long long)n1 << 60);
+                o = make_uint4((uint32_t)h0, (uint32_t)(h0 >> 32), (uint32_t)h1, (uint32_t)(h1 >> 32));
+            } else {
+                auto h16 = [&](uint32_t x) -> uint32_t { return x == kPadProbe ? 0xFFFFu : (x & mask); };
+                o = make_uint4(h16(c[0]) | (h16(c[1]) << 16), h16(c[2]) | (h16(c[3]) << 16),
+                               h16(c[4]) | (h16(c[5]) << 16), h16(c[6]) | (h16(c[7]) << 16));
+            }
+            buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = o;
+        } else {  // segment full: exact fallback, probe by probe
+#pragma unroll
+            for (int e = 0; e < GS; ++e)
+                if (c[e] != kPadProbe) spill(c[e], 0u);
+        }
+    } else if constexpr (Pay::mode == kModeInline) {
+        const uint4 e01 = reinterpret_cast<const uint4 *>(stage)[2 * gi];      // cell0 w0 cell1 w1
+        const uint4 e23 = reinterpret_cast<const uint4 *>(stage)[2 * gi + 1];  // cell2 w2 cell3 w3
+        const uint32_t b = e01.x >> g.shift;
+        const uint32_t slot = delta[b] + gi;
+        const bool room = slot < g.segcap;
+        const uint32_t wmax = 1u << (31 - g.shift);  // weights below this ride inside the probe word
+        auto enc = [&](uint32_t cell, uint32_t w) -> uint32_t {
+            if (cell == kPadProbe) return kPadProbe;
+            if (room && w < wmax) return (w << g.shift) | (cell & mask);
+            spill(cell, w);  // big / negative weight, or segment full: exact saturating add on the table
+            return kPadProbe;
+        };
+        const uint4 o = make_uint4(enc(e01.x, e01.y), enc(e01.z, e01.w), enc(e23.x, e23.y), enc(e23.z, e23.w));
+        if (room) buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = o;
+    } else {  // keyed
+        const uint2 e0 = reinterpret_cast<const uint2 *>(stage)[3 * gi];
+        const uint2 e1 = reinterpret_cast<const uint2 *>(stage)[3 * gi + 1];
+        const uint2 e2 = reinterpret_cast<const uint2 *>(stage)[3 * gi + 2];
+        const uint32_t b = e0.x >> g.shift;
+        const uint32_t slot = delta[b] + gi;
+        if (slot < g.segcap) {
+            auto enc = [&](uint2 e) -> uint32_t {
+                return e.x == kPadProbe ? kPadProbe : ((e.y << g.shift) | (e.x & mask));
+            };
+            buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] =
+                make_uint4((uint32_t)tile, enc(e0), enc(e1), enc(e2));
+        } else {
+            if (e0.x != kPadProbe) spill(e0.x, (uint32_t)base + e0.y);
+            if (e1.x != kPadProbe) spill(e1.x, (uint32_t)base + e1.y);
+            if (e2.x != kPadProbe) spill(e2.x, (uint32_t)base + e2.y);
+        }
+    }
+}
+
 // (the second launch bound is hipcc's "min waves per SIMD": 4 = two workgroups per CU = at most 128 VGPRs; without it
 // small source changes tip the keyed instantiation to 133 VGPRs and one workgroup per CU, 15 % slower)
 template <class Src, class IdxFn, class Pay, class Spill, int KT>
@@ -191,7 +272,10 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
     uint32_t *wave_tot = cur + B;
     unsigned long long *t_acc = reinterpret_cast<unsigned long long *>(wave_tot + 8);  // phase profile (dbg & 32), 12 slots
     uint32_t *stage = wave_tot + 8 + 24;
-    const uint32_t k = g.k;
+    // KT other than the round-up sizes 8 / 16 / 32 is an exact instantiation (with_kt): k == KT, and every per-probe
+    // "j < k" test below folds away (28 exec-mask branch sequences per tile for k = 7)
+    constexpr bool kExactK = KT != 8 && KT != 16 && KT != 32;
+    const uint32_t k = kExactK ? (uint32_t)KT : g.k;
     const uint32_t mask = (1u << g.shift) - 1;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
 
@@ -231,6 +315,7 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
 
         // ---- hash + histogram: rank = my position among this tile's probes of the same slice
         uint32_t idx[KPT][KT], rank[KPT][KT], payload[KPT];
+        uint32_t fold = 0;
         const uint64_t base = tile * TILE;
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
@@ -257,6 +342,7 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
                     for (int j = 0; j < KT; ++j) {
                         if ((uint32_t)j < k) {
                             idx[q][j] = idxfn.from32((uint32_t)j, h[j]);
+                            if (g.dbg & 2) { fold ^= idx[q][j]; continue; }  // bench-only: hashing alone
                             rank[q][j] = atomicAdd(&hist[idx[q][j] >> g.shift], 1u);  // ds_add_rtn_u32
                         }
                     }
@@ -284,6 +370,18 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
                     }
                 }
             }
+        }
+        if (g.dbg & 2) {  // bench-only: keep the hashes alive, skip the rest of the tile (uniform)
+            if (fold == 0x12345u) segcnt[0] = fold;
+            if (kPartPipeline) {
+                const uint64_t nbase = (tile + gridDim.x) * TILE;
+#pragma unroll
+                for (int q = 0; q < KPT; ++q) {
+                    const uint64_t i = nbase + (uint64_t)q * kPartThreads + threadIdx.x;
+                    kcur[q] = src.load(i < n ? i : n - 1);
+                }
+            }
+            continue;
         }
         PSK_TICK(9);
         lds_barrier();
@@ -378,78 +476,7 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
         if (!(g.dbg & 1)) {
             const uint32_t ngroups = tile_probes / GS;
             for (uint32_t gi = threadIdx.x; gi < ngroups; gi += kPartThreads) {
-                if constexpr (Pay::mode == kModePlain) {
-                    // the LDS stage holds full cell indices (the first one names the slice); HBM gets them packed
-                    uint32_t c[GS];
-                    if constexpr (GS == 6) {
-                        const uint2 a0 = reinterpret_cast<const uint2 *>(stage)[3 * gi];
-                        const uint2 a1 = reinterpret_cast<const uint2 *>(stage)[3 * gi + 1];
-                        const uint2 a2 = reinterpret_cast<const uint2 *>(stage)[3 * gi + 2];
-                        c[0] = a0.x; c[1] = a0.y; c[2] = a1.x; c[3] = a1.y; c[4] = a2.x; c[5] = a2.y;
-                    } else {
-                        const uint4 a0 = reinterpret_cast<const uint4 *>(stage)[2 * gi];
-                        const uint4 a1 = reinterpret_cast<const uint4 *>(stage)[2 * gi + 1];
-                        c[0] = a0.x; c[1] = a0.y; c[2] = a0.z; c[3] = a0.w; c[4] = a1.x; c[5] = a1.y; c[6] = a1.z; c[7] = a1.w;
-                    }
-                    const uint32_t b = c[0] >> g.shift;
-                    const uint32_t slot = delta[b] + gi;
-                    if (slot < g.segcap) {
-                        uint4 o;
-                        if constexpr (GS == 6) {
-                            // two 64-bit halves: 3 x 20-bit local indices + the number of valid ones in bits 60..63
-                            uint32_t nv = 0;
-#pragma unroll
-                            for (int e = 0; e < 6; ++e) nv += c[e] != kPadProbe;  // pads trail
-                            const uint32_t n0 = nv < 3 ? nv : 3, n1 = nv - n0;
-                            const unsigned long long h0 = (unsigned long long)(c[0] & mask) | ((unsigned long long)(c[1] & mask) << 20) |
-                                                          ((unsigned long long)(c[2] & mask) << 40) | ((unsigned long long)n0 << 60);
-                            const unsigned long long h1 = (unsigned long long)(c[3] & mask) | ((unsigned long long)(c[4] & mask) << 20) |
-                                                          ((unsigned long long)(c[5] & mask) << 40) | ((unsigned long long)n1 << 60);
-                            o = make_uint4((uint32_t)h0, (uint32_t)(h0 >> 32), (uint32_t)h1, (uint32_t)(h1 >> 32));
-                        } else {
-                            auto h16 = [&](uint32_t x) -> uint32_t { return x == kPadProbe ? 0xFFFFu : (x & mask); };
-                            o = make_uint4(h16(c[0]) | (h16(c[1]) << 16), h16(c[2]) | (h16(c[3]) << 16),
-                                           h16(c[4]) | (h16(c[5]) << 16), h16(c[6]) | (h16(c[7]) << 16));
-                        }
-                        buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = o;
-                    } else {  // segment full: exact fallback, probe by probe
-#pragma unroll
-                        for (int e = 0; e < GS; ++e)
-                            if (c[e] != kPadProbe) spill(c[e], 0u);
-                    }
-                } else if constexpr (Pay::mode == kModeInline) {
-                    const uint4 e01 = reinterpret_cast<const uint4 *>(stage)[2 * gi];      // cell0 w0 cell1 w1
-                    const uint4 e23 = reinterpret_cast<const uint4 *>(stage)[2 * gi + 1];  // cell2 w2 cell3 w3
-                    const uint32_t b = e01.x >> g.shift;
-                    const uint32_t slot = delta[b] + gi;
-                    const bool room = slot < g.segcap;
-                    const uint32_t wmax = 1u << (31 - g.shift);  // weights below this ride inside the probe word
-                    auto enc = [&](uint32_t cell, uint32_t w) -> uint32_t {
-                        if (cell == kPadProbe) return kPadProbe;
-                        if (room && w < wmax) return (w << g.shift) | (cell & mask);
-                        spill(cell, w);  // big / negative weight, or segment full: exact saturating add on the table
-                        return kPadProbe;
-                    };
-                    const uint4 o = make_uint4(enc(e01.x, e01.y), enc(e01.z, e01.w), enc(e23.x, e23.y), enc(e23.z, e23.w));
-                    if (room) buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = o;
-                } else {  // keyed
-                    const uint2 e0 = reinterpret_cast<const uint2 *>(stage)[3 * gi];
-                    const uint2 e1 = reinterpret_cast<const uint2 *>(stage)[3 * gi + 1];
-                    const uint2 e2 = reinterpret_cast<const uint2 *>(stage)[3 * gi + 2];
-                    const uint32_t b = e0.x >> g.shift;
-                    const uint32_t slot = delta[b] + gi;
-                    if (slot < g.segcap) {
-                        auto enc = [&](uint2 e) -> uint32_t {
-                            return e.x == kPadProbe ? kPadProbe : ((e.y << g.shift) | (e.x & mask));
-                        };
-                        buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] =
-                            make_uint4((uint32_t)tile, enc(e0), enc(e1), enc(e2));
-                    } else {
-                        if (e0.x != kPadProbe) spill(e0.x, (uint32_t)base + e0.y);
-                        if (e1.x != kPadProbe) spill(e1.x, (uint32_t)base + e1.y);
-                        if (e2.x != kPadProbe) spill(e2.x, (uint32_t)base + e2.y);
-                    }
-                }
+                emit_group<Pay, Spill>(stage, delta, g, mask, gi, tile, base, spill, buckets);
             }
         }
         // (pipelined form) no barrier needed here: the next iteration touches only hist (last read two barriers
