@@ -695,11 +695,29 @@ __global__ __launch_bounds__(kBlock) void k_weight_sum(const W *w, uint64_t n, l
     long long s = 0;
     unsigned long long a = 0;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const long long v = (long long)w[i];
+    auto acc = [&](W x) {
+        const long long v = (long long)x;
         s += v;
         a += (unsigned long long)(v < 0 ? -v : v);
+    };
+    uint64_t done = 0;
+    if (sizeof(W) == 4 && ((uintptr_t)w & 15) == 0) {  // 16-byte loads, two in flight per lane (a dword loop was latency bound)
+        struct alignas(16) W4 { W x, y, z, t; };
+        const W4 *w4 = reinterpret_cast<const W4 *>(w);
+        const uint64_t n4 = n / 4;
+        uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+        for (; i + stride < n4; i += 2 * stride) {
+            const W4 p = w4[i], q = w4[i + stride];
+            acc(p.x); acc(p.y); acc(p.z); acc(p.t);
+            acc(q.x); acc(q.y); acc(q.z); acc(q.t);
+        }
+        if (i < n4) {
+            const W4 p = w4[i];
+            acc(p.x); acc(p.y); acc(p.z); acc(p.t);
+        }
+        done = n4 * 4;
     }
+    for (uint64_t i = done + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) acc(w[i]);
     for (int o = 32; o > 0; o >>= 1) {
         s += __shfl_down(s, o);
         a += __shfl_down(a, o);
