@@ -167,6 +167,12 @@ int psk_cms_update_ordered(psk_sketch *s, int layout, const void *data, const ui
  * out[i*depth + j] = fnv_1a(key_i, seed=j)  (hashes.py:71-103); layout != PSK_KEYS_HASHES */
 int psk_fnv1a_hash(int layout, const void *data, const uint64_t *offsets, uint64_t n, uint32_t key_len,
                    uint32_t depth, int where, uint64_t *out, int device, void *stream);
+/* the digest families (hashes.py:17-40,125-150 default_md5 / default_sha256): a CHAIN, tmp = H(tmp).digest() per depth
+ * step, out[i*depth + j] = LE64 of the first 8 bytes of link j.  Byte layouts only (PSK_KEYS_FIXED / PSK_KEYS_VARLEN8);
+ * the reference UTF-8-encodes a str for these families (hashes.py:34), which is the caller's packing job. */
+enum psk_digest { PSK_DIGEST_MD5 = 0, PSK_DIGEST_SHA256 = 1 };
+int psk_digest_chain(int algo, int layout, const void *data, const uint64_t *offsets, uint64_t n, uint32_t key_len,
+                     uint32_t depth, int where, uint64_t *out, int device, void *stream);
 
 /* ------------------------------------------------------ table algebra (device pointers)
  * Streaming kernels over whole tables; also the local half of the multi-GPU merge.

@@ -65,6 +65,7 @@ PROTOTYPES = {
     "psk_cms_check_meanmin": (_int, [_vp, *_KEYS, _int, _i64, _vp, _vp]),
     "psk_cms_update_ordered": (_int, [_vp, *_KEYS, _vp, _int, _int, _i64, _int, _vp, _vp]),
     "psk_fnv1a_hash": (_int, [*_KEYS, _u32, _int, _vp, _int, _vp]),
+    "psk_digest_chain": (_int, [_int, *_KEYS, _u32, _int, _vp, _int, _vp]),
     "psk_table_or": (_int, [_vp, _vp, _u64, _int, _vp]),
     "psk_table_and": (_int, [_vp, _vp, _u64, _int, _vp]),
     "psk_table_popcount": (_int, [_vp, _u64, C.POINTER(_u64), _int, _vp]),

@@ -24,8 +24,8 @@ import numpy as np
 from . import _native as N
 from ._base import DeviceTable
 from .exceptions import InitializationError, SimilarityError
-from .hashes import HashFuncT, HashResultsT, KeyT, default_fnv_1a
-from .keys import KeyBatch, pack_hashes, pack_keys
+from .hashes import HashFuncT, HashResultsT, KeyT, default_fnv_1a, device_digest
+from .keys import KeyBatch, digest_batch, pack_hashes, pack_keys
 
 _LN2_SQUARED = 0.4804530139182   # bloom.py:477 (the literal the reference and its C sibling use)
 _LN2 = 0.6931471805599453        # bloom.py:478
@@ -190,6 +190,8 @@ class BloomFilter:
         """keys -> device-ready batch; a custom hash_function is evaluated here, on the host, per key"""
         if self._fused:
             b = pack_keys(keys)
+        elif device_digest(self._hash_func) is not None:  # default_md5 / default_sha256: digest chains on the GPU
+            b = digest_batch(keys, device_digest(self._hash_func), self._number_hashes, self._tab.device, self._tab.stream)
         else:
             if isinstance(keys, (str, bytes, bytearray, memoryview)):
                 keys = [keys]

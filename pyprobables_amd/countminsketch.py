@@ -23,8 +23,8 @@ from . import _native as N
 from ._base import DeviceTable, weights_arg
 from .bloom import _existing_file, _torch_dtype
 from .exceptions import CountMinSketchError, InitializationError
-from .hashes import HashFuncT, HashResultsT, KeyT, default_fnv_1a
-from .keys import KeyBatch, pack_hashes, pack_keys
+from .hashes import HashFuncT, HashResultsT, KeyT, default_fnv_1a, device_digest
+from .keys import KeyBatch, digest_batch, pack_hashes, pack_keys
 
 _I32_MAX, _I32_MIN = 2**31 - 1, -(2**31)
 _I64_MAX, _I64_MIN = 2**63 - 1, -(2**63)
@@ -200,6 +200,8 @@ class CountMinSketch:
     def _batch(self, keys) -> KeyBatch:
         if self._fused:
             b = pack_keys(keys)
+        elif device_digest(self._hash_function) is not None:  # default_md5 / default_sha256: digest chains on the GPU
+            b = digest_batch(keys, device_digest(self._hash_function), self._depth, self._tab.device, self._tab.stream)
         else:
             if isinstance(keys, (str, bytes, bytearray, memoryview)):
                 keys = [keys]

@@ -1,6 +1,7 @@
 // psk_capi.hip -- the extern "C" boundary (include/psk.h) over the gfx950 kernels in psk_device.hpp.
 // Host side: handle bookkeeping, host<->device staging for PSK_HOST buffers, launch geometry.
 #include "psk_host.hpp"
+#include "psk_digest.hpp"
 
 #include <map>
 #include <mutex>
@@ -791,6 +792,32 @@ extern "C" int psk_fnv1a_hash(int layout, const void *data, const uint64_t *offs
             HIP_TRY(hipGetLastError());
             return (int)PSK_OK;
         }));
+    }
+    return finish(where, &o, st);
+}
+
+// hashes.py:125-150 default_md5 / default_sha256 as digest chains (psk_digest.hpp); byte keys only
+extern "C" int psk_digest_chain(int algo, int layout, const void *data, const uint64_t *offsets, uint64_t n, uint32_t key_len,
+                                uint32_t depth, int where, uint64_t *out, int device, void *stream)
+{
+    if (algo != PSK_DIGEST_MD5 && algo != PSK_DIGEST_SHA256) return fail(PSK_EINVAL, "unknown digest %d", algo);
+    if (layout != PSK_KEYS_FIXED && layout != PSK_KEYS_VARLEN8)
+        return fail(PSK_EINVAL, "digest chains hash bytes: use PSK_KEYS_FIXED or PSK_KEYS_VARLEN8 (a str is UTF-8 encoded by the caller)");
+    if (n && depth && !out) return fail(PSK_EINVAL, "out is NULL");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    Batch b;
+    PSK_TRY(stage_batch(g_hkeys, g_hoffs, layout, data, offsets, n, key_len, where, st, &b));
+    OutBuf o;
+    PSK_TRY(stage_out(g_hout, out, n * depth * 8, where, &o));
+    if (n && depth) {
+        const uint64_t *offs = layout == PSK_KEYS_VARLEN8 ? b.offs : nullptr;
+        const dim3 grid((unsigned)((n + 255) / 256 > 65535 ? 65535 : (n + 255) / 256));
+        if (algo == PSK_DIGEST_MD5)
+            hipLaunchKernelGGL((k_digest_chain<Md5>), grid, dim3(256), 0, st, (const uint8_t *)b.data, offs, key_len, n, depth, (uint64_t *)o.dev);
+        else
+            hipLaunchKernelGGL((k_digest_chain<Sha256>), grid, dim3(256), 0, st, (const uint8_t *)b.data, offs, key_len, n, depth, (uint64_t *)o.dev);
+        HIP_TRY(hipGetLastError());
     }
     return finish(where, &o, st);
 }

@@ -96,3 +96,13 @@ def default_md5(key: KeyT, *args, **kwargs) -> bytes:
 def default_sha256(key: KeyT, *args, **kwargs) -> bytes:
     """chained sha256 family (hashes.py:139-150)"""
     return hashlib.sha256(key).digest()
+
+
+def device_digest(hash_function):
+    """the engine's digest id (include/psk.h ``psk_digest``) when ``hash_function`` is one of the reference's built-in
+    digest families, else None: those run as HIP kernels instead of per key on the host"""
+    if hash_function is default_md5:
+        return 0
+    if hash_function is default_sha256:
+        return 1
+    return None

@@ -132,3 +132,37 @@ def pack_hashes(hashes, need: int) -> KeyBatch:
     if a.shape[0] and a.shape[1] < need:
         raise ValueError(f"need at least {need} hashes per key, got {a.shape[1]}")
     return KeyBatch(N.KEYS_HASHES, _np_ptr(a) if a.size else 0, 0, a.shape[0], a.shape[1], N.HOST, None, [a])
+
+
+# ---------------------------------------------------------------- digest families on the device
+def _pack_bytes_utf8(keys) -> KeyBatch:
+    """byte image of every key for the digest families: a str is UTF-8 encoded (hashes.py:34 -- unlike the FNV
+    family, which walks code points)"""
+    if _is_key(keys):
+        keys = [keys]
+    if (torch is not None and isinstance(keys, torch.Tensor)) or isinstance(keys, np.ndarray):
+        return pack_keys(keys)  # raw (n, L) byte matrices
+    raw = []
+    for k in keys:
+        if isinstance(k, str):
+            raw.append(k.encode("utf-8"))
+        elif isinstance(k, (bytes, bytearray, memoryview)):
+            raw.append(bytes(k))
+        else:
+            raise TypeError(f"keys must be str or bytes-like, got {type(k).__name__}")
+    return pack_keys(raw)
+
+
+def digest_batch(keys, algo: int, depth: int, device: int, stream=None) -> KeyBatch:
+    """keys -> PSK_KEYS_HASHES batch of the chained md5 / sha256 family (hashes.py:125-150), computed by the engine
+    (``psk_digest_chain``).  Device key tensors stay on the device; host keys come back as a host hash matrix."""
+    b = _pack_bytes_utf8(keys)
+    if b.layout not in (N.KEYS_FIXED, N.KEYS_VARLEN8):
+        raise TypeError("digest families hash bytes")
+    if b.where == N.DEVICE:
+        out = torch.empty((b.n, depth), dtype=torch.int64, device=f"cuda:{device}")
+        N.check(N.lib().psk_digest_chain(algo, *b.args(), depth, N.DEVICE, out.data_ptr(), device, stream))
+        return KeyBatch(N.KEYS_HASHES, out.data_ptr() if b.n else 0, 0, b.n, depth, N.DEVICE, device, [out, *b.keep])
+    out = np.empty((b.n, depth), dtype=np.uint64)
+    N.check(N.lib().psk_digest_chain(algo, *b.args(), depth, N.HOST, out.ctypes.data if out.size else None, device, stream))
+    return KeyBatch(N.KEYS_HASHES, _np_ptr(out) if out.size else 0, 0, b.n, depth, N.HOST, None, [out])
