@@ -104,18 +104,26 @@ static int set_dyn_lds(K kernel, size_t bytes)
     return raise_dyn_lds((const void *)kernel, bytes);
 }
 
-// Pass 1 for one concrete (Src, IdxFn, Pay, Spill, KT): sizes the (slice, workgroup) segments for `n` keys,
+// Pass 1 for one concrete (Src, IdxFn, Pay, Spill, KT, NT): sizes the (slice, workgroup) segments for `n` keys,
 // grows the handle's bucket buffer, launches.  g->nwg / g->segcap are filled in for pass 2.
-template <class Src, class IdxFn, class Pay, class Spill, int KT>
-static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, PartGeom *g,
-                          uint64_t n, hipStream_t st)
+template <class Pay, int KT, int NT>
+static size_t scatter_lds_bytes(const PartGeom *g)
 {
-    using Tile = PartTile<Pay, KT>;
-    const uint64_t ntiles = (n + Tile::TILE - 1) / Tile::TILE;
+    using Tile = PartTile<Pay, KT, NT>;
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
     const size_t stage_words = ((size_t)Tile::TILE * kk + (size_t)(Tile::GS - 1) * g->nbuckets) * (Tile::pair ? 2 : 1);
-    const size_t lds = (5 * (size_t)g->nbuckets + 8 + 24 + stage_words) * 4;
-    uint64_t per_cu = lds > 76 * 1024 ? 1 : 2;
+    return (5 * (size_t)g->nbuckets + 16 + 24 + stage_words) * 4;
+}
+
+template <class Src, class IdxFn, class Pay, class Spill, int KT, int NT>
+static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, PartGeom *g,
+                             uint64_t n, hipStream_t st)
+{
+    using Tile = PartTile<Pay, KT, NT>;
+    const uint64_t ntiles = (n + Tile::TILE - 1) / Tile::TILE;
+    const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
+    const size_t lds = scatter_lds_bytes<Pay, KT, NT>(g);
+    uint64_t per_cu = NT > 512 ? 1 : (lds > 76 * 1024 ? 1 : 2);
     if (g->dbg & 8) per_cu = 1;  // ablation: one workgroup per CU
     uint64_t nwg = 256 * per_cu;
     if (nwg > ntiles) nwg = ntiles;
@@ -128,12 +136,25 @@ static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, con
     g->tile = (uint32_t)Tile::TILE;
     PSK_TRY(ensure(s->s_part, (uint64_t)g->nbuckets * nwg * segcap * 16 + 256));
     PSK_TRY(ensure(s->s_cnt, (uint64_t)g->nbuckets * nwg * 4 + 128));  // + 12 x u64 of phase profile (dbg & 32)
-    auto kern = k_part_scatter<Src, IdxFn, Pay, Spill, KT>;
+    auto kern = k_part_scatter<Src, IdxFn, Pay, Spill, KT, NT>;
     PSK_TRY(set_dyn_lds(kern, lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kPartThreads), lds, st, src, idxfn, pay, spill, *g, n,
-                       (uint32_t *)s->s_cnt.p, (uint4 *)s->s_part.p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT), lds, st, src, idxfn, pay, spill, *g, n, (uint32_t *)s->s_cnt.p,
+                       (uint4 *)s->s_part.p);
     HIP_TRY(hipGetLastError());
     return PSK_OK;
+}
+
+// workgroup size: 1024 threads for small k when the (twice as large) LDS stage fits, else 512 (see PartTile::NT)
+constexpr size_t kScatterLdsBudget = 160 * 1024;
+template <class Src, class IdxFn, class Pay, class Spill, int KT>
+static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, PartGeom *g,
+                          uint64_t n, hipStream_t st)
+{
+    if constexpr (KT <= 8) {
+        if (!(g->dbg & 16) && scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget)
+            return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st);
+    }
+    return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, kPartThreads>(s, src, idxfn, pay, spill, g, n, st);
 }
 
 // compile-time hash count: exact for the common small k on the 16-byte fast layout, rounded up otherwise

@@ -28,10 +28,10 @@
 
 namespace psk {
 
-constexpr int kPartThreads = 512;      // 8 wavefronts per workgroup
+constexpr int kPartThreads = 512;       // 8 wavefronts per workgroup (k > 8); small k uses 16, see PartTile::NT
 constexpr int kPartProbes = 32;        // probes held in registers per thread (= keys/thread * KT); 16 with payload
 constexpr int kPartMaxBuckets = 2048;
-constexpr int kPartScanPerThread = kPartMaxBuckets / kPartThreads;  // 4
+constexpr int kPartScanPerThread = 4;   // slices per lane of a scanning thread: 64 x 4 = one wave covers 256 slices
 constexpr bool kPartPipeline = true;   // prefetch the next tile's keys under the current tile (see k_part_scatter)
 constexpr bool kPartHash32 = true;     // explicit 32-bit FNV chains for power-of-two tables
 constexpr uint32_t kPadProbe = 0xFFFFFFFFu;  // filler that pads every run to whole groups; pass 2 skips it
@@ -143,8 +143,9 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
     return x;
 }
 
-// block-wide exclusive scan of one uint32 per thread (512 threads = 8 waves)
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot /*LDS[8]*/, uint32_t *total)
+// block-wide exclusive scan of one uint32 per thread (NT threads = NT/64 waves)
+template <int NT>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot /*LDS[16]*/, uint32_t *total)
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint32_t inc = wave_inclusive_scan(v);
@@ -152,7 +153,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
     lds_barrier();
     uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < kPartThreads / 64; ++w) {
+    for (int w = 0; w < NT / 64; ++w) {
         const uint32_t t = wave_tot[w];
         if (w < wid) base += t;
         tot += t;
@@ -163,14 +164,19 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
 
 // ------------------------------------------------------------------------------------ pass 1
 // KT = hashes computed per key (>= k, compile time so the probes stay in registers).
-// dynamic LDS: hist[2][B] | off[B] | delta[B] | cur[B] | wave_tot[8] | profile[24] | stage (1 or 2 words per probe)
-template <class Pay, int KT>
+// dynamic LDS: hist[2][B] | off[B] | delta[B] | cur[B] | wave_tot[16] | profile[24] | stage (1 or 2 words per probe)
+template <class Pay, int KT, int NT_ = kPartThreads>
 struct PartTile {
     static constexpr bool pair = Pay::mode != kModePlain;           // stage entry = (cell, payload)
     static constexpr int GS = Pay::group;                           // probes per 16-byte output group
     static constexpr int PP = kPartProbes / 2;                      // 16 probes per thread: <= 100 VGPRs, 2 workgroups per CU
     static constexpr int KPT = PP / KT >= 1 ? PP / KT : 1;          // keys per thread per tile
-    static constexpr int TILE = kPartThreads * KPT;                 // keys per tile
+    // Threads per workgroup: 512, or (host's choice, small k, when the LDS stage fits) 1024 = one workgroup per CU: the
+    // per-tile fixed costs (scan, barriers) are then paid once per 14 K probes instead of per 7 K; measured +5 % over
+    // two 512-thread workgroups per CU.  Large k stays at 512: 32-probe threads need more than the 128 VGPRs a
+    // 1024-thread workgroup can have.
+    static constexpr int NT = NT_;
+    static constexpr int TILE = NT * KPT;                           // keys per tile
 };
 
 // Write-out of ONE 16-byte group of the sorted LDS stage: lane = group gi of the tile; its first probe is always
@@ -256,12 +262,12 @@ __device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t
 
 // (the second launch bound is hipcc's "min waves per SIMD": 4 = two workgroups per CU = at most 128 VGPRs; without it
 // small source changes tip the keyed instantiation to 133 VGPRs and one workgroup per CU, 15 % slower)
-template <class Src, class IdxFn, class Pay, class Spill, int KT>
-__global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatter(Src src, IdxFn idxfn, Pay pay, Spill spill, PartGeom g,
+template <class Src, class IdxFn, class Pay, class Spill, int KT, int NTHREADS>
+__global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Src src, IdxFn idxfn, Pay pay, Spill spill, PartGeom g,
                                                                uint64_t n, uint32_t *segcnt, uint4 *buckets)
 {
-    using T = PartTile<Pay, KT>;
-    constexpr int KPT = T::KPT, TILE = T::TILE, GS = T::GS;
+    using T = PartTile<Pay, KT, NTHREADS>;
+    constexpr int KPT = T::KPT, TILE = T::TILE, GS = T::GS, NT = T::NT;
     constexpr bool PAIR = T::pair;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t B = g.nbuckets;
@@ -270,8 +276,8 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
     uint32_t *delta = off + B;
     uint32_t *cur = delta + B;  // groups already appended to my segment of every slice, across all my tiles
     uint32_t *wave_tot = cur + B;
-    unsigned long long *t_acc = reinterpret_cast<unsigned long long *>(wave_tot + 8);  // phase profile (dbg & 32), 12 slots
-    uint32_t *stage = wave_tot + 8 + 24;
+    unsigned long long *t_acc = reinterpret_cast<unsigned long long *>(wave_tot + 16);  // phase profile (dbg & 32), 12 slots
+    uint32_t *stage = wave_tot + 16 + 24;
     // KT other than the round-up sizes 8 / 16 / 32 is an exact instantiation (with_kt): k == KT, and every per-probe
     // "j < k" test below folds away (28 exec-mask branch sequences per tile for k = 7)
     constexpr bool kExactK = KT != 8 && KT != 16 && KT != 32;
@@ -279,8 +285,8 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
     const uint32_t mask = (1u << g.shift) - 1;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
 
-    for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) cur[b] = 0;
-    for (uint32_t b = threadIdx.x; b < 2 * B; b += kPartThreads) hist0[b] = 0;
+    for (uint32_t b = threadIdx.x; b < B; b += NT) cur[b] = 0;
+    for (uint32_t b = threadIdx.x; b < 2 * B; b += NT) hist0[b] = 0;
     uint32_t parity = 0;
     lds_barrier();
 
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
     if (kPartPipeline) {
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
-            const uint64_t i = (uint64_t)blockIdx.x * TILE + (uint64_t)q * kPartThreads + threadIdx.x;
+            const uint64_t i = (uint64_t)blockIdx.x * TILE + (uint64_t)q * NT + threadIdx.x;
             kcur[q] = src.load(i < n ? i : n - 1);  // coalesced; clamped, never branched around (a conditional load
         }                                           // makes hipcc wait vmcnt(0) per element: serial round trips)
     }
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
         const uint64_t base = tile * TILE;
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
-            const uint64_t i = base + (uint64_t)q * kPartThreads + threadIdx.x;
+            const uint64_t i = base + (uint64_t)q * NT + threadIdx.x;
             if (i < n) {
                 const typename Src::Key key = kPartPipeline ? kcur[q] : src.load(i);
                 if (PAIR) payload[q] = pay(i, base);
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
                 const uint64_t nbase = (tile + gridDim.x) * TILE;
 #pragma unroll
                 for (int q = 0; q < KPT; ++q) {
-                    const uint64_t i = nbase + (uint64_t)q * kPartThreads + threadIdx.x;
+                    const uint64_t i = nbase + (uint64_t)q * NT + threadIdx.x;
                     kcur[q] = src.load(i < n ? i : n - 1);
                 }
             }
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
             const uint64_t nbase = (tile + gridDim.x) * TILE;
 #pragma unroll
             for (int q = 0; q < KPT; ++q) {
-                const uint64_t i = nbase + (uint64_t)q * kPartThreads + threadIdx.x;
+                const uint64_t i = nbase + (uint64_t)q * NT + threadIdx.x;
                 kcur[q] = src.load(i < n ? i : n - 1);  // unconditional (clamped) on purpose, see above
             }
         }
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
             mine[c] = b < B ? hist[b] : 0;
             s += (mine[c] + GS - 1) / GS * GS;
         }
-        for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) hist_next[b] = 0;  // ready for the next tile
+        for (uint32_t b = threadIdx.x; b < B; b += NT) hist_next[b] = 0;  // ready for the next tile
         PSK_TICK(6);
         uint32_t tile_probes;  // padded
         uint32_t run;
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
                 run = 0;
             }
         } else {
-            run = block_exclusive_scan(s, wave_tot, &tile_probes);
+            run = block_exclusive_scan<NT>(s, wave_tot, &tile_probes);
         }
         PSK_TICK(7);
 #pragma unroll
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
         // (in the scan phase that was 4 slices x up to GS-1 serial stores on the single scanning wave: 18 % of pass 1)
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
-            const uint64_t i = base + (uint64_t)q * kPartThreads + threadIdx.x;
+            const uint64_t i = base + (uint64_t)q * NT + threadIdx.x;
             if (i < n) {
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
             }
         }
         // (after the sort stores: idx / rank are dead by now, so this costs no registers)
-        for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
+        for (uint32_t b = threadIdx.x; b < B; b += NT) {
             const uint32_t cnt = hist[b], padded = (cnt + GS - 1) / GS * GS, at = off[b];
             for (uint32_t e = cnt; e < padded; ++e) {
                 if (PAIR) reinterpret_cast<uint2 *>(stage)[at + e] = make_uint2(kPadProbe, 0u);
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
             if (kPartPipeline) Src::pin(kcur[q]);  // next tile's keys have landed: nothing to wait for later
         if (!(g.dbg & 1)) {
             const uint32_t ngroups = tile_probes / GS;
-            for (uint32_t gi = threadIdx.x; gi < ngroups; gi += kPartThreads) {
+            for (uint32_t gi = threadIdx.x; gi < ngroups; gi += NT) {
                 emit_group<Pay, Spill>(stage, delta, g, mask, gi, tile, base, spill, buckets);
             }
         }
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(kPartThreads, (KT <= 8 ? 4 : 1)) void k_part_scatte
     }
 #undef PSK_TICK
     // publish how many groups of each of my segments are valid (the kernel boundary orders it before pass 2)
-    for (uint32_t b = threadIdx.x; b < B; b += kPartThreads) {
+    for (uint32_t b = threadIdx.x; b < B; b += NT) {
         const uint32_t c = cur[b];
         segcnt[(uint64_t)b * g.nwg + blockIdx.x] = c < g.segcap ? c : g.segcap;
     }

@@ -24,11 +24,11 @@ import ctypes as C
 N.set_option("part_debug", 32)
 blm.add_many(keys); torch.cuda.synchronize()
 buf = (C.c_uint64 * 12)()
-N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 512, buf))   # clear whatever warm-up left
+N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 256, buf))   # clear whatever warm-up left
 for _ in range(3):
     blm.add_many(keys)
 torch.cuda.synchronize()
-N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 512, buf))
+N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 256, buf))
 names = ["(wgs)", "zero+bar", "hash+hist+bar", "scan+bar", "sort+bar", "writeout(+bar)"]
 tot = sum(buf[1:12])
 names += ["  scan: read hist+zero", "  scan: wave scan", "  scan: cursor+pads", "  hash+hist (own work)"]
@@ -40,11 +40,11 @@ N.set_option("part_debug", 0)
 # same phase profile for the lookup (keyed) variant
 N.set_option("part_debug", 32)
 blm.check_many(keys); torch.cuda.synchronize()
-N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 512, buf))
+N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 256, buf))
 for _ in range(3):
     blm.check_many(keys)
 torch.cuda.synchronize()
-N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 512, buf))
+N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 256, buf))
 tot = sum(buf[1:12])
 for i in [1, 9, 2, 6, 7, 8, 3, 4, 5]:
     print(f"check phase {names[i]:24s} {buf[i]/buf[0]/3:10.0f} ticks per WG per launch  ({100.0*buf[i]/tot:5.1f} %)")
