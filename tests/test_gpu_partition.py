@@ -25,13 +25,13 @@ def pa():
 def force_partition():
     from pyprobables_amd import _native as N
 
-    old = (N.get_option("partition"), N.get_option("partition_min_keys"), N.get_option("partition_max_keys"))
+    names = ("partition", "partition_min_keys", "partition_max_keys", "partition_cache_bytes")
+    old = [N.get_option(k) for k in names]
     N.set_option("partition", 1)
     N.set_option("partition_min_keys", 1)
     yield N
-    N.set_option("partition", old[0])
-    N.set_option("partition_min_keys", old[1])
-    N.set_option("partition_max_keys", old[2])
+    for k, v in zip(names, old):
+        N.set_option(k, v)
 
 
 def _dev(a):
@@ -130,6 +130,33 @@ def test_bloom_partitioned_rounds(pa, oracle, force_partition):
     blm.add_many(_dev(keys))
     ob.add_keys(keys)
     assert np.array_equal(_table(blm), ob.bloom)
+
+
+def test_cache_sized_rounds_are_exact(pa, oracle, force_partition):
+    """partition_cache_bytes cuts a batch into equal rounds (Infinity Cache budget): insert, lookup and weighted
+    counter adds must not depend on where the cuts fall"""
+    n = 2_500_000
+    keys = oracle.gen_keys16(5, n)
+    dk = _dev(keys)
+    blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    ob.add_keys(keys[: n // 2])
+    want = ob.check_keys(keys)
+    for budget in (240 << 20, 24 << 20, 0):  # 1 round, ~4 insert / ~7 lookup rounds (1 M key floor), feature off
+        force_partition.set_option("partition_cache_bytes", budget)
+        blm.clear()
+        blm.add_many(dk[: n // 2])
+        assert np.array_equal(_table(blm), ob.bloom), budget
+        assert np.array_equal(blm.check_many(dk).cpu().numpy().astype(np.uint8), want), budget
+    w = oracle.gen_weights(0, n)
+    oc = oracle.OracleCMS(2**20, 5)
+    oc.add_keys(keys, w)
+    for budget in (240 << 20, 16 << 20):
+        force_partition.set_option("partition_cache_bytes", budget)
+        cms = pa.CountMinSketch(width=2**20, depth=5)
+        cms.add_many(dk, _dev(w))
+        assert np.array_equal(np.frombuffer(bytes(cms._bins), dtype=np.int32), oc.bins), budget
+        assert cms.elements_added == oc.els_added
 
 
 def test_partitioned_equals_direct(pa, oracle, force_partition):
