@@ -9,6 +9,9 @@
  * ctypes stub a pyprobables maintainer would add to bind them.
  *
  * Conventions
+ *   - threading: psk_last_error() is thread-local; a sketch handle owns scratch buffers, so one handle must not be
+ *     used from two threads / two streams at the same time (different handles are independent).  Every call leaves
+ *     the calling thread's current HIP device as it found it.
  *   - plain pointers and sizes only; every function returns a psk status code
  *     (PSK_OK == 0, negative on error; text via psk_last_error()); no exceptions
  *     cross the boundary.

@@ -85,7 +85,7 @@ static int create_common(int kind, uint64_t m, uint32_t k, uint64_t padded, uint
     if (e != hipSuccess || ndev == 0)
         return fail(PSK_ENODEV, "no HIP device available (%s)", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
     if (device < 0 || device >= ndev) return fail(PSK_EINVAL, "device %d out of range [0,%d)", device, ndev);
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     psk_sketch *s = new (std::nothrow) psk_sketch();
     if (!s) return fail(PSK_ENOMEM, "host allocation failed");
     s->kind = kind;
@@ -142,7 +142,8 @@ extern "C" int psk_cms_create(uint64_t width, uint32_t depth, int device, void *
 extern "C" int psk_destroy(psk_sketch *s)
 {
     if (!s) return PSK_OK;
-    hipSetDevice(s->device);
+    DeviceScope scope;
+    (void)scope.enter(s->device);
     if (s->owns_table && s->table) hipFree(s->table);
     if (s->ctr) hipFree(s->ctr);
     for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt}) {
@@ -158,8 +159,8 @@ extern "C" int psk_destroy(psk_sketch *s)
         if (!(s)) return fail(PSK_EINVAL, "sketch handle is NULL");                      \
         if ((want_kind) >= 0 && (s)->kind != (want_kind))                                \
             return fail(PSK_EINVAL, "wrong sketch kind %d for this call", (s)->kind);    \
-        HIP_TRY(hipSetDevice((s)->device));                                              \
-    } while (0)
+    } while (0);                                                                         \
+    PSK_USE_DEVICE((s)->device)
 
 extern "C" int psk_clear(psk_sketch *s, void *stream)
 {
@@ -429,7 +430,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
 extern "C" int psk_debug_phase_profile(psk_sketch *s, uint32_t nbuckets, uint32_t nwg, uint64_t out[12])
 {
     if (!s || !s->s_cnt.p) return fail(PSK_EINVAL, "no partition scratch yet");
-    HIP_TRY(hipSetDevice(s->device));
+    PSK_USE_DEVICE(s->device);
     HIP_TRY(hipDeviceSynchronize());
     char *p = (char *)s->s_cnt.p + (size_t)nbuckets * nwg * 4;
     HIP_TRY(hipMemcpy(out, p, 96, hipMemcpyDeviceToHost));
@@ -779,7 +780,7 @@ extern "C" int psk_fnv1a_hash(int layout, const void *data, const uint64_t *offs
 {
     if (layout == PSK_KEYS_HASHES) return fail(PSK_EINVAL, "psk_fnv1a_hash needs a key layout");
     if (n && depth && !out) return fail(PSK_EINVAL, "out is NULL");
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     Batch b;
     PSK_TRY(stage_batch(g_hkeys, g_hoffs, layout, data, offsets, n, key_len, where, st, &b));
@@ -804,7 +805,7 @@ extern "C" int psk_digest_chain(int algo, int layout, const void *data, const ui
     if (layout != PSK_KEYS_FIXED && layout != PSK_KEYS_VARLEN8)
         return fail(PSK_EINVAL, "digest chains hash bytes: use PSK_KEYS_FIXED or PSK_KEYS_VARLEN8 (a str is UTF-8 encoded by the caller)");
     if (n && depth && !out) return fail(PSK_EINVAL, "out is NULL");
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     Batch b;
     PSK_TRY(stage_batch(g_hkeys, g_hoffs, layout, data, offsets, n, key_len, where, st, &b));
@@ -834,7 +835,7 @@ static int check_vec(const void *a, const void *b, uint64_t nwords32)
 extern "C" int psk_table_or(void *dst, const void *src, uint64_t nwords32, int device, void *stream)
 {
     PSK_TRY(check_vec(dst, src, nwords32));
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     if (!nwords32) return PSK_OK;
     hipLaunchKernelGGL((k_table_binop<OpOr>), dim3(grid_for(nwords32 / 4)), dim3(kBlock), 0, (hipStream_t)stream, (uint4 *)dst,
                        (const uint4 *)src, nwords32 / 4, OpOr{});
@@ -845,7 +846,7 @@ extern "C" int psk_table_or(void *dst, const void *src, uint64_t nwords32, int d
 extern "C" int psk_table_and(void *dst, const void *src, uint64_t nwords32, int device, void *stream)
 {
     PSK_TRY(check_vec(dst, src, nwords32));
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     if (!nwords32) return PSK_OK;
     hipLaunchKernelGGL((k_table_binop<OpAnd>), dim3(grid_for(nwords32 / 4)), dim3(kBlock), 0, (hipStream_t)stream, (uint4 *)dst,
                        (const uint4 *)src, nwords32 / 4, OpAnd{});
@@ -857,7 +858,7 @@ static int table_count(const void *tab, uint64_t nwords32, int mode, uint64_t *o
 {
     PSK_TRY(check_vec(tab, tab, nwords32));
     if (!out_host) return fail(PSK_EINVAL, "out is NULL");
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, 8));
@@ -887,7 +888,7 @@ extern "C" int psk_table_nonzero_u32(const void *tab, uint64_t nwords32, uint64_
 extern "C" int psk_table_add_sat_i32(void *dst, const void *src, uint64_t n, int device, void *stream)
 {
     if (!dst || !src) return fail(PSK_EINVAL, "table pointer is NULL");
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     if (!n) return PSK_OK;
     hipLaunchKernelGGL(k_add_sat_i32, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, (int32_t *)dst, (const int32_t *)src, n);
     HIP_TRY(hipGetLastError());
@@ -897,7 +898,7 @@ extern "C" int psk_table_add_sat_i32(void *dst, const void *src, uint64_t n, int
 extern "C" int psk_table_add_u32(void *dst, const void *src, uint64_t n, uint64_t *overflowed_host, int device, void *stream)
 {
     if (!dst || !src) return fail(PSK_EINVAL, "table pointer is NULL");
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, 8));
@@ -918,7 +919,7 @@ extern "C" int psk_table_add_u32(void *dst, const void *src, uint64_t n, uint64_
 extern "C" int psk_cbf_intersect(void *dst, const void *a, const void *b, uint64_t n, uint64_t *overflowed_host, int device, void *stream)
 {
     if (!dst || !a || !b) return fail(PSK_EINVAL, "table pointer is NULL");
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, 8));
@@ -940,7 +941,7 @@ extern "C" int psk_cbf_intersect(void *dst, const void *a, const void *b, uint64
 extern "C" int psk_cbf_jaccard_counts(const void *a, const void *b, uint64_t n, uint64_t out_host[2], int device, void *stream)
 {
     if (!a || !b || !out_host) return fail(PSK_EINVAL, "NULL argument");
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, 16));
@@ -961,7 +962,7 @@ extern "C" int psk_cbf_jaccard_counts(const void *a, const void *b, uint64_t n, 
 extern "C" int psk_release_scratch(psk_sketch *s)
 {
     if (!s) return fail(PSK_EINVAL, "sketch handle is NULL");
-    HIP_TRY(hipSetDevice(s->device));
+    PSK_USE_DEVICE(s->device);
     HIP_TRY(hipDeviceSynchronize());
     for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt}) {
         if (b->p) HIP_TRY(hipFree(b->p));
@@ -975,7 +976,7 @@ extern "C" int psk_or_reduce_slices(void *dst, const void *src, uint32_t nslices
 {
     PSK_TRY(check_vec(dst, src, slice_words32));
     if (nslices == 0) return fail(PSK_EINVAL, "nslices must be > 0");
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     if (!slice_words32) return PSK_OK;
     hipLaunchKernelGGL(k_or_reduce, dim3(grid_for(slice_words32 / 4)), dim3(kBlock), 0, (hipStream_t)stream, (uint4 *)dst,
                        (const uint4 *)src, nslices, slice_words32 / 4);
@@ -987,7 +988,7 @@ extern "C" int psk_or_reduce_slices(void *dst, const void *src, uint32_t nslices
 extern "C" int psk_gen_keys16(void *dst_dev, uint64_t start, uint64_t n, uint64_t seed, int device, void *stream)
 {
     if (n && (!dst_dev || ((uintptr_t)dst_dev & 15))) return fail(PSK_EINVAL, "dst must be a 16-byte aligned device pointer");
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     if (!n) return PSK_OK;
     hipLaunchKernelGGL(k_gen_keys16, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, (ulonglong2 *)dst_dev, start, n, seed);
     HIP_TRY(hipGetLastError());
@@ -997,7 +998,7 @@ extern "C" int psk_gen_keys16(void *dst_dev, uint64_t start, uint64_t n, uint64_
 extern "C" int psk_gen_weights(void *dst_dev, uint64_t start, uint64_t n, uint64_t seed, int device, void *stream)
 {
     if (n && !dst_dev) return fail(PSK_EINVAL, "dst is NULL");
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     if (!n) return PSK_OK;
     hipLaunchKernelGGL(k_gen_weights, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, (int32_t *)dst_dev, start, n, seed);
     HIP_TRY(hipGetLastError());
@@ -1009,7 +1010,7 @@ extern "C" int psk_gups(void *table_dev, uint64_t nwords32, uint64_t n, int op, 
 {
     if (!table_dev || !nwords32) return fail(PSK_EINVAL, "bad table");
     if (op == 2 && !sink_dev) return fail(PSK_EINVAL, "load mode needs a sink");
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     if (!n) return PSK_OK;
     hipStream_t st = (hipStream_t)stream;
     dim3 g(grid_for(n)), blk(kBlock);

@@ -37,7 +37,31 @@ PSK_HIDDEN int fail(int code, const char *fmt, ...);  // records the thread-loca
             return rc__;         \
     } while (0)
 
-// ------------------------------------------------------------------ handle
+// Every entry point works on the device its handle / `device` argument names and puts the caller's current device back
+// before it returns: the library must not move the calling thread (torch, another runtime) to a different GPU.
+struct DeviceScope {
+    int prev = -1;
+    bool moved = false;
+    int enter(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev == dev) return hipSuccess;
+        const hipError_t e = hipSetDevice(dev);
+        moved = e == hipSuccess && prev >= 0;
+        return (int)e;
+    }
+    ~DeviceScope()
+    {
+        if (moved) (void)hipSetDevice(prev);
+    }
+};
+#define PSK_USE_DEVICE(dev)                                                                                   \
+    DeviceScope psk_device_scope__;                                                                           \
+    do {                                                                                                      \
+        const hipError_t e__ = (hipError_t)psk_device_scope__.enter(dev);                                     \
+        if (e__ != hipSuccess) return fail(PSK_EHIP, "hipSetDevice(%d) failed: %s", (int)(dev), hipGetErrorString(e__)); \
+    } while (0)
+
 // ------------------------------------------------------------------ handle
 struct DevBuf {
     void *p = nullptr;    // device scratch, grown on demand

@@ -128,7 +128,7 @@ extern "C" int psk_idx_test(const void *table_dev, const uint32_t *idx_dev, uint
 {
     if (n && (!table_dev || !idx_dev || !out_dev)) return fail(PSK_EINVAL, "NULL argument");
     if (k == 0) return fail(PSK_EINVAL, "k must be > 0");
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     if (!n) return PSK_OK;
     hipLaunchKernelGGL(k_idx_test, dim3(grid_keys(n)), dim3(kBlock), 0, (hipStream_t)stream, (const uint32_t *)table_dev, idx_dev, n,
                        k, out_dev, accumulate);
@@ -141,7 +141,7 @@ extern "C" int psk_idx_insert(void *table_dev, const uint32_t *idx_dev, const ui
 {
     if (n && (!table_dev || !idx_dev)) return fail(PSK_EINVAL, "NULL argument");
     if (k == 0) return fail(PSK_EINVAL, "k must be > 0");
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     if (!n) return PSK_OK;
     hipLaunchKernelGGL(k_idx_insert, dim3(grid_keys(n)), dim3(kBlock), 0, (hipStream_t)stream, (uint32_t *)table_dev, idx_dev,
                        flag_dev, n, k);
@@ -156,7 +156,7 @@ extern "C" int psk_idx_resolve_ordered(const void *table_dev, const uint32_t *id
     if (n && (!table_dev || !idx_dev || !first_dev || !flag_dev || !count_dev)) return fail(PSK_EINVAL, "NULL argument");
     if (k == 0) return fail(PSK_EINVAL, "k must be > 0");
     if (n >= 0xFFFFFFFFULL) return fail(PSK_EINVAL, "at most 2^32-2 keys per ordered batch");
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     if (inserted_host) *inserted_host = 0;
     if (!n) return PSK_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -182,7 +182,7 @@ extern "C" int psk_idx_resolve_ordered(const void *table_dev, const uint32_t *id
 extern "C" int psk_bytes_or(void *dst_dev, const void *src_dev, uint64_t n, int device, void *stream)
 {
     if (n && (!dst_dev || !src_dev)) return fail(PSK_EINVAL, "NULL argument");
-    HIP_TRY(hipSetDevice(device));
+    PSK_USE_DEVICE(device);
     if (!n) return PSK_OK;
     hipLaunchKernelGGL(k_bytes_or, dim3(grid_keys(n)), dim3(kBlock), 0, (hipStream_t)stream, (uint8_t *)dst_dev,
                        (const uint8_t *)src_dev, n);
