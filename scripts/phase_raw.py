@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Raw phase-profile slots of pass 1 (bench-only): bins kernel (part_debug 32) vs count/scan/sort kernel (32 | 256)."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+
+import bench
+import pyprobables_amd as pa
+from pyprobables_amd import _native as N
+
+n = 10_000_000
+keys = bench.gen_keys(n, 0, 0)
+blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01, device=0)
+blm.add_many(keys)
+for extra, label in ((0, "bins"), (256, "sort")):
+    for which, fn in (("insert", lambda: blm.add_many(keys)), ("check", lambda: blm.check_many(keys))):
+        for dbg, tag in ((0, "full"), (4, "no hashing"), (1, "no stores"), (2, "hash only")):
+            if dbg == 2 and extra == 0:
+                continue
+            N.set_option("part_debug", dbg | extra)
+            ms = bench.timed_loop(fn, 10, warm=3)
+            print(f"{label} {which:6s} {tag:10s} {ms*1e3:8.1f} us", flush=True)
+        N.set_option("part_debug", 32 | extra)
+        fn(); torch.cuda.synchronize()
+        buf = (C.c_uint64 * 12)()
+        nwg = 256
+        N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, nwg, buf))
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, nwg, buf))
+        tot = sum(buf[1:12]) or 1
+        print(f"{label} {which:6s} wgs={buf[0]} " + " ".join(f"[{i}]={100.0*buf[i]/tot:.1f}%" for i in range(1, 12) if buf[i]) + f" total={tot/max(buf[0],1):.0f}")
+N.set_option("part_debug", 0)
