@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Raw phase-profile slots of pass 1 (bench-only): bins kernel (part_debug 32) vs count/scan/sort kernel (32 | 256)."""
+"""Raw phase-profile slots (part_debug 32) and ablation timings of pass 1, insert and lookup (bench-only)."""
 import ctypes as C
 import sys
 from pathlib import Path
@@ -15,11 +15,9 @@ n = 10_000_000
 keys = bench.gen_keys(n, 0, 0)
 blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01, device=0)
 blm.add_many(keys)
-for extra, label in ((0, "bins"), (256, "sort")):
+for extra, label in ((0, "scatter"),):
     for which, fn in (("insert", lambda: blm.add_many(keys)), ("check", lambda: blm.check_many(keys))):
         for dbg, tag in ((0, "full"), (4, "no hashing"), (1, "no stores"), (2, "hash only")):
-            if dbg == 2 and extra == 0:
-                continue
             N.set_option("part_debug", dbg | extra)
             ms = bench.timed_loop(fn, 10, warm=3)
             print(f"{label} {which:6s} {tag:10s} {ms*1e3:8.1f} us", flush=True)
