@@ -126,6 +126,14 @@ int psk_bloom_check(psk_sketch *s, int layout, const void *data, const uint64_t 
                     uint32_t key_len, int where, uint8_t *out, void *stream);
 int psk_bloom_check_bits(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
                          uint32_t key_len, int where, uint64_t *out_bits, uint64_t *hits, void *stream);
+/* Split lookup for DEVICE-resident keys: _begin hashes and partitions the batch without ever reading the table, _finish
+ * probes it and writes out_dev[n] (0/1).  Everything between the two calls may still change the table -- the point is
+ * to run pass 1 under a multi-GPU merge (pyprobables_amd/parallel.py) that is in flight on another stream.  The key
+ * buffers must stay valid and unchanged until _finish; one pending lookup per handle.  Result == psk_bloom_check at
+ * _finish time (bit-exact; an overflowing bucket segment is re-checked on the device). */
+int psk_bloom_check_begin(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n, uint32_t key_len,
+                          void *stream);
+int psk_bloom_check_finish(psk_sketch *s, uint8_t *out_dev, void *stream);
 
 /* ----------------------------------------------------- CountingBloomFilter
  * Unordered batches (weights: uint32[n] or NULL = all 1).  Bit-exact with the reference for

@@ -54,6 +54,8 @@ PROTOTYPES = {
     "psk_rescan_bound": (_int, [_vp, _vp]),
     "psk_bloom_add": (_int, [_vp, *_KEYS, _int, _vp]),
     "psk_bloom_check": (_int, [_vp, *_KEYS, _int, _vp, _vp]),
+    "psk_bloom_check_begin": (_int, [_vp, *_KEYS, _vp]),
+    "psk_bloom_check_finish": (_int, [_vp, _vp, _vp]),
     "psk_bloom_check_bits": (_int, [_vp, *_KEYS, _int, _vp, _vp, _vp]),
     "psk_cbf_add": (_int, [_vp, *_KEYS, _vp, _int, _vp]),
     "psk_cbf_remove": (_int, [_vp, *_KEYS, _vp, _int, _vp]),

@@ -245,6 +245,30 @@ class BloomFilter:
         """membership of every key: numpy bool[n] (host input) or torch bool[n] on the device (device input)"""
         return self._check_batch(self._batch(keys))
 
+    def check_many_begin(self, keys) -> None:
+        """first half of a split lookup: hash + partition a device-resident batch WITHOUT reading the table (so it can
+        run while a multi-GPU merge of the table is in flight, see ``parallel.merge_bloom_async``).  Finish with
+        :meth:`check_many_finish`; the keys must stay alive and unchanged until then."""
+        self._flush()
+        if getattr(self, "_split", None) is not None:
+            raise RuntimeError("a split lookup is already pending on this filter")
+        b = self._batch(keys)
+        if b.where == N.DEVICE:
+            N.check(N.lib().psk_bloom_check_begin(self._tab.handle, *b.args(), self._tab.stream))
+            self._split = ("engine", b)
+        else:  # host batches gain nothing from the split: looked up at finish time
+            self._split = ("late", b)
+
+    def check_many_finish(self):
+        """second half: membership of the batch given to :meth:`check_many_begin`, against the table as it is NOW"""
+        kind, b = self._split
+        self._split = None
+        if kind == "late":
+            return self._check_batch(b)
+        out = torch_mod().empty(b.n, dtype=_torch_dtype("uint8"), device=f"cuda:{self._tab.device}")
+        N.check(N.lib().psk_bloom_check_finish(self._tab.handle, out.data_ptr(), self._tab.stream))
+        return out.view(_torch_dtype("bool"))
+
     def add_alt_many(self, hashes) -> None:
         """pre-hashed batch: (n, >=k) uint64"""
         self._add_batch(pack_hashes(hashes, self._number_hashes))
@@ -417,6 +441,12 @@ class BloomFilter:
         if cu == 0:
             return 1.0
         return self._combine(second, "psk_table_and")._cnt_number_bits_set() / cu
+
+
+def torch_mod():
+    import torch  # noqa: PLC0415
+
+    return torch
 
 
 def _torch_dtype(name: str):

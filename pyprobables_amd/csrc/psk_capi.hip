@@ -146,7 +146,7 @@ extern "C" int psk_destroy(psk_sketch *s)
     (void)scope.enter(s->device);
     if (s->owns_table && s->table) hipFree(s->table);
     if (s->ctr) hipFree(s->ctr);
-    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt}) {
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag}) {
         if (b->p) hipFree(b->p);
         if (b->pin) hipHostFree(b->pin);
     }
@@ -459,7 +459,7 @@ extern "C" int psk_bloom_add(psk_sketch *s, int layout, const void *data, const 
     Batch b;
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
     bool done = false;
-    PSK_TRY(bloom_add_partitioned(s, b, st, &done));
+    if (!s->pend.active) PSK_TRY(bloom_add_partitioned(s, b, st, &done));  // (a pending split lookup owns the bucket buffer)
     if (done) return finish(where, nullptr, st);
     PSK_TRY(with_source(b, [&](auto src) {
         if (s->pow2) return launch_apply(src, BloomAdd<true>{(uint32_t *)s->table, s->md, s->k}, n, st);
@@ -481,7 +481,7 @@ extern "C" int psk_bloom_check(psk_sketch *s, int layout, const void *data, cons
     PSK_TRY(stage_out(s->s_out, out, n, where, &o));
     {
         bool done = false;
-        PSK_TRY(bloom_check_partitioned(s, b, (uint8_t *)o.dev, st, &done));
+        if (!s->pend.active) PSK_TRY(bloom_check_partitioned(s, b, (uint8_t *)o.dev, st, &done));
         if (done) return finish(where, &o, st);
     }
     PSK_TRY(with_source(b, [&](auto src) {
@@ -506,6 +506,60 @@ extern "C" int psk_bloom_indices(psk_sketch *s, int layout, const void *data, co
         return launch_apply(src, BloomIndexOut<false>{out_idx_dev, s->md, s->k}, n, st);
     }));
     return finish(where, nullptr, st);
+}
+
+// Split lookup (see include/psk.h): begin = hash + partition (never reads the table), finish = probe.
+extern "C" int psk_bloom_check_begin(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                                     uint32_t key_len, void *stream)
+{
+    CHECK_HANDLE(s, PSK_KIND_BLOOM);
+    PSK_TRY(check_hashes_width(s, layout, key_len));
+    if (s->pend.active) return fail(PSK_EINVAL, "a split lookup is already pending on this handle");
+    Batch b;
+    b.layout = layout;
+    b.data = data;
+    b.offs = offsets;
+    b.n = n;
+    b.key_len = key_len;
+    if (n && !data) return fail(PSK_EINVAL, "keys are NULL");
+    return bloom_check_begin_partitioned(s, b, (hipStream_t)stream);
+}
+
+extern "C" int psk_bloom_check_finish(psk_sketch *s, uint8_t *out_dev, void *stream)
+{
+    CHECK_HANDLE(s, PSK_KIND_BLOOM);
+    if (!s->pend.active) return fail(PSK_EINVAL, "no split lookup pending on this handle");
+    s->pend.active = false;
+    const Batch b = s->pend.b;
+    if (b.n && !out_dev) return fail(PSK_EINVAL, "out is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    bool redo = false;
+    PSK_TRY(bloom_check_finish_partitioned(s, out_dev, st, &redo));
+    if (!s->pend.scattered) {  // batch / table not eligible for the partitioned path: plain direct lookup now
+        return with_source(b, [&](auto src) {
+            if (s->pow2) return launch_apply(src, BloomCheck<true>{(const uint32_t *)s->table, s->md, s->k, out_dev}, b.n, st);
+            return launch_apply(src, BloomCheck<false>{(const uint32_t *)s->table, s->md, s->k, out_dev}, b.n, st);
+        });
+    }
+    if (redo) {  // exact redo of the first round, taken on the device only if a segment overflowed during begin
+        const uint64_t cnt0 = b.n < s->pend.round_keys ? b.n : s->pend.round_keys;
+        const uint32_t *flag = (const uint32_t *)s->s_flag.p;
+        PSK_TRY(with_source(sub_batch(b, 0, cnt0), [&](auto src) {
+            using Src = decltype(src);
+            if (s->pow2) {
+                using Op = BloomCheck<true>;
+                hipLaunchKernelGGL((k_apply_if<Src, Op>), dim3(grid_for(cnt0)), dim3(kBlock), 0, st, flag, src,
+                                   Op{(const uint32_t *)s->table, s->md, s->k, out_dev}, cnt0);
+            } else {
+                using Op = BloomCheck<false>;
+                hipLaunchKernelGGL((k_apply_if<Src, Op>), dim3(grid_for(cnt0)), dim3(kBlock), 0, st, flag, src,
+                                   Op{(const uint32_t *)s->table, s->md, s->k, out_dev}, cnt0);
+            }
+            HIP_TRY(hipGetLastError());
+            return (int)PSK_OK;
+        }));
+    }
+    return PSK_OK;
 }
 
 extern "C" int psk_bloom_check_bits(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
@@ -963,8 +1017,9 @@ extern "C" int psk_release_scratch(psk_sketch *s)
 {
     if (!s) return fail(PSK_EINVAL, "sketch handle is NULL");
     PSK_USE_DEVICE(s->device);
+    if (s->pend.active) return fail(PSK_EINVAL, "a split lookup is pending: finish it before releasing the scratch buffers");
     HIP_TRY(hipDeviceSynchronize());
-    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt}) {
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag}) {
         if (b->p) HIP_TRY(hipFree(b->p));
         b->p = nullptr;
         b->cap = 0;

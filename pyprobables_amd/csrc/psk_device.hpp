@@ -252,6 +252,22 @@ __global__ __launch_bounds__(kBlock) void k_apply(Src src, Op op, uint64_t n)
     }
 }
 
+// k_apply that only runs when a device-side flag is raised (the rare exact redo of a split lookup)
+template <class Src, class Op>
+__global__ __launch_bounds__(kBlock) void k_apply_if(const uint32_t *flag, Src src, Op op, uint64_t n)
+{
+    if (*flag == 0) return;
+    op.prepare();
+    const uint32_t k = op.k;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const typename Src::Key key = src.load(i);
+        typename Op::State st = op.begin(i);
+        for_each_hash(src, key, i, k, [&](uint32_t j, uint64_t h) { op.apply(st, j, h); });
+        op.end(st, i);
+    }
+}
+
 // ---------------------------------------------------------------- Bloom ops
 struct Empty {};
 

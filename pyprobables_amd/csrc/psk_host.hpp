@@ -62,6 +62,15 @@ struct DeviceScope {
         if (e__ != hipSuccess) return fail(PSK_EHIP, "hipSetDevice(%d) failed: %s", (int)(dev), hipGetErrorString(e__)); \
     } while (0)
 
+// ---------------------------------------------------------- key batches
+struct Batch {  // device-resident view of one key batch
+    int layout;
+    const void *data;
+    const uint64_t *offs;
+    uint64_t n;
+    uint32_t key_len;
+};
+
 // ------------------------------------------------------------------ handle
 struct DevBuf {
     void *p = nullptr;    // device scratch, grown on demand
@@ -84,18 +93,18 @@ struct psk_sketch {
     long long *ctr;    // device int64[PSK_CTR_COUNT]
     DevBuf s_keys, s_offs, s_w, s_out, s_aux;  // staging for PSK_HOST buffers
     DevBuf s_part, s_cnt;                      // partitioned path: bucket buffer + per-bucket fill counts
+    DevBuf s_flag;                             // split lookup: "a segment overflowed" flag
+    // split lookup (psk_bloom_check_begin / _finish): pass 1 of the first round has run, the rest waits for the table
+    struct {
+        bool active = false, scattered = false;
+        Batch b{};            // device-resident batch (the caller keeps it alive until finish)
+        PartGeom g{};
+        uint64_t round_keys = 0;
+    } pend;
 };
 
 PSK_HIDDEN int ensure(DevBuf &b, uint64_t bytes);  // grow a scratch buffer
 
-// ---------------------------------------------------------- key batches
-struct Batch {  // device-resident view of one key batch
-    int layout;
-    const void *data;
-    const uint64_t *offs;
-    uint64_t n;
-    uint32_t key_len;
-};
 
 // ------------------------------------------------- partitioned (large-batch) path
 // Tunables (psk_set_option): the partitioned path is taken when the batch has at least g_part_min_keys keys and
@@ -262,6 +271,8 @@ static inline Batch sub_batch(const Batch &b, uint64_t start, uint64_t cnt)
 // the launchers (one translation unit each); *done = false when the batch / table is not eligible
 PSK_HIDDEN int bloom_add_partitioned(psk_sketch *s, const Batch &b, hipStream_t st, bool *done);
 PSK_HIDDEN int bloom_check_partitioned(psk_sketch *s, const Batch &b, uint8_t *out_dev, hipStream_t st, bool *done);
+PSK_HIDDEN int bloom_check_begin_partitioned(psk_sketch *s, const Batch &b, hipStream_t st);
+PSK_HIDDEN int bloom_check_finish_partitioned(psk_sketch *s, uint8_t *out_dev, hipStream_t st, bool *redo_flag_possible);
 PSK_HIDDEN int cms_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);
 PSK_HIDDEN int cms_remove_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);
 PSK_HIDDEN int cbf_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);

@@ -119,8 +119,11 @@ struct SpillCounter {  // saturating CAS add (countminsketch.py:280-284,312-316 
 struct SpillBloomTest {  // lookup probe: test it directly (bloom.py:269-271); `key` is the index inside this round
     const uint32_t *tab;
     uint8_t *out;
+    uint32_t *defer;  // split lookup (psk_bloom_check_begin): the table is not final yet -- just raise the flag, the
+                      // finish step then re-checks the whole round with the direct kernel
     __device__ __forceinline__ void operator()(uint32_t idx, uint32_t key) const
     {
+        if (defer) { *defer = 1u; return; }
         if (((tab[idx >> 5] >> (idx & 31)) & 1u) == 0) out[key] = 0;
     }
 };

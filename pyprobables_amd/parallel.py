@@ -93,3 +93,36 @@ def merge_counters(sk, group=None) -> None:
         N.check(N.lib().psk_rescan_bound(sk._tab.handle, sk._tab.stream))
     total = _sum_int(els, t.device, group)
     sk._els_added = total
+
+
+class MergeHandle:
+    """a merge running on its own HIP stream; ``wait()`` makes torch's current stream wait for it"""
+
+    def __init__(self, stream, device):
+        self._stream, self._device = stream, device
+
+    def wait(self) -> None:
+        if self._stream is not None:
+            torch.cuda.current_stream(self._device).wait_stream(self._stream)
+            self._stream = None
+
+
+_merge_streams: dict = {}
+
+
+def merge_bloom_async(blm, group=None, or_reduce=hip_or_reduce) -> MergeHandle:
+    """``merge_bloom`` (table only, no host sync) on a side stream, so that table-independent work -- typically pass 1 of
+    the next lookup, ``BloomFilter.check_many_begin`` -- overlaps the collective.  Everything already enqueued on the
+    current stream (the inserts) is ordered before the merge; call ``wait()`` before anything reads the merged table."""
+    t = blm.table_tensor
+    if not t.is_cuda:  # gloo / CPU tensors (tests): nothing to overlap
+        allreduce_or_(t, group, or_reduce)
+        return MergeHandle(None, None)
+    dev = t.device
+    side = _merge_streams.get(dev.index)
+    if side is None:
+        side = _merge_streams[dev.index] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        allreduce_or_(t, group, or_reduce)
+    return MergeHandle(side, dev)

@@ -312,3 +312,57 @@ def test_partitioned_more_layouts_and_big_k(pa, oracle, force_partition):
     oc.add_keys(k13, w)
     assert np.array_equal(np.frombuffer(bytes(cms._bins), dtype=np.int32), oc.bins)
     assert cms.elements_added == oc.els_added
+
+
+# ------------------------------------------------------------------ split lookup (pass 1 before the table is final)
+def test_split_lookup_sees_the_table_at_finish_time(pa, oracle, force_partition):
+    n = 600_000
+    keys = oracle.gen_keys16(21, n)
+    dk = _dev(keys)
+    for est, fpr in ((28005615, 0.01), (3_000_000, 0.02)):  # power-of-two and general m
+        blm = pa.BloomFilter(est_elements=est, false_positive_rate=fpr)
+        ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+        blm.add_many(dk[: n // 4])
+        ob.add_keys(keys[: n // 4])
+        blm.check_many_begin(dk)                 # hashes + partitions; must not look at the table
+        blm.add_many(dk[n // 4: n // 2])          # the table changes while the lookup is pending
+        ob.add_keys(keys[n // 4: n // 2])
+        got = blm.check_many_finish().cpu().numpy().astype(np.uint8)
+        assert np.array_equal(got, ob.check_keys(keys))
+        assert np.array_equal(_table(blm), ob.bloom)
+        with pytest.raises(Exception):
+            blm.check_many_finish()                # nothing pending any more
+
+
+def test_split_lookup_rounds_and_small_batches(pa, oracle, force_partition):
+    keys = oracle.gen_keys16(2, 50_000)
+    dk = _dev(keys)
+    blm = pa.BloomFilter(est_elements=400_000, false_positive_rate=0.01)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    blm.add_many(dk[:20_000])
+    ob.add_keys(keys[:20_000])
+    want = ob.check_keys(keys)
+    force_partition.set_option("partition_max_keys", 7000)  # 8 rounds: only the first is partitioned ahead
+    blm.check_many_begin(dk)
+    assert np.array_equal(blm.check_many_finish().cpu().numpy().astype(np.uint8), want)
+    force_partition.set_option("partition", 0)               # not eligible: finish falls back to the direct kernel
+    blm.check_many_begin(dk)
+    assert np.array_equal(blm.check_many_finish().cpu().numpy().astype(np.uint8), want)
+    blm.check_many_begin(keys)                                # host batch: looked up at finish time
+    assert np.array_equal(np.asarray(blm.check_many_finish(), dtype=np.uint8), want)
+
+
+def test_split_lookup_segment_overflow_is_redone_exactly(pa, oracle, force_partition):
+    # all keys identical: their probes overflow <= k segments during begin; finish must re-check the round on the device
+    key = oracle.gen_keys16(9, 1)
+    keys = np.repeat(key, 150_000, axis=0)
+    keys[::500] = oracle.gen_keys16(500, 300)
+    dk = _dev(keys)
+    blm = pa.BloomFilter(est_elements=2_000_000, false_positive_rate=0.01)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    blm.check_many_begin(dk)
+    blm.add_many(dk[1:2])      # the repeated key goes in only now
+    ob.add_keys(keys[1:2])
+    got = blm.check_many_finish().cpu().numpy().astype(np.uint8)
+    assert np.array_equal(got, ob.check_keys(keys))
+    assert got[1] == 1 and got.sum() >= 150_000 - 300

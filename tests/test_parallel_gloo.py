@@ -67,7 +67,12 @@ def _worker(rank, world, port, n_total, m_bits, out_dir):
     raw = np.zeros(padded, dtype=np.uint8)
     raw[: ob.bloom.size] = ob.bloom
     blm = _FakeSketch(torch.from_numpy(raw.view(np.int32).copy()), hi - lo)
-    parallel.merge_bloom(blm, or_reduce=_torch_or_reduce)
+    if rank % 2 == 0:
+        parallel.merge_bloom(blm, or_reduce=_torch_or_reduce)
+    else:  # the async form must be the same collective (on CPU tensors it simply runs inline)
+        h = parallel.merge_bloom_async(blm, or_reduce=_torch_or_reduce)
+        h.wait()
+        blm.elements_added = parallel._sum_int(blm.elements_added, blm.table_tensor.device)
 
     # ---- CMS: per-rank replica -> allreduce(SUM)
     w = oracle.gen_weights(lo, hi - lo)
