@@ -283,7 +283,7 @@ def main():
             "algorithmic_bytes_per_key": BYTES["bloom_insert"],
             "avg_kernel_ms": ins_ms,
             "limiter": "pass 1 is co-limited by VALU (the k FNV-1a chains alone are 75 us of its 165 us: scripts/ablate.py dbg=2) "
-                       "and the LDS counting sort, not by HBM (460 MB in 165 us); pass 2 streams at ~5.5 TB/s",
+                       "and the LDS counting sort, not by HBM (430 MB in 165 us); pass 2 streams at ~5.5 TB/s",
         },
         "detail": {
             "insert_Mkeys_s": n / ins_ms / 1e3,
