@@ -1,0 +1,30 @@
+"""The drop-in boundary is a C ABI: build examples/psk_demo.c with the system C compiler, link it against
+libpsk_hip.so + the ROCm HIP runtime (no Python, no torch in the process) and run it on the GPU."""
+
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_plain_c_program_drives_the_engine(tmp_path):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cc = shutil.which("gcc") or shutil.which("cc")
+    rocm_lib = Path("/opt/rocm/lib")
+    if cc is None or not (rocm_lib / "libamdhip64.so").exists():
+        pytest.skip("no C compiler / ROCm runtime")
+    lib_dir = ROOT / "pyprobables_amd" / "csrc"
+    exe = tmp_path / "psk_demo"
+    subprocess.run([cc, "-O2", "-std=c11", str(ROOT / "examples" / "psk_demo.c"), "-I", str(ROOT / "include"), "-L", str(lib_dir),
+                    "-lpsk_hip", "-L", str(rocm_lib), "-lamdhip64", f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{rocm_lib}", "-o", str(exe)],
+                   check=True)
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "PSK C ABI OK" in run.stdout
