@@ -6,7 +6,7 @@
 // and the kernels pinned to that transaction ceiling.  Here the table is cut into slices that fit
 // one CU's LDS (<= 128 KiB of the 160 KiB):
 //   pass 1  k_part_scatter : hash the keys, bin every probe by slice (LDS histogram + LDS counting
-//                            sort per tile of 1024..2048 keys) and append each bin as a coalesced run of
+//                            sort per tile of 1024..4096 keys) and append each bin as a coalesced run of
 //                            16-byte GROUPS to the (slice, workgroup) SEGMENT of the bucket buffer in HBM.
 //                            Segments are private to one workgroup, so the append cursor lives in LDS: no
 //                            global atomics, no cross-workgroup line sharing (a first version reserved
@@ -29,7 +29,7 @@
 namespace psk {
 
 constexpr int kPartThreads = 512;       // 8 wavefronts per workgroup (k > 8); small k uses 16, see PartTile::NT
-constexpr int kPartProbes = 32;        // probes held in registers per thread (= keys/thread * KT); 16 with payload
+constexpr int kPartProbes = 32;        // PartTile::PP = kPartProbes / 2 = 16 probes per thread per tile (<= 128 VGPRs)
 constexpr int kPartMaxBuckets = 2048;
 constexpr int kPartScanPerThread = 4;   // slices per lane of a scanning thread: 64 x 4 = one wave covers 256 slices
 constexpr bool kPartPipeline = true;   // prefetch the next tile's keys under the current tile (see k_part_scatter)
