@@ -81,7 +81,9 @@ int psk_device_count(int *count);
 /* process-wide tunables: "partition" (0 = direct kernels only, 1 = auto), "partition_min_keys" (Bloom inserts with
  * at least this many keys -- 4x as many for lookups and counter adds -- take the partitioned path), "partition_max_keys" (keys per partition round), "partition_cache_bytes" (bucket-buffer budget per round, default
  * 240 MiB: batches whose buffer would exceed 1.5x this are cut into equal rounds so that pass 2 reads pass 1's output from
- * the 256 MB Infinity Cache instead of HBM; 0 disables) */
+ * the 256 MB Infinity Cache instead of HBM; 0 disables), "partition_two_level_slices" (default 2048: tables cut into more
+ * LDS-sized slices than this are partitioned in two levels -- coarse buckets, then slices; 0 = such tables use the direct
+ * kernels) */
 int psk_set_option(const char *name, int64_t value);
 int psk_get_option(const char *name, int64_t *value);
 /* bench-only: s_memtime totals per phase of the last partition pass 1 (option part_debug & 32) */

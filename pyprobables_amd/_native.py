@@ -140,6 +140,10 @@ def lib():
         for env, opt in (("PSK_PART_DEBUG", "part_debug"),):  # bench-only ablation bits, see PartGeom::dbg
             if os.environ.get(env):
                 L.psk_set_option(opt.encode(), int(os.environ[env]))
+        for item in filter(None, os.environ.get("PSK_OPTIONS", "").split(",")):  # e.g. PSK_OPTIONS=partition_two_level_slices=0
+            name, _, value = item.partition("=")
+            if L.psk_set_option(name.strip().encode(), int(value)) != 0:
+                raise NativeLibraryError(f"PSK_OPTIONS: {(L.psk_last_error() or b'').decode()}")
     return _lib
 
 

@@ -94,6 +94,7 @@ struct psk_sketch {
     DevBuf s_keys, s_offs, s_w, s_out, s_aux;  // staging for PSK_HOST buffers
     DevBuf s_part, s_cnt;                      // partitioned path: bucket buffer + per-bucket fill counts
     DevBuf s_flag;                             // split lookup: "a segment overflowed" flag
+    DevBuf s_part2, s_cnt2;                    // two-level path: bucket buffer + fill counts after the second split
     // split lookup (psk_bloom_check_begin / _finish): pass 1 of the first round has run, the rest waits for the table
     struct {
         bool active = false, scattered = false;
@@ -109,10 +110,11 @@ PSK_HIDDEN int ensure(DevBuf &b, uint64_t bytes);  // grow a scratch buffer
 // ------------------------------------------------- partitioned (large-batch) path
 // Tunables (psk_set_option): the partitioned path is taken when the batch has at least g_part_min_keys keys and
 // the table geometry allows it; g_part_mode 0 = never, 1 = auto.
-extern PSK_HIDDEN int64_t g_part_mode, g_part_min_keys, g_part_max_keys, g_part_cache_bytes, g_part_debug;
+extern PSK_HIDDEN int64_t g_part_mode, g_part_min_keys, g_part_max_keys, g_part_cache_bytes, g_part_two_level_slices, g_part_debug;
 
 // slices of a table of `cells` cells; max_shift = log2(cells one LDS slice may hold)
-static inline bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_shift, PartGeom *g)
+static inline bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_shift, PartGeom *g,
+                               uint64_t max_buckets = kPartMaxBuckets)
 {
     if (cells >= (1ULL << 32) || cells < (1ULL << 16)) return false;  // cell index 0xFFFFFFFF is the pad marker
     const uint32_t lg = 63 - __builtin_clzll(cells);  // floor(log2 cells)
@@ -120,7 +122,7 @@ static inline bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_
     if (shift > (int)max_shift) shift = max_shift;
     if (shift < (int)min_shift) shift = min_shift;
     const uint64_t B = (cells + (1ULL << shift) - 1) >> shift;
-    if (B > (uint64_t)kPartMaxBuckets) return false;
+    if (B > max_buckets) return false;
     g->nbuckets = (uint32_t)B;
     g->shift = (uint32_t)shift;
     g->dbg = (uint32_t)g_part_debug;
@@ -256,6 +258,44 @@ static inline uint64_t part_round_keys(uint64_t n, uint32_t k, int group)
         }
     }
     return rk ? rk : 1;
+}
+
+// Two-level path (k_part_scatter by coarse bucket, then k_part_split by slice) for tables cut into more than
+// `partition_two_level_slices` slices.  Fills level 1 (g1: coarse buckets) from the final geometry g2; the caller runs
+// launch_scatter(..., g1, ...) with an inline-mode payload, then split_level2<OUT>(), then pass 2 on s_part2 / s_cnt2.
+constexpr uint32_t kSplitParts = 16;  // level-2 segments per slice = waves of a pass-2 workgroup
+static inline bool two_level_geometry(const PartGeom &g2, PartGeom *g1, uint32_t *sub_bits)
+{
+    if (g_part_two_level_slices <= 0 || (int64_t)g2.nbuckets <= g_part_two_level_slices) return false;
+    uint32_t sb = 1;
+    while (((g2.nbuckets + (1u << sb) - 1) >> sb) > 256) ++sb;
+    if ((1u << sb) > (uint32_t)kSplitMaxSub) return false;
+    *g1 = g2;
+    g1->nbuckets = (g2.nbuckets + (1u << sb) - 1) >> sb;
+    g1->shift = g2.shift + sb;
+    *sub_bits = sb;
+    return g1->shift <= 31;
+}
+
+template <int OUT, class Spill>
+static int split_level2(psk_sketch *s, const PartGeom &g1, PartGeom *g2, uint32_t sub_bits, uint64_t probes, const Spill &spill,
+                        hipStream_t st)
+{
+    constexpr int GS = OUT == 0 ? 6 : (OUT == 1 ? 8 : 4);
+    const uint32_t P = kSplitParts;
+    const uint32_t per = (g1.nwg + P - 1) / P;
+    if (per > (uint32_t)kSplitMaxSegs) return fail(PSK_EINVAL, "two-level split: too many level-1 segments per part");
+    const double mean = (double)probes / ((double)g2->nbuckets * P);  // probes per (slice, part) segment
+    // groups: mean/GS + half a group of padding per split tile that touches the slice + 8 sigma
+    const double tiles = (double)probes / ((double)g1.nbuckets * P) / (kSplitThreads * 3.0) + 1.0;
+    g2->nwg = P;
+    g2->segcap = (uint32_t)(mean / GS + tiles + 8.0 * __builtin_sqrt(mean) / GS + 16.0);
+    PSK_TRY(ensure(s->s_part2, (uint64_t)g2->nbuckets * P * g2->segcap * 16 + 256));
+    PSK_TRY(ensure(s->s_cnt2, (uint64_t)g2->nbuckets * P * 4 + 64));
+    hipLaunchKernelGGL((k_part_split<OUT, Spill>), dim3(P, g1.nbuckets), dim3(kSplitThreads), 0, st, g1, (const uint32_t *)s->s_cnt.p,
+                       (const uint4 *)s->s_part.p, *g2, sub_bits, (uint32_t *)s->s_cnt2.p, (uint4 *)s->s_part2.p, spill);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
 }
 
 // view of keys [start, start+cnt) of a device batch

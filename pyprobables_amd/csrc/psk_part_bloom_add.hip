@@ -7,8 +7,42 @@ int bloom_add_partitioned(psk_sketch *s, const Batch &b, hipStream_t st, bool *d
     *done = false;
     if (!part_wanted(b.n, s->k)) return PSK_OK;
     PartGeom g;
-    if (!part_slices(s->m, 20, 7, &g)) return PSK_OK;
+    if (!part_slices(s->m, 20, 7, &g, 16384)) return PSK_OK;
     g.k = s->k;
+    PartGeom g1;
+    uint32_t sub_bits = 0;
+    if (two_level_geometry(g, &g1, &sub_bits)) {
+        // more slices than one pass can bin well: coarse buckets first (inline 32-bit probes), then k_part_split
+        const uint64_t round_keys = part_round_keys(b.n, s->k, PayZero::group);
+        for (uint64_t start = 0; start < b.n; start += round_keys) {
+            const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
+            const Batch sub = sub_batch(b, start, cnt);
+            bool handled = false;
+            SpillBloomOr spill{(uint32_t *)s->table};
+            PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
+                using Src = decltype(src);
+                return with_kt<Src>(s->k, [&](auto kt) {
+                    constexpr int KT = decltype(kt)::value;
+                    if (s->pow2)
+                        return launch_scatter<Src, IdxBloom<true>, PayZero, SpillBloomOr, KT>(s, src, IdxBloom<true>{s->md}, PayZero{},
+                                                                                              spill, &g1, cnt, st);
+                    return launch_scatter<Src, IdxBloom<false>, PayZero, SpillBloomOr, KT>(s, src, IdxBloom<false>{s->md}, PayZero{},
+                                                                                           spill, &g1, cnt, st);
+                });
+            }));
+            if (!handled) return PSK_OK;
+            PartGeom g2 = g;
+            PSK_TRY((split_level2<0, SpillBloomOr>(s, g1, &g2, sub_bits, cnt * (uint64_t)s->k, spill, st)));
+            const size_t lds = (size_t)1 << (g2.shift - 3);
+            PSK_TRY(set_dyn_lds(k_bloom_apply, lds));
+            hipLaunchKernelGGL(k_bloom_apply, dim3(g2.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->padded_bytes / 4,
+                               g2, (const uint32_t *)s->s_cnt2.p, (const uint4 *)s->s_part2.p);
+            HIP_TRY(hipGetLastError());
+        }
+        *done = true;
+        return PSK_OK;
+    }
+    if (g.nbuckets > (uint32_t)kPartMaxBuckets) return PSK_OK;
     const uint64_t round_keys = part_round_keys(b.n, s->k, PayNone::group);
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;

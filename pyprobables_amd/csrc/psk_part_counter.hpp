@@ -12,8 +12,52 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
     // unit-weight batches cannot wrap a 32-bit partial sum when n*k < 2^31 (weighted ones are checked on the device)
     if (!w_dev && b.n * (uint64_t)s->k >= (1ULL << 31)) return PSK_OK;
     PartGeom g;
-    if (!part_slices(cells, 15, 5, &g)) return PSK_OK;  // 2^15 counters = 128 KiB per slice
+    if (!part_slices(cells, 15, 5, &g, 16384)) return PSK_OK;  // 2^15 counters = 128 KiB per slice
     g.k = s->k;
+    unsigned long long *sat2 = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
+    PartGeom g1;
+    uint32_t sub_bits = 0;
+    if (two_level_geometry(g, &g1, &sub_bits)) {
+        // Pass 2 read-modify-writes every slice of the table: only worth it when the batch brings enough probes
+        // (direct atomics into a 1 GiB table run at ~20 G/s; the table RMW at ~4 TB/s)
+        if (b.n * (uint64_t)s->k < cells / 8) return PSK_OK;
+        const uint64_t round_keys = part_round_keys(b.n, s->k, PayWeight::group);
+        SpillCounter<SIGNED> spill{(uint32_t *)s->table, w_dev == nullptr, NEG, sat2};
+        for (uint64_t start = 0; start < b.n; start += round_keys) {
+            const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
+            const Batch sub = sub_batch(b, start, cnt);
+            bool handled = false;
+            PayWeight pay{w_dev ? w_dev + start : nullptr};  // level 1 is always inline: weight (or 1) << shift1 | index in the coarse bucket
+            PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
+                using Src = decltype(src);
+                return with_kt<Src>(s->k, [&](auto kt) {
+                    constexpr int KT = decltype(kt)::value;
+                    if (s->pow2) return launch_scatter<Src, IDX<true>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<true>{s->md}, pay, spill, &g1, cnt, st);
+                    return launch_scatter<Src, IDX<false>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<false>{s->md}, pay, spill, &g1, cnt, st);
+                });
+            }));
+            if (!handled) return PSK_OK;
+            PartGeom g2 = g;
+            const size_t lds = (size_t)4 << g2.shift;
+            if (w_dev) {
+                PSK_TRY((split_level2<2, SpillCounter<SIGNED>>(s, g1, &g2, sub_bits, cnt * (uint64_t)s->k, spill, st)));
+                auto kern = k_counter_apply<SIGNED, true, NEG>;
+                PSK_TRY(set_dyn_lds(kern, lds));
+                hipLaunchKernelGGL(kern, dim3(g2.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g2,
+                                   (const uint32_t *)s->s_cnt2.p, (const uint4 *)s->s_part2.p, (const long long *)s->ctr, sat2);
+            } else {
+                PSK_TRY((split_level2<1, SpillCounter<SIGNED>>(s, g1, &g2, sub_bits, cnt * (uint64_t)s->k, spill, st)));
+                auto kern = k_counter_apply<SIGNED, false, NEG>;
+                PSK_TRY(set_dyn_lds(kern, lds));
+                hipLaunchKernelGGL(kern, dim3(g2.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g2,
+                                   (const uint32_t *)s->s_cnt2.p, (const uint4 *)s->s_part2.p, (const long long *)s->ctr, sat2);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        *done = true;
+        return PSK_OK;
+    }
+    if (g.nbuckets > (uint32_t)kPartMaxBuckets) return PSK_OK;
     const uint64_t round_keys = part_round_keys(b.n, s->k, w_dev ? PayWeight::group : PayUnit::group);
     unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
     for (uint64_t start = 0; start < b.n; start += round_keys) {

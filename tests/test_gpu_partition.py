@@ -25,7 +25,7 @@ def pa():
 def force_partition():
     from pyprobables_amd import _native as N
 
-    names = ("partition", "partition_min_keys", "partition_max_keys", "partition_cache_bytes")
+    names = ("partition", "partition_min_keys", "partition_max_keys", "partition_cache_bytes", "partition_two_level_slices")
     old = [N.get_option(k) for k in names]
     N.set_option("partition", 1)
     N.set_option("partition_min_keys", 1)
@@ -366,3 +366,76 @@ def test_split_lookup_segment_overflow_is_redone_exactly(pa, oracle, force_parti
     got = blm.check_many_finish().cpu().numpy().astype(np.uint8)
     assert np.array_equal(got, ob.check_keys(keys))
     assert got[1] == 1 and got.sum() >= 150_000 - 300
+
+
+# ------------------------------------------------------------------ two-level path (coarse buckets, then k_part_split)
+@pytest.mark.parametrize("est,fpr,n", [
+    (28005615, 0.01, 700_000),    # 256 slices -> 128 coarse buckets x 2
+    (3_000_000, 0.01, 400_000),   # general m, 28 slices
+    (60_000_000, 0.02, 900_000),  # ~ 490 Mbit: 468 slices, last one partial
+    (967126, 0.12447325804747715, 300_000),  # k = 3, m = 2^22: 4 slices -> not two-level (<= threshold), still exact
+])
+def test_two_level_bloom_insert_vs_oracle(pa, oracle, force_partition, est, fpr, n):
+    force_partition.set_option("partition_two_level_slices", 4)
+    keys = oracle.gen_keys16(31, n)
+    blm = pa.BloomFilter(est_elements=est, false_positive_rate=fpr)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    blm.add_many(_dev(keys[: n // 2]))
+    blm.add_many(_dev(keys[n // 3:]))       # overlapping second batch into a non-empty table
+    ob.add_keys(keys)
+    assert np.array_equal(_table(blm), ob.bloom)
+    assert np.array_equal(blm.check_many(_dev(keys[:50_000])).cpu().numpy().astype(np.uint8), ob.check_keys(keys[:50_000]))
+
+
+def test_two_level_bloom_overflow_and_layouts(pa, oracle, force_partition):
+    force_partition.set_option("partition_two_level_slices", 4)
+    key = oracle.gen_keys16(3, 1)
+    keys = np.repeat(key, 120_000, axis=0)   # every probe in <= k slices: level-1 AND level-2 segments overflow -> spills
+    keys[::700] = oracle.gen_keys16(100, 172)
+    blm = pa.BloomFilter(est_elements=4_000_000, false_positive_rate=0.01)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    blm.add_many(_dev(keys))
+    ob.add_keys(keys)
+    assert np.array_equal(_table(blm), ob.bloom)
+    rng = np.random.default_rng(8)
+    ragged = [bytes(rng.integers(0, 256, size=int(l), dtype=np.uint8)) for l in rng.integers(0, 40, size=40_000)]
+    blm.add_many(ragged)
+    ob.add_varlen(ragged)
+    assert np.array_equal(_table(blm), ob.bloom)
+
+
+@pytest.mark.parametrize("width,depth,weighted", [(2**20, 5, True), (2**20, 5, False), (300_007, 4, True), (2**18, 7, False)])
+def test_two_level_counter_adds_vs_oracle(pa, oracle, force_partition, width, depth, weighted):
+    force_partition.set_option("partition_two_level_slices", 4)
+    n = 500_000
+    keys = oracle.gen_keys16(77, n // 2)
+    keys = np.concatenate([keys, keys])      # every key twice
+    w = oracle.gen_weights(0, n)
+    w[::997] = 5000                          # too big for the level-1 inline field (2^11): exact spill
+    cms = pa.CountMinSketch(width=width, depth=depth)
+    oc = oracle.OracleCMS(width, depth)
+    if weighted:
+        cms.add_many(_dev(keys), _dev(w))
+        oc.add_keys(keys, w)
+        cms.remove_many(_dev(keys[:1000]), _dev(w[:1000]))
+        oc.remove_keys(keys[:1000], w[:1000])
+    else:
+        cms.add_many(_dev(keys))
+        oc.add_keys(keys)
+    assert np.array_equal(np.frombuffer(bytes(cms._bins), dtype=np.int32), oc.bins)
+    assert cms.elements_added == oc.els_added
+
+
+def test_two_level_cbf_add_vs_oracle(pa, oracle, force_partition):
+    force_partition.set_option("partition_two_level_slices", 4)
+    n = 400_000
+    keys = oracle.gen_keys16(5, n)
+    w = (1 + (np.arange(n) % 4)).astype(np.uint32)
+    cbf = pa.CountingBloomFilter(est_elements=2_000_000, false_positive_rate=0.01)
+    oc = oracle.OracleCBF(cbf.number_bits, cbf.number_hashes)
+    cbf.add_many(_dev(keys), w)
+    oc.update_keys(keys, w.astype(np.int64))
+    cbf.add_many(_dev(keys[:100_000]))
+    oc.update_keys(keys[:100_000], np.ones(100_000, dtype=np.int64))
+    assert np.array_equal(np.frombuffer(bytes(cbf.bloom), dtype=np.uint32), oc.bloom)
+    assert cbf.elements_added == oc.els_added
