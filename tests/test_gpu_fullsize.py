@@ -116,6 +116,21 @@ def test_cfg4_cbf_1GiB_mixed_stream(pa, oracle):
     assert int(last.min()) >= 1                                # the last batch was never removed
 
 
+def test_cfg4_cbf_1GiB_large_batches_take_the_two_level_path(pa, oracle):
+    """8192 slices: one 10 M-key batch brings enough probes for coarse buckets -> k_part_split -> per-slice fold"""
+    n = 10_000_000
+    cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    oc = oracle.OracleCBF(2**28, 7)
+    w = (1 + (np.arange(n) % 3)).astype(np.uint32)
+    cbf.add_many(dev_keys(0, n), torch.from_numpy(w.view(np.int32)).cuda())
+    cbf.add_many(dev_keys(n // 2, n))                          # unit weights, overlapping keys
+    oc.update_keys(oracle.gen_keys16(0, n), w.astype(np.int64))
+    oc.update_keys(oracle.gen_keys16(n // 2, n), np.ones(n, dtype=np.int64))
+    assert np.array_equal(cbf.table_tensor.cpu().numpy().view(np.uint32), oc.bloom)
+    assert cbf.elements_added == oc.els_added
+    assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+
+
 def test_cfg5_bloom_2p31_two_shards_or_merge(pa, oracle):
     from pyprobables_amd import _native as N
 
