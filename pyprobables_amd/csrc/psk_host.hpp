@@ -146,7 +146,9 @@ static size_t scatter_lds_bytes(const PartGeom *g)
 {
     using Tile = PartTile<Pay, KT, NT>;
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
-    const size_t stage_words = ((size_t)Tile::TILE * kk + (size_t)(Tile::GS - 1) * g->nbuckets) * (Tile::pair ? 2 : 1);
+    // stage (one word per probe in every mode) + one slice id per group for the payload modes
+    const size_t stage_cap = (((size_t)Tile::TILE * kk + (size_t)(Tile::GS - 1) * g->nbuckets) + 3) & ~(size_t)3;
+    const size_t stage_words = stage_cap + (Tile::pair ? stage_cap / Tile::GS + 4 : 0);
     return (5 * (size_t)g->nbuckets + 16 + 24 + stage_words) * 4;
 }
 
@@ -186,9 +188,14 @@ static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, con
                           uint64_t n, hipStream_t st)
 {
     if constexpr (KT <= 8) {
-        if (!(g->dbg & 16) && scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget)
+        // keyed probes carry (key index in tile << shift | bit in slice) in 32 bits, 0xFFFFFFFF being the pad: the tile must
+        // stay below 2^(32 - shift) keys (1024-thread tiles of k = 3, 4 are 5120 / 4096 keys: too many for 2^20-bit slices)
+        const bool ids_fit = Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, 1024>::TILE << g->shift) < (1ULL << 32);
+        if (!(g->dbg & 16) && ids_fit && scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget)
             return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st);
     }
+    static_assert(Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, kPartThreads>::TILE << 20) < (1ULL << 32),
+                  "512-thread tiles must keep keyed probes inside 32 bits for the largest slice (2^20 bits)");
     return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, kPartThreads>(s, src, idxfn, pay, spill, g, n, st);
 }
 

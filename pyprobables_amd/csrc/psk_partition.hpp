@@ -175,7 +175,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
 // dynamic LDS: hist[2][B] | off[B] | delta[B] | cur[B] | wave_tot[16] | profile[24] | stage (1 or 2 words per probe)
 template <class Pay, int KT, int NT_ = kPartThreads>
 struct PartTile {
-    static constexpr bool pair = Pay::mode != kModePlain;           // stage entry = (cell, payload)
+    static constexpr bool pair = Pay::mode != kModePlain;           // probes carry a payload (weight / key id): the stage holds
+                                                                    // the final 32-bit word and a per-group slice id (gb[])
     static constexpr int GS = Pay::group;                           // probes per 16-byte output group
     static constexpr int PP = kPartProbes / 2;                      // 16 probes per thread: <= 100 VGPRs, 2 workgroups per CU
     static constexpr int KPT = PP / KT >= 1 ? PP / KT : 1;          // keys per thread per tile
@@ -190,8 +191,8 @@ struct PartTile {
 // Write-out of ONE 16-byte group of the sorted LDS stage: lane = group gi of the tile; its first probe is always
 // real (pads trail), so it names the slice.  delta[b] turns the stage group index into the slot of my segment.
 template <class Pay, class Spill>
-__device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t *delta, const PartGeom &g, uint32_t mask, uint32_t gi,
-                                           uint64_t tile, uint64_t base, const Spill &spill, uint4 *buckets)
+__device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t *gb, const uint32_t *delta, const PartGeom &g, uint32_t mask,
+                                           uint32_t gi, uint64_t tile, uint64_t base, const Spill &spill, uint4 *buckets)
 {
     constexpr int GS = Pay::group;
     if constexpr (Pay::mode == kModePlain) {
@@ -234,36 +235,28 @@ __device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t
                 if (c[e] != kPadProbe) spill(c[e], 0u);
         }
     } else if constexpr (Pay::mode == kModeInline) {
-        const uint4 e01 = reinterpret_cast<const uint4 *>(stage)[2 * gi];      // cell0 w0 cell1 w1
-        const uint4 e23 = reinterpret_cast<const uint4 *>(stage)[2 * gi + 1];  // cell2 w2 cell3 w3
-        const uint32_t b = e01.x >> g.shift;
-        const uint32_t slot = delta[b] + gi;
-        const bool room = slot < g.segcap;
-        const uint32_t wmax = 1u << (31 - g.shift);  // weights below this ride inside the probe word
-        auto enc = [&](uint32_t cell, uint32_t w) -> uint32_t {
-            if (cell == kPadProbe) return kPadProbe;
-            if (room && w < wmax) return (w << g.shift) | (cell & mask);
-            spill(cell, w);  // big / negative weight, or segment full: exact saturating add on the table
-            return kPadProbe;
-        };
-        const uint4 o = make_uint4(enc(e01.x, e01.y), enc(e01.z, e01.w), enc(e23.x, e23.y), enc(e23.z, e23.w));
-        if (room) buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = o;
-    } else {  // keyed
-        const uint2 e0 = reinterpret_cast<const uint2 *>(stage)[3 * gi];
-        const uint2 e1 = reinterpret_cast<const uint2 *>(stage)[3 * gi + 1];
-        const uint2 e2 = reinterpret_cast<const uint2 *>(stage)[3 * gi + 2];
-        const uint32_t b = e0.x >> g.shift;
+        const uint4 e = reinterpret_cast<const uint4 *>(stage)[gi];  // four final words (weight << shift | cell in slice)
+        const uint32_t b = gb[gi];
         const uint32_t slot = delta[b] + gi;
         if (slot < g.segcap) {
-            auto enc = [&](uint2 e) -> uint32_t {
-                return e.x == kPadProbe ? kPadProbe : ((e.y << g.shift) | (e.x & mask));
-            };
-            buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] =
-                make_uint4((uint32_t)tile, enc(e0), enc(e1), enc(e2));
+            buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = e;
+        } else {  // segment full: exact saturating add on the table, probe by probe
+            const uint32_t w[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                if (w[x] != kPadProbe) spill((b << g.shift) | (w[x] & mask), w[x] >> g.shift);
+        }
+    } else {  // keyed
+        const uint32_t e0 = stage[3 * gi], e1 = stage[3 * gi + 1], e2 = stage[3 * gi + 2];
+        const uint32_t b = gb[gi];
+        const uint32_t slot = delta[b] + gi;
+        if (slot < g.segcap) {
+            buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = make_uint4((uint32_t)tile, e0, e1, e2);
         } else {
-            if (e0.x != kPadProbe) spill(e0.x, (uint32_t)base + e0.y);
-            if (e1.x != kPadProbe) spill(e1.x, (uint32_t)base + e1.y);
-            if (e2.x != kPadProbe) spill(e2.x, (uint32_t)base + e2.y);
+            const uint32_t w[3] = {e0, e1, e2};
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+                if (w[x] != kPadProbe) spill((b << g.shift) | (w[x] & mask), (uint32_t)base + (w[x] >> g.shift));
         }
     }
 }
@@ -286,6 +279,9 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     uint32_t *wave_tot = cur + B;
     unsigned long long *t_acc = reinterpret_cast<unsigned long long *>(wave_tot + 16);  // phase profile (dbg & 32), 12 slots
     uint32_t *stage = wave_tot + 16 + 24;
+    // slice id of every stage group (payload modes); sits behind the stage: TILE * k probes + (GS - 1) pads per slice
+    const uint32_t stage_cap = ((uint32_t)TILE * (g.k < (uint32_t)KT ? g.k : (uint32_t)KT) + (uint32_t)(GS - 1) * B + 3u) & ~3u;
+    uint32_t *gb = stage + stage_cap;
     // KT other than the round-up sizes 8 / 16 / 32 is an exact instantiation (with_kt): k == KT, and every per-probe
     // "j < k" test below folds away (28 exec-mask branch sequences per tile for k = 7)
     constexpr bool kExactK = KT != 8 && KT != 16 && KT != 32;
@@ -465,8 +461,20 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
                 for (int j = 0; j < KT; ++j) {
                     if ((uint32_t)j < k) {
                         const uint32_t p = off[idx[q][j] >> g.shift] + rank[q][j];
-                        if (PAIR) reinterpret_cast<uint2 *>(stage)[p] = make_uint2(idx[q][j], payload[q]);
-                        else stage[p] = idx[q][j];
+                        if constexpr (PAIR) {
+                            // final word (payload << shift | index in the slice); the slice of every group is kept
+                            // aside by whoever fills the group's first slot
+                            const uint32_t cell = idx[q][j];
+                            uint32_t enc = (payload[q] << g.shift) | (cell & mask);
+                            if (Pay::mode == kModeInline && payload[q] >= (1u << (31 - g.shift))) {
+                                spill(cell, payload[q]);  // big / negative weight: exact saturating add on the table
+                                enc = kPadProbe;
+                            }
+                            stage[p] = enc;
+                            if (p % GS == 0) gb[p / GS] = cell >> g.shift;
+                        } else {
+                            stage[p] = idx[q][j];
+                        }
                     }
                 }
             }
@@ -475,8 +483,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         for (uint32_t b = threadIdx.x; b < B; b += NT) {
             const uint32_t cnt = hist[b], padded = (cnt + GS - 1) / GS * GS, at = off[b];
             for (uint32_t e = cnt; e < padded; ++e) {
-                if (PAIR) reinterpret_cast<uint2 *>(stage)[at + e] = make_uint2(kPadProbe, 0u);
-                else stage[at + e] = kPadProbe;
+                stage[at + e] = kPadProbe;
             }
         }
         lds_barrier();
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         if (!(g.dbg & 1)) {
             const uint32_t ngroups = tile_probes / GS;
             for (uint32_t gi = threadIdx.x; gi < ngroups; gi += NT) {
-                emit_group<Pay, Spill>(stage, delta, g, mask, gi, tile, base, spill, buckets);
+                emit_group<Pay, Spill>(stage, gb, delta, g, mask, gi, tile, base, spill, buckets);
             }
         }
         // (pipelined form) no barrier needed here: the next iteration touches only hist (last read two barriers

@@ -314,6 +314,21 @@ def test_partitioned_more_layouts_and_big_k(pa, oracle, force_partition):
     assert cms.elements_added == oc.els_added
 
 
+@pytest.mark.parametrize("est,fpr", [(62_000_000, 0.12447325804747715), (45_000_000, 0.05), (28005615, 0.01)])
+def test_lookup_key_ids_fit_the_probe_word(pa, oracle, force_partition, est, fpr):
+    """k = 3 / 4 / 7 on tables with 2^20-bit slices: the keyed probe packs (key index in tile << 20 | bit in slice) into
+    32 bits, so the tile size has to respect the slice size (1024-thread tiles of k = 3 would need 33 bits)"""
+    n = 200_000
+    keys = oracle.gen_keys16(4, n)
+    blm = pa.BloomFilter(est_elements=est, false_positive_rate=fpr)
+    assert blm.number_bits >= 2**28
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    blm.add_many(_dev(keys[: n // 2]))
+    ob.add_keys(keys[: n // 2])
+    assert np.array_equal(_table(blm), ob.bloom)
+    assert np.array_equal(blm.check_many(_dev(keys)).cpu().numpy().astype(np.uint8), ob.check_keys(keys))
+
+
 # ------------------------------------------------------------------ split lookup (pass 1 before the table is final)
 def test_split_lookup_sees_the_table_at_finish_time(pa, oracle, force_partition):
     n = 600_000
