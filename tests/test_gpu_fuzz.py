@@ -151,3 +151,42 @@ def test_fuzz_cbf(pa, oracle, engine_options, seed):
         probe[:500] = keys[:500] if n >= 500 else probe[:500]
         assert np.array_equal(cbf.check_many(probe), oc.check_keys(probe))
     assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+
+
+# large tables: 2^20-bit Bloom slices / 2^15-cell counter slices at their maximum, every k class, both partition levels
+@pytest.mark.parametrize("seed", range(20))
+def test_fuzz_big_tables(pa, oracle, engine_options, seed):
+    rng = np.random.default_rng(5000 + seed)
+    engine_options.set_option("partition", 1)
+    engine_options.set_option("partition_min_keys", 1)
+    engine_options.set_option("partition_two_level_slices", int(rng.choice([2048, 64, 256])))
+    k_fpr = {3: 0.12, 4: 0.06, 5: 0.03, 6: 0.016, 7: 0.008, 8: 0.004, 10: 0.001, 13: 0.00012}
+    k = int(rng.choice(list(k_fpr)))
+    n = int(rng.choice([150_000, 600_000, 1_500_000]))
+    keys = oracle.gen_keys16(seed * 7_000_000, n)
+    dk = _dev(keys)
+    if seed % 2 == 0:  # Bloom, 2^28 .. 2^29 bits
+        m_target = int(rng.choice([2**28, 3 * 2**27, 2**29]))
+        est = int(m_target * 0.4804530139182 / -np.log(k_fpr[k]))
+        blm = pa.BloomFilter(est_elements=est, false_positive_rate=k_fpr[k])
+        assert blm.number_hashes == k and blm.number_bits >= 2**27
+        ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+        blm.add_many(dk[: n // 2])
+        ob.add_keys(keys[: n // 2])
+        assert np.array_equal(np.frombuffer(bytes(blm.bloom), dtype=np.uint8), ob.bloom)
+        assert np.array_equal(blm.check_many(dk).cpu().numpy().astype(np.uint8), ob.check_keys(keys))
+    else:  # counters, 2^24 .. 2^27 cells
+        cells_target = int(rng.choice([2**24, 2**26, 2**27]))
+        est = int(cells_target * 0.4804530139182 / -np.log(k_fpr[k]))
+        cbf = pa.CountingBloomFilter(est_elements=est, false_positive_rate=k_fpr[k])
+        assert cbf.number_hashes == k
+        oc = oracle.OracleCBF(cbf.number_bits, cbf.number_hashes)
+        w = rng.integers(1, 9, size=n).astype(np.uint32)
+        w[:: 4001] = 3000  # beyond the level-1 inline field of the two-level path
+        cbf.add_many(dk, _dev(w.view(np.int32)))
+        oc.update_keys(keys, w.astype(np.int64))
+        cbf.add_many(dk[: n // 3])
+        oc.update_keys(keys[: n // 3], np.ones(n // 3, dtype=np.int64))
+        assert np.array_equal(np.frombuffer(bytes(cbf.bloom), dtype=np.uint32), oc.bloom)
+        assert cbf.elements_added == oc.els_added
+        assert np.array_equal(cbf.check_many(dk[:50_000]).cpu().numpy().view(np.uint32), oc.check_keys(keys[:50_000]))
