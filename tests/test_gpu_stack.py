@@ -182,3 +182,25 @@ def test_differential_vs_oracle(pa, oracle, seed):
     probe = oracle.gen_keys16(seed * 1_000_000, pool + 500)
     assert np.array_equal(blm.check_many(probe).astype(np.uint8), st.check_keys([bytes(r) for r in probe]))
     print(f"seed {seed}: est={est} fpr={fpr} queue={queue} n={n} filters={st.nfilters}")
+
+
+def test_multi_window_batch(pa, oracle):
+    """one add_many larger than the hashing window (2^22 keys): the windows must chain like one ordered stream"""
+    n, pool = 5_000_000, 3_000_000
+    est, fpr = 1_200_000, 0.02
+    rng = np.random.default_rng(12)
+    sel = rng.integers(0, pool, size=n)
+    keys16 = oracle.gen_keys16(9_000_000, pool)
+    batch = np.ascontiguousarray(keys16[sel])
+    blm = pa.ExpandingBloomFilter(est_elements=est, false_positive_rate=fpr)
+    blm.add_many(torch.from_numpy(batch).cuda())
+    st = oracle.OracleStack(est, fpr, max_filters=16)
+    blob = np.ascontiguousarray(batch).reshape(-1)
+    offs = np.arange(0, 16 * (n + 1), 16, dtype=np.uint64)
+    import ctypes as C
+
+    rc = oracle.lib().psk_o_stack_add_varlen(st.stack.ctypes.data, st.filter_bytes, st.max_filters, C.byref(st._n), st.counts.ctypes.data,
+                                             st.m, st.k, st.est, st.queue, blob.ctypes.data, offs.ctypes.data, n, 0, C.byref(st._added))
+    assert rc == 0
+    assert [b.elements_added for b in blm._blooms] == [int(c) for c in st.counts[: st.nfilters]]
+    assert bytes(blm) == st.export_bytes()
