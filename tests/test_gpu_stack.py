@@ -204,3 +204,28 @@ def test_multi_window_batch(pa, oracle):
     assert rc == 0
     assert [b.elements_added for b in blm._blooms] == [int(c) for c in st.counts[: st.nfilters]]
     assert bytes(blm) == st.export_bytes()
+
+
+def test_custom_hash_function_route(pa):
+    """a user callable runs per key on the host and enters through the pre-hashed layout: same stack as the fused family
+    when it computes the same hashes (expandingbloom_test.py:40-45 style), md5 family through the digest kernel"""
+    def my_hash(key, depth=1):
+        return pa.default_fnv_1a(key, depth)
+
+    keys = [f"{i}" for i in range(400)] + ["é", ""]
+    a = pa.ExpandingBloomFilter(est_elements=30, false_positive_rate=0.05)
+    b = pa.ExpandingBloomFilter(est_elements=30, false_positive_rate=0.05, hash_function=my_hash)
+    a.add_many(keys)
+    for i in range(0, len(keys), 37):
+        b.add_many(keys[i:i + 37])
+    assert bytes(a) == bytes(b) and a.expansions == b.expansions > 3
+    probes = [f"p{i}" for i in range(200)] + keys[:50]
+    assert list(a.check_many(probes)) == list(b.check_many(probes)) and b.check("17") and b.hash_function is my_hash
+    b.add_alt(my_hash("brand new", b._k))
+    assert b.check_alt(my_hash("brand new", b._k)) and b.elements_added == len(keys) + 1
+    m = pa.ExpandingBloomFilter(est_elements=30, false_positive_rate=0.05, hash_function=pa.default_md5)
+    m.add_many(keys)
+    one = pa.ExpandingBloomFilter(est_elements=30, false_positive_rate=0.05, hash_function=pa.default_md5)
+    for key in keys:
+        one.add(key)
+    assert bytes(m) == bytes(one) and all(m.check_many(keys))
