@@ -168,10 +168,17 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if rank != 0:  # only rank 0 reports; keep library banners of the other ranks off the job's stdout
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N > 1 through torch.distributed.run (one process per GPU)")
+    # PSK_BENCH_SINGLE_DEVICE=1 (test hook): every rank uses cuda:0 and the gloo backend, so that the N > 1 logic (shard
+    # offsets, two real replicas, merge, overlap) can be driven on a one-GPU box; RCCL refuses two ranks on one device
+    single_device = bool(os.environ.get("PSK_BENCH_SINGLE_DEVICE"))
+    if single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     # PSK_BENCH_FORCE_DIST=1 drives the whole N > 1 code path (RCCL init, merge, barriers) with a single rank
@@ -186,7 +193,10 @@ def main():
             os.environ["PSK_FORCE_MERGE_PATH"] = "1"
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if single_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     import pyprobables_amd as pa
     from pyprobables_amd import parallel
@@ -245,6 +255,14 @@ def main():
     fence()
     ok = bool(state["res"].all().item())  # every inserted key must be found (size-independent parity property)
     bits_set = blm._cnt_number_bits_set()
+    merged_ok = None
+    if distributed:
+        # multi-GPU parity, outside the timed region: the merged replica must equal ONE filter fed every rank's keys
+        ref = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01, device=dev)
+        for r in range(world):
+            ref.add_many(gen_keys(n, r * n, dev))
+        merged_ok = bool(torch.equal(ref.table_tensor, blm.table_tensor))
+        del ref
 
     ms_step = elapsed / args.steps * 1e3
     total_ops = 2 * n * world
@@ -302,6 +320,7 @@ def main():
             "clear_ms": timer.mean_ms("clear"),
             "merge_ms": timer.mean_ms("merge") if distributed and not overlapped else None,
             "all_inserted_found": ok,
+            "merged_table_equals_single_stream": merged_ok,
             "bits_set": bits_set,
         },
     }
@@ -311,12 +330,23 @@ def main():
         line["cpu_baseline"] = cpu_baseline(min(n, 10_000_000))
     elif rank == 0:
         line["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line must be the LAST thing on stdout: RCCL's NCCL_DEBUG=VERSION banner sits in the C stdio buffer
+        # until exit, so drain C stdio first (the other ranks' stdout was sent to /dev/null at start)
+        import ctypes  # noqa: PLC0415
+
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
     if not ok:
         raise SystemExit("parity property violated: an inserted key was not found")
+    if merged_ok is False:
+        raise SystemExit("parity property violated: the merged table differs from the single-stream filter")
 
 
 if __name__ == "__main__":
