@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=10_000_000, help="keys per rank per step")
+    ap.add_argument("--n", "--keys-per-rank", dest="n", type=int, default=10_000_000, help="keys per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-detail", action="store_true", help="skip the CMS / CBF / GUPS side measurements")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: merge, then look up (no lookup pass 1 under the merge)")
