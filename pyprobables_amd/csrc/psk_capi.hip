@@ -607,7 +607,7 @@ static int account_weights(psk_sketch *s, const W *w_dev, uint64_t n, int which,
     if (n == 0) return PSK_OK;
     if (w_dev) {
         HIP_TRY(hipMemsetAsync(s->ctr + 6, 0, sizeof(long long), st));  // per-batch sum|w| (partitioned path wrap check)
-        hipLaunchKernelGGL((k_weight_sum<W>), dim3(grid_for(n) > 512 ? 512 : grid_for(n)), dim3(kBlock), 0, st, w_dev, n,
+        hipLaunchKernelGGL((k_weight_sum<W>), dim3(grid_for(n) > 256 ? 256 : grid_for(n)), dim3(kBlock), 0, st, w_dev, n,
                            s->ctr, which, bound_mult);
     } else {
         hipLaunchKernelGGL(k_ctr_add, dim3(1), dim3(1), 0, st, s->ctr, which, (long long)n, (long long)n * bound_mult);

@@ -722,12 +722,14 @@ __global__ __launch_bounds__(kBlock) void k_weight_sum(const W *w, uint64_t n, l
         const W4 *w4 = reinterpret_cast<const W4 *>(w);
         const uint64_t n4 = n / 4;
         uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-        for (; i + stride < n4; i += 2 * stride) {
-            const W4 p = w4[i], q = w4[i + stride];
+        for (; i + 3 * stride < n4; i += 4 * stride) {  // four 16-byte loads in flight per lane
+            const W4 p = w4[i], q = w4[i + stride], r = w4[i + 2 * stride], u = w4[i + 3 * stride];
             acc(p.x); acc(p.y); acc(p.z); acc(p.t);
             acc(q.x); acc(q.y); acc(q.z); acc(q.t);
+            acc(r.x); acc(r.y); acc(r.z); acc(r.t);
+            acc(u.x); acc(u.y); acc(u.z); acc(u.t);
         }
-        if (i < n4) {
+        for (; i < n4; i += stride) {
             const W4 p = w4[i];
             acc(p.x); acc(p.y); acc(p.z); acc(p.t);
         }
