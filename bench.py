@@ -138,7 +138,7 @@ def side_measurements(device, n):
     return out
 
 
-def cpu_baseline(n_sample, reps=3):
+def cpu_baseline(n_sample, reps=6):
     """the plain-C oracle (kind 'port') on this box's host cores, single thread"""
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle
