@@ -23,7 +23,6 @@ The JSON line also carries
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -33,7 +32,6 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)

@@ -8,12 +8,11 @@ same constructor keywords, ``add`` / ``check`` / ``in``, ``add_alt`` / ``check_a
 
 from __future__ import annotations
 
-import ctypes as C
 import math
 import struct
 from array import array
 from binascii import hexlify, unhexlify
-from io import BytesIO, IOBase
+from io import IOBase
 from mmap import mmap
 from numbers import Number
 from pathlib import Path

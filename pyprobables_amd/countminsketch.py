@@ -9,7 +9,6 @@ bit-exact whenever it does not depend on the order (same-sign weights, or no bin
 
 from __future__ import annotations
 
-import ctypes as C
 import math
 import struct
 from io import BytesIO, IOBase
