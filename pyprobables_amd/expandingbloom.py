@@ -210,7 +210,7 @@ class ExpandingBloomFilter:
                 return
             # Look at a window of the remaining keys: the chunk ends at the room-th candidate anyway, so testing far
             # beyond it against every filter would be wasted work (a window of repeats just yields a smaller chunk).
-            win = rem if room is None else min(rem, 2 * room + 65536)
+            win = rem if room is None else min(rem, room + room // 16 + 65536)
             present = self._present(idx, s, win)
             cand = present == 0
             ncand = int(cand.sum().item())
