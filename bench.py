@@ -239,7 +239,7 @@ def main():
         step(False)
     fence()
     t0 = time.perf_counter()
-    sample_every = max(1, args.steps // 10)  # the insert launch is event-timed on every sample_every-th step (>= 10 samples)
+    sample_every = max(1, min(20, args.steps // 3))  # the insert launch is event-timed on every sample_every-th step (>= 3 samples)
     for it in range(args.steps):
         step(it % sample_every == 0)
     fence()
