@@ -603,3 +603,27 @@ def test_bloom_per_key_add_loop_is_write_combined(pa, oracle):
     assert blm.elements_added == 0 and blm._cnt_number_bits_set() == 0
     with pytest.raises(TypeError):
         blm.add(123)
+
+
+def test_work_follows_torchs_current_stream(pa, oracle):
+    """device batches are enqueued on torch's CURRENT stream: two filters driven from two side streams at the same time
+    (independent handles), then joined -- results as if run one after the other"""
+    n = 400_000
+    keys = oracle.gen_keys16(123, n)
+    dk = torch.from_numpy(keys).cuda()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    filters = [pa.BloomFilter(est_elements=2_000_000, false_positive_rate=0.01) for _ in streams]
+    outs = []
+    for st, blm, part in zip(streams, filters, (dk[: n // 2], dk[n // 2:])):
+        with torch.cuda.stream(st):
+            blm.add_many(part)
+            outs.append(blm.check_many(dk))
+    for st in streams:
+        torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    for blm, res, (lo, hi) in zip(filters, outs, ((0, n // 2), (n // 2, n))):
+        ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+        ob.add_keys(keys[lo:hi])
+        assert np.array_equal(np.frombuffer(bytes(blm.bloom), dtype=np.uint8), ob.bloom)
+        assert np.array_equal(res.cpu().numpy().astype(np.uint8), ob.check_keys(keys))
