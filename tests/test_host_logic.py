@@ -134,3 +134,47 @@ def test_public_surface_names():
         assert hasattr(pa.CountMinSketch, meth)
     for meth in ("remove", "remove_alt", "remove_many"):
         assert hasattr(pa.CountingBloomFilter, meth)
+
+
+def test_vectorised_key_packing_equals_the_per_key_path(monkeypatch):
+    """homogeneous lists are packed with one join / one encode; the result must be the buffer the careful per-key loop
+    builds (layout, bytes, offsets), for latin-1 and wide strings, ragged / fixed / empty byte keys"""
+    import numpy as np
+
+    from pyprobables_amd import _native as N
+    from pyprobables_amd import keys as K
+
+    def image(b):
+        import ctypes as C
+
+        if b.layout == N.KEYS_FIXED:
+            size = b.n * b.key_len
+            data = bytes((C.c_uint8 * size).from_address(b.data)) if size else b""
+            return (b.layout, b.n, b.key_len, data, None)
+        offs = np.ctypeslib.as_array((C.c_uint64 * (b.n + 1)).from_address(b.offsets)).copy()
+        width = 4 if b.layout == N.KEYS_VARLEN32 else 1
+        size = int(offs[-1]) * width
+        data = bytes((C.c_uint8 * size).from_address(b.data)) if size else b""
+        return (b.layout, b.n, 0, data, offs.tolist())
+
+    rng = np.random.default_rng(3)
+    cases = [
+        [f"key-{i}" for i in range(300)],                      # ragged latin-1 str
+        [f"{i:08d}" for i in range(300)],                      # fixed-length str
+        ["é", "", "abc", "\xff\x00"],                          # latin-1 edge values, empties
+        ["日本語", "a", "", "😀 emoji"],                          # wide: code points, never UTF-8
+        [bytes(rng.integers(0, 256, size=int(n), dtype=np.uint8)) for n in rng.integers(0, 20, size=200)],
+        [bytes(rng.integers(0, 256, size=16, dtype=np.uint8)) for _ in range(100)],
+        [b"", b""],
+        [bytearray(b"ab"), b"cd", memoryview(b"efg")],
+    ]
+    for keys in cases:
+        fast = image(K.pack_keys(keys))
+        with monkeypatch.context() as m:
+            m.setattr(K, "_pack_homogeneous", lambda keys, n: None)
+            slow = image(K.pack_keys(keys))
+        assert fast == slow, keys[:3]
+    with pytest.raises(TypeError):
+        K.pack_keys(["a", 3])
+    mixed = K.pack_keys(["ab", b"cd"])   # mixed str / bytes still works (careful path)
+    assert mixed.n == 2
