@@ -185,6 +185,12 @@ def _pack_bytes_utf8(keys) -> KeyBatch:
         keys = [keys]
     if (torch is not None and isinstance(keys, torch.Tensor)) or isinstance(keys, np.ndarray):
         return pack_keys(keys)  # raw (n, L) byte matrices
+    keys = list(keys)
+    try:
+        if "".join(keys).isascii():  # ASCII: UTF-8 bytes == code points, the vectorised packing applies as is
+            return pack_keys(keys)
+    except TypeError:
+        pass
     raw = []
     for k in keys:
         if isinstance(k, str):
