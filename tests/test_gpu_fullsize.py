@@ -131,6 +131,23 @@ def test_cfg4_cbf_1GiB_large_batches_take_the_two_level_path(pa, oracle):
     assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
 
 
+def test_bloom_4gbit_takes_the_two_level_path(pa, oracle):
+    """m just below 2^32 bits: 4022 slices of 2^20 bits -> coarse buckets + k_part_split for inserts; lookups direct"""
+    n = 3_000_000
+    blm = pa.BloomFilter(est_elements=440_000_000, false_positive_rate=0.01)
+    assert 2**31 < blm.number_bits < 2**32 and blm.number_hashes == 7
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    keys = oracle.gen_keys16(42, n)
+    dk = torch.from_numpy(keys).cuda()
+    blm.add_many(dk[: n // 2])
+    blm.add_many(dk[n // 3:])
+    ob.add_keys(keys)
+    assert torch.equal(blm.table_tensor.cpu()[: ob.bloom.size // 4].view(torch.uint8), torch.from_numpy(ob.bloom[: ob.bloom.size // 4 * 4]))
+    assert blm._cnt_number_bits_set() == ob.bits_set()
+    probe = oracle.gen_keys16(42 + n - 100_000, 200_000)
+    assert np.array_equal(blm.check_many(torch.from_numpy(probe).cuda()).cpu().numpy().astype(np.uint8), ob.check_keys(probe))
+
+
 def test_cfg5_bloom_2p31_two_shards_or_merge(pa, oracle):
     from pyprobables_amd import _native as N
 
