@@ -148,6 +148,22 @@ def test_bloom_4gbit_takes_the_two_level_path(pa, oracle):
     assert np.array_equal(blm.check_many(torch.from_numpy(probe).cuda()).cpu().numpy().astype(np.uint8), ob.check_keys(probe))
 
 
+def test_bloom_beyond_2p32_bits_uses_64bit_indices(pa, oracle):
+    """m > 2^32: bit indices no longer fit 32 bits, the partitioned path steps aside, the direct kernels carry on"""
+    n = 1_000_000
+    blm = pa.BloomFilter(est_elements=500_000_000, false_positive_rate=0.01)
+    assert blm.number_bits > 2**32
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    keys = oracle.gen_keys16(7, n)
+    dk = torch.from_numpy(keys).cuda()
+    blm.add_many(dk[: n // 2])
+    ob.add_keys(keys[: n // 2])
+    assert blm._cnt_number_bits_set() == ob.bits_set()
+    assert np.array_equal(blm.check_many(dk).cpu().numpy().astype(np.uint8), ob.check_keys(keys))
+    top = np.flatnonzero(ob.bloom[2**29:])[:5] + 2**29        # some set bytes above bit 2^32
+    assert len(top) and np.array_equal(blm.table_tensor.view(torch.uint8)[torch.from_numpy(top).cuda()].cpu().numpy(), ob.bloom[top])
+
+
 def test_cfg5_bloom_2p31_two_shards_or_merge(pa, oracle):
     from pyprobables_amd import _native as N
 
