@@ -30,7 +30,7 @@ def build(force: bool = False) -> Path:
     src = _HERE / "psk_oracle.c"
     if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < src.stat().st_mtime:
         subprocess.run(
-            ["gcc", "-O2", "-fPIC", "-std=c11", "-fno-strict-aliasing", "-shared", "-o", str(_LIB_PATH), str(src), "-lm"],
+            ["gcc", "-O2", "-fPIC", "-std=gnu11", "-pthread", "-fno-strict-aliasing", "-shared", "-o", str(_LIB_PATH), str(src), "-lm"],
             check=True,
         )
     return _LIB_PATH
@@ -106,6 +106,20 @@ def lib():
         L.psk_o_cms_check_keys.argtypes = [vp, u64, u32, vp, u64, u64, i64, ci, vp]
         L.psk_o_cms_join.restype = None
         L.psk_o_cms_join.argtypes = [vp, vp, u64]
+        L.psk_o_estimate_elements.restype = i64
+        L.psk_o_estimate_elements.argtypes = [u64, u64, u32]
+        L.psk_o_bloom_combine.restype = None
+        L.psk_o_bloom_combine.argtypes = [vp, vp, vp, u64, ci]
+        L.psk_o_bloom_jaccard.restype = C.c_double
+        L.psk_o_bloom_jaccard.argtypes = [vp, vp, u64, u64p]
+        L.psk_o_cbf_combine.restype = u64
+        L.psk_o_cbf_combine.argtypes = [vp, vp, vp, u64, ci]
+        L.psk_o_cbf_jaccard.restype = C.c_double
+        L.psk_o_cbf_jaccard.argtypes = [vp, vp, u64, u64p]
+        L.psk_o_cbf_nonzero.restype = u64
+        L.psk_o_cbf_nonzero.argtypes = [vp, u64]
+        L.psk_o_bloom_insert_check_mt.restype = u64
+        L.psk_o_bloom_insert_check_mt.argtypes = [vp, u64, u32, u64, u64, u64, u32]
         L.psk_o_splitmix64.restype = u64
         L.psk_o_splitmix64.argtypes = [u64]
         L.psk_o_gen_keys16.restype = None
@@ -232,6 +246,32 @@ class OracleBloom:
     def bits_set(self) -> int:
         return int(lib().psk_o_bloom_bits_set(_ptr(self.bloom), self.bloom.size))
 
+    def estimate_elements(self) -> int:
+        """bloom.py:340-352"""
+        return int(lib().psk_o_estimate_elements(self.bits_set(), self.m, self.k))
+
+    def _combine(self, other: "OracleBloom", op: int) -> "OracleBloom":
+        res = OracleBloom(self.m, self.k)
+        lib().psk_o_bloom_combine(_ptr(res.bloom), _ptr(self.bloom), _ptr(other.bloom), self.bloom.size, op)
+        res.els_added = res.estimate_elements()  # bloom.py:398 / :427
+        return res
+
+    def union(self, other: "OracleBloom") -> "OracleBloom":
+        """bloom.py:401-428"""
+        return self._combine(other, 0)
+
+    def intersection(self, other: "OracleBloom") -> "OracleBloom":
+        """bloom.py:371-399"""
+        return self._combine(other, 1)
+
+    def jaccard_index(self, other: "OracleBloom") -> float:
+        """bloom.py:430-460"""
+        return float(lib().psk_o_bloom_jaccard(_ptr(self.bloom), _ptr(other.bloom), self.bloom.size, None))
+
+    def insert_check_mt(self, start: int, n: int, nthreads: int, seed: int = 0x5EED) -> int:
+        """all-cores baseline leg: per-thread replica + OR merge + lookups; returns the number of keys found"""
+        return int(lib().psk_o_bloom_insert_check_mt(_ptr(self.bloom), self.m, self.k, start, n, seed, nthreads))
+
 
 def splitmix64(x: int) -> int:
     """the stream generator of SURVEY.md 8(d)"""
@@ -326,6 +366,35 @@ class OracleCBF:
         out = np.empty(a.shape[0], dtype=np.uint32)
         lib().psk_o_cbf_check_keys(_ptr(self.bloom), self.m, self.k, _ptr(a), a.shape[0], a.shape[1], _ptr(out))
         return out
+
+    def bits_set(self) -> int:
+        """countingbloom.py:302-304"""
+        return int(lib().psk_o_cbf_nonzero(_ptr(self.bloom), self.m))
+
+    def estimate_elements(self) -> int:
+        """bloom.py:340-352 on the non-zero count"""
+        return int(lib().psk_o_estimate_elements(self.bits_set(), self.m, self.k))
+
+    def _combine(self, other: "OracleCBF", op: int) -> "OracleCBF":
+        res = OracleCBF(self.m, self.k)
+        if lib().psk_o_cbf_combine(_ptr(res.bloom), _ptr(self.bloom), _ptr(other.bloom), self.m, op):
+            raise OverflowError("unsigned int is greater than maximum")  # what array('I') raises in the reference
+        est = res.estimate_elements()
+        res._els.value = est & 0xFFFFFFFFFFFFFFFF
+        res.els_estimate = est  # (may be -1: countingbloom.py:239 / :299 store it as is)
+        return res
+
+    def union(self, other: "OracleCBF") -> "OracleCBF":
+        """countingbloom.py:271-300"""
+        return self._combine(other, 0)
+
+    def intersection(self, other: "OracleCBF") -> "OracleCBF":
+        """countingbloom.py:210-240"""
+        return self._combine(other, 1)
+
+    def jaccard_index(self, other: "OracleCBF") -> float:
+        """countingbloom.py:242-269"""
+        return float(lib().psk_o_cbf_jaccard(_ptr(self.bloom), _ptr(other.bloom), self.m, None))
 
 
 class OracleCMS:
