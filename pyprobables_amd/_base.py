@@ -148,14 +148,18 @@ class DeviceTable:
         return (a.ctypes.data if a.size else 0), (lambda: a)
 
 
-def weights_arg(w, n: int, np_dtype, where: int, keep: list, lo: int, hi: int):
-    """per-key weights -> (address or None, host_sum or None).  Scalars are broadcast on the host."""
+def weights_arg(w, n: int, np_dtype, where: int, keep: list, lo: int, hi: int, device: int | None = None):
+    """per-key weights -> (address or None, host_sum or None).  Scalars are broadcast on the host.
+    ``device``: the sketch's HIP device -- host weights that accompany a device batch are uploaded THERE (not to
+    torch's current device) and device weights must already live there."""
     if w is None:
         return None, n
     if torch is not None and isinstance(w, torch.Tensor):
         if w.is_cuda:
             if where != N.DEVICE:
                 raise ValueError("device weights need a device key batch")
+            if device is not None and w.device.index != device:
+                raise ValueError(f"weights live on cuda:{w.device.index}, the sketch on cuda:{device}")
             want = torch.int32 if np_dtype in (np.int32, np.uint32) else torch.int64
             t = w.to(want).contiguous()
             if t.numel() != n:
@@ -178,7 +182,8 @@ def weights_arg(w, n: int, np_dtype, where: int, keep: list, lo: int, hi: int):
         a = np.ascontiguousarray(src, dtype=np_dtype)
     total = int(a.astype(np.int64).sum()) if a.size else 0
     if where == N.DEVICE:
-        t = torch.from_numpy(a.view(np.int32 if a.dtype.itemsize == 4 else np.int64)).cuda()
+        target = f"cuda:{device}" if device is not None else "cuda"
+        t = torch.from_numpy(a.view(np.int32 if a.dtype.itemsize == 4 else np.int64)).to(target)
         keep.append(t)
         return t.data_ptr(), total
     keep.append(a)

@@ -23,7 +23,7 @@ import numpy as np
 from . import _native as N
 from ._base import DeviceTable
 from .exceptions import InitializationError, SimilarityError
-from .hashes import HashFuncT, HashResultsT, KeyT, default_fnv_1a, device_digest
+from .hashes import HashFuncT, HashResultsT, KeyT, default_fnv_1a, device_digest, is_fused_fnv
 from .keys import KeyBatch, digest_batch, pack_hashes, pack_keys
 
 _LN2_SQUARED = 0.4804530139182   # bloom.py:477 (the literal the reference and its C sibling use)
@@ -103,6 +103,8 @@ class BloomFilter:
         self._num_bits = int(n_bits)
         self._bloom_length = self._table_len(n_bits)
         self._hash_func = default_fnv_1a if hash_func is None else hash_func
+        self._is_fused = is_fused_fnv(hash_func)          # decided once: ours, None, or the reference's own default_fnv_1a
+        self._digest = device_digest(self._hash_func)      # default_md5 / default_sha256 (ours or the reference's)
         self._els_added = 0
         self._tab = DeviceTable(self._KIND, self._num_bits, self._number_hashes, self._dev_arg)
 
@@ -162,7 +164,7 @@ class BloomFilter:
     @property
     def _fused(self) -> bool:
         """True when the kernel computes the hashes itself (default FNV-1a family)"""
-        return self._hash_func is default_fnv_1a
+        return self._is_fused
 
     # ------------------------------------------------------------------ working set (bloom.py:216-272)
     def clear(self) -> None:
@@ -177,9 +179,9 @@ class BloomFilter:
 
     def _flush(self) -> None:
         if self._pending:
-            keys, self._pending = self._pending, []
-            b = self._batch(keys)
+            b = self._batch(self._pending)
             N.check(N.lib().psk_bloom_add(self._tab.handle, *b.args(), b.where, self._tab.stream))
+            self._pending = []  # only once the engine has taken them: a failing flush must not lose counted keys
 
     def hashes(self, key: KeyT, depth: int | None = None) -> HashResultsT:
         """the plugin call site (bloom.py:223-232)"""
@@ -189,8 +191,8 @@ class BloomFilter:
         """keys -> device-ready batch; a custom hash_function is evaluated here, on the host, per key"""
         if self._fused:
             b = pack_keys(keys)
-        elif device_digest(self._hash_func) is not None:  # default_md5 / default_sha256: digest chains on the GPU
-            b = digest_batch(keys, device_digest(self._hash_func), self._number_hashes, self._tab.device, self._tab.stream)
+        elif self._digest is not None:  # default_md5 / default_sha256: digest chains on the GPU
+            b = digest_batch(keys, self._digest, self._number_hashes, self._tab.device, self._tab.stream)
         else:
             if isinstance(keys, (str, bytes, bytearray, memoryview)):
                 keys = [keys]
@@ -260,10 +262,13 @@ class BloomFilter:
 
     def check_many_finish(self):
         """second half: membership of the batch given to :meth:`check_many_begin`, against the table as it is NOW"""
+        if getattr(self, "_split", None) is None:
+            raise RuntimeError("check_many_finish() without a pending check_many_begin()")
         kind, b = self._split
         self._split = None
         if kind == "late":
             return self._check_batch(b)
+        self._flush()  # add() calls made since begin: the answer is against the table as it is NOW
         out = torch_mod().empty(b.n, dtype=_torch_dtype("uint8"), device=f"cuda:{self._tab.device}")
         N.check(N.lib().psk_bloom_check_finish(self._tab.handle, out.data_ptr(), self._tab.stream))
         return out.view(_torch_dtype("bool"))

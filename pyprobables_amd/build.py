@@ -27,6 +27,8 @@ SOURCES = [
 HEADERS = ["psk_device.hpp", "psk_partition.hpp", "psk_host.hpp", "psk_part_counter.hpp", "../../include/psk.h"]
 OUT = CSRC / "libpsk_hip.so"
 OBJ = CSRC / "build"
+OUT_KNOBS = CSRC / "libpsk_hip_knobs.so"
+OBJ_KNOBS = CSRC / "build_knobs"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fvisibility-inlines-hidden"]
 
 
@@ -48,31 +50,35 @@ def needs_build() -> bool:
     return _newest_header() > t or any((CSRC / f).stat().st_mtime > t for f in SOURCES)
 
 
-def _compile(src: str, force: bool, verbose: bool) -> Path:
-    obj = OBJ / (Path(src).stem + ".o")
+def _compile(src: str, force: bool, verbose: bool, objdir: Path, extra: list) -> Path:
+    obj = objdir / (Path(src).stem + ".o")
     dep = max((CSRC / src).stat().st_mtime, _newest_header())
     if force or not obj.exists() or obj.stat().st_mtime < dep:
-        cmd = [hipcc(), *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc(), *FLAGS, *extra, "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=str(CSRC))
     return obj
 
 
-def build(force: bool = False, verbose: bool = True) -> Path:
-    if not force and not needs_build():
-        return OUT
-    OBJ.mkdir(exist_ok=True)
+def build(force: bool = False, verbose: bool = True, knobs: bool = False) -> Path:
+    """knobs=True: the bench-only build with the ablation / phase-profile bits compiled in (-DPSK_BENCH_KNOBS=1) ->
+    csrc/libpsk_hip_knobs.so; never loaded unless PSK_LIB_PATH points at it (scripts/ablate.py, scripts/profile_sq.sh)"""
+    out = OUT_KNOBS if knobs else OUT
+    if not knobs and not force and not needs_build():
+        return out
+    objdir = OBJ_KNOBS if knobs else OBJ
+    extra = ["-DPSK_BENCH_KNOBS=1"] if knobs else []
+    objdir.mkdir(exist_ok=True)
     jobs = min(len(SOURCES), os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=jobs) as pool:
-        objs = list(pool.map(lambda s: _compile(s, force, verbose), SOURCES))
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-no-hip-rt", "-o", str(OUT), *map(str, objs)]
+        objs = list(pool.map(lambda s: _compile(s, force, verbose, objdir, extra), SOURCES))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-no-hip-rt", "-o", str(out), *map(str, objs)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=str(CSRC))
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(OUT)
+    print(build(force="--force" in sys.argv, knobs="--knobs" in sys.argv))

@@ -124,7 +124,7 @@ class CountingBloomFilter(BloomFilter):
 
     def _update_batch(self, fn, b: KeyBatch, num_els) -> None:
         keep: list = []
-        w_addr, _ = weights_arg(num_els, b.n, np.uint32, b.where, keep, 0, _U32_MAX)
+        w_addr, _ = weights_arg(num_els, b.n, np.uint32, b.where, keep, 0, _U32_MAX, self._tab.device)
         N.check(fn(self._tab.handle, *b.args(), w_addr, b.where, self._tab.stream))
         self._dirty = True
 

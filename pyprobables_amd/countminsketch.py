@@ -22,7 +22,7 @@ from . import _native as N
 from ._base import DeviceTable, weights_arg
 from .bloom import _existing_file, _torch_dtype
 from .exceptions import CountMinSketchError, InitializationError
-from .hashes import HashFuncT, HashResultsT, KeyT, default_fnv_1a, device_digest
+from .hashes import HashFuncT, HashResultsT, KeyT, default_fnv_1a, device_digest, is_fused_fnv
 from .keys import KeyBatch, digest_batch, pack_hashes, pack_keys
 
 _I32_MAX, _I32_MIN = 2**31 - 1, -(2**31)
@@ -48,6 +48,8 @@ class CountMinSketch:
         self._query = self._DEFAULT_QUERY
         self._tab: DeviceTable | None = None
         self._hash_function = default_fnv_1a if hash_function is None else hash_function
+        self._is_fused = is_fused_fnv(hash_function)
+        self._digest = device_digest(self._hash_function)
         if filepath is not None and _existing_file(filepath):
             self._parse_bytes(Path(filepath).expanduser().resolve().read_bytes())
             return
@@ -140,7 +142,7 @@ class CountMinSketch:
 
     @property
     def _fused(self) -> bool:
-        return self._hash_function is default_fnv_1a
+        return self._is_fused
 
     # ------------------------------------------------------------------ dunder / io
     def __str__(self) -> str:
@@ -199,8 +201,8 @@ class CountMinSketch:
     def _batch(self, keys) -> KeyBatch:
         if self._fused:
             b = pack_keys(keys)
-        elif device_digest(self._hash_function) is not None:  # default_md5 / default_sha256: digest chains on the GPU
-            b = digest_batch(keys, device_digest(self._hash_function), self._depth, self._tab.device, self._tab.stream)
+        elif self._digest is not None:  # default_md5 / default_sha256: digest chains on the GPU
+            b = digest_batch(keys, self._digest, self._depth, self._tab.device, self._tab.stream)
         else:
             if isinstance(keys, (str, bytes, bytearray, memoryview)):
                 keys = [keys]
@@ -268,7 +270,7 @@ class CountMinSketch:
 
     def _update_batch(self, fn, b: KeyBatch, num_els) -> None:
         keep: list = []
-        w_addr, _ = weights_arg(num_els, b.n, np.int32, b.where, keep, _I32_MIN, _I32_MAX)
+        w_addr, _ = weights_arg(num_els, b.n, np.int32, b.where, keep, _I32_MIN, _I32_MAX, self._tab.device)
         N.check(fn(self._tab.handle, *b.args(), w_addr, b.where, self._tab.stream))
         self._dirty = True
 

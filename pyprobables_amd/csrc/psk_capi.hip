@@ -693,7 +693,6 @@ extern "C" int psk_cbf_update_ordered(psk_sketch *s, int layout, const void *dat
 {
     CHECK_HANDLE(s, PSK_KIND_CBF);
     PSK_TRY(check_hashes_width(s, layout, key_len));
-    if (s->k > (uint32_t)kMaxKOrdered) return fail(PSK_EINVAL, "ordered updates support k <= %d", kMaxKOrdered);
     if (opmode < PSK_OP_ADD || opmode > PSK_OP_SIGNED) return fail(PSK_EINVAL, "bad opmode %d", opmode);
     hipStream_t st = (hipStream_t)stream;
     Batch b;
@@ -702,15 +701,20 @@ extern "C" int psk_cbf_update_ordered(psk_sketch *s, int layout, const void *dat
     PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
     OutBuf o;
     PSK_TRY(stage_out(s->s_out, out, out ? n * 4 : 0, where, &o));
+    uint64_t *wide = nullptr;  // k beyond the register arrays (fpr below ~1e-20): index / value lists live in device scratch
+    if (s->k > (uint32_t)kMaxKOrdered) {
+        PSK_TRY(ensure(s->s_aux, 16ULL * s->k));
+        wide = (uint64_t *)s->s_aux.p;
+    }
     if (n) {
         PSK_TRY(with_source(b, [&](auto src) {
             using Src = decltype(src);
             if (s->pow2)
                 hipLaunchKernelGGL((k_cbf_ordered<Src, true>), dim3(1), dim3(64), 0, st, src, (uint32_t *)s->table, s->md,
-                                   s->k, w, opmode, n, (uint32_t *)(out ? o.dev : nullptr), (unsigned long long *)s->ctr);
+                                   s->k, w, opmode, n, (uint32_t *)(out ? o.dev : nullptr), (unsigned long long *)s->ctr, wide);
             else
                 hipLaunchKernelGGL((k_cbf_ordered<Src, false>), dim3(1), dim3(64), 0, st, src, (uint32_t *)s->table, s->md,
-                                   s->k, w, opmode, n, (uint32_t *)(out ? o.dev : nullptr), (unsigned long long *)s->ctr);
+                                   s->k, w, opmode, n, (uint32_t *)(out ? o.dev : nullptr), (unsigned long long *)s->ctr, wide);
             HIP_TRY(hipGetLastError());
             return (int)PSK_OK;
         }));
@@ -782,7 +786,6 @@ extern "C" int psk_cms_check_meanmin(psk_sketch *s, int layout, const void *data
 {
     CHECK_HANDLE(s, PSK_KIND_CMS);
     PSK_TRY(check_hashes_width(s, layout, key_len));
-    if (s->k > (uint32_t)kMaxDepthMeanMin) return fail(PSK_EINVAL, "mean-min query supports depth <= %d", kMaxDepthMeanMin);
     if (s->m < 2) return fail(PSK_EINVAL, "mean-min query needs width >= 2 (divides by width-1)");
     if (n && !out) return fail(PSK_EINVAL, "out is NULL");
     hipStream_t st = (hipStream_t)stream;
@@ -790,6 +793,24 @@ extern "C" int psk_cms_check_meanmin(psk_sketch *s, int layout, const void *data
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
     OutBuf o;
     PSK_TRY(stage_out(s->s_out, out, n * 8, where, &o));
+    if (s->k > (uint32_t)kMaxDepthMeanMin) {
+        // deeper than the per-lane register array: the ordered kernel in query-only mode (one lane, scratch list)
+        PSK_TRY(ensure(s->s_aux, 8ULL * s->k));
+        if (n) {
+            PSK_TRY(with_source(b, [&](auto src) {
+                using Src = decltype(src);
+                if (s->pow2)
+                    hipLaunchKernelGGL((k_cms_ordered<Src, true>), dim3(1), dim3(64), 0, st, src, (int32_t *)s->table, s->md, s->k,
+                                       (const int64_t *)nullptr, 3, (int)PSK_Q_MEANMIN, elements_added, n, (int64_t *)o.dev, s->ctr, (int64_t *)s->s_aux.p);
+                else
+                    hipLaunchKernelGGL((k_cms_ordered<Src, false>), dim3(1), dim3(64), 0, st, src, (int32_t *)s->table, s->md, s->k,
+                                       (const int64_t *)nullptr, 3, (int)PSK_Q_MEANMIN, elements_added, n, (int64_t *)o.dev, s->ctr, (int64_t *)s->s_aux.p);
+                HIP_TRY(hipGetLastError());
+                return (int)PSK_OK;
+            }));
+        }
+        return finish(where, &o, st);
+    }
     PSK_TRY(with_source(b, [&](auto src) {
         if (s->pow2)
             return launch_apply(src, CmsCheckMeanMin<true>{(const int32_t *)s->table, s->md, s->k, elements_added, (int64_t *)o.dev}, n, st);
@@ -804,7 +825,6 @@ extern "C" int psk_cms_update_ordered(psk_sketch *s, int layout, const void *dat
 {
     CHECK_HANDLE(s, PSK_KIND_CMS);
     PSK_TRY(check_hashes_width(s, layout, key_len));
-    if (s->k > (uint32_t)kMaxDepthMeanMin) return fail(PSK_EINVAL, "ordered updates support depth <= %d", kMaxDepthMeanMin);
     if (opmode < PSK_OP_ADD || opmode > PSK_OP_SIGNED) return fail(PSK_EINVAL, "bad opmode %d", opmode);
     if (query < PSK_Q_MIN || query > PSK_Q_MEANMIN) return fail(PSK_EINVAL, "bad query %d", query);
     if (query == PSK_Q_MEANMIN && s->m < 2) return fail(PSK_EINVAL, "mean-min query needs width >= 2");
@@ -815,14 +835,19 @@ extern "C" int psk_cms_update_ordered(psk_sketch *s, int layout, const void *dat
     PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
     OutBuf o;
     PSK_TRY(stage_out(s->s_out, out, out ? (n + 1) * 8 : 0, where, &o));  // out[n] = elements_added after the batch
+    int64_t *wide = nullptr;  // depth beyond the register array: the per-op value list lives in device scratch
+    if (s->k > (uint32_t)kMaxDepthMeanMin) {
+        PSK_TRY(ensure(s->s_aux, 8ULL * s->k));
+        wide = (int64_t *)s->s_aux.p;
+    }
     PSK_TRY(with_source(b, [&](auto src) {
         using Src = decltype(src);
         if (s->pow2)
             hipLaunchKernelGGL((k_cms_ordered<Src, true>), dim3(1), dim3(64), 0, st, src, (int32_t *)s->table, s->md, s->k, w,
-                               opmode, query, elements_added_in, n, (int64_t *)(out ? o.dev : nullptr), s->ctr);
+                               opmode, query, elements_added_in, n, (int64_t *)(out ? o.dev : nullptr), s->ctr, wide);
         else
             hipLaunchKernelGGL((k_cms_ordered<Src, false>), dim3(1), dim3(64), 0, st, src, (int32_t *)s->table, s->md, s->k, w,
-                               opmode, query, elements_added_in, n, (int64_t *)(out ? o.dev : nullptr), s->ctr);
+                               opmode, query, elements_added_in, n, (int64_t *)(out ? o.dev : nullptr), s->ctr, wide);
         HIP_TRY(hipGetLastError());
         return (int)PSK_OK;
     }));

@@ -564,19 +564,21 @@ __global__ __launch_bounds__(kBlock) void k_cbf_remove(Src src, uint32_t *tab, M
 // ------------------------------------------------- ordered (sequential) execution on the device
 // One lane walks the batch in order and applies the reference semantics literally, including every
 // op's return value: exact for ANY stream (ill-formed removes, saturation, mixed signs).
+// `wide`: device scratch of 2 * k uint64 for k > kMaxKOrdered (the reference has no limit on k), else nullptr
 template <class Src, bool POW2>
 __global__ void k_cbf_ordered(Src src, uint32_t *tab, Mod md, uint32_t k, const int64_t *weights, int opmode,
-                              uint64_t n, uint32_t *out, unsigned long long *ctr)
+                              uint64_t n, uint32_t *out, unsigned long long *ctr, uint64_t *wide)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     unsigned long long added = 0, removed = 0, sat = 0, abs_sum = 0;
+    uint64_t idx_r[kMaxKOrdered], vals_r[kMaxKOrdered];
+    uint64_t *idx = wide ? wide : idx_r, *vals = wide ? wide + k : vals_r;
     for (uint64_t i = 0; i < n; ++i) {
         const typename Src::Key key = src.load(i);
         int64_t w = weights ? weights[i] : 1;
         bool rem = opmode == 1;
         if (opmode == 2 && w < 0) { rem = true; w = -w; }
         abs_sum += (unsigned long long)(w < 0 ? -w : w);
-        uint64_t idx[kMaxKOrdered];
         for (uint32_t s = 0; s < k; ++s) {
             uint64_t h[1];
             src.template hash<1>(key, i, s, h);
@@ -585,7 +587,6 @@ __global__ void k_cbf_ordered(Src src, uint32_t *tab, Mod md, uint32_t k, const 
         uint32_t ret;
         if (!rem) {  // countingbloom.py:135-155
             uint64_t mn = ~0ULL;
-            uint64_t vals[kMaxKOrdered];
             for (uint32_t s = 0; s < k; ++s) vals[s] = (uint64_t)tab[idx[s]] + (uint64_t)w;  // :146 pre-read
             for (uint32_t s = 0; s < k; ++s) {
                 if (vals[s] > 0xFFFFFFFFULL) { tab[idx[s]] = 0xFFFFFFFFu; vals[s] = 0xFFFFFFFFULL; ++sat; }
@@ -617,19 +618,22 @@ __global__ void k_cbf_ordered(Src src, uint32_t *tab, Mod md, uint32_t k, const 
     ctr[4] = (nb < ctr[4] || nb > (1ULL << 62)) ? (1ULL << 62) : nb;
 }
 
+// opmode 3 (internal): query only -- every op adds 0, i.e. returns check()'s value under `query` and changes nothing
+// `wide`: device scratch of `depth` int64 for depth > kMaxDepthMeanMin, else nullptr
 template <class Src, bool POW2>
 __global__ void k_cms_ordered(Src src, int32_t *bins, Mod md, uint32_t depth, const int64_t *weights, int opmode,
-                              int query, int64_t els, uint64_t n, int64_t *out, long long *ctr)
+                              int query, int64_t els, uint64_t n, int64_t *out, long long *ctr, int64_t *wide)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     unsigned long long sat = 0, abs_sum = 0;
+    int64_t vals_r[kMaxDepthMeanMin];
+    int64_t *vals = wide ? wide : vals_r;
     for (uint64_t i = 0; i < n; ++i) {
         const typename Src::Key key = src.load(i);
-        int64_t w = weights ? weights[i] : 1;
+        int64_t w = opmode == 3 ? 0 : (weights ? weights[i] : 1);
         bool rem = opmode == 1;
         if (opmode == 2 && w < 0) { rem = true; w = -w; }
         abs_sum += (unsigned long long)(w < 0 ? -w : w);
-        int64_t vals[kMaxDepthMeanMin];
         for (uint32_t s = 0; s < depth; ++s) {
             uint64_t h[1];
             src.template hash<1>(key, i, s, h);
@@ -662,6 +666,7 @@ __global__ void k_cms_ordered(Src src, int32_t *bins, Mod md, uint32_t depth, co
         } else r = vals[0];
         if (out) out[i] = r;
     }
+    if (opmode == 3) return;
     ctr[5] = els;
     if (out) out[n] = els;  // out is int64[n + 1]: the caller gets elements_added with the results, no second read-back
     ctr[3] += (long long)sat;

@@ -161,7 +161,7 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
     const size_t lds = scatter_lds_bytes<Pay, KT, NT>(g);
     uint64_t per_cu = NT > 512 ? 1 : (lds > 76 * 1024 ? 1 : 2);
-    if (g->dbg & 8) per_cu = 1;  // ablation: one workgroup per CU
+    if (kBenchKnobs && (g->dbg & 8)) per_cu = 1;  // ablation: one workgroup per CU
     uint64_t nwg = 256 * per_cu;
     if (nwg > ntiles) nwg = ntiles;
     const uint64_t tiles_per_wg = (ntiles + nwg - 1) / nwg;
@@ -191,7 +191,7 @@ static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, con
         // keyed probes carry (key index in tile << shift | bit in slice) in 32 bits, 0xFFFFFFFF being the pad: the tile must
         // stay below 2^(32 - shift) keys (1024-thread tiles of k = 3, 4 are 5120 / 4096 keys: too many for 2^20-bit slices)
         const bool ids_fit = Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, 1024>::TILE << g->shift) < (1ULL << 32);
-        if (!(g->dbg & 16) && ids_fit && scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget)
+        if (!(kBenchKnobs && (g->dbg & 16)) && ids_fit && scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget)
             return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st);
     }
     static_assert(Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, kPartThreads>::TILE << 20) < (1ULL << 32),

@@ -26,8 +26,16 @@
 #pragma once
 #include "psk_device.hpp"
 
+// Bench-only ablation / phase-profile knobs (PartGeom::dbg) exist only in a -DPSK_BENCH_KNOBS=1 build
+// (python -m pyprobables_amd.build --knobs -> csrc/libpsk_hip_knobs.so, loaded through PSK_LIB_PATH by scripts/ablate.py);
+// in the shipped library every `dbg & bit` test below is a compile-time false.
+#ifndef PSK_BENCH_KNOBS
+#define PSK_BENCH_KNOBS 0
+#endif
+
 namespace psk {
 
+constexpr bool kBenchKnobs = PSK_BENCH_KNOBS != 0;
 constexpr int kPartThreads = 512;       // 8 wavefronts per workgroup (k > 8); small k uses 16, see PartTile::NT
 constexpr int kPartProbes = 32;        // PartTile::PP = kPartProbes / 2 = 16 probes per thread per tile (<= 128 VGPRs)
 constexpr int kPartMaxBuckets = 2048;
@@ -271,6 +279,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     constexpr int KPT = T::KPT, TILE = T::TILE, GS = T::GS, NT = T::NT;
     constexpr bool PAIR = T::pair;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t dbg = kBenchKnobs ? g.dbg : 0u;  // folds to 0 in the shipped build
     const uint32_t B = g.nbuckets;
     uint32_t *hist0 = smem;  // two copies: tile t counts in one while the scan phase of tile t zeroes the other
     uint32_t *off = hist0 + 2 * B;
@@ -308,14 +317,14 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
 
     // phase profile (dbg & 32): lane 0 of wave 0 accumulates s_memtime deltas per phase; bench-only
     unsigned long long t_prev = 0;  // (the accumulators live in LDS: 12 x 64-bit in registers cost 24 VGPRs on every lane)
-    if ((g.dbg & 32) && threadIdx.x < 12) t_acc[threadIdx.x] = 0;
+    if ((dbg & 32) && threadIdx.x < 12) t_acc[threadIdx.x] = 0;
 #define PSK_TICK(ph)                                                                   \
-    if ((g.dbg & 32) && threadIdx.x == 0) {                                            \
+    if ((dbg & 32) && threadIdx.x == 0) {                                            \
         const unsigned long long t_now = __builtin_readcyclecounter();                 \
         t_acc[ph] += t_now - t_prev;                                                   \
         t_prev = t_now;                                                                \
     }
-    if ((g.dbg & 32) && threadIdx.x == 0) t_prev = __builtin_readcyclecounter();
+    if ((dbg & 32) && threadIdx.x == 0) t_prev = __builtin_readcyclecounter();
 
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t *hist = hist0 + (size_t)(parity ? B : 0);
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
                 if (PAIR) payload[q] = pay(i, base);
                 if constexpr (IdxFn::lo32) {  // 32-bit chains (power-of-two table: the upper hash halves are dead)
                     uint32_t h[KT];
-                    if (g.dbg & 4) {
+                    if (dbg & 4) {
                         for (int j = 0; j < KT; ++j) h[j] = (uint32_t)(((uint64_t)(i * 2654435761u + j * 40503u) * 0x9E3779B97F4A7C15ULL) >> 13);
                     } else if constexpr (KT <= 8 || KT % 4 != 0) {  // exact k: every chain is live
                         src.template hash32<KT>(key, i, 0, h);
@@ -352,13 +361,13 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
                     for (int j = 0; j < KT; ++j) {
                         if ((uint32_t)j < k) {
                             idx[q][j] = idxfn.from32((uint32_t)j, h[j]);
-                            if (g.dbg & 2) { fold ^= idx[q][j]; continue; }  // bench-only: hashing alone
+                            if (dbg & 2) { fold ^= idx[q][j]; continue; }  // bench-only: hashing alone
                             rank[q][j] = atomicAdd(&hist[idx[q][j] >> g.shift], 1u);  // ds_add_rtn_u32
                         }
                     }
                 } else {
                     uint64_t h[KT];
-                    if (g.dbg & 4) {
+                    if (dbg & 4) {
                         for (int j = 0; j < KT; ++j) h[j] = ((uint64_t)(i * 2654435761u + j * 40503u) * 0x9E3779B97F4A7C15ULL) >> 13;
                     } else if constexpr (KT <= 8 || KT % 4 != 0) {  // exact k: every chain is live
                         src.template hash<KT>(key, i, 0, h);
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
                 }
             }
         }
-        if (g.dbg & 2) {  // bench-only: keep the hashes alive, skip the rest of the tile (uniform)
+        if (dbg & 2) {  // bench-only: keep the hashes alive, skip the rest of the tile (uniform)
             if (fold == 0x12345u) segcnt[0] = fold;
             if (kPartPipeline) {
                 const uint64_t nbase = (tile + gridDim.x) * TILE;
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
 #pragma unroll
         for (int q = 0; q < KPT; ++q)
             if (kPartPipeline) Src::pin(kcur[q]);  // next tile's keys have landed: nothing to wait for later
-        if (!(g.dbg & 1)) {
+        if (!(dbg & 1)) {
             const uint32_t ngroups = tile_probes / GS;
             for (uint32_t gi = threadIdx.x; gi < ngroups; gi += NT) {
                 emit_group<Pay, Spill>(stage, gb, delta, g, mask, gi, tile, base, spill, buckets);
@@ -506,7 +515,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         PSK_TICK(5);
     }
     lds_barrier();
-    if ((g.dbg & 32) && threadIdx.x == 0) {  // counts land behind the segment counts (host reserves the room)
+    if ((dbg & 32) && threadIdx.x == 0) {  // counts land behind the segment counts (host reserves the room)
         unsigned long long *prof = reinterpret_cast<unsigned long long *>(segcnt + (size_t)g.nbuckets * g.nwg);
         for (int ph = 1; ph < 12; ++ph) atomicAdd(prof + ph, t_acc[ph]);
         atomicAdd(prof, 1ULL);
@@ -785,7 +794,8 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint3
     const uint32_t slice_words = 1u << (g.shift - 5);
     const uint32_t mask = (1u << g.shift) - 1;
     const uint64_t w0 = (uint64_t)b * slice_words;
-    for (uint32_t w = threadIdx.x * 4; w < slice_words && !(g.dbg & 128); w += kApplyThreads * 4) {
+    const uint32_t dbg = kBenchKnobs ? g.dbg : 0u;
+    for (uint32_t w = threadIdx.x * 4; w < slice_words && !(dbg & 128); w += kApplyThreads * 4) {
         const uint64_t gw = w0 + w;
         uint4 t = make_uint4(0, 0, 0, 0);
         if (gw + 3 < tab_words) t = *reinterpret_cast<const uint4 *>(tab + gw);
@@ -799,7 +809,7 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint3
     __syncthreads();
     for_each_group_padded(buckets, segcnt, g, b, make_uint4(kPadProbe, kPadProbe, kPadProbe, kPadProbe),
       [&](const uint4 q) {  // a pad probe reads a harmless in-slice word
-        if (g.dbg & 64) return make_uint4(0, ~0u, ~0u, ~0u);
+        if (dbg & 64) return make_uint4(0, ~0u, ~0u, ~0u);
         return make_uint4(0, smem[(q.y & mask) >> 5], smem[(q.z & mask) >> 5], smem[(q.w & mask) >> 5]);
       },
       [&](const uint4 q, const uint4 w) {  // the rare miss stores

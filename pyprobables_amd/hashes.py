@@ -98,11 +98,37 @@ def default_sha256(key: KeyT, *args, **kwargs) -> bytes:
     return hashlib.sha256(key).digest()
 
 
+_PROBE_KEY, _PROBE_DEPTH = "this is a test \u20ac", 3  # a code point > 255: FNV walks code points, the digests UTF-8 bytes
+
+
+def _same_family(hash_function, ours) -> bool:
+    """``hash_function`` is ``ours``, or the reference's own function of the same name (``probables.hashes.<name>``,
+    what a user who switches to this package passes in: bloom.py:496-499 installs exactly that object by default).
+    The foreign function is accepted by NAME and then probed, like the reference compares two filters' hash families
+    through ``hashes("test")`` (bloom.py:563-568): a look-alike that disagrees stays on the per-key host route."""
+    if hash_function is ours:
+        return True
+    mod = getattr(hash_function, "__module__", None)
+    name = getattr(hash_function, "__qualname__", getattr(hash_function, "__name__", None))
+    if mod != "probables.hashes" or name != ours.__name__:
+        return False
+    try:
+        return list(hash_function(_PROBE_KEY, _PROBE_DEPTH)) == ours(_PROBE_KEY, _PROBE_DEPTH)
+    except Exception:
+        return False
+
+
+def is_fused_fnv(hash_function) -> bool:
+    """True when the kernels may compute the hashes themselves: the default FNV-1a family, ours or the reference's"""
+    return hash_function is None or _same_family(hash_function, default_fnv_1a)
+
+
 def device_digest(hash_function):
-    """the engine's digest id (include/psk.h ``psk_digest``) when ``hash_function`` is one of the reference's built-in
-    digest families, else None: those run as HIP kernels instead of per key on the host"""
-    if hash_function is default_md5:
+    """the engine's digest id (include/psk.h ``psk_digest``) when ``hash_function`` is one of the built-in digest
+    families (ours or the reference's ``probables.hashes.default_md5`` / ``default_sha256``), else None: those run as
+    HIP kernels instead of per key on the host"""
+    if _same_family(hash_function, default_md5):
         return 0
-    if hash_function is default_sha256:
+    if _same_family(hash_function, default_sha256):
         return 1
     return None

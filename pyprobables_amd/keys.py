@@ -65,8 +65,8 @@ def _pack_homogeneous(keys: list, n: int):
             joined = b"".join(keys)
         except TypeError:
             return None
-        if not all(isinstance(k, (bytes, bytearray, memoryview)) for k in (keys[0], keys[-1])):
-            return None
+        if not set(map(type, keys)) <= {bytes, bytearray, memoryview}:  # b"".join takes ANY buffer (numpy arrays, array('B')):
+            return None                                                 # those are not keys -- the per-key path raises
     lens = np.fromiter(map(len, keys), dtype=np.int64, count=n)
     if wide_ok:
         try:

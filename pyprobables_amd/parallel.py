@@ -44,6 +44,30 @@ def hip_or_reduce(dst, src, nslices: int, slice_words: int) -> None:
     N.check(N.lib().psk_or_reduce_slices(dst.data_ptr(), src.data_ptr(), nslices, slice_words, dst.device.index, stream))
 
 
+_merge_bufs: dict = {}
+
+
+def _merge_buffers(table, world: int, slice_words: int):
+    """(work | None, recv, mine) for one (table, world): allocated once, reused by every merge of that table -- the
+    collective sits inside timed loops and two table-sized allocations per call are not free"""
+    key = (table.data_ptr(), table.numel(), world, str(table.device))
+    bufs = _merge_bufs.get(key)
+    if bufs is None:
+        padded = slice_words * world
+        work = None if padded == table.numel() else torch.zeros(padded, dtype=table.dtype, device=table.device)
+        recv = torch.empty(padded, dtype=table.dtype, device=table.device)
+        mine = torch.empty(slice_words, dtype=table.dtype, device=table.device)
+        if len(_merge_bufs) >= 8:  # tables come and go (tests): keep the cache small
+            _merge_bufs.pop(next(iter(_merge_bufs)))
+        bufs = _merge_bufs[key] = (work, recv, mine)
+    return bufs
+
+
+def release_merge_buffers() -> None:
+    """drop the cached exchange buffers (one table-sized buffer per merged table)"""
+    _merge_bufs.clear()
+
+
 def allreduce_or_(table, group=None, or_reduce=hip_or_reduce):
     """in-place bitwise-OR all-reduce of a 1-D int32 tensor (all_to_all -> OR kernel -> all_gather)"""
     world = dist.get_world_size(group)
@@ -52,17 +76,15 @@ def allreduce_or_(table, group=None, or_reduce=hip_or_reduce):
     n = table.numel()
     slice_words = -(-n // world)
     slice_words = (slice_words + 3) & ~3  # 16-byte slices for the uint4 kernel
-    padded = slice_words * world
-    work = table
-    if padded != n:
-        work = torch.zeros(padded, dtype=table.dtype, device=table.device)
+    work, recv, mine = _merge_buffers(table, world, slice_words)
+    src = table
+    if work is not None:  # n is not a multiple of 4 * world words: exchange a zero-padded copy
         work[:n].copy_(table)
-    recv = torch.empty_like(work)
-    dist.all_to_all_single(recv, work, group=group)            # slice j of every rank lands on rank j
-    mine = torch.empty(slice_words, dtype=table.dtype, device=table.device)
+        src = work
+    dist.all_to_all_single(recv, src, group=group)             # slice j of every rank lands on rank j
     or_reduce(mine, recv, world, slice_words)                  # OR of the R partial slices
-    dist.all_gather_into_tensor(work, mine, group=group)       # every rank gets the full merged table
-    if padded != n:
+    dist.all_gather_into_tensor(src, mine, group=group)        # every rank gets the full merged table
+    if work is not None:
         table.copy_(work[:n])
     return table
 
@@ -71,6 +93,14 @@ def _sum_int(value: int, device, group=None) -> int:
     t = torch.tensor([value], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return int(t.item())
+
+
+def _sum_wide(value: int, device, group=None) -> int:
+    """exact SUM of python ints that may sit near the 64-bit rails: (high, low) 32-bit limbs, summed separately"""
+    t = torch.tensor([value >> 32, value & 0xFFFFFFFF], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    hi, lo = (int(x) for x in t.tolist())
+    return (hi << 32) + lo
 
 
 def merge_bloom(blm, group=None, or_reduce=hip_or_reduce, sync_elements: bool = True) -> None:
@@ -84,15 +114,53 @@ def merge_bloom(blm, group=None, or_reduce=hip_or_reduce, sync_elements: bool = 
         blm.elements_added = _sum_int(blm.elements_added, blm.table_tensor.device, group)
 
 
-def merge_counters(sk, group=None) -> None:
-    """CountMinSketch / CountingBloomFilter: SUM all-reduce of the counter table + elements_added"""
+_I32_MAX, _I32_MIN, _U32_MAX = 2**31 - 1, -(2**31), 2**32 - 1
+_I64_MAX, _I64_MIN, _U64_MAX = 2**63 - 1, -(2**63), 2**64 - 1
+
+
+def _abs_bound(sk, t, unsigned: bool) -> int:
+    """upper bound on |any counter| of this rank's replica: the engine's device-resident PSK_CTR_ABS_BOUND when the
+    sketch has a handle, else (CPU tensors in the gloo tests) the exact maximum"""
+    tab = getattr(sk, "_tab", None)
+    if tab is not None and getattr(tab, "handle", None):
+        return int(tab.counters()[N.CTR_ABS_BOUND])
+    if t.numel() == 0:
+        return 0
+    w = t.to(torch.int64)
+    return int(((w & 0xFFFFFFFF) if unsigned else w.abs()).max().item())
+
+
+def merge_counters(sk, group=None, unsigned: bool | None = None) -> None:
+    """CountMinSketch / CountingBloomFilter: SUM all-reduce of the counter table + elements_added.
+
+    A 32-bit ``all_reduce(SUM)`` wraps silently, so the ranks first agree on the SUM of their per-replica bounds on
+    |counter|.  Below the rail the plain 32-bit reduction is exact.  Otherwise the tables are widened to int64, summed,
+    and clamped to the rails the way ``join`` does (countminsketch.py:380-391: INT32_MAX / INT32_MIN; the CBF add
+    clamps at 2^32-1, countingbloom.py:149-151) -- for add-only streams exactly the table ONE sketch fed every rank's
+    updates would hold, since its saturating adds stop at the same rail."""
+    if unsigned is None:
+        unsigned = getattr(type(sk), "_KIND", "") == "cbf"
     els = sk.elements_added  # folds the device-side tallies
     t = sk.table_tensor
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    bound_sum = _sum_int(min(_abs_bound(sk, t, unsigned), 1 << 40), t.device, group)
+    if bound_sum <= (_U32_MAX if unsigned else _I32_MAX):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)   # wrap-free: no global counter can reach a rail
+    else:
+        wide = t.to(torch.int64)
+        if unsigned:
+            wide &= 0xFFFFFFFF                                   # the int32 tensor holds uint32 bit patterns
+        dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=group)
+        if unsigned:
+            wide.clamp_(max=_U32_MAX)
+            wide[wide > _I32_MAX] -= 1 << 32                     # back to the int32 bit pattern
+        else:
+            wide.clamp_(min=_I32_MIN, max=_I32_MAX)
+        t.copy_(wide.to(torch.int32))
     if t.is_cuda:
         N.check(N.lib().psk_rescan_bound(sk._tab.handle, sk._tab.stream))
-    total = _sum_int(els, t.device, group)
-    sk._els_added = total
+    # elements_added: SUM over ranks, then the reference's scalar clamp (countminsketch.py:285-287 / countingbloom.py:154)
+    total = _sum_wide(els, t.device, group)
+    sk._els_added = max(min(total, _U64_MAX if unsigned else _I64_MAX), 0 if unsigned else _I64_MIN)
 
 
 class MergeHandle:

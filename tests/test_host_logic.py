@@ -178,3 +178,45 @@ def test_vectorised_key_packing_equals_the_per_key_path(monkeypatch):
         K.pack_keys(["a", 3])
     mixed = K.pack_keys(["ab", b"cd"])   # mixed str / bytes still works (careful path)
     assert mixed.n == 2
+
+
+def _foreign(name, impl):
+    """a function that looks like the reference's own `probables.hashes.<name>` (module + qualified name)"""
+    def fn(key, depth=1):
+        return impl(key, depth)
+    fn.__module__, fn.__name__, fn.__qualname__ = "probables.hashes", name, name
+    return fn
+
+
+def test_reference_hash_functions_are_recognised_as_the_fused_families():
+    """the literal drop-in scenario: a user passes the REFERENCE's default_fnv_1a (bloom.py:496-499 installs that object
+    by default); it must take the fused kernels, not the per-key host route.  Accepted by name, then probed."""
+    assert H.is_fused_fnv(None) and H.is_fused_fnv(H.default_fnv_1a)
+    assert H.is_fused_fnv(_foreign("default_fnv_1a", H.default_fnv_1a))
+    assert H.device_digest(_foreign("default_md5", H.default_md5)) == 0
+    assert H.device_digest(_foreign("default_sha256", H.default_sha256)) == 1
+    # a look-alike that hashes differently stays a plugin (host route), whatever it is called
+    assert not H.is_fused_fnv(_foreign("default_fnv_1a", lambda k, d: [1] * d))
+    assert not H.is_fused_fnv(_foreign("default_fnv_1a", H.default_md5))
+    # same results but an unrelated function object (a user wrapper) is NOT taken over: only identity or the reference's name
+    assert not H.is_fused_fnv(lambda k, d: H.default_fnv_1a(k, d))
+    assert H.device_digest(H.default_fnv_1a) is None and H.device_digest(_foreign("default_fnv_1a", H.default_fnv_1a)) is None
+    # a function that raises on the probe is simply a plugin
+    def boom(key, depth=1):
+        raise RuntimeError("no")
+    boom.__module__, boom.__qualname__, boom.__name__ = "probables.hashes", "default_fnv_1a", "default_fnv_1a"
+    assert not H.is_fused_fnv(boom)
+
+
+def test_homogeneous_packing_rejects_non_key_elements():
+    """every element of a bytes list is type-checked (b''.join accepts any buffer: a numpy array in the middle used to be
+    hashed as its raw bytes, while the per-key path and add() raise TypeError for it)"""
+    good = [b"abc", b"defg", b"hi"]
+    assert pack_keys(good).n == 3
+    bad = [b"abc", np.arange(4, dtype=np.uint8), b"hi"]
+    with pytest.raises(TypeError):
+        pack_keys(bad)
+    import array as _array
+    with pytest.raises(TypeError):
+        pack_keys([b"abc", _array.array("B", [1, 2, 3]), b"hi"])
+    assert pack_keys([b"abc", bytearray(b"xy"), memoryview(b"z")]).n == 3

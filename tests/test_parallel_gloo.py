@@ -120,3 +120,43 @@ def test_hip_or_reduce_refuses_cpu_tensors():
 
     with pytest.raises(RuntimeError):
         hip_or_reduce(torch.zeros(4, dtype=torch.int32), torch.zeros(8, dtype=torch.int32), 2, 4)
+
+
+def _wrap_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pyprobables_amd import parallel
+
+    # CMS (int32, both rails): bin 0 would wrap past INT32_MAX, bin 1 past INT32_MIN, bin 2 stays exact, bin 3 mixed signs
+    per_rank = [[2**31 - 10, -(2**31) + 5, 1000, 2**31 - 1], [100, -50, 2345, -(2**31)]]
+    cms = _FakeSketch(torch.tensor(per_rank[rank], dtype=torch.int32), 2**62 + 7)
+    parallel.merge_counters(cms, unsigned=False)
+    # CBF (uint32 bit patterns in an int32 tensor): cell 0 would wrap past 2^32-1, cell 1 is exact above 2^31
+    u = np.array([[3_000_000_000, 2_000_000_000, 7], [2_000_000_000, 2_000_000_000, 8]][rank], dtype=np.uint32)
+    cbf = _FakeSketch(torch.from_numpy(u.view(np.int32).copy()), 2**63 + 11)
+    parallel.merge_counters(cbf, unsigned=True)
+    # small tables keep the plain 32-bit path (bound sum below the rail)
+    small = _FakeSketch(torch.tensor([5, -7, 2**29 - 1], dtype=torch.int32), 3)
+    parallel.merge_counters(small, unsigned=False)
+    np.save(Path(out_dir) / f"wrap_cms_{rank}.npy", cms.table_tensor.numpy())
+    np.save(Path(out_dir) / f"wrap_cbf_{rank}.npy", cbf.table_tensor.numpy().view(np.uint32))
+    np.save(Path(out_dir) / f"wrap_small_{rank}.npy", small.table_tensor.numpy())
+    (Path(out_dir) / f"wrap_els_{rank}.txt").write_text(f"{cms.elements_added} {cbf.elements_added} {small.elements_added}")
+    dist.destroy_process_group()
+
+
+def test_counter_merge_that_would_wrap_is_clamped_like_join(tmp_path):
+    """a 32-bit all_reduce(SUM) wraps silently; the merge agrees on the summed bounds first and, above the rail, sums in
+    64 bits and clamps exactly like countminsketch.py:380-391 (join) / countingbloom.py:149-151"""
+    port = _free_port()
+    mp.spawn(_wrap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert np.load(tmp_path / f"wrap_cms_{r}.npy").tolist() == [2**31 - 1, -(2**31), 3345, -1]
+        assert np.load(tmp_path / f"wrap_cbf_{r}.npy").tolist() == [2**32 - 1, 4_000_000_000, 15]
+        assert np.load(tmp_path / f"wrap_small_{r}.npy").tolist() == [10, -14, 2**30 - 2]
+        e_cms, e_cbf, e_small = map(int, (tmp_path / f"wrap_els_{r}.txt").read_text().split())
+        assert e_cms == 2**63 - 1          # 2 x (2^62 + 7) clamps at the int64 rail (countminsketch.py:285-287)
+        assert e_cbf == 2**64 - 1          # 2 x (2^63 + 11) clamps at the uint64 rail (countingbloom.py:154)
+        assert e_small == 6
