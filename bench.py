@@ -1,23 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the sketch engine on MI355X.
+"""bench.py -- benchmarks of the sketch engine on MI355X (one JSON line on stdout, printed by rank 0).
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfg5]
 
-Workload (BASELINE.json configs[1]): BloomFilter(est_elements=28005615, fpr=0.01) -> m = 2^28 bits, k = 7,
-default_fnv_1a; one STEP = clear the filter, batch-insert 10M synthetic 16-byte keys, (N > 1: merge the
-per-GPU replicas with allreduce(OR) over RCCL), batch-check the same 10M keys.  Keys are generated on the
-device (counter-based splitmix64) before the timed region, i.e. inputs are resident in HBM.
-`value` = all ranks' key operations (insert + lookup) per second, in million keys/s.  Weak scaling: every
-rank owns 10M keys of the stream.
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its own ranks (one process per GPU,
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...``); launched under
+torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.
 
-The JSON line also carries
-  roofline     -- the dominant kernel (Bloom insert): algorithmic bytes (72 B/key = 16 B key + 7 x (4 B read +
-                  4 B write)) / average kernel time from HIP events on the launch stream, vs 8 TB/s HBM peak.
-  cpu_baseline -- the plain-C oracle (oracle/, a port of the reference semantics) timed on this box's host
-                  cores on a bounded sample of the same workload (rank 0, N = 1 only).
-  detail       -- per-phase rates, CMS (2^20 x 5) and CBF rates, and the measured random-access ceilings
-                  (GUPS-style atomics / gathers into a table of the same size).
+Configurations (BASELINE.json `configs`); inputs are generated on the device (counter-based splitmix64
+stream) BEFORE the timed region, i.e. they are resident in HBM when the clock starts:
+
+  cfg2 (default, the headline)  BloomFilter(28005615, 0.01) -> m = 2^28 bits, k = 7.  One STEP per rank = clear the filter,
+        batch-insert 10M 16-byte keys, (N > 1: allreduce(OR) over RCCL), batch-check the same 10M keys.
+        `value` = all ranks' key operations (insert + lookup) per second.  Weak scaling: every rank owns 10M keys.
+  cfg3  CountMinSketch(width=2^20, depth=5).  STEP = clear + 100M weighted updates as 10 passes over 10M keys
+        (+ SUM merge for N > 1).  `value` = updates per second.
+  cfg4  CountingBloomFilter(28005615, 0.01) -> 2^28 x uint32 = 1 GiB.  STEP = clear + the 50-batch mixed stream: batch b
+        adds the 1M keys [bB, (b+1)B) and (b >= 1) removes the first B/2 keys of batch b-1 -- 74.5M operations in
+        1M-key batches.  `value` = operations per second.
+  cfg5  BloomFilter(224044920, 0.01) -> m = 2^31 bits (256 MiB per replica).  N_total keys (default 10^9) are split by
+        key range over the ranks; STEP = clear + insert the shard + allreduce(OR) + check the shard.  Strong scaling.
+
+Every line carries
+  roofline      the dominant kernel of the configuration (cfg2: the Bloom insert launch = k_part_scatter + k_bloom_apply):
+                ALGORITHMIC bytes (72 B per inserted key, 45 per Bloom lookup, 60 per CMS update, ...) divided
+                by the launch time measured with HIP events on the launch stream, against the 8 TB/s HBM peak.
+  rooflines     the same object for the other operations of the metric (Bloom check, CMS add, CMS / CBF lookups ...).
+  cpu_baseline  the plain-C oracle (a port of the reference semantics) on this box's host cores: 1 thread, all cores
+                (per-thread replica + OR merge), and a pure-Python mirror of the reference's per-key loop on a 100k-key
+                sample (N = 1, rank 0, bounded to ~20 s of host work).
 """
 
 from __future__ import annotations
@@ -25,6 +36,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -32,49 +45,128 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SEED = 0x5EED
-BYTES = {"bloom_insert": 72, "bloom_check": 45, "cms_add": 60, "cms_check": 40, "cbf_add": 76, "cbf_check": 48}
+# algorithmic bytes per unit of work (L = 16-byte key, k = 7, d = 5)
+BYTES = {"bloom_insert": 72, "bloom_check": 45, "cms_add": 60, "cms_check": 40, "cbf_add": 76, "cbf_remove": 76, "cbf_check": 48}
+DEFAULT_STEPS = {"cfg2": (200, 20), "cfg3": (20, 3), "cfg4": (10, 2), "cfg5": (5, 1)}
+PMC_FILE = ROOT / "profiles" / "r02_pmc_traffic.json"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", "--keys-per-rank", dest="n", type=int, default=10_000_000, help="keys per rank per step")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(DEFAULT_STEPS), default="cfg2")
+    ap.add_argument("--n", "--keys-per-rank", dest="n", type=int, default=10_000_000, help="cfg2/cfg3: keys per rank per step")
+    ap.add_argument("--n-total", type=int, default=1_000_000_000, help="cfg5: keys in the whole stream (all ranks)")
+    ap.add_argument("--batch", type=int, default=1_000_000, help="cfg4: keys per batch")
+    ap.add_argument("--batches", type=int, default=50, help="cfg4: batches per step")
+    ap.add_argument("--spinup", type=float, default=1.0, help="seconds of untimed steps before warm-up (clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-detail", action="store_true", help="skip the CMS / CBF / GUPS side measurements")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: merge, then look up (no lookup pass 1 under the merge)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    ds, dw = DEFAULT_STEPS[args.config]
+    args.steps = ds if args.steps is None else args.steps
+    args.warmup = dw if args.warmup is None else args.warmup
+    return args
 
 
-def gen_keys(n, start, device):
-    from pyprobables_amd import _native as N
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start the N ranks ourselves"""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    sys.exit(subprocess.call(cmd, env=env))
 
-    t = torch.empty((n, 16), dtype=torch.uint8, device=f"cuda:{device}")
-    N.check(N.lib().psk_gen_keys16(t.data_ptr(), start, n, SEED, device, torch.cuda.current_stream(device).cuda_stream or None))
-    return t
 
+# ----------------------------------------------------------------------------------------------- plumbing
+class Ctx:
+    """rank / device / process group of this process"""
 
-def gen_weights(n, start, device):
-    from pyprobables_amd import _native as N
+    def __init__(self, args):
+        import torch
 
-    t = torch.empty(n, dtype=torch.int32, device=f"cuda:{device}")
-    N.check(N.lib().psk_gen_weights(t.data_ptr(), start, n, SEED, device, torch.cuda.current_stream(device).cuda_stream or None))
-    return t
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", 0))
+        self.world = int(os.environ.get("WORLD_SIZE", 1))
+        local_rank = int(os.environ.get("LOCAL_RANK", 0))
+        if self.rank != 0:  # only rank 0 reports; keep library banners of the other ranks off the job's stdout
+            os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+        if args.gpus != self.world and self.world > 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        # PSK_BENCH_SINGLE_DEVICE=1 (test hook): every rank uses cuda:0 and the gloo backend, so that the N > 1 logic (shard
+        # offsets, real replicas, merge, overlap) can be driven on a one-GPU box; RCCL refuses two ranks on one device
+        self.single_device = bool(os.environ.get("PSK_BENCH_SINGLE_DEVICE"))
+        if self.single_device:
+            local_rank = 0
+        self.dev = local_rank
+        torch.cuda.set_device(local_rank)
+        self.dist = None
+        # PSK_BENCH_FORCE_DIST=1 drives the whole N > 1 code path (RCCL init, merge, barriers) with a single rank
+        self.distributed = self.world > 1 or bool(os.environ.get("PSK_BENCH_FORCE_DIST"))
+        if self.distributed:
+            import torch.distributed as dist
+
+            if self.world == 1:
+                os.environ.setdefault("MASTER_PORT", "29533")
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
+                os.environ["PSK_FORCE_MERGE_PATH"] = "1"
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.single_device:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            self.dist = dist
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds: float) -> float:
+        if self.dist is None:
+            return seconds
+        te = self.torch.tensor([seconds], dtype=self.torch.float64, device=f"cuda:{self.dev}")
+        self.dist.all_reduce(te, op=self.dist.ReduceOp.MAX)
+        return float(te.item())
+
+    def stream(self):
+        return self.torch.cuda.current_stream(self.dev).cuda_stream or None
+
+    def gen_keys(self, n, start):
+        from pyprobables_amd import _native as N
+
+        t = self.torch.empty((n, 16), dtype=self.torch.uint8, device=f"cuda:{self.dev}")
+        N.check(N.lib().psk_gen_keys16(t.data_ptr(), start, n, SEED, self.dev, self.stream()))
+        return t
+
+    def gen_weights(self, n, start):
+        from pyprobables_amd import _native as N
+
+        t = self.torch.empty(n, dtype=self.torch.int32, device=f"cuda:{self.dev}")
+        N.check(N.lib().psk_gen_weights(t.data_ptr(), start, n, SEED, self.dev, self.stream()))
+        return t
 
 
 class EventTimer:
     """HIP events on torch's current stream == the stream the engine launches on"""
 
-    def __init__(self):
-        self.pairs = {}
+    def __init__(self, torch):
+        self.torch, self.pairs = torch, {}
 
     def time(self, name, fn):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a, b = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
         a.record()
         r = fn()
         b.record()
@@ -86,7 +178,7 @@ class EventTimer:
         return sum(a.elapsed_time(b) for a, b in p) / len(p) if p else float("nan")
 
 
-def timed_loop(fn, iters, warm=2):
+def timed_loop(torch, fn, iters, warm=2):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -99,49 +191,42 @@ def timed_loop(fn, iters, warm=2):
     return a.elapsed_time(b) / iters
 
 
-def side_measurements(device, n):
-    """CMS / CBF rates and the GUPS-style random-access ceilings (not part of `value`)"""
-    import pyprobables_amd as pa
-    from pyprobables_amd import _native as N
-
-    out = {}
-    keys = gen_keys(n, 0, device)
-    w = gen_weights(n, 0, device)
-    cms = pa.CountMinSketch(width=2**20, depth=5, device=device)
-    ms = timed_loop(lambda: cms.add_many(keys, w), 5)
-    out["cms_add_Mupd_s"] = n / ms / 1e3
-    out["cms_add_GBs"] = n * BYTES["cms_add"] / ms / 1e6
-    ms = timed_loop(lambda: cms.check_many(keys), 5)
-    out["cms_check_Mkeys_s"] = n / ms / 1e3
-    del cms
-    ncbf = min(n, 10_000_000)
-    cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, device=device)  # 2^28 x u32 = 1 GiB
-    ms = timed_loop(lambda: cbf.add_many(keys[:ncbf]), 3, warm=1)
-    out["cbf_add_Mops_s"] = ncbf / ms / 1e3
-    ms = timed_loop(lambda: cbf.remove_many(keys[:ncbf]), 1, warm=0)
-    out["cbf_remove_Mops_s"] = ncbf / ms / 1e3
-    ms = timed_loop(lambda: cbf.check_many(keys[:ncbf]), 3, warm=1)
-    out["cbf_check_Mkeys_s"] = ncbf / ms / 1e3
-    del cbf
-    # random-access ceilings at the headline table size (2^23 words = 32 MiB) and at 1 GiB
-    st = lambda: torch.cuda.current_stream(device).cuda_stream or None  # noqa: E731
-    sink = torch.zeros(1, dtype=torch.int64, device=f"cuda:{device}")
-    nprobe = 7 * n
-    for label, words in (("32MiB", 2**23), ("1GiB", 2**28)):
-        tab = torch.zeros(words, dtype=torch.int32, device=f"cuda:{device}")
-        for op, name in ((0, "atomic_or"), (1, "atomic_add"), (2, "gather")):
-            ms = timed_loop(lambda: N.check(N.lib().psk_gups(tab.data_ptr(), words, nprobe, op, 12345, sink.data_ptr(), device, st())), 3, warm=1)
-            out[f"gups_{name}_{label}_Gprobes_s"] = nprobe / ms / 1e6
-        del tab
-    return out
+def pmc_traffic(op: str, n: int):
+    """HBM-side bytes per launch of `op` from the committed PMC profile of the same workload and kernels
+    (scripts/profile.sh -> profiles/r02_pmc_traffic.json); None when there is no matching record"""
+    try:
+        pmc = json.loads(PMC_FILE.read_text())
+        if pmc["keys"] == n and op in pmc:
+            return pmc[op]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
-def cpu_baseline(n_sample, reps=6):
-    """the plain-C oracle (kind 'port') on this box's host cores, single thread"""
+def roofline(op: str, kernel: str, units: int, ms: float, limiter: str, traffic_op: str | None = None):
+    """roofline object of one launch: `units` units of work of BYTES[op] algorithmic bytes each in `ms` milliseconds"""
+    ach = units * BYTES[op] / (ms * 1e-3) / 1e9 if ms == ms and ms > 0 else None
+    traffic = pmc_traffic(traffic_op or op, units)
+    return {
+        "bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": None if ach is None else ach / HBM_PEAK_GBS, "traffic": traffic,
+        "traffic_source": f"{PMC_FILE.relative_to(ROOT)} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; bytes per launch)" if traffic else None,
+        "algorithmic_bytes_per_launch": units * BYTES[op], "algorithmic_bytes_per_unit": BYTES[op], "avg_kernel_ms": ms,
+        "limiter": limiter,
+    }
+
+
+# ----------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(n_sample: int, reps: int = 3):
+    """(i) a pure-Python mirror of the reference's per-key loop on a 100k-key sample, (ii) the plain-C
+    oracle (kind 'port') on one core and on all host cores (per-thread replica + OR merge).  ~20 s of host work."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle
+    import pymirror
 
-    ob = oracle.OracleBloom(2**28, 7)
+    m, k = 2**28, 7
+    # -- C port, one thread: `value`
+    ob = oracle.OracleBloom(m, k)
     t_total, ops = 0.0, 0
     for r in range(reps):
         keys = oracle.gen_keys16(r * n_sample, n_sample)
@@ -151,186 +236,439 @@ def cpu_baseline(n_sample, reps=6):
         t_total += time.perf_counter() - t0
         ops += 2 * n_sample
         assert bool(res.all())
-    return {
-        "value": ops / t_total / 1e6,
-        "unit": "Mkeys/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"{reps} x (insert {n_sample} + check {n_sample}) 16-byte keys into m=2^28 k=7, oracle/psk_oracle.c (gcc -O2)",
-        "seconds": t_total,
-    }
+    one = {"value": ops / t_total / 1e6, "unit": "Mkeys/s", "cores": 1, "kind": "port", "seconds": t_total,
+           "sample": f"{reps} x (insert {n_sample} + check {n_sample}) 16-byte keys into m=2^28 k=7, oracle/psk_oracle.c (gcc -O2), 1 thread"}
+    # -- C port, all cores
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_mt = n_sample * 4
+    obm = oracle.OracleBloom(m, k)
+    t0 = time.perf_counter()
+    found = obm.insert_check_mt(0, n_mt, cores)
+    t_mt = time.perf_counter() - t0
+    allc = {"value": 2 * n_mt / t_mt / 1e6, "unit": "Mkeys/s", "cores": cores, "kind": "port", "seconds": t_mt, "all_found": found == n_mt,
+            "sample": f"insert {n_mt} + check {n_mt} keys, {cores} threads: per-thread 32 MiB replica, OR merge, lookups (oracle/psk_oracle.c, key generation included)"}
+    # -- pure-Python mirror (what the reference's interpreted loop costs here; never the reference itself)
+    n_py = 100_000
+    mb = pymirror.MirrorBloom(m, k)
+    pkeys = [pymirror.key16(i) for i in range(n_py)]
+    t0 = time.perf_counter()
+    for kx in pkeys:
+        mb.add(kx)
+    ok = all(mb.check(kx) for kx in pkeys)
+    t_py = time.perf_counter() - t0
+    py = {"value": 2 * n_py / t_py / 1e6, "unit": "Mkeys/s", "cores": 1, "kind": "python-mirror", "seconds": t_py, "all_found": ok,
+          "sample": f"insert {n_py} + check {n_py} keys through oracle/pymirror.py (interpreted per-key FNV-1a + add_alt/check_alt, bigint arithmetic like the reference)"}
+    return {**one, "legs": {"port_1core": dict(one), "port_allcores": allc, "python_mirror": py}}
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if rank != 0:  # only rank 0 reports; keep library banners of the other ranks off the job's stdout
-        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N > 1 through torch.distributed.run (one process per GPU)")
-    # PSK_BENCH_SINGLE_DEVICE=1 (test hook): every rank uses cuda:0 and the gloo backend, so that the N > 1 logic (shard
-    # offsets, two real replicas, merge, overlap) can be driven on a one-GPU box; RCCL refuses two ranks on one device
-    single_device = bool(os.environ.get("PSK_BENCH_SINGLE_DEVICE"))
-    if single_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dist = None
-    # PSK_BENCH_FORCE_DIST=1 drives the whole N > 1 code path (RCCL init, merge, barriers) with a single rank
-    distributed = world > 1 or bool(os.environ.get("PSK_BENCH_FORCE_DIST"))
-    if distributed:
-        import torch.distributed as dist
+# ----------------------------------------------------------------------------------------------- cfg2
+class Cfg2:
+    """headline: Bloom m = 2^28, k = 7; clear + insert 10M + (merge) + check 10M per rank per step"""
 
-        if world == 1:
-            os.environ.setdefault("MASTER_PORT", "29533")
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
-            os.environ["PSK_FORCE_MERGE_PATH"] = "1"
+    def __init__(self, ctx: Ctx, args):
+        import pyprobables_amd as pa
+        from pyprobables_amd import parallel
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if single_device:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-
-    import pyprobables_amd as pa
-    from pyprobables_amd import parallel
-
-    dev, n = local_rank, args.n
-    keys = gen_keys(n, rank * n, dev)  # rank r owns keys [r*n, (r+1)*n) of the stream: resident before timing
-    blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01, device=dev)
-    assert blm.number_bits == 2**28 and blm.number_hashes == 7
-    timer = EventTimer()
-    state = {}
+        self.ctx, self.args, self.pa, self.parallel = ctx, args, pa, parallel
+        self.n = args.n
+        self.keys = ctx.gen_keys(self.n, ctx.rank * self.n)  # rank r owns keys [r*n, (r+1)*n): resident before timing
+        self.blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01, device=ctx.dev)
+        assert self.blm.number_bits == 2**28 and self.blm.number_hashes == 7
+        self.timer = EventTimer(ctx.torch)
+        self.state = {}
+        self.ops_per_step = 2 * self.n * ctx.world
 
     # A timing-enabled HIP event is a barrier packet: the next kernel cannot be dispatched ahead of it, ~7 us of bubble
     # each.  The timed steps therefore carry only the ONE event pair the roofline needs (around the insert launch), and
     # only on a sample of the steps; the other phases are timed in a separate instrumented pass after the timed region.
-    def step(record, every_phase=False):
+    def step(self, record=False, every_phase=False):
         plain = lambda _n, f: f()  # noqa: E731
-        t = timer.time if (record and every_phase) else plain
-        ti = timer.time if record else plain
+        t = self.timer.time if (record and every_phase) else plain
+        ti = self.timer.time if record else plain
+        blm, keys, ctx = self.blm, self.keys, self.ctx
         t("clear", blm.clear)
         ti("insert" if not every_phase else "insert_detail", lambda: blm.add_many(keys))
-        if distributed and not args.no_overlap:
+        if ctx.distributed and not self.args.no_overlap:
             # merge on a side stream; pass 1 of the lookup (hash + partition: it never reads the table) runs under it
             def merge_and_check():
-                h = parallel.merge_bloom_async(blm)
+                h = self.parallel.merge_bloom_async(blm)
                 blm.check_many_begin(keys)
                 h.wait()
                 return blm.check_many_finish()
 
-            state["res"] = t("merge+check", merge_and_check)
+            self.state["res"] = t("merge+check", merge_and_check)
         else:
-            if distributed:
-                t("merge", lambda: parallel.merge_bloom(blm, sync_elements=False))  # table merge only: no host sync
-            state["res"] = t("check", lambda: blm.check_many(keys))
+            if ctx.distributed:
+                t("merge", lambda: self.parallel.merge_bloom(blm, sync_elements=False))  # table merge only: no host sync
+            self.state["res"] = t("check", lambda: blm.check_many(keys))
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def instrumented(self):
+        for _ in range(min(self.args.steps, 10)):
+            self.step(True, every_phase=True)
 
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    sample_every = max(1, min(20, args.steps // 3))  # the insert launch is event-timed on every sample_every-th step (>= 3 samples)
-    for it in range(args.steps):
-        step(it % sample_every == 0)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev}")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-    for _ in range(min(args.steps, 10)):  # instrumented pass (not part of `value`): per-phase HIP-event times
-        step(True, every_phase=True)
-    fence()
-    ok = bool(state["res"].all().item())  # every inserted key must be found (size-independent parity property)
-    bits_set = blm._cnt_number_bits_set()
-    merged_ok = None
-    if distributed:
-        # multi-GPU parity, outside the timed region: the merged replica must equal ONE filter fed every rank's keys
-        ref = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01, device=dev)
-        for r in range(world):
-            ref.add_many(gen_keys(n, r * n, dev))
-        merged_ok = bool(torch.equal(ref.table_tensor, blm.table_tensor))
-        del ref
-
-    ms_step = elapsed / args.steps * 1e3
-    total_ops = 2 * n * world
-    ins_ms, chk_ms = timer.mean_ms("insert"), timer.mean_ms("check")
-    overlapped = distributed and not args.no_overlap
-    mc_ms = timer.mean_ms("merge+check") if overlapped else None
-    ach = n * BYTES["bloom_insert"] / (ins_ms * 1e-3) / 1e9
-    traffic = None  # HBM bytes per insert launch from the committed PMC profile (same workload, same kernels)
-    try:
-        pmc = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
-        if pmc["keys"] == n:
-            traffic = pmc["bloom_insert"]["hbm_bytes_per_launch"]
-    except Exception:
-        traffic = None
-    line = {
-        "metric": "million keys/sec insert+lookup (Bloom m=2^28 k=7)",
-        "value": total_ops / (elapsed / args.steps) / 1e6,
-        "unit": "Mkeys/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": ms_step,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u64",
-        "data": "synthetic",
-        "config": {
-            "workload": "BloomFilter(est_elements=28005615, fpr=0.01): m=2^28 bits, k=7, default_fnv_1a; per rank per step: "
-                        "clear + insert 10M x 16B keys + (merge) + check the same 10M",
-            "keys_per_rank": n, "key_bytes": 16, "m_bits": 2**28, "k": 7,
-            "parallelism": f"key-range x{world}, replica per GPU, allreduce(OR)" if world > 1 else "single GPU",
-        },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "Bloom insert = k_part_scatter<KeysFixed16,IdxBloom<pow2>,PayNone,SpillBloomOr,7> + k_bloom_apply "
-                      "(one insert launch = both kernels; avg_kernel_ms is their sum between two HIP events)",
-            "achieved": ach,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per insert launch)" if traffic else None,
-            "algorithmic_bytes_per_launch": n * BYTES["bloom_insert"],
-            "algorithmic_bytes_per_key": BYTES["bloom_insert"],
-            "avg_kernel_ms": ins_ms,
-            "limiter": "pass 1 is co-limited by VALU (the k FNV-1a chains alone are 75 us of its 165 us: scripts/ablate.py dbg=2) "
-                       "and the LDS counting sort, not by HBM (430 MB in 165 us); pass 2 streams at ~5.5 TB/s",
-        },
-        "detail": {
+    def finish(self, ms_step):
+        ctx, args, n, torch, timer, blm = self.ctx, self.args, self.n, self.ctx.torch, self.timer, self.blm
+        ok = bool(self.state["res"].all().item())  # every inserted key must be found (size-independent parity property)
+        bits_set = blm._cnt_number_bits_set()
+        merged_ok = None
+        if ctx.distributed:
+            # multi-GPU parity, outside the timed region: the merged replica must equal ONE filter fed every rank's keys
+            ref = self.pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01, device=ctx.dev)
+            for r in range(ctx.world):
+                ref.add_many(ctx.gen_keys(n, r * n))
+            merged_ok = bool(torch.equal(ref.table_tensor, blm.table_tensor))
+            del ref
+        ins_ms, chk_ms = timer.mean_ms("insert"), timer.mean_ms("check")
+        overlapped = ctx.distributed and not args.no_overlap
+        detail = {
             "insert_Mkeys_s": n / ins_ms / 1e3,
             "check_Mkeys_s": None if overlapped else n / chk_ms / 1e3,
-            "check_GBs": None if overlapped else n * BYTES["bloom_check"] / chk_ms / 1e6,
-            "merge_plus_check_ms": mc_ms,  # N > 1: allreduce(OR) with the lookup's pass 1 running under it, then pass 2
+            "merge_plus_check_ms": timer.mean_ms("merge+check") if overlapped else None,  # allreduce(OR) with lookup pass 1 under it, then pass 2
             "clear_ms": timer.mean_ms("clear"),
-            "merge_ms": timer.mean_ms("merge") if distributed and not overlapped else None,
-            "all_inserted_found": ok,
-            "merged_table_equals_single_stream": merged_ok,
-            "bits_set": bits_set,
-        },
+            "merge_ms": timer.mean_ms("merge") if ctx.distributed and not overlapped else None,
+            "all_inserted_found": ok, "merged_table_equals_single_stream": merged_ok, "bits_set": bits_set,
+        }
+        rooflines = {}
+        if not overlapped:
+            rooflines["bloom_check"] = roofline(
+                "bloom_check", "Bloom lookup = rounds x (k_part_scatter<KeysFixed16,IdxBloom<pow2>,PayKeyId,SpillBloomTest,7> + k_bloom_test)",
+                n, chk_ms, "pass 1 as the insert's (hash + LDS counting sort) with keyed probes; pass 2 streams the probes back "
+                "from the Infinity Cache against an LDS-resident slice")
+        if ctx.rank == 0 and ctx.world == 1 and not args.no_detail:
+            side, rl = side_measurements(ctx, n, blm, self.keys)
+            detail.update(side)
+            rooflines.update(rl)
+        line = {
+            "metric": "million keys/sec insert+lookup (Bloom m=2^28 k=7)",
+            "config": {
+                "workload": "cfg2: BloomFilter(est_elements=28005615, fpr=0.01): m=2^28 bits, k=7, default_fnv_1a; per rank per step: "
+                            "clear + insert 10M x 16B keys + (merge) + check the same 10M",
+                "keys_per_rank": n, "key_bytes": 16, "m_bits": 2**28, "k": 7,
+                "parallelism": f"key-range x{ctx.world}, replica per GPU, allreduce(OR)" if ctx.world > 1 else "single GPU",
+            },
+            "roofline": roofline(
+                "bloom_insert", "Bloom insert = k_part_scatter<KeysFixed16,IdxBloom<pow2>,PayNone,SpillBloomOr,7> + k_bloom_apply "
+                "(one insert launch = both kernels; avg_kernel_ms is their sum between two HIP events)", n, ins_ms,
+                "pass 1 is co-limited by VALU (the k FNV-1a chains) and the LDS counting sort, not by HBM; pass 2 streams at ~5.5 TB/s"),
+            "rooflines": rooflines, "detail": detail,
+        }
+        fails = []
+        if not ok:
+            fails.append("parity property violated: an inserted key was not found")
+        if merged_ok is False:
+            fails.append("parity property violated: the merged table differs from the single-stream filter")
+        return line, fails
+
+
+def side_measurements(ctx: Ctx, n, blm, keys):
+    """lookups with misses, CMS / CBF rates and the GUPS-style random-access ceilings (not part of `value`)"""
+    import pyprobables_amd as pa
+    from pyprobables_amd import _native as N
+
+    torch, dev = ctx.torch, ctx.dev
+    out, rl = {}, {}
+    # Bloom lookups that MISS (the timed step only looks up inserted keys: every probe hits).  blm holds keys [0, n).
+    fresh = ctx.gen_keys(n, 10 * n)
+    mixed = torch.cat([keys[: n // 2], fresh[: n - n // 2]])
+    ms = timed_loop(torch, lambda: blm.check_many(fresh), 5)
+    out["check_all_fresh_Mkeys_s"] = n / ms / 1e3
+    ms = timed_loop(torch, lambda: blm.check_many(mixed), 5)
+    out["check_half_fresh_Mkeys_s"] = n / ms / 1e3
+    res = blm.check_many(mixed)
+    out["check_half_fresh_hits"] = int(res.sum().item())          # n/2 true members + the false positives among the fresh half
+    out["check_half_fresh_members_found"] = bool(res[: n // 2].all().item())
+    del fresh, mixed, res
+    w = ctx.gen_weights(n, 0)
+    cms = pa.CountMinSketch(width=2**20, depth=5, device=dev)
+    ms = timed_loop(torch, lambda: cms.add_many(keys, w), 5)
+    out["cms_add_Mupd_s"] = n / ms / 1e3
+    rl["cms_add"] = roofline("cms_add", "CMS weighted add = k_weight_sum + k_part_scatter<...,IdxCms<pow2>,PayWeight,...,5> + k_counter_apply",
+                             n, ms, "pass 1 (5 FNV-1a chains + LDS counting sort), pass 2 folds 2^15-cell slices", "cms_add_weighted")
+    ms = timed_loop(torch, lambda: cms.check_many(keys), 5)
+    out["cms_check_Mkeys_s"] = n / ms / 1e3
+    rl["cms_check"] = roofline("cms_check", "CMS lookup (min over 5 rows)", n, ms, "see DESIGN.md 3.2")
+    del cms
+    ncbf = min(n, 10_000_000)
+    cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, device=dev)  # 2^28 x u32 = 1 GiB
+    ms = timed_loop(torch, lambda: cbf.add_many(keys[:ncbf]), 3, warm=1)
+    out["cbf_add_Mops_s"] = ncbf / ms / 1e3
+    rl["cbf_add"] = roofline("cbf_add", "CBF add into the 1 GiB table (two-level partition: k_part_scatter + k_part_split + k_counter_apply)",
+                             ncbf, ms, "the fold read-modify-writes the whole 1 GiB table")
+    ms = timed_loop(torch, lambda: cbf.check_many(keys[:ncbf]), 3, warm=1)
+    out["cbf_check_Mkeys_s"] = ncbf / ms / 1e3
+    rl["cbf_check"] = roofline("cbf_check", "CBF lookup (min over 7 counters, 1 GiB table)", ncbf, ms, "see DESIGN.md 3.2")
+    ms = timed_loop(torch, lambda: cbf.remove_many(keys[:ncbf]), 1, warm=0)
+    out["cbf_remove_Mops_s"] = ncbf / ms / 1e3
+    del cbf
+    # random-access ceilings at the headline table size (2^23 words = 32 MiB) and at 1 GiB
+    sink = torch.zeros(1, dtype=torch.int64, device=f"cuda:{dev}")
+    nprobe = 7 * n
+    for label, words in (("32MiB", 2**23), ("1GiB", 2**28)):
+        tab = torch.zeros(words, dtype=torch.int32, device=f"cuda:{dev}")
+        for op, name in ((0, "atomic_or"), (1, "atomic_add"), (2, "gather")):
+            ms = timed_loop(torch, lambda: N.check(N.lib().psk_gups(tab.data_ptr(), words, nprobe, op, 12345, sink.data_ptr(), dev, ctx.stream())), 3, warm=1)
+            out[f"gups_{name}_{label}_Gprobes_s"] = nprobe / ms / 1e6
+        del tab
+    return out, rl
+
+
+# ----------------------------------------------------------------------------------------------- cfg3
+class Cfg3:
+    """CountMinSketch 2^20 x 5: 100M weighted updates per step as 10 passes over 10M keys"""
+
+    PASSES = 10
+
+    def __init__(self, ctx: Ctx, args):
+        import pyprobables_amd as pa
+        from pyprobables_amd import parallel
+
+        self.ctx, self.args, self.pa, self.parallel = ctx, args, pa, parallel
+        self.n = args.n
+        base = ctx.rank * self.n * self.PASSES
+        self.keys = ctx.gen_keys(self.n, ctx.rank * self.n)                       # update i uses key (i mod n) of the rank's range
+        self.w = [ctx.gen_weights(self.n, base + p * self.n) for p in range(self.PASSES)]  # and weight w(i): 400 MB resident
+        self.cms = pa.CountMinSketch(width=2**20, depth=5, device=ctx.dev)
+        self.timer = EventTimer(ctx.torch)
+        self.ops_per_step = self.n * self.PASSES * ctx.world
+
+    def step(self, record=False, every_phase=False):
+        t = self.timer.time if record else (lambda _n, f: f())
+        self.cms.clear()
+        for p in range(self.PASSES):
+            if record and p == 1:
+                t("add", lambda: self.cms.add_many(self.keys, self.w[p]))
+            else:
+                self.cms.add_many(self.keys, self.w[p])
+        if self.ctx.distributed:
+            self.parallel.merge_counters(self.cms)
+
+    def instrumented(self):
+        pass
+
+    def finish(self, ms_step):
+        ctx, torch, n, cms = self.ctx, self.ctx.torch, self.n, self.cms
+        # parity properties over the whole stream (the cell-by-cell compare with the oracle is tests/test_gpu_fullsize.py):
+        # every update lands once per row; elements_added is the sum of the weights
+        wsum = sum(int(w.to(torch.int64).sum().item()) for w in self.w)
+        if ctx.dist is not None:
+            tt = torch.tensor([wsum], dtype=torch.int64, device=f"cuda:{ctx.dev}")
+            ctx.dist.all_reduce(tt)
+            wsum = int(tt.item())
+        els = cms.elements_added
+        total = int(cms.table_tensor[: 5 * 2**20].to(torch.int64).sum().item())
+        ok = els == wsum and total == 5 * wsum and cms.batch_diagnostics()["saturated"] == 0
+        # and a prefix against the oracle: one pass of 1M keys into a fresh sketch
+        prefix_ok = None
+        if ctx.rank == 0:
+            sys.path.insert(0, str(ROOT / "oracle"))
+            import numpy as np
+            import oracle
+
+            m = 1_000_000
+            c2 = self.pa.CountMinSketch(width=2**20, depth=5, device=ctx.dev)
+            c2.add_many(ctx.gen_keys(m, 0), ctx.gen_weights(m, 0))
+            oc = oracle.OracleCMS(2**20, 5)
+            oc.add_keys(oracle.gen_keys16(0, m), oracle.gen_weights(0, m))
+            prefix_ok = bool(np.array_equal(c2.table_tensor.cpu().numpy()[: oc.bins.size], oc.bins)) and c2.elements_added == oc.els_added
+        add_ms = self.timer.mean_ms("add")
+        chk_ms = timed_loop(torch, lambda: cms.check_many(self.keys), 5)
+        line = {
+            "metric": "million updates/sec (CMS 2^20 x 5, 100M weighted adds)",
+            "config": {"workload": "cfg3: CountMinSketch(width=2^20, depth=5): per rank per step clear + 100M weighted updates "
+                                   "(10 passes over 10M 16-byte keys, weights 1..7) + (SUM merge)",
+                       "keys_per_rank": n, "passes": self.PASSES, "width": 2**20, "depth": 5,
+                       "parallelism": f"key-range x{ctx.world}, replica per GPU, allreduce(SUM)" if ctx.world > 1 else "single GPU"},
+            "roofline": roofline("cms_add", "CMS weighted add = k_weight_sum + k_part_scatter<...,IdxCms<pow2>,PayWeight,...,5> + k_counter_apply "
+                                 "(one pass of 10M updates between two HIP events)", n, add_ms,
+                                 "pass 1 (5 FNV-1a chains + LDS counting sort), pass 2 folds 2^15-cell slices", "cms_add_weighted"),
+            "rooflines": {"cms_check": roofline("cms_check", "CMS lookup (min over 5 rows)", n, chk_ms, "see DESIGN.md 3.2")},
+            "detail": {"add_Mupd_s": n / add_ms / 1e3, "check_Mkeys_s": n / chk_ms / 1e3, "elements_added": els,
+                       "sum_bins_equals_depth_x_weights": ok, "prefix_1M_equals_oracle": prefix_ok},
+        }
+        fails = [] if ok and prefix_ok is not False else ["parity property violated (cfg3)"]
+        return line, fails
+
+
+# ----------------------------------------------------------------------------------------------- cfg4
+class Cfg4:
+    """CountingBloomFilter 2^28 x u32 (1 GiB): the 50-batch add / remove stream in 1M-key batches"""
+
+    def __init__(self, ctx: Ctx, args):
+        import pyprobables_amd as pa
+
+        if ctx.world > 1:
+            raise SystemExit("cfg4 is a single-GPU configuration (removes must follow their adds: SURVEY.md 8e)")
+        self.ctx, self.args, self.pa = ctx, args, pa
+        self.B, self.nb = args.batch, args.batches
+        self.keys = ctx.gen_keys(self.B * self.nb, 0)   # 50M keys = 800 MB resident
+        self.cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, device=ctx.dev)
+        assert self.cbf.number_bits == 2**28
+        self.adds, self.removes = self.B * self.nb, (self.nb - 1) * (self.B // 2)
+        self.ops_per_step = self.adds + self.removes
+        self.timer = EventTimer(ctx.torch)
+
+    def step(self, record=False, every_phase=False):
+        cbf, keys, B = self.cbf, self.keys, self.B
+        run = lambda: self._stream(cbf, keys, B)  # noqa: E731
+        cbf.clear()
+        if record:
+            self.timer.time("stream", run)
+        else:
+            run()
+
+    def _stream(self, cbf, keys, B):
+        for b in range(self.nb):
+            cbf.add_many(keys[b * B:(b + 1) * B])
+            if b >= 1:
+                cbf.remove_many(keys[(b - 1) * B:(b - 1) * B + B // 2])  # each key removed at most once: well-formed
+        cbf.synchronize()  # (deferred updates, if any, are part of the step)
+
+    def instrumented(self):
+        pass
+
+    def finish(self, ms_step):
+        ctx, torch, cbf = self.ctx, self.ctx.torch, self.cbf
+        expect = self.adds - self.removes
+        els = cbf.elements_added
+        total = int(cbf.table_tensor.view(torch.int32).to(torch.int64).sum().item())
+        diag = cbf.batch_diagnostics()
+        ok = els == expect and total == 7 * expect and diag == {"violations": 0, "saturated": 0}
+        ms = self.timer.mean_ms("stream")
+        line = {
+            "metric": "million ops/sec (CBF m=2^28 k=7, mixed add/remove stream in 1M-key batches)",
+            "config": {"workload": f"cfg4: CountingBloomFilter(28005615, 0.01): 2^28 x uint32 = 1 GiB; per step clear + {self.nb} batches: "
+                                   f"add {self.B} keys, remove the first {self.B // 2} keys of the previous batch",
+                       "batch_keys": self.B, "batches": self.nb, "ops_per_step": self.ops_per_step, "parallelism": "single GPU"},
+            "roofline": roofline("cbf_add", "CBF stream = per fold: k_part_scatter (coarse) + k_part_split + k_counter_apply over the 1 GiB table",
+                                 self.ops_per_step, ms, "the fold read-modify-writes the whole 1 GiB table; batches are combined before it"),
+            "rooflines": {},
+            "detail": {"elements_added": els, "expected_elements": expect, "sum_counters_equals_k_x_live": total == 7 * expect, "diagnostics": diag},
+        }
+        return line, ([] if ok else ["parity property violated (cfg4)"])
+
+
+# ----------------------------------------------------------------------------------------------- cfg5
+class Cfg5:
+    """Bloom m = 2^31 sharded by key range: clear + insert shard + allreduce(OR) + check shard"""
+
+    def __init__(self, ctx: Ctx, args):
+        import pyprobables_amd as pa
+        from pyprobables_amd import parallel
+
+        self.ctx, self.args, self.pa, self.parallel = ctx, args, pa, parallel
+        self.lo, self.hi = parallel.shard_range(args.n_total, ctx.rank, ctx.world)
+        self.n = self.hi - self.lo
+        # the shard's keys, generated on the device in rounds of 32M keys (512 MB) and kept resident
+        self.chunks, R = [], 1 << 25
+        for s in range(self.lo, self.hi, R):
+            self.chunks.append(ctx.gen_keys(min(R, self.hi - s), s))
+        self.blm = pa.BloomFilter(est_elements=224044920, false_positive_rate=0.01, device=ctx.dev)
+        assert self.blm.number_bits == 2**31 and self.blm.number_hashes == 7
+        self.timer = EventTimer(ctx.torch)
+        self.ops_per_step = 2 * args.n_total
+        self.found = None
+
+    def step(self, record=False, every_phase=False):
+        t = self.timer.time if record else (lambda _n, f: f())
+        blm = self.blm
+        blm.clear()
+        t("insert", lambda: [blm.add_many(c) for c in self.chunks])
+        if self.ctx.distributed:
+            t("merge", lambda: self.parallel.merge_bloom(blm, sync_elements=False))
+        self.found = t("check", lambda: [blm.check_many(c) for c in self.chunks])
+
+    def instrumented(self):
+        pass
+
+    def finish(self, ms_step):
+        ctx, torch = self.ctx, self.ctx.torch
+        ok = all(bool(r.all().item()) for r in self.found)
+        # merged == single stream on a prefix (fresh filters; the full-size compare with the oracle is in tests/)
+        merged_ok = None
+        if ctx.distributed:
+            npre = 4_000_000
+            lo, hi = self.parallel.shard_range(npre, ctx.rank, ctx.world)
+            a = self.pa.BloomFilter(est_elements=224044920, false_positive_rate=0.01, device=ctx.dev)
+            a.add_many(ctx.gen_keys(hi - lo, lo))
+            self.parallel.merge_bloom(a)
+            b = self.pa.BloomFilter(est_elements=224044920, false_positive_rate=0.01, device=ctx.dev)
+            b.add_many(ctx.gen_keys(npre, 0))
+            merged_ok = bool(torch.equal(a.table_tensor, b.table_tensor)) and a.elements_added == npre
+            del a, b
+        ins, chk, mrg = self.timer.mean_ms("insert"), self.timer.mean_ms("check"), self.timer.mean_ms("merge")
+        line = {
+            "metric": "million keys/sec insert+lookup (Bloom m=2^31 k=7, key stream sharded by rank, allreduce(OR))",
+            "scaling": "strong",
+            "config": {"workload": "cfg5: BloomFilter(224044920, 0.01): m=2^31 bits (256 MiB replica), k=7; per step clear + insert the rank's "
+                                   "key range + allreduce(OR) + check the rank's key range",
+                       "keys_total": self.args.n_total, "keys_per_rank": self.n, "m_bits": 2**31, "k": 7,
+                       "parallelism": f"key-range x{ctx.world}, replica per GPU, allreduce(OR) = all_to_all + OR kernel + all_gather"},
+            "roofline": roofline("bloom_insert", "Bloom insert, m=2^31 (2048 slices): k_part_scatter + k_bloom_apply per 32M-key chunk", self.n, ins,
+                                 "short (tile, slice) runs at 2048 slices: pass 1 is write-out bound"),
+            "rooflines": {"bloom_check": roofline("bloom_check", "Bloom lookup, m=2^31", self.n, chk, "as the insert")},
+            "detail": {"insert_ms": ins, "merge_ms": None if mrg != mrg else mrg, "check_ms": chk,
+                       "insert_Mkeys_s_per_gpu": self.n / ins / 1e3, "check_Mkeys_s_per_gpu": self.n / chk / 1e3,
+                       "merge_GBs_per_gpu": None if mrg != mrg else 2**28 / mrg / 1e6,
+                       "all_inserted_found": ok, "merged_prefix_equals_single_stream": merged_ok},
+        }
+        fails = []
+        if not ok:
+            fails.append("parity property violated: an inserted key was not found")
+        if merged_ok is False:
+            fails.append("parity property violated: merged prefix differs from the single-stream filter")
+        return line, fails
+
+
+WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5}
+DTYPES = {"cfg2": "u64", "cfg3": "i32", "cfg4": "u32", "cfg5": "u64"}  # arithmetic type of the path (hash chains / counters)
+
+
+def main():
+    args = parse()
+    self_launch(args)
+    ctx = Ctx(args)
+    torch = ctx.torch
+    wl = WORKLOADS[args.config](ctx, args)
+
+    # clock ramp: a fresh process starts at idle clocks and the first tens of milliseconds after a fence run slow; spin
+    # the same step untimed first so that short runs (the driver's --steps 20) measure the steady state
+    t_spin = time.perf_counter()
+    spun = 0
+    while time.perf_counter() - t_spin < args.spinup:
+        wl.step(False)
+        spun += 1
+        if spun % 8 == 0:
+            torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        wl.step(False)
+    ctx.fence()
+    t0 = time.perf_counter()
+    sample_every = max(1, min(20, args.steps // 3))  # the dominant launch is event-timed on every sample_every-th step (>= 3 samples)
+    for it in range(args.steps):
+        wl.step(it % sample_every == 0)
+    ctx.fence()
+    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    wl.instrumented()  # per-phase HIP-event times (not part of `value`)
+    ctx.fence()
+    body, fails = wl.finish(elapsed / args.steps * 1e3)
+
+    line = {
+        "metric": body.pop("metric"),
+        "value": wl.ops_per_step / (elapsed / args.steps) / 1e6,
+        "unit": "Mkeys/s" if args.config in ("cfg2", "cfg5") else ("Mupdates/s" if args.config == "cfg3" else "Mops/s"),
+        "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": body.pop("scaling", "weak"), "vs_baseline": None, "dtype": DTYPES[args.config],
+        "data": "synthetic",
     }
-    if rank == 0 and world == 1 and not args.no_detail:
-        line["detail"].update(side_measurements(dev, n))
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(min(n, 10_000_000))
-    elif rank == 0:
+    body["config"]["clock_spinup"] = f"{spun} untimed steps (~{args.spinup:g} s) before the {args.warmup} warm-up steps"
+    line.update(body)
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(min(args.n, 10_000_000))
+    elif ctx.rank == 0:
         line["cpu_baseline"] = None
-    if dist is not None:
-        dist.destroy_process_group()
-    if rank == 0:
+    if ctx.dist is not None:
+        ctx.dist.destroy_process_group()
+    if ctx.rank == 0:
         # the JSON line must be the LAST thing on stdout: RCCL's NCCL_DEBUG=VERSION banner sits in the C stdio buffer
         # until exit, so drain C stdio first (the other ranks' stdout was sent to /dev/null at start)
         import ctypes  # noqa: PLC0415
@@ -341,10 +679,8 @@ def main():
         except Exception:
             pass
         print(json.dumps(line), flush=True)
-    if not ok:
-        raise SystemExit("parity property violated: an inserted key was not found")
-    if merged_ok is False:
-        raise SystemExit("parity property violated: the merged table differs from the single-stream filter")
+    if fails:
+        raise SystemExit("; ".join(fails))
 
 
 if __name__ == "__main__":

@@ -22,20 +22,64 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def _run(cmd, env, timeout=900):
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=str(ROOT))
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    return json.loads(run.stdout.strip().splitlines()[-1])  # the JSON line is the last thing on stdout
+
+
 @pytest.mark.parametrize("extra", [[], ["--no-overlap"]])
 def test_two_ranks_merge_to_the_single_stream_filter(extra):
+    """a PLAIN `python bench.py --gpus 2` starts its own ranks (the driver's invocation form)"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, PSK_BENCH_SINGLE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spinup", "0", "--keys-per-rank", "2000000", *extra]
+    line = _run(cmd, env)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["cpu_baseline"] is None
+    assert line["detail"]["all_inserted_found"] is True
+    assert line["detail"]["merged_table_equals_single_stream"] is True
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["achieved"] > 0
+
+
+def test_launched_under_torch_distributed_run():
+    """the other launch form: python -m torch.distributed.run ... bench.py --gpus 2"""
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     env = dict(os.environ, PSK_BENCH_SINGLE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--keys-per-rank", "2000000",
-           *extra]
-    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
-    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
-    last = run.stdout.strip().splitlines()[-1]
-    line = json.loads(last)  # the JSON line is the last thing on stdout
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["cpu_baseline"] is None
-    assert line["detail"]["all_inserted_found"] is True
-    assert line["detail"]["merged_table_equals_single_stream"] is True
-    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["achieved"] > 0
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spinup", "0",
+           "--keys-per-rank", "1000000"]
+    line = _run(cmd, env)
+    assert line["n_gpus"] == 2 and line["detail"]["merged_table_equals_single_stream"] is True
+
+
+def test_cfg5_two_ranks_through_the_real_allreduce_or():
+    """cfg5 geometry (m = 2^31, 256 MiB replicas) through all_to_all + psk_or_reduce_slices + all_gather with two ranks:
+    the merged prefix must equal the single-stream filter (checked inside bench.py), every inserted key is found"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, PSK_BENCH_SINGLE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--config", "cfg5", "--n-total", "6000001", "--steps", "1", "--warmup", "1", "--spinup", "0"]
+    line = _run(cmd, env)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["detail"]["all_inserted_found"] is True and line["detail"]["merged_prefix_equals_single_stream"] is True
+    assert line["config"]["m_bits"] == 2**31
+
+
+@pytest.mark.parametrize("cfg,extra", [("cfg3", ["--keys-per-rank", "1000000"]), ("cfg4", ["--batch", "200000", "--batches", "6"])])
+def test_other_configs_emit_a_valid_line(cfg, extra):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--config", cfg, "--steps", "2", "--warmup", "1", "--spinup", "0", "--no-cpu-baseline", *extra]
+    line = _run(cmd, env)
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["achieved"] > 0
+    assert cfg in line["config"]["workload"]
