@@ -205,6 +205,22 @@ int psk_cbf_jaccard_counts(const void *a, const void *b, uint64_t n, uint64_t ou
 int psk_or_reduce_slices(void *dst, const void *src, uint32_t nslices, uint64_t slice_words32, int device,
                          void *stream);
 
+/* ------------------------------------------------------ multi-GPU merge (SURVEY.md 8b "psk_merge_allreduce", 8e)
+ * One rank per GPU holds a full-size replica fed with its own range of the key stream; ONE collective makes every replica
+ * the table a single sketch fed the whole stream would hold.  `nccl_comm` is the caller's ncclComm_t (RCCL) for this rank,
+ * passed as void* (ncclCommInitRank / ncclCommInitAll: one communicator per device); the handle's table is merged in
+ * place on `stream`.  RCCL is looked up in the host process (no link-time dependency of libpsk_hip.so).
+ *   psk_merge_or   Bloom: allreduce(OR) = grouped ncclSend/ncclRecv of the bit-range slices (slice j goes straight to rank
+ *                  j), the engine's OR-reduce kernel, ncclAllGather.  bloom.py:401-428 (union is a bytewise OR).
+ *                  elements_added of the merged filter is the SUM over ranks (the caller's scalar).
+ *   psk_merge_sum  CMS / CBF: allreduce(SUM) of the counters -- 32-bit while the summed per-rank bounds prove that no counter
+ *                  reaches a rail, else 64-bit and clamped like join (countminsketch.py:380-391; CBF at 2^32-1,
+ *                  countingbloom.py:149-151); the tallies of psk_get_counters (added / removed / violations / saturated)
+ *                  become global totals.  Synchronises `stream` once (8-byte read-back of the summed bound).
+ * One-rank communicators return at once (option "merge_single_rank" = 1 runs the collective path anyway: tests). */
+int psk_merge_or(psk_sketch *s, void *nccl_comm, void *stream);
+int psk_merge_sum(psk_sketch *s, void *nccl_comm, void *stream);
+
 /* --------------------------------------------- filters whose insert depends on a lookup
  * ExpandingBloomFilter / RotatingBloomFilter (expandingbloom.py:140-170, :320-331): a key goes into the newest filter
  * unless ANY filter of the stack already reports it.  All filters share (m, k, hash): hash once, then index kernels.

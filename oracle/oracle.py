@@ -119,7 +119,7 @@ def lib():
         L.psk_o_cbf_nonzero.restype = u64
         L.psk_o_cbf_nonzero.argtypes = [vp, u64]
         L.psk_o_bloom_insert_check_mt.restype = u64
-        L.psk_o_bloom_insert_check_mt.argtypes = [vp, u64, u32, u64, u64, u64, u32]
+        L.psk_o_bloom_insert_check_mt.argtypes = [vp, u64, u32, u64, u64, u64, u32, C.POINTER(C.c_double)]
         L.psk_o_splitmix64.restype = u64
         L.psk_o_splitmix64.argtypes = [u64]
         L.psk_o_gen_keys16.restype = None
@@ -269,8 +269,12 @@ class OracleBloom:
         return float(lib().psk_o_bloom_jaccard(_ptr(self.bloom), _ptr(other.bloom), self.bloom.size, None))
 
     def insert_check_mt(self, start: int, n: int, nthreads: int, seed: int = 0x5EED) -> int:
-        """all-cores baseline leg: per-thread replica + OR merge + lookups; returns the number of keys found"""
-        return int(lib().psk_o_bloom_insert_check_mt(_ptr(self.bloom), self.m, self.k, start, n, seed, nthreads))
+        """all-cores baseline leg: per-thread replica + OR merge + lookups; returns the number of keys found
+        (``self.mt_seconds``: wall time of the three phases, replicas allocated and touched beforehand)"""
+        sec = C.c_double(0.0)
+        found = int(lib().psk_o_bloom_insert_check_mt(_ptr(self.bloom), self.m, self.k, start, n, seed, nthreads, C.byref(sec)))
+        self.mt_seconds = sec.value
+        return found
 
 
 def splitmix64(x: int) -> int:

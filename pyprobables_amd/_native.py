@@ -78,6 +78,8 @@ PROTOTYPES = {
     "psk_cbf_jaccard_counts": (_int, [_vp, _vp, _u64, C.POINTER(_u64), _int, _vp]),
     "psk_release_scratch": (_int, [_vp]),
     "psk_or_reduce_slices": (_int, [_vp, _vp, _u32, _u64, _int, _vp]),
+    "psk_merge_or": (_int, [_vp, _vp, _vp]),
+    "psk_merge_sum": (_int, [_vp, _vp, _vp]),
     "psk_bloom_indices": (_int, [_vp, _int, _vp, _vp, _u64, _u32, _int, _vp, _vp]),
     "psk_idx_test": (_int, [_vp, _vp, _u64, _u32, _vp, _int, _int, _vp]),
     "psk_idx_resolve_ordered": (_int, [_vp, _vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _int, _vp]),

@@ -23,6 +23,7 @@ SOURCES = [
     "psk_part_cms_remove.hip",
     "psk_part_cbf.hip",
     "psk_index_ops.hip",
+    "psk_merge.hip",
 ]
 HEADERS = ["psk_device.hpp", "psk_partition.hpp", "psk_host.hpp", "psk_part_counter.hpp", "../../include/psk.h"]
 OUT = CSRC / "libpsk_hip.so"

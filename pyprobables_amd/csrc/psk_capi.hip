@@ -146,7 +146,7 @@ extern "C" int psk_destroy(psk_sketch *s)
     (void)scope.enter(s->device);
     if (s->owns_table && s->table) hipFree(s->table);
     if (s->ctr) hipFree(s->ctr);
-    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2}) {
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge}) {
         if (b->p) hipFree(b->p);
         if (b->pin) hipHostFree(b->pin);
     }
@@ -414,6 +414,7 @@ int64_t g_part_max_keys = 1 << 25;   // keys per partition round (bounds the buc
 int64_t g_part_cache_bytes = 240 << 20;  // bucket-buffer budget per round: the part of the 256 MB MALL we count on
 int64_t g_part_two_level_slices = 2048;     // tables cut into more slices than this take the two-level path (0 = never)
 int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGeom::dbg); 0 in production
+extern PSK_HIDDEN int64_t g_merge_single_rank;  // psk_merge.hip
 
 extern "C" int psk_set_option(const char *name, int64_t value)
 {
@@ -424,6 +425,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "partition_cache_bytes")) g_part_cache_bytes = value;
     else if (!strcmp(name, "partition_two_level_slices")) g_part_two_level_slices = value;
     else if (!strcmp(name, "part_debug")) g_part_debug = value;
+    else if (!strcmp(name, "merge_single_rank")) g_merge_single_rank = value;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
 }
@@ -1047,7 +1049,7 @@ extern "C" int psk_release_scratch(psk_sketch *s)
     PSK_USE_DEVICE(s->device);
     if (s->pend.active) return fail(PSK_EINVAL, "a split lookup is pending: finish it before releasing the scratch buffers");
     HIP_TRY(hipDeviceSynchronize());
-    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2}) {
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge}) {
         if (b->p) HIP_TRY(hipFree(b->p));
         b->p = nullptr;
         b->cap = 0;

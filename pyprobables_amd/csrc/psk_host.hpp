@@ -95,6 +95,7 @@ struct psk_sketch {
     DevBuf s_part, s_cnt;                      // partitioned path: bucket buffer + per-bucket fill counts
     DevBuf s_flag;                             // split lookup: "a segment overflowed" flag
     DevBuf s_part2, s_cnt2;                    // two-level path: bucket buffer + fill counts after the second split
+    DevBuf s_merge;                            // multi-GPU merge (psk_merge_or / _sum): exchange buffers
     // split lookup (psk_bloom_check_begin / _finish): pass 1 of the first round has run, the rest waits for the table
     struct {
         bool active = false, scattered = false;

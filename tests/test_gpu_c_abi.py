@@ -28,3 +28,23 @@ def test_plain_c_program_drives_the_engine(tmp_path):
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "PSK C ABI OK" in run.stdout
+
+
+def test_plain_c_program_merges_replicas_over_rccl(tmp_path):
+    """examples/psk_merge_demo.c: one thread per GPU, psk_merge_or / psk_merge_sum over RCCL communicators the C host made
+    itself (ncclCommInitAll); on a one-GPU box the single-rank communicator still drives the whole collective path"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cc = shutil.which("gcc") or shutil.which("cc")
+    rocm = Path("/opt/rocm")
+    if cc is None or not (rocm / "lib" / "librccl.so").exists() or not (rocm / "include" / "rccl" / "rccl.h").exists():
+        pytest.skip("no C compiler / RCCL development files")
+    lib_dir = ROOT / "pyprobables_amd" / "csrc"
+    exe = tmp_path / "psk_merge_demo"
+    subprocess.run([cc, "-O2", "-std=gnu11", "-pthread", "-D__HIP_PLATFORM_AMD__", str(ROOT / "examples" / "psk_merge_demo.c"), "-I", str(ROOT / "include"),
+                    "-I", str(rocm / "include"), "-L", str(lib_dir), "-lpsk_hip", "-L", str(rocm / "lib"), "-lamdhip64", "-lrccl",
+                    f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{rocm / 'lib'}", "-o", str(exe)], check=True)
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "PSK MERGE OK" in run.stdout
