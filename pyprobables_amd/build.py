@@ -24,8 +24,11 @@ SOURCES = [
     "psk_part_cbf.hip",
     "psk_index_ops.hip",
     "psk_merge.hip",
+    "psk_part_cms_check.hip",
+    "psk_part_cbf_check.hip",
 ]
-HEADERS = ["psk_device.hpp", "psk_partition.hpp", "psk_host.hpp", "psk_part_counter.hpp", "../../include/psk.h"]
+HEADERS = ["psk_device.hpp", "psk_partition.hpp", "psk_host.hpp", "psk_part_counter.hpp", "psk_lookup.hpp", "psk_part_lookup.hpp", "psk_digest.hpp",
+           "../../include/psk.h"]
 OUT = CSRC / "libpsk_hip.so"
 OBJ = CSRC / "build"
 OUT_KNOBS = CSRC / "libpsk_hip_knobs.so"

@@ -146,7 +146,7 @@ extern "C" int psk_destroy(psk_sketch *s)
     (void)scope.enter(s->device);
     if (s->owns_table && s->table) hipFree(s->table);
     if (s->ctr) hipFree(s->ctr);
-    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge}) {
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run}) {
         if (b->p) hipFree(b->p);
         if (b->pin) hipHostFree(b->pin);
     }
@@ -682,6 +682,11 @@ extern "C" int psk_cbf_check(psk_sketch *s, int layout, const void *data, const 
     PSK_TRY(stage_out(s->s_out, out, n * 4, where, &o));
     // countingbloom.py:174 takes the min over ALL supplied hashes (not just the first k)
     const uint32_t kk = layout == PSK_KEYS_HASHES ? key_len : s->k;
+    {
+        bool done = false;
+        PSK_TRY(cbf_check_partitioned(s, b, kk, (uint32_t *)o.dev, st, &done));
+        if (done) return finish(where, &o, st);
+    }
     PSK_TRY(with_source(b, [&](auto src) {
         if (s->pow2) return launch_apply(src, CbfCheck<true>{(const uint32_t *)s->table, s->md, kk, (uint32_t *)o.dev}, n, st);
         return launch_apply(src, CbfCheck<false>{(const uint32_t *)s->table, s->md, kk, (uint32_t *)o.dev}, n, st);
@@ -776,6 +781,11 @@ extern "C" int psk_cms_check(psk_sketch *s, int layout, const void *data, const 
     OutBuf o;
     PSK_TRY(stage_out(s->s_out, out, n * 4, where, &o));
     const bool mean = query == PSK_Q_MEAN;
+    {
+        bool done = false;
+        PSK_TRY(cms_check_partitioned(s, b, query, 0, o.dev, st, &done));
+        if (done) return finish(where, &o, st);
+    }
     PSK_TRY(with_source(b, [&](auto src) {
         if (s->pow2) return launch_apply(src, CmsCheck<true>{(const int32_t *)s->table, s->md, s->k, (int32_t *)o.dev, mean}, n, st);
         return launch_apply(src, CmsCheck<false>{(const int32_t *)s->table, s->md, s->k, (int32_t *)o.dev, mean}, n, st);
@@ -812,6 +822,11 @@ extern "C" int psk_cms_check_meanmin(psk_sketch *s, int layout, const void *data
             }));
         }
         return finish(where, &o, st);
+    }
+    {
+        bool done = false;
+        PSK_TRY(cms_check_partitioned(s, b, PSK_Q_MEANMIN, elements_added, o.dev, st, &done));
+        if (done) return finish(where, &o, st);
     }
     PSK_TRY(with_source(b, [&](auto src) {
         if (s->pow2)
@@ -1049,7 +1064,7 @@ extern "C" int psk_release_scratch(psk_sketch *s)
     PSK_USE_DEVICE(s->device);
     if (s->pend.active) return fail(PSK_EINVAL, "a split lookup is pending: finish it before releasing the scratch buffers");
     HIP_TRY(hipDeviceSynchronize());
-    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge}) {
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run}) {
         if (b->p) HIP_TRY(hipFree(b->p));
         b->p = nullptr;
         b->cap = 0;

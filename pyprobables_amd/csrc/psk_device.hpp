@@ -477,6 +477,32 @@ __device__ __forceinline__ void cbf_sat_add(uint32_t *p, uint32_t w, unsigned lo
     }
 }
 
+// the decrement of a well-formed remove (countingbloom.py:203-206 with to_remove == num_els): frozen counters stay, a
+// counter that would go below zero is left alone and tallied as a contract violation
+__device__ __forceinline__ void cbf_sat_sub(uint32_t *p, uint32_t w, unsigned long long *viol_ctr)
+{
+    uint32_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (old == 0xFFFFFFFFu) return;
+        if (old < w) { atomicAdd(viol_ctr, 1ULL); return; }
+        if (__hip_atomic_compare_exchange_strong(p, &old, old - w, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    }
+}
+
+template <bool POW2>
+struct CbfSub {  // unordered decrement of every index (no min pre-check): the write-combined remove of well-formed streams
+    uint32_t *tab;
+    Mod md;
+    uint32_t k;
+    const uint32_t *weights;
+    unsigned long long *viol_ctr;
+    struct State { uint32_t w; };
+    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ State begin(uint64_t i) const { return State{weights ? weights[i] : 1u}; }
+    __device__ __forceinline__ void apply(State &st, uint32_t, uint64_t h) const { cbf_sat_sub(tab + reduce<POW2>(md, h), st.w, viol_ctr); }
+    __device__ __forceinline__ void end(State &, uint64_t) const {}
+};
+
 template <bool POW2>
 struct CbfAdd {  // countingbloom.py:135-155 add_alt (k independent increments; duplicates add twice)
     uint32_t *tab;
@@ -709,9 +735,10 @@ __global__ __launch_bounds__(kBlock) void k_hash(Src src, uint64_t *out, uint32_
 // --------------------------------------------------------- counter helpers
 // sum of a weight vector into the per-sketch device counters (selects fast/saturating path, feeds
 // elements_added).  which: 0 = ADDED, 1 = REMOVED, -1 = neither;  bound_mult: k for CBF, 1 for CMS.
+// grow_bound = 0: the batch only lowers counters (CBF removes): ctr[4] is left alone, ctr[6] still gets the batch's sum
 template <class W>
 __global__ __launch_bounds__(kBlock) void k_weight_sum(const W *w, uint64_t n, long long *ctr, int which,
-                                                       long long bound_mult)
+                                                       long long bound_mult, int grow_bound = 1)
 {
     long long s = 0;
     unsigned long long a = 0;
@@ -758,8 +785,10 @@ __global__ __launch_bounds__(kBlock) void k_weight_sum(const W *w, uint64_t n, l
             atomicAdd((unsigned long long *)(ctr + 6), a * (unsigned long long)bound_mult);  // this batch only (zeroed by the host before)
             // saturating bound: never wraps back below the threshold
             unsigned long long add = a * (unsigned long long)bound_mult;
-            unsigned long long old = atomicAdd((unsigned long long *)(ctr + 4), add);
-            if (old + add < old || (long long)(old + add) < 0) atomicExch((unsigned long long *)(ctr + 4), 1ULL << 62);
+            if (grow_bound) {
+                unsigned long long old = atomicAdd((unsigned long long *)(ctr + 4), add);
+                if (old + add < old || (long long)(old + add) < 0) atomicExch((unsigned long long *)(ctr + 4), 1ULL << 62);
+            }
         }
     }
 }

@@ -96,6 +96,7 @@ struct psk_sketch {
     DevBuf s_flag;                             // split lookup: "a segment overflowed" flag
     DevBuf s_part2, s_cnt2;                    // two-level path: bucket buffer + fill counts after the second split
     DevBuf s_merge;                            // multi-GPU merge (psk_merge_or / _sum): exchange buffers
+    DevBuf s_vals, s_perm, s_run;              // partitioned counter lookups: values, per-key stage positions, per-(tile, slice) runs
     // split lookup (psk_bloom_check_begin / _finish): pass 1 of the first round has run, the rest waits for the table
     struct {
         bool active = false, scattered = false;
@@ -106,6 +107,14 @@ struct psk_sketch {
 };
 
 PSK_HIDDEN int ensure(DevBuf &b, uint64_t bytes);  // grow a scratch buffer
+
+static inline int grid_for_keys(uint64_t n)  // direct kernels: 256 CUs x 16 blocks, grid-stride beyond that
+{
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    const uint64_t cap = 256ULL * 16;
+    if (g > cap) g = cap;
+    return (int)(g ? g : 1);
+}
 
 
 // ------------------------------------------------- partitioned (large-batch) path
@@ -324,3 +333,6 @@ PSK_HIDDEN int bloom_check_finish_partitioned(psk_sketch *s, uint8_t *out_dev, h
 PSK_HIDDEN int cms_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);
 PSK_HIDDEN int cms_remove_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);
 PSK_HIDDEN int cbf_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);
+// lookups (psk_lookup.hpp): query = psk_query; out_dev int32 (min / mean) or int64 (mean-min); kk = hashes per key
+PSK_HIDDEN int cms_check_partitioned(psk_sketch *s, const Batch &b, int query, int64_t els_added, void *out_dev, hipStream_t st, bool *done);
+PSK_HIDDEN int cbf_check_partitioned(psk_sketch *s, const Batch &b, uint32_t kk, uint32_t *out_dev, hipStream_t st, bool *done);

@@ -1,0 +1,206 @@
+// psk_lookup.hpp -- partitioned LOOKUPS for the counter structures (CountMinSketch.check, CountingBloomFilter.check).
+//
+// The direct lookup kernels fetch one 64-byte line across the fabric per 4-byte counter (266-454 B per key where 40-48
+// are algorithmic, rocprof r01) and sit on the fabric's request ceiling (~64 G gathers/s).  A lookup needs a RETURN trip
+// as well: the k counters of one key live in k different slices, i.e. they are read by k different workgroups.  Three
+// passes, every byte moved in coalesced 16-byte pieces:
+//
+//   pass 1  k_part_scatter (psk_partition.hpp), payload-free probes (8 x 16-bit slice-local cells per group, the unit
+//           counter-add format) + two by-products of its LDS counting sort:
+//             perm[key]      the position of each of the key's k probes inside the tile's sorted stage (16 bits each,
+//                            one 16-byte store per key and 8 probes)
+//             runinfo[tile][slice] = (first group of the tile's run inside its (slice, workgroup) segment,
+//                                     stage offset << 16 | probe count)
+//   pass 2  k_counter_gather: one workgroup per slice keeps the slice (2^15 counters = 128 KiB) in LDS, streams the slice's
+//           probe groups and writes the counter VALUES to a buffer shaped like the probe buffer (same group, same slot).
+//   pass 3  k_lookup_collect: one workgroup per tile copies the tile's runs of values back into the tile's sorted order in
+//           LDS (runinfo), then every key picks its k values through perm[] and applies the query -- min / mean /
+//           mean-min (countminsketch.py:429-453) or the CBF min (countingbloom.py:166-174) -- and stores its result.
+//
+// Probes carry no key id and results need no atomics.  A (slice, workgroup) segment that overflows (adversarial /
+// duplicate-heavy batches) raises a device flag; the host then enqueues the flag-guarded direct kernel over the round
+// (k_apply_if), so the result is exact for any input.
+#pragma once
+#include "psk_partition.hpp"
+
+namespace psk {
+
+struct PayUnitLookup {  // as PayUnit (8 x 16-bit cells per group) + the by-products pass 3 needs
+    static constexpr int mode = kModePlain;
+    static constexpr int group = 8;
+    static constexpr bool lookup = true;
+    uint4 *perm;       // [round keys][(KT + 7) / 8]
+    uint2 *runinfo;    // [tiles][slices]
+    __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
+};
+
+struct SpillRaiseFlag {  // a lookup probe that found its segment full: the round is redone by the direct kernel
+    uint32_t *flag;
+    __device__ __forceinline__ void operator()(uint32_t, uint32_t) const { *flag = 1u; }
+};
+
+// ------------------------------------------------------------------------------------ pass 2
+constexpr int kGatherDepth = 8;
+
+// vals[group * 8 + e] = counter addressed by probe e of the group (pads: unspecified)
+static __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const uint32_t *tab, uint64_t tab_cells, PartGeom g,
+                                                                         const uint32_t *segcnt, const uint4 *buckets, uint4 *vals)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t b = blockIdx.x;
+    const uint32_t slice_cells = 1u << g.shift;
+    const uint32_t mask = slice_cells - 1;
+    const uint64_t c0 = (uint64_t)b * slice_cells;
+    for (uint32_t w = threadIdx.x * 4; w < slice_cells; w += kApplyThreads * 4) {
+        const uint64_t gc = c0 + w;
+        uint4 t = make_uint4(0, 0, 0, 0);
+        if (gc + 3 < tab_cells) t = *reinterpret_cast<const uint4 *>(tab + gc);
+        else {
+            if (gc + 0 < tab_cells) t.x = tab[gc + 0];
+            if (gc + 1 < tab_cells) t.y = tab[gc + 1];
+            if (gc + 2 < tab_cells) t.z = tab[gc + 2];
+        }
+        *reinterpret_cast<uint4 *>(smem + w) = t;
+    }
+    __syncthreads();
+    for_each_batch_at<kGatherDepth>(buckets, segcnt, g, b, make_uint4(0, 0, 0, 0), [&](const uint4 (&q)[kGatherDepth], const uint64_t (&at)[kGatherDepth], const uint32_t (&)[kGatherDepth]) {
+        uint4 lo[kGatherDepth], hi[kGatherDepth];
+#pragma unroll
+        for (int d = 0; d < kGatherDepth; ++d) {  // the 8 LDS reads of every group first (a pad cell 0xFFFF reads a harmless in-slice word)
+            lo[d] = make_uint4(smem[q[d].x & 0xFFFFu & mask], smem[(q[d].x >> 16) & mask], smem[q[d].y & 0xFFFFu & mask], smem[(q[d].y >> 16) & mask]);
+            hi[d] = make_uint4(smem[q[d].z & 0xFFFFu & mask], smem[(q[d].z >> 16) & mask], smem[q[d].w & 0xFFFFu & mask], smem[(q[d].w >> 16) & mask]);
+        }
+#pragma unroll
+        for (int d = 0; d < kGatherDepth; ++d) {
+            if (at[d] != ~0ULL) {
+                vals[2 * at[d]] = lo[d];
+                vals[2 * at[d] + 1] = hi[d];
+            }
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------ pass 3
+// queries: v[0..k) are the key's counters in hash order
+struct QueryCmsMin {   // countminsketch.py:429-432
+    using Out = int32_t;
+    template <int KT>
+    __device__ __forceinline__ Out operator()(const uint32_t (&v)[KT], uint32_t k) const
+    {
+        int32_t mn = INT32_MAX;
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+            if ((uint32_t)j < k) mn = (int32_t)v[j] < mn ? (int32_t)v[j] : mn;
+        return mn;
+    }
+};
+struct QueryCmsMean {  // countminsketch.py:434-436
+    using Out = int32_t;
+    template <int KT>
+    __device__ __forceinline__ Out operator()(const uint32_t (&v)[KT], uint32_t k) const
+    {
+        int64_t sum = 0;
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+            if ((uint32_t)j < k) sum += (int32_t)v[j];
+        return (int32_t)floordiv(sum, (int64_t)k);
+    }
+};
+struct QueryCmsMeanMin {  // countminsketch.py:438-453
+    using Out = int64_t;
+    int64_t els_added, width;
+    template <int KT>
+    __device__ __forceinline__ Out operator()(const uint32_t (&v)[KT], uint32_t k) const
+    {
+        int64_t x[KT];
+        bool all_zero = true;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            x[j] = (uint32_t)j < k ? (int64_t)(int32_t)v[j] : INT64_MAX;  // unused slots sort to the end
+            if ((uint32_t)j < k) all_zero &= x[j] == 0;
+        }
+        if (all_zero) return 0;                                                    // :440-441
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+            if ((uint32_t)j < k) x[j] = x[j] - floordiv(els_added - x[j], width - 1);  // :442-446
+        sort_small(x, (uint32_t)KT);
+        return (k % 2 == 0) ? floordiv(x[k / 2] + x[k / 2 - 1], 2) : x[k / 2];     // :448-452
+    }
+};
+struct QueryCbfMin {   // countingbloom.py:166-174
+    using Out = uint32_t;
+    template <int KT>
+    __device__ __forceinline__ Out operator()(const uint32_t (&v)[KT], uint32_t k) const
+    {
+        uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+            if ((uint32_t)j < k) mn = v[j] < mn ? v[j] : mn;
+        return mn;
+    }
+};
+
+constexpr int kCollectThreads = 1024;
+
+// dynamic LDS: runinfo[B] (uint2) | stage[stage_cap] (values in the tile's sorted order)
+template <class Query, int KT>
+__global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query, PartGeom g, uint64_t n, const uint4 *perm, const uint2 *runinfo,
+                                                                    const uint32_t *vals, uint32_t stage_cap, typename Query::Out *out)
+{
+    constexpr int GS = 8, P4 = (KT + 7) / 8;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint2 *info = reinterpret_cast<uint2 *>(smem);
+    uint32_t *stage = smem + 2 * g.nbuckets;
+    const uint32_t B = g.nbuckets, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t k = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
+    const uint64_t ntiles = (n + g.tile - 1) / g.tile;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t wg = (uint32_t)(tile % g.nwg);  // the pass-1 workgroup that owned this tile names the segments
+        for (uint32_t b = threadIdx.x; b < B; b += kCollectThreads) info[b] = runinfo[tile * B + b];
+        __syncthreads();
+        // ---- the tile's runs of values, back into the sorted order of pass 1's LDS stage: wave w takes slices w, w+16, ...;
+        // four runs are in flight per lane before LDS is written (one run is ~tile*k/B values: about one per lane)
+        for (uint32_t b0 = wave; b0 < B; b0 += 4 * (kCollectThreads / 64)) {
+            uint32_t v[4], at[4];
+            bool live[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t b = b0 + (uint32_t)u * (kCollectThreads / 64);
+                live[u] = false;
+                if (b < B) {
+                    const uint2 ri = info[b];
+                    const uint32_t cnt = ri.y & 0xFFFFu, off = ri.y >> 16;
+                    const uint64_t src = (seg_index(g, b, wg) * g.segcap + ri.x) * GS;
+                    const uint32_t room = ri.x < g.segcap ? (g.segcap - ri.x) * GS : 0;  // (an overflowed run: the flag is up, the redo overwrites out[])
+                    at[u] = off + lane;
+                    live[u] = lane < cnt && lane < room;
+                    if (live[u]) v[u] = vals[src + lane];
+                    for (uint32_t e = lane + 64; e < cnt && e < room; e += 64) stage[off + e] = vals[src + e];  // long runs (skewed batches)
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (live[u]) stage[at[u]] = v[u];
+        }
+        __syncthreads();
+        // ---- every key picks its k values through perm[]
+        const uint64_t base = tile * g.tile;
+        const uint64_t end = base + g.tile < n ? base + g.tile : n;
+        for (uint64_t i = base + threadIdx.x; i < end; i += kCollectThreads) {
+            uint32_t p[8 * P4];
+#pragma unroll
+            for (int c = 0; c < P4; ++c) {
+                const uint4 w = perm[i * P4 + c];
+                p[8 * c + 0] = w.x & 0xFFFFu; p[8 * c + 1] = w.x >> 16; p[8 * c + 2] = w.y & 0xFFFFu; p[8 * c + 3] = w.y >> 16;
+                p[8 * c + 4] = w.z & 0xFFFFu; p[8 * c + 5] = w.z >> 16; p[8 * c + 6] = w.w & 0xFFFFu; p[8 * c + 7] = w.w >> 16;
+            }
+            uint32_t v[KT];
+#pragma unroll
+            for (int j = 0; j < KT; ++j) v[j] = (uint32_t)j < k ? stage[p[j] < stage_cap ? p[j] : 0] : 0u;
+            out[i] = query.template operator()<KT>(v, k);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace psk

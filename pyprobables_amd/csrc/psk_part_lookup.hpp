@@ -1,0 +1,83 @@
+// psk_part_lookup.hpp -- launcher template of the partitioned counter lookups (psk_lookup.hpp: pass 1 with perm / runinfo
+// by-products, pass 2 k_counter_gather, pass 3 k_lookup_collect), shared by the CMS and CBF translation units.
+#pragma once
+#include "psk_host.hpp"
+#include "psk_lookup.hpp"
+
+// keys per round such that what one round writes and reads back (probes 2 B, values 4 B, perm 16 B per 8 probes) stays
+// inside the Infinity Cache budget (`partition_cache_bytes`), like part_round_keys does for the update paths
+static inline uint64_t lookup_round_keys(uint64_t n, uint32_t k)
+{
+    uint64_t rk = (uint64_t)g_part_max_keys < n ? (uint64_t)g_part_max_keys : n;
+    if (g_part_cache_bytes > 0 && n) {
+        const double per_key = (double)k * 6.0 * 1.2 + 16.0 * (double)((k + 7) / 8);
+        const double total = per_key * (double)n;
+        if (total > 1.25 * (double)g_part_cache_bytes) {
+            const uint64_t rounds = (uint64_t)(total / (double)g_part_cache_bytes) + 1;
+            uint64_t per = ((n + rounds - 1) / rounds + 4095) & ~4095ULL;
+            if (per < 1u << 20) per = 1u << 20;
+            if (per < rk) rk = per;
+        }
+    }
+    return rk ? rk : 1;
+}
+
+// IDX: index functor family (IdxCms / IdxBloom); `query` is the pass-3 epilogue; `redo(flag, st)` enqueues the flag-guarded
+// direct kernel over the whole batch (exactness when a segment overflowed).  *done = false: nothing was launched.
+template <template <bool> class IDX, class Query, class Redo>
+static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint32_t kk, uint64_t cells, const Query &query,
+                                            typename Query::Out *out_dev, hipStream_t st, bool *done, Redo &&redo)
+{
+    *done = false;
+    if (!part_wanted(b.n, kk, 4)) return PSK_OK;
+    PartGeom g;
+    if (!part_slices(cells, 15, 5, &g)) return PSK_OK;  // 2^15 counters = 128 KiB per slice; beyond 2048 slices: direct kernels
+    g.k = kk;
+    const uint64_t round_keys = lookup_round_keys(b.n, kk);
+    PSK_TRY(ensure(s->s_flag, 8));
+    uint32_t *flag = (uint32_t *)s->s_flag.p;
+    HIP_TRY(hipMemsetAsync(flag, 0, 4, st));
+    for (uint64_t start = 0; start < b.n; start += round_keys) {
+        const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
+        const Batch sub = sub_batch(b, start, cnt);
+        bool handled = false;
+        PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
+            using Src = decltype(src);
+            return with_kt<Src>(kk, [&](auto kt) {
+                constexpr int KT = decltype(kt)::value;
+                constexpr int P4 = (KT + 7) / 8;
+                using TileSmall = PartTile<PayUnitLookup, KT, kPartThreads>;  // the smaller of the two tile sizes bounds the tile count
+                const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE;
+                PSK_TRY(ensure(s->s_perm, cnt * P4 * 16));
+                PSK_TRY(ensure(s->s_run, max_tiles * g.nbuckets * 8));
+                PayUnitLookup pay{(uint4 *)s->s_perm.p, (uint2 *)s->s_run.p};
+                SpillRaiseFlag spill{flag};
+                if (s->pow2) PSK_TRY((launch_scatter<Src, IDX<true>, PayUnitLookup, SpillRaiseFlag, KT>(s, src, IDX<true>{s->md}, pay, spill, &g, cnt, st)));
+                else PSK_TRY((launch_scatter<Src, IDX<false>, PayUnitLookup, SpillRaiseFlag, KT>(s, src, IDX<false>{s->md}, pay, spill, &g, cnt, st)));
+                // pass 2: the counters behind every probe, in the probe buffer's shape
+                PSK_TRY(ensure(s->s_vals, (uint64_t)g.nbuckets * g.nwg * g.segcap * 32 + 256));
+                const size_t lds2 = (size_t)4 << g.shift;
+                PSK_TRY(set_dyn_lds(k_counter_gather, lds2));
+                hipLaunchKernelGGL(k_counter_gather, dim3(g.nbuckets), dim3(kApplyThreads), lds2, st, (const uint32_t *)s->table, cells, g,
+                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint4 *)s->s_vals.p);
+                HIP_TRY(hipGetLastError());
+                // pass 3: back to key order, query epilogue
+                const uint32_t kq = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
+                const uint32_t stage_cap = (uint32_t)(((size_t)g.tile * kq + (size_t)7 * g.nbuckets + 3) & ~(size_t)3);
+                if (stage_cap > 0xFFFFu) return fail(PSK_EINVAL, "lookup tile of %u probes does not fit 16-bit stage positions", stage_cap);
+                const size_t lds3 = ((size_t)2 * g.nbuckets + stage_cap) * 4;
+                const uint64_t ntiles = (cnt + g.tile - 1) / g.tile;
+                auto kern = k_lookup_collect<Query, KT>;
+                PSK_TRY(set_dyn_lds(kern, lds3));
+                hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(kCollectThreads), lds3, st, query, g, cnt,
+                                   (const uint4 *)s->s_perm.p, (const uint2 *)s->s_run.p, (const uint32_t *)s->s_vals.p, stage_cap, out_dev + start);
+                HIP_TRY(hipGetLastError());
+                return (int)PSK_OK;
+            });
+        }));
+        if (!handled) return PSK_OK;  // layout without a partitioned instantiation: nothing was launched (first round)
+    }
+    PSK_TRY(redo(flag, st));  // runs only if a segment overflowed (device-side flag): exact for any input
+    *done = true;
+    return PSK_OK;
+}

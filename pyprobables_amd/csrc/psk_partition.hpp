@@ -20,7 +20,7 @@
 //   packed  6 x 20-bit bit-in-slice (+ 2 x 4-bit counts)     Bloom insert            (2.67 B / probe)
 //           8 x 16-bit cell-in-slice (0xFFFF = pad)          unit-weight counter adds (2 B / probe)
 //   inline  4 x (weight << shift | cell index within slice)  weighted counter adds, weight < 2^(31-shift)
-//   keyed   tile id, 3 x (key index within tile << shift | bit index within slice)      Bloom lookups
+//   keyed   4 x (tile bit << 31 | key index within tile << shift | bit index within slice)   Bloom lookups (4 B / probe)
 // Anything that does not fit (segment overflow on adversarial / duplicate-heavy batches, weights too
 // large to inline) falls back to an exact direct atomic on the table, so the result is always exact.
 #pragma once
@@ -84,6 +84,17 @@ struct IdxCms {  // countminsketch.py:275:  (h % width) + i*width
     }
 };
 
+// (a payload functor with `static constexpr bool lookup = true` asks pass 1 for the by-products the partitioned
+// lookups need -- psk_lookup.hpp: perm[] and runinfo[])
+template <class Pay, class = void>
+struct pay_max_kpt { static constexpr int value = 1 << 20; };
+template <class Pay>
+struct pay_max_kpt<Pay, decltype((void)Pay::max_kpt)> { static constexpr int value = Pay::max_kpt; };
+template <class Pay, class = void>
+struct pay_is_lookup { static constexpr bool value = false; };
+template <class Pay>
+struct pay_is_lookup<Pay, decltype((void)Pay::lookup)> { static constexpr bool value = Pay::lookup; };
+
 // payload functors: the second word a probe carries through the LDS sort (key i of a tile starting at base)
 struct PayNone {   // Bloom insert: 6 probes per group, 20-bit slice-local bit indices
     static constexpr int mode = kModePlain;
@@ -106,9 +117,16 @@ struct PayZero {   // level 1 of the two-level Bloom insert: 4 x 32-bit (0 << sh
     static constexpr int mode = kModeInline;
     __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0u; }
 };
+// Bloom lookups: 4 probes per group, word = tile bit << 31 | key index within the tile << shift | bit index within the slice.
+// The four top bits of a group spell the tile's ordinal inside its workgroup's sequence (tile = ordinal * nwg + wg, wg = the
+// segment's workgroup), so a round holds at most 16 tiles per workgroup; the tile is at most 2^(31 - shift) keys
+// (max_kpt = 2: 2048 keys with 1024 threads).  Trailing slots of a run's last group repeat its first probe (a lookup
+// probe may be tested twice), so there is no pad marker in HBM.
 struct PayKeyId {
-    static constexpr int group = 3;
+    static constexpr int group = 4;
     static constexpr int mode = kModeKeyed;
+    static constexpr int max_kpt = 2;
+    static constexpr uint32_t max_tiles_per_wg = 16;
     __device__ __forceinline__ uint32_t operator()(uint64_t i, uint64_t base) const { return (uint32_t)(i - base); }
 };
 
@@ -126,6 +144,7 @@ struct SpillCounter {  // saturating CAS add (countminsketch.py:280-284,312-316 
     {
         const uint32_t v = unit ? 1u : w;
         if (SIGNED) cms_sat_add((int32_t *)tab + idx, neg ? -(int64_t)(int32_t)v : (int64_t)(int32_t)v, sat_ctr);
+        else if (neg) cbf_sat_sub(tab + idx, v, sat_ctr - 1);  // (the violations tally sits right before the saturation tally)
         else cbf_sat_add(tab + idx, v, sat_ctr);
     }
 };
@@ -187,7 +206,8 @@ struct PartTile {
                                                                     // the final 32-bit word and a per-group slice id (gb[])
     static constexpr int GS = Pay::group;                           // probes per 16-byte output group
     static constexpr int PP = kPartProbes / 2;                      // 16 probes per thread: <= 100 VGPRs, 2 workgroups per CU
-    static constexpr int KPT = PP / KT >= 1 ? PP / KT : 1;          // keys per thread per tile
+    static constexpr int KPT0 = PP / KT >= 1 ? PP / KT : 1;
+    static constexpr int KPT = KPT0 < pay_max_kpt<Pay>::value ? KPT0 : pay_max_kpt<Pay>::value;  // keys per thread per tile
     // Threads per workgroup: 512, or (host's choice, small k, when the LDS stage fits) 1024 = one workgroup per CU: the
     // per-tile fixed costs (scan, barriers) are then paid once per 14 K probes instead of per 7 K; measured +5 % over
     // two 512-thread workgroups per CU.  Large k stays at 512: 32-probe threads need more than the 128 VGPRs a
@@ -254,16 +274,19 @@ __device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t
             for (int x = 0; x < 4; ++x)
                 if (w[x] != kPadProbe) spill((b << g.shift) | (w[x] & mask), w[x] >> g.shift);
         }
-    } else {  // keyed
-        const uint32_t e0 = stage[3 * gi], e1 = stage[3 * gi + 1], e2 = stage[3 * gi + 2];
+    } else {  // keyed: `tile` is the tile's ordinal inside this workgroup's sequence (< 16), spelled by the four top bits
+        const uint4 e = reinterpret_cast<const uint4 *>(stage)[gi];
         const uint32_t b = gb[gi];
         const uint32_t slot = delta[b] + gi;
+        const uint32_t w[4] = {e.x, e.y, e.z, e.w};  // LDS words are 31 bits; kPadProbe marks the unused trailing slots
         if (slot < g.segcap) {
-            buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = make_uint4((uint32_t)tile, e0, e1, e2);
-        } else {
-            const uint32_t w[3] = {e0, e1, e2};
+            uint32_t o[4];
 #pragma unroll
-            for (int x = 0; x < 3; ++x)
+            for (int x = 0; x < 4; ++x) o[x] = (w[x] == kPadProbe ? w[0] : w[x]) | ((((uint32_t)tile >> x) & 1u) << 31);
+            buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
                 if (w[x] != kPadProbe) spill((b << g.shift) | (w[x] & mask), (uint32_t)base + (w[x] >> g.shift));
         }
     }
@@ -326,7 +349,9 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     }
     if ((dbg & 32) && threadIdx.x == 0) t_prev = __builtin_readcyclecounter();
 
+    uint32_t ordinal = ~0u;  // of the tile inside this workgroup's sequence (keyed probes carry it)
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        ++ordinal;
         uint32_t *hist = hist0 + (size_t)(parity ? B : 0);
         uint32_t *hist_next = hist0 + (size_t)(parity ? 0 : B);
         parity ^= 1u;
@@ -462,14 +487,17 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
 
         // ---- counting-sort the probes into the LDS stage; one thread per slice also fills its run's trailing pads
         // (in the scan phase that was 4 slices x up to GS-1 serial stores on the single scanning wave: 18 % of pass 1)
+        constexpr bool LOOKUP = pay_is_lookup<Pay>::value;
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
             const uint64_t i = base + (uint64_t)q * NT + threadIdx.x;
             if (i < n) {
+                uint32_t pos[LOOKUP ? 8 * ((KT + 7) / 8) : 1] = {};  // lookups: where each of my probes sits in the sorted stage
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     if ((uint32_t)j < k) {
                         const uint32_t p = off[idx[q][j] >> g.shift] + rank[q][j];
+                        if constexpr (LOOKUP) pos[j] = p;
                         if constexpr (PAIR) {
                             // final word (payload << shift | index in the slice); the slice of every group is kept
                             // aside by whoever fills the group's first slot
@@ -486,6 +514,12 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
                         }
                     }
                 }
+                if constexpr (LOOKUP) {  // perm[key]: 16-bit stage positions, one 16-byte store per 8 probes
+#pragma unroll
+                    for (int c = 0; c < (KT + 7) / 8; ++c)
+                        pay.perm[i * ((KT + 7) / 8) + c] = make_uint4(pos[8 * c] | (pos[8 * c + 1] << 16), pos[8 * c + 2] | (pos[8 * c + 3] << 16),
+                                                                      pos[8 * c + 4] | (pos[8 * c + 5] << 16), pos[8 * c + 6] | (pos[8 * c + 7] << 16));
+                }
             }
         }
         // (after the sort stores: idx / rank are dead by now, so this costs no registers)
@@ -494,6 +528,8 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
             for (uint32_t e = cnt; e < padded; ++e) {
                 stage[at + e] = kPadProbe;
             }
+            // runinfo[tile][slice]: first group of this tile's run inside my segment of the slice, stage offset << 16 | count
+            if constexpr (LOOKUP) pay.runinfo[tile * B + b] = make_uint2(delta[b] + at / GS, (at << 16) | cnt);
         }
         lds_barrier();
         PSK_TICK(4);
@@ -506,7 +542,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         if (!(dbg & 1)) {
             const uint32_t ngroups = tile_probes / GS;
             for (uint32_t gi = threadIdx.x; gi < ngroups; gi += NT) {
-                emit_group<Pay, Spill>(stage, gb, delta, g, mask, gi, tile, base, spill, buckets);
+                emit_group<Pay, Spill>(stage, gb, delta, g, mask, gi, Pay::mode == kModeKeyed ? (uint64_t)ordinal : tile, base, spill, buckets);
             }
         }
         // (pipelined form) no barrier needed here: the next iteration touches only hist (last read two barriers
@@ -674,6 +710,42 @@ constexpr int kApplyWaves = kApplyThreads / 64;
 // sum of the per-segment chunk counts) and D chunks -- whichever segments they fall in -- are kept in flight per
 // lane before LDS is touched.  chunk -> (segment, offset) is scalar work: ballot + popcount + two readlanes.
 // `body` gets the D groups of a batch; absent ones hold `pad`.
+// body(q, at, wg): the D groups, their flat index in the bucket buffer (~0 = absent) and the pass-1 workgroup of their segment
+template <int D, class Body>
+__device__ __forceinline__ void for_each_batch_at(const uint4 *buckets, const uint32_t *segcnt, const PartGeom &g, uint32_t b,
+                                                  const uint4 pad, Body body)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nseg = g.nwg > wave ? (g.nwg - wave + kApplyWaves - 1) / kApplyWaves : 0;  // <= 32
+    uint32_t mycnt = 0;
+    if (lane < nseg) mycnt = segcnt[(uint64_t)b * g.nwg + wave + kApplyWaves * lane];
+    const uint32_t chunks = (mycnt + 63) >> 6;
+    const uint32_t incl = wave_inclusive_scan(chunks), excl = incl - chunks;
+    const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    for (uint32_t c0 = 0; c0 < C; c0 += D) {
+        uint4 q[D];
+        uint64_t at[D];
+        uint32_t wg[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const uint32_t cc = c0 + d;
+            const uint32_t seg = (uint32_t)__builtin_popcountll(__ballot(incl <= cc));  // uniform; == 64 past the end
+            const uint32_t sl = seg < 64 ? seg : 63;
+            const uint32_t v = (cc - (uint32_t)__builtin_amdgcn_readlane((int)excl, sl)) * 64 + lane;
+            const uint32_t cnt = seg < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)mycnt, sl) : 0;
+            wg[d] = wave + kApplyWaves * sl;
+            const uint64_t base = seg_index(g, b, wg[d]) * g.segcap;
+            q[d] = pad;
+            at[d] = ~0ULL;
+            if (v < cnt) {
+                q[d] = buckets[base + v];
+                at[d] = base + v;
+            }
+        }
+        body(q, at, wg);
+    }
+}
+
 template <int D, class Body>
 __device__ __forceinline__ void for_each_batch(const uint4 *buckets, const uint32_t *segcnt, const PartGeom &g, uint32_t b,
                                                const uint4 pad, Body body)
@@ -785,7 +857,7 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *
 
 // Bloom lookup: the slice is loaded into LDS; a probe whose bit is clear zeroes its key's result byte
 // (out[] is pre-set to 1; every writer stores the same 0, so plain byte stores suffice).
-// group = (tile id, 3 x (key index in tile << shift | bit index in slice))
+// group = 4 x (tile bit << 31 | key index in tile << shift | bit index in slice), see PayKeyId
 static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint32_t *tab, uint64_t tab_words, PartGeom g,
                                                               const uint32_t *segcnt, const uint4 *buckets, uint8_t *out)
 {
@@ -807,20 +879,31 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint3
         *reinterpret_cast<uint4 *>(smem + w) = t;
     }
     __syncthreads();
-    for_each_group_padded(buckets, segcnt, g, b, make_uint4(kPadProbe, kPadProbe, kPadProbe, kPadProbe),
-      [&](const uint4 q) {  // a pad probe reads a harmless in-slice word
-        if (dbg & 64) return make_uint4(0, ~0u, ~0u, ~0u);
-        return make_uint4(0, smem[(q.y & mask) >> 5], smem[(q.z & mask) >> 5], smem[(q.w & mask) >> 5]);
-      },
-      [&](const uint4 q, const uint4 w) {  // the rare miss stores
-        const bool my = q.y != kPadProbe && ((w.y >> (q.y & 31)) & 1u) == 0;
-        const bool mz = q.z != kPadProbe && ((w.z >> (q.z & 31)) & 1u) == 0;
-        const bool mw = q.w != kPadProbe && ((w.w >> (q.w & 31)) & 1u) == 0;
-        if (my | mz | mw) {
-            const uint32_t kbase = q.x * g.tile;
-            if (my) out[kbase + (q.y >> g.shift)] = 0;
-            if (mz) out[kbase + (q.z >> g.shift)] = 0;
-            if (mw) out[kbase + (q.w >> g.shift)] = 0;
+    const uint32_t kmask = (1u << (31 - g.shift)) - 1;
+    for_each_batch_at<kApplyDepth>(buckets, segcnt, g, b, make_uint4(0, 0, 0, 0), [&](const uint4 (&q)[kApplyDepth], const uint64_t (&at)[kApplyDepth],
+                                                                                     const uint32_t (&wg)[kApplyDepth]) {
+        // the LDS reads of the whole batch first (no control dependence: they issue back to back), then the tests
+        uint4 w[kApplyDepth];
+#pragma unroll
+        for (int d = 0; d < kApplyDepth; ++d) {
+            if (dbg & 64) { w[d] = make_uint4(~0u, ~0u, ~0u, ~0u); continue; }
+            w[d] = make_uint4(smem[(q[d].x & mask) >> 5], smem[(q[d].y & mask) >> 5], smem[(q[d].z & mask) >> 5], smem[(q[d].w & mask) >> 5]);
+        }
+#pragma unroll
+        for (int d = 0; d < kApplyDepth; ++d) {  // the rare miss stores
+            const bool live = at[d] != ~0ULL;
+            const bool mx = live && ((w[d].x >> (q[d].x & 31)) & 1u) == 0;
+            const bool my = live && ((w[d].y >> (q[d].y & 31)) & 1u) == 0;
+            const bool mz = live && ((w[d].z >> (q[d].z & 31)) & 1u) == 0;
+            const bool mw = live && ((w[d].w >> (q[d].w & 31)) & 1u) == 0;
+            if (mx | my | mz | mw) {
+                const uint32_t ordinal = (q[d].x >> 31) | ((q[d].y >> 31) << 1) | ((q[d].z >> 31) << 2) | ((q[d].w >> 31) << 3);
+                const uint32_t kbase = (ordinal * g.nwg + wg[d]) * g.tile;
+                if (mx) out[kbase + ((q[d].x >> g.shift) & kmask)] = 0;
+                if (my) out[kbase + ((q[d].y >> g.shift) & kmask)] = 0;
+                if (mz) out[kbase + ((q[d].z >> g.shift) & kmask)] = 0;
+                if (mw) out[kbase + ((q[d].w >> g.shift) & kmask)] = 0;
+            }
         }
     });
 }
@@ -848,6 +931,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, 
             const uint64_t cell = c0 + (x & mask);
             const uint32_t w = x >> g.shift;
             if (SIGNED) cms_sat_add((int32_t *)tab + cell, NEG ? -(int64_t)w : (int64_t)w, sat_ctr);
+            else if (NEG) cbf_sat_sub(tab + cell, w, sat_ctr - 1);
             else cbf_sat_add(tab + cell, w, sat_ctr);
         };
         for_each_group(buckets, segcnt, g, b, pad4, [&](const uint4 q) { slow(q.x); slow(q.y); slow(q.z); slow(q.w); });
@@ -869,8 +953,16 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, 
         for_each_group(buckets, segcnt, g, b, pad4, [&](const uint4 q) { add2(q.x); add2(q.y); add2(q.z); add2(q.w); });
     }
     __syncthreads();
-    unsigned long long sat = 0;
+    unsigned long long sat = 0, viol = 0;
     auto fold = [&](uint32_t t, uint32_t d) -> uint32_t {  // the reference's saturating add
+        if (!SIGNED && NEG) {
+            // CBF decrement (countingbloom.py:203-206 with to_remove == num_els, i.e. a well-formed stream): a counter frozen
+            // at 2^32-1 stays; one that would go below zero means the stream was not well-formed -- tallied, clamped at 0
+            const uint32_t amount = 0u - d;
+            if (t == 0xFFFFFFFFu) return t;
+            if (t < amount) { ++viol; return 0u; }
+            return t - amount;
+        }
         if (SIGNED) {
             int64_t v = (int64_t)(int32_t)t + (int64_t)(int32_t)d;
             if (v > INT32_MAX) { v = INT32_MAX; ++sat; }
@@ -916,6 +1008,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, 
         }
     }
     if (sat) atomicAdd(sat_ctr, sat);
+    if (viol) atomicAdd(sat_ctr - 1, viol);
 }
 
 }  // namespace psk
