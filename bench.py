@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--spinup", type=float, default=1.0, help="seconds of untimed steps before warm-up (clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-detail", action="store_true", help="skip the CMS / CBF / GUPS side measurements")
+    ap.add_argument("--no-combine", action="store_true", help="cfg4: apply every 1M-key batch at once (no write-combining of update batches)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: merge, then look up (no lookup pass 1 under the merge)")
     args = ap.parse_args()
     ds, dw = DEFAULT_STEPS[args.config]
@@ -500,7 +501,7 @@ class Cfg4:
         self.ctx, self.args, self.pa = ctx, args, pa
         self.B, self.nb = args.batch, args.batches
         self.keys = ctx.gen_keys(self.B * self.nb, 0)   # 50M keys = 800 MB resident
-        self.cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, device=ctx.dev)
+        self.cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, device=ctx.dev, combine_updates=not args.no_combine)
         assert self.cbf.number_bits == 2**28
         self.adds, self.removes = self.B * self.nb, (self.nb - 1) * (self.B // 2)
         self.ops_per_step = self.adds + self.removes
@@ -537,7 +538,11 @@ class Cfg4:
             "metric": "million ops/sec (CBF m=2^28 k=7, mixed add/remove stream in 1M-key batches)",
             "config": {"workload": f"cfg4: CountingBloomFilter(28005615, 0.01): 2^28 x uint32 = 1 GiB; per step clear + {self.nb} batches: "
                                    f"add {self.B} keys, remove the first {self.B // 2} keys of the previous batch",
-                       "batch_keys": self.B, "batches": self.nb, "ops_per_step": self.ops_per_step, "parallelism": "single GPU"},
+                       "batch_keys": self.B, "batches": self.nb, "ops_per_step": self.ops_per_step, "parallelism": "single GPU",
+                       "combine_updates": not self.args.no_combine,
+                       "note": "combine_updates: the 1M-key batches are collected on the device (D2D copy of the keys) and applied as one "
+                               "partitioned update per 2^24 keys, all inside the timed step (the stream ends with a flush); removes are "
+                               "decrements, exact for this well-formed stream"},
             "roofline": roofline("cbf_add", "CBF stream = per fold: k_part_scatter (coarse) + k_part_split + k_counter_apply over the 1 GiB table",
                                  self.ops_per_step, ms, "the fold read-modify-writes the whole 1 GiB table; batches are combined before it"),
             "rooflines": {},

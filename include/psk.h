@@ -150,6 +150,19 @@ int psk_cbf_remove(psk_sketch *s, int layout, const void *data, const uint64_t *
                    uint32_t key_len, const uint32_t *weights, int where, void *stream);
 int psk_cbf_check(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
                   uint32_t key_len, int where, uint32_t *out, void *stream);
+/* Write-combined updates (opt-in).  The fold of a big counter table read-modify-writes the whole table whatever the batch
+ * brings (1 GiB at BASELINE config 4), so small batches -- the config's 1M-key add / remove batches -- are collected on the
+ * device and applied as ONE partitioned update per list once "combine_keys" keys (psk_set_option, default 2^24) are waiting:
+ * first the adds (countingbloom.py:135-155), then the removes as plain decrements of every index by the key's weight
+ * (countingbloom.py:203-206 with to_remove == num_els).  Exact for well-formed streams (every remove targets a key with at
+ * least num_els live inserts at that point of the stream; nothing saturates) -- the contract of the unordered batch ops
+ * above; a decrement below zero is tallied in PSK_CTR_VIOLATIONS.  Unlike psk_cbf_remove no per-key min is read first, so a
+ * remove of an ABSENT key is a violation here, not a no-op.  Every other entry point on the handle (check, read_table,
+ * get_counters, synchronize, merge ...) applies what is waiting first; psk_clear / psk_write_table drop it.  Before handing
+ * the raw table pointer (psk_table_info) to anything else call psk_flush.  remove = 0: add, 1: remove. */
+int psk_cbf_update_combined(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                            uint32_t key_len, const uint32_t *weights, int remove, int where, void *stream);
+int psk_flush(psk_sketch *s, void *stream);
 /* Ordered (one-at-a-time, in sequence) execution of the reference semantics on the GPU, including
  * each op's return value: exact for ANY stream.  weights int64[n] or NULL (=1); opmode psk_opmode. */
 int psk_cbf_update_ordered(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,

@@ -83,8 +83,14 @@ class DeviceTable:
             return torch.cuda.current_stream(self.device).cuda_stream or None
         return None
 
+    def flush(self):
+        """apply write-combined updates that are still waiting in the engine (CBF ``combine_updates``); a no-op otherwise"""
+        N.check(N.lib().psk_flush(self.handle, self.stream))
+
     @property
     def ptr(self) -> int:
+        """raw device pointer of the table (pending write-combined updates are applied first)"""
+        self.flush()
         p = C.c_void_p()
         N.check(N.lib().psk_table_info(self.handle, C.byref(p), None, None))
         return p.value

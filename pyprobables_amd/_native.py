@@ -60,6 +60,8 @@ PROTOTYPES = {
     "psk_cbf_add": (_int, [_vp, *_KEYS, _vp, _int, _vp]),
     "psk_cbf_remove": (_int, [_vp, *_KEYS, _vp, _int, _vp]),
     "psk_cbf_check": (_int, [_vp, *_KEYS, _int, _vp, _vp]),
+    "psk_cbf_update_combined": (_int, [_vp, *_KEYS, _vp, _int, _int, _vp]),
+    "psk_flush": (_int, [_vp, _vp]),
     "psk_cbf_update_ordered": (_int, [_vp, *_KEYS, _vp, _int, _int, _vp, _vp]),
     "psk_cms_add": (_int, [_vp, *_KEYS, _vp, _int, _vp]),
     "psk_cms_remove": (_int, [_vp, *_KEYS, _vp, _int, _vp]),

@@ -26,6 +26,7 @@ SOURCES = [
     "psk_merge.hip",
     "psk_part_cms_check.hip",
     "psk_part_cbf_check.hip",
+    "psk_part_cbf_remove.hip",
 ]
 HEADERS = ["psk_device.hpp", "psk_partition.hpp", "psk_host.hpp", "psk_part_counter.hpp", "psk_lookup.hpp", "psk_part_lookup.hpp", "psk_digest.hpp",
            "../../include/psk.h"]

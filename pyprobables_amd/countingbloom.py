@@ -36,9 +36,32 @@ class CountingBloomFilter(BloomFilter):
     _ELEM = struct.Struct("I")
     _MISMATCH = "The parameter second must be of type CountingBloomFilter"
 
+    def __init__(self, est_elements=None, false_positive_rate=None, filepath=None, hex_string=None, hash_function=None,
+                 device=None, combine_updates: bool = False):
+        """``combine_updates`` (extra, off by default): ``add_many`` / ``remove_many`` batches are collected on the device
+        and applied as one partitioned update per 2^24 keys (``psk_cbf_update_combined``): folding a big table costs a
+        pass over the WHOLE table whatever the batch size, so streams of small batches (BASELINE config 4: 1M-key
+        batches into 1 GiB) only run fast when combined.  Removes are then plain decrements -- exact for well-formed
+        streams (every remove targets a key with enough live inserts), the contract of the unordered batch ops; a remove
+        of an absent key is tallied in ``batch_diagnostics()['violations']`` instead of being a no-op.  Reads
+        (``check*``, ``bloom``, ``export``, ``elements_added`` ...) always see every update handed over."""
+        self._combine = bool(combine_updates)
+        super().__init__(est_elements, false_positive_rate, filepath, hex_string, hash_function, device)
+
+    @classmethod
+    def frombytes(cls, b, hash_function=None, device=None):
+        inst = super().frombytes(b, hash_function, device)
+        inst._combine = False
+        return inst
+
     @staticmethod
     def _insufficient_msg() -> str:
         return "Insufecient parameters to set up the Counting Bloom Filter"  # (sic) countingbloom.py:73
+
+    def _flush(self) -> None:
+        super()._flush()
+        if self._tab is not None and getattr(self, "_combine", False):
+            self._tab.flush()
 
     def _table_len(self, n_bits: int) -> int:
         return int(n_bits)  # one uint32 per position (countingbloom.py:77)
@@ -122,14 +145,18 @@ class CountingBloomFilter(BloomFilter):
         N.check(N.lib().psk_cbf_check(self._tab.handle, *b.args(), b.where, addr, self._tab.stream))
         return fin()
 
-    def _update_batch(self, fn, b: KeyBatch, num_els) -> None:
+    def _update_batch(self, remove: bool, b: KeyBatch, num_els) -> None:
         keep: list = []
         w_addr, _ = weights_arg(num_els, b.n, np.uint32, b.where, keep, 0, _U32_MAX, self._tab.device)
-        N.check(fn(self._tab.handle, *b.args(), w_addr, b.where, self._tab.stream))
+        if getattr(self, "_combine", False):  # write-combined: collected on the device, applied per 2^24 keys
+            N.check(N.lib().psk_cbf_update_combined(self._tab.handle, *b.args(), w_addr, int(remove), b.where, self._tab.stream))
+        else:
+            fn = N.lib().psk_cbf_remove if remove else N.lib().psk_cbf_add
+            N.check(fn(self._tab.handle, *b.args(), w_addr, b.where, self._tab.stream))
         self._dirty = True
 
     def _add_batch(self, b: KeyBatch, num_els=None) -> None:  # type: ignore[override]
-        self._update_batch(N.lib().psk_cbf_add, b, num_els)
+        self._update_batch(False, b, num_els)
 
     def add_many(self, keys, num_els=None) -> None:  # type: ignore[override]
         """``num_els``: None (=1), an int, or one count per key"""
@@ -139,10 +166,10 @@ class CountingBloomFilter(BloomFilter):
         self._add_batch(pack_hashes(hashes, self._number_hashes), num_els)
 
     def remove_many(self, keys, num_els=None) -> None:
-        self._update_batch(N.lib().psk_cbf_remove, self._batch(keys), num_els)
+        self._update_batch(True, self._batch(keys), num_els)
 
     def remove_alt_many(self, hashes, num_els=None) -> None:
-        self._update_batch(N.lib().psk_cbf_remove, pack_hashes(hashes, self._number_hashes), num_els)
+        self._update_batch(True, pack_hashes(hashes, self._number_hashes), num_els)
 
     def check_many(self, keys):
         """uint32[n] numpy (host input) / int32-bits torch tensor (device input): min counter per key"""

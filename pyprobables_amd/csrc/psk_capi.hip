@@ -146,7 +146,8 @@ extern "C" int psk_destroy(psk_sketch *s)
     (void)scope.enter(s->device);
     if (s->owns_table && s->table) hipFree(s->table);
     if (s->ctr) hipFree(s->ctr);
-    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run}) {
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run,
+                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w}) {
         if (b->p) hipFree(b->p);
         if (b->pin) hipHostFree(b->pin);
     }
@@ -166,6 +167,8 @@ extern "C" int psk_clear(psk_sketch *s, void *stream)
 {
     CHECK_HANDLE(s, -1);
     hipStream_t st = (hipStream_t)stream;
+    s->comb.add.n = s->comb.rem.n = 0;  // write-combined updates that have not reached the table are cleared with it
+    s->comb.add.unit = s->comb.rem.unit = true;
     HIP_TRY(hipMemsetAsync(s->table, 0, s->padded_bytes, st));
     HIP_TRY(hipMemsetAsync(s->ctr, 0, sizeof(long long) * PSK_CTR_COUNT, st));
     return PSK_OK;
@@ -174,6 +177,7 @@ extern "C" int psk_clear(psk_sketch *s, void *stream)
 extern "C" int psk_synchronize(psk_sketch *s, void *stream)
 {
     CHECK_HANDLE(s, -1);
+    PSK_TRY(flush_combined(s, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return PSK_OK;
 }
@@ -192,6 +196,7 @@ extern "C" int psk_read_table(psk_sketch *s, void *dst_host, uint64_t nbytes, vo
     CHECK_HANDLE(s, -1);
     if (!dst_host || nbytes > s->padded_bytes) return fail(PSK_EINVAL, "bad read_table arguments");
     hipStream_t st = (hipStream_t)stream;
+    PSK_TRY(flush_combined(s, st));
     HIP_TRY(hipMemcpyAsync(dst_host, s->table, nbytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return PSK_OK;
@@ -202,6 +207,8 @@ extern "C" int psk_write_table(psk_sketch *s, const void *src_host, uint64_t nby
     CHECK_HANDLE(s, -1);
     if (!src_host || nbytes > s->padded_bytes) return fail(PSK_EINVAL, "bad write_table arguments");
     hipStream_t st = (hipStream_t)stream;
+    s->comb.add.n = s->comb.rem.n = 0;  // the table is replaced: pending updates go with the old contents
+    s->comb.add.unit = s->comb.rem.unit = true;
     HIP_TRY(hipMemsetAsync(s->table, 0, s->padded_bytes, st));
     HIP_TRY(hipMemcpyAsync(s->table, src_host, nbytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(s->ctr, 0, sizeof(long long) * PSK_CTR_COUNT, st));
@@ -221,6 +228,7 @@ extern "C" int psk_rescan_bound(psk_sketch *s, void *stream)
     CHECK_HANDLE(s, -1);
     if (s->kind == PSK_KIND_BLOOM) return PSK_OK;
     hipStream_t st = (hipStream_t)stream;
+    PSK_TRY(flush_combined(s, st));
     HIP_TRY(hipMemsetAsync(s->ctr + PSK_CTR_ABS_BOUND, 0, sizeof(long long), st));
     const uint64_t nel = s->logical_bytes / 4;
     hipLaunchKernelGGL(k_absmax, dim3(grid_for(nel)), dim3(kBlock), 0, st, (const uint32_t *)s->table, nel,
@@ -234,6 +242,7 @@ extern "C" int psk_get_counters(psk_sketch *s, int64_t out[PSK_CTR_COUNT], void 
     CHECK_HANDLE(s, -1);
     if (!out) return fail(PSK_EINVAL, "out is NULL");
     hipStream_t st = (hipStream_t)stream;
+    PSK_TRY(flush_combined(s, st));  // the tallies describe every update handed over so far
     HIP_TRY(hipMemcpyAsync(out, s->ctr, sizeof(long long) * PSK_CTR_COUNT, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return PSK_OK;
@@ -414,6 +423,7 @@ int64_t g_part_max_keys = 1 << 25;   // keys per partition round (bounds the buc
 int64_t g_part_cache_bytes = 240 << 20;  // bucket-buffer budget per round: the part of the 256 MB MALL we count on
 int64_t g_part_two_level_slices = 2048;     // tables cut into more slices than this take the two-level path (0 = never)
 int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGeom::dbg); 0 in production
+extern int64_t g_combine_keys;       // defined with the write-combined CBF updates below
 extern PSK_HIDDEN int64_t g_merge_single_rank;  // psk_merge.hip
 
 extern "C" int psk_set_option(const char *name, int64_t value)
@@ -426,6 +436,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "partition_two_level_slices")) g_part_two_level_slices = value;
     else if (!strcmp(name, "part_debug")) g_part_debug = value;
     else if (!strcmp(name, "merge_single_rank")) g_merge_single_rank = value;
+    else if (!strcmp(name, "combine_keys")) g_combine_keys = value;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
 }
@@ -450,6 +461,7 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "partition_max_keys")) *value = g_part_max_keys;
     else if (!strcmp(name, "partition_cache_bytes")) *value = g_part_cache_bytes;
     else if (!strcmp(name, "partition_two_level_slices")) *value = g_part_two_level_slices;
+    else if (!strcmp(name, "combine_keys")) *value = g_combine_keys;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
 }
@@ -603,28 +615,117 @@ extern "C" int psk_bloom_check_bits(psk_sketch *s, int layout, const void *data,
 }
 
 // ------------------------------------------------------ counters / weights
+// grow_bound = false: the batch only lowers counters (CBF removes) -- the wrap-free bound on |counter| stays as it is
 template <class W>
-static int account_weights(psk_sketch *s, const W *w_dev, uint64_t n, int which, long long bound_mult, hipStream_t st)
+static int account_weights(psk_sketch *s, const W *w_dev, uint64_t n, int which, long long bound_mult, hipStream_t st, bool grow_bound = true)
 {
     if (n == 0) return PSK_OK;
     if (w_dev) {
         HIP_TRY(hipMemsetAsync(s->ctr + 6, 0, sizeof(long long), st));  // per-batch sum|w| (partitioned path wrap check)
         hipLaunchKernelGGL((k_weight_sum<W>), dim3(grid_for(n) > 256 ? 256 : grid_for(n)), dim3(kBlock), 0, st, w_dev, n,
-                           s->ctr, which, bound_mult);
+                           s->ctr, which, bound_mult, (int)grow_bound);
     } else {
-        hipLaunchKernelGGL(k_ctr_add, dim3(1), dim3(1), 0, st, s->ctr, which, (long long)n, (long long)n * bound_mult);
+        hipLaunchKernelGGL(k_ctr_add, dim3(1), dim3(1), 0, st, s->ctr, which, (long long)n, grow_bound ? (long long)n * bound_mult : 0LL);
     }
     HIP_TRY(hipGetLastError());
     return PSK_OK;
 }
 
 // ----------------------------------------------------- CountingBloomFilter
+int64_t g_combine_keys = 1 << 24;  // keys per write-combining list (psk_set_option "combine_keys")
+
+// one unordered CBF update over a DEVICE-resident batch: add (countingbloom.py:135-155) or the unchecked decrement
+static int cbf_apply_device(psk_sketch *s, const Batch &b, const uint32_t *w, bool remove, hipStream_t st)
+{
+    if (b.n == 0) return PSK_OK;
+    PSK_TRY(account_weights(s, w, b.n, remove ? PSK_CTR_REMOVED : PSK_CTR_ADDED, (long long)s->k, st, !remove));
+    unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
+    bool done = false;
+    PSK_TRY(remove ? cbf_remove_partitioned(s, b, w, st, &done) : cbf_add_partitioned(s, b, w, st, &done));
+    if (done) return PSK_OK;
+    return with_source(b, [&](auto src) {
+        if (remove) {
+            if (s->pow2) return launch_apply(src, CbfSub<true>{(uint32_t *)s->table, s->md, s->k, w, sat - 1}, b.n, st);
+            return launch_apply(src, CbfSub<false>{(uint32_t *)s->table, s->md, s->k, w, sat - 1}, b.n, st);
+        }
+        if (s->pow2) return launch_apply(src, CbfAdd<true>{(uint32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, b.n, st);
+        return launch_apply(src, CbfAdd<false>{(uint32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, b.n, st);
+    });
+}
+
+int flush_combined(psk_sketch *s, hipStream_t st)
+{
+    if (s->kind != PSK_KIND_CBF || (s->comb.add.n == 0 && s->comb.rem.n == 0)) return PSK_OK;
+    // adds first: a remove whose add waits in the same window must find it applied
+    for (int pass = 0; pass < 2; ++pass) {
+        psk_sketch::PendList &l = pass == 0 ? s->comb.add : s->comb.rem;
+        if (l.n == 0) continue;
+        Batch b{PSK_KEYS_FIXED, l.keys.p, nullptr, l.n, s->comb.key_len};
+        const uint64_t n = l.n;
+        l.n = 0;  // (cleared first: a failure must not re-apply the list on the next call)
+        const bool unit = l.unit;
+        l.unit = true;
+        (void)n;
+        PSK_TRY(cbf_apply_device(s, b, unit ? nullptr : (const uint32_t *)l.w.p, pass == 1, st));
+    }
+    return PSK_OK;
+}
+
+extern "C" int psk_flush(psk_sketch *s, void *stream)
+{
+    CHECK_HANDLE(s, -1);
+    return flush_combined(s, (hipStream_t)stream);
+}
+
+extern "C" int psk_cbf_update_combined(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
+                                       uint32_t key_len, const uint32_t *weights, int remove, int where, void *stream)
+{
+    CHECK_HANDLE(s, PSK_KIND_CBF);
+    PSK_TRY(check_hashes_width(s, layout, key_len));
+    if (where != PSK_HOST && where != PSK_DEVICE) return fail(PSK_EINVAL, "`where` must be PSK_HOST or PSK_DEVICE");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return PSK_OK;
+    const uint64_t cap = g_combine_keys > 0 ? (uint64_t)g_combine_keys : 0;
+    const bool combinable = layout == PSK_KEYS_FIXED && key_len > 0 && data && n < cap;
+    if (!combinable || (s->comb.key_len && s->comb.key_len != key_len) || (s->comb.cap && s->comb.cap != cap)) {
+        PSK_TRY(flush_combined(s, st));
+        if (!combinable) {  // other layouts, empty keys, batches as large as a list: applied at once (same semantics)
+            Batch b;
+            PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+            const uint32_t *w;
+            PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
+            PSK_TRY(cbf_apply_device(s, b, w, remove != 0, st));
+            return finish(where, nullptr, st);
+        }
+    }
+    psk_sketch::PendList &l = remove ? s->comb.rem : s->comb.add;
+    if (l.n + n > cap) PSK_TRY(flush_combined(s, st));
+    s->comb.key_len = key_len;
+    s->comb.cap = cap;
+    PSK_TRY(ensure(l.keys, cap * (uint64_t)key_len));  // full capacity at once: growing would drop the pending keys
+    PSK_TRY(ensure(l.w, cap * 4));
+    const hipMemcpyKind kind = where == PSK_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    HIP_TRY(hipMemcpyAsync((uint8_t *)l.keys.p + l.n * (uint64_t)key_len, data, n * (uint64_t)key_len, kind, st));
+    uint32_t *wdst = (uint32_t *)l.w.p + l.n;
+    if (weights) {
+        if (l.unit && l.n) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)l.w.p, 1, l.n, st));  // earlier unit batches get their 1s now
+        HIP_TRY(hipMemcpyAsync(wdst, weights, n * 4, kind, st));
+        l.unit = false;
+    } else if (!l.unit) {
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)wdst, 1, n, st));
+    }
+    l.n += n;
+    if (where == PSK_HOST) HIP_TRY(hipStreamSynchronize(st));  // the caller may reuse its buffers on return
+    return PSK_OK;
+}
+
 extern "C" int psk_cbf_add(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
                            uint32_t key_len, const uint32_t *weights, int where, void *stream)
 {
     CHECK_HANDLE(s, PSK_KIND_CBF);
     PSK_TRY(check_hashes_width(s, layout, key_len));
     hipStream_t st = (hipStream_t)stream;
+    PSK_TRY(flush_combined(s, st));  // write-combined updates reach the table before anything else touches it
     Batch b;
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
     const uint32_t *w;
@@ -643,16 +744,80 @@ extern "C" int psk_cbf_add(psk_sketch *s, int layout, const void *data, const ui
     return finish(where, nullptr, st);
 }
 
+// countingbloom.py:198-203 for a whole batch: from the min over the key's counters (a lookup) to the amount actually removed
+//   mn == 0 (absent) or mn == 2^32-1 (frozen): nothing;  else to_remove = min(mn, num_els)
+// a partial removal (mn < num_els) makes the result depend on the order inside the batch: tallied as a violation
+static __global__ __launch_bounds__(kBlock) void k_cbf_to_remove(const uint32_t *mins, const uint32_t *weights, uint64_t n, uint32_t *to_remove,
+                                                                 unsigned long long *viol_ctr)
+{
+    unsigned long long viol = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t mn = mins[i], w = weights ? weights[i] : 1u;
+        uint32_t tr = 0;
+        if (mn != 0 && mn != 0xFFFFFFFFu) {
+            tr = mn > w ? w : mn;
+            viol += tr != w;
+        }
+        to_remove[i] = tr;
+    }
+    for (int o = 32; o > 0; o >>= 1) viol += __shfl_down(viol, o);
+    if ((threadIdx.x & 63) == 0 && viol) atomicAdd(viol_ctr, viol);
+}
+
+// Large remove batches: the remove is a lookup (the min of the key's k counters) followed by a conditional decrement, so it
+// is composed from the two partitioned pipelines instead of 2k random fabric transactions per key: mins <- lookup,
+// to_remove <- k_cbf_to_remove, then the partitioned decrement with to_remove as per-key weights (weight 0 = no-op).
+static int cbf_remove_composed(psk_sketch *s, const Batch &b, const uint32_t *w, hipStream_t st, bool *done)
+{
+    *done = false;
+    if (!part_wanted(b.n, s->k, 4)) return PSK_OK;
+    PSK_TRY(ensure(s->s_aux, b.n * 8 + 64));
+    uint32_t *mins = (uint32_t *)s->s_aux.p, *amount = mins + ((b.n + 3) & ~3ULL);
+    bool looked = false;
+    PSK_TRY(cbf_check_partitioned(s, b, s->k, mins, st, &looked));
+    if (!looked) {
+        // tables beyond the one-level lookup (more than 2048 LDS slices): direct gathers for the mins -- worth it only when
+        // the decrement can take the two-level fold (the batch brings at least cells / 8 probes)
+        if (b.n * (uint64_t)s->k < s->m / 8) return PSK_OK;
+        PSK_TRY(with_source(b, [&](auto src) {
+            if (s->pow2) return launch_apply(src, CbfCheck<true>{(const uint32_t *)s->table, s->md, s->k, mins}, b.n, st);
+            return launch_apply(src, CbfCheck<false>{(const uint32_t *)s->table, s->md, s->k, mins}, b.n, st);
+        }));
+    }
+    hipLaunchKernelGGL(k_cbf_to_remove, dim3(grid_for(b.n) > 1024 ? 1024 : grid_for(b.n)), dim3(kBlock), 0, st, (const uint32_t *)mins, w, b.n, amount,
+                       (unsigned long long *)(s->ctr + PSK_CTR_VIOLATIONS));
+    HIP_TRY(hipGetLastError());
+    PSK_TRY(account_weights(s, (const uint32_t *)amount, b.n, PSK_CTR_REMOVED, (long long)s->k, st, false));
+    bool dec = false;
+    PSK_TRY(cbf_remove_partitioned(s, b, amount, st, &dec));
+    if (!dec) {  // not eligible after all: the same decrement through the direct kernel
+        unsigned long long *viol = (unsigned long long *)(s->ctr + PSK_CTR_VIOLATIONS);
+        PSK_TRY(with_source(b, [&](auto src) {
+            if (s->pow2) return launch_apply(src, CbfSub<true>{(uint32_t *)s->table, s->md, s->k, amount, viol}, b.n, st);
+            return launch_apply(src, CbfSub<false>{(uint32_t *)s->table, s->md, s->k, amount, viol}, b.n, st);
+        }));
+    }
+    *done = true;
+    return PSK_OK;
+}
+
 extern "C" int psk_cbf_remove(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
                               uint32_t key_len, const uint32_t *weights, int where, void *stream)
 {
     CHECK_HANDLE(s, PSK_KIND_CBF);
     PSK_TRY(check_hashes_width(s, layout, key_len));
     hipStream_t st = (hipStream_t)stream;
+    PSK_TRY(flush_combined(s, st));  // write-combined updates reach the table before anything else touches it
     Batch b;
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
     const uint32_t *w;
     PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
+    {
+        bool done = false;
+        PSK_TRY(cbf_remove_composed(s, b, w, st, &done));
+        if (done) return finish(where, nullptr, st);
+    }
     if (n) {
         PSK_TRY(with_source(b, [&](auto src) {
             using Src = decltype(src);
@@ -676,6 +841,7 @@ extern "C" int psk_cbf_check(psk_sketch *s, int layout, const void *data, const 
     if (n && !out) return fail(PSK_EINVAL, "out is NULL");
     if (layout == PSK_KEYS_HASHES && key_len == 0) return fail(PSK_EINVAL, "check needs at least one hash per key");
     hipStream_t st = (hipStream_t)stream;
+    PSK_TRY(flush_combined(s, st));  // write-combined updates reach the table before anything else touches it
     Batch b;
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
     OutBuf o;
@@ -702,6 +868,7 @@ extern "C" int psk_cbf_update_ordered(psk_sketch *s, int layout, const void *dat
     PSK_TRY(check_hashes_width(s, layout, key_len));
     if (opmode < PSK_OP_ADD || opmode > PSK_OP_SIGNED) return fail(PSK_EINVAL, "bad opmode %d", opmode);
     hipStream_t st = (hipStream_t)stream;
+    PSK_TRY(flush_combined(s, st));  // write-combined updates reach the table before anything else touches it
     Batch b;
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
     const int64_t *w;
@@ -1063,8 +1230,10 @@ extern "C" int psk_release_scratch(psk_sketch *s)
     if (!s) return fail(PSK_EINVAL, "sketch handle is NULL");
     PSK_USE_DEVICE(s->device);
     if (s->pend.active) return fail(PSK_EINVAL, "a split lookup is pending: finish it before releasing the scratch buffers");
+    PSK_TRY(flush_combined(s, nullptr));
     HIP_TRY(hipDeviceSynchronize());
-    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run}) {
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run,
+                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w}) {
         if (b->p) HIP_TRY(hipFree(b->p));
         b->p = nullptr;
         b->cap = 0;

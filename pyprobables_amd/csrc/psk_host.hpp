@@ -97,6 +97,18 @@ struct psk_sketch {
     DevBuf s_part2, s_cnt2;                    // two-level path: bucket buffer + fill counts after the second split
     DevBuf s_merge;                            // multi-GPU merge (psk_merge_or / _sum): exchange buffers
     DevBuf s_vals, s_perm, s_run;              // partitioned counter lookups: values, per-key stage positions, per-(tile, slice) runs
+    // write-combined CBF updates (psk_cbf_update_combined): key batches wait here until a list is full, then each list is
+    // applied as ONE partitioned update (the fold of a big table read-modify-writes the whole table whatever the batch size)
+    struct PendList {
+        DevBuf keys, w;      // uint8[cap][key_len], uint32[cap]
+        uint64_t n = 0;
+        bool unit = true;    // every batch so far had unit weights
+    };
+    struct {
+        uint32_t key_len = 0;
+        uint64_t cap = 0;    // keys per list
+        PendList add, rem;
+    } comb;
     // split lookup (psk_bloom_check_begin / _finish): pass 1 of the first round has run, the rest waits for the table
     struct {
         bool active = false, scattered = false;
@@ -177,7 +189,12 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
     const uint64_t tiles_per_wg = (ntiles + nwg - 1) / nwg;
     const double mean = (double)tiles_per_wg * Tile::TILE * kk / (double)g->nbuckets;  // probes per segment
     // 16-byte groups per segment: mean/GS, + ~half a group of padding per (tile, slice) run, + 8 sigma
-    const uint64_t segcap = (uint64_t)(mean / Tile::GS + 0.5 * (double)tiles_per_wg + 8.0 * __builtin_sqrt(mean) / Tile::GS + 16.0);
+    uint64_t segcap = (uint64_t)(mean / Tile::GS + 0.5 * (double)tiles_per_wg + 8.0 * __builtin_sqrt(mean) / Tile::GS + 16.0);
+    if (pay_is_lookup<Pay>::value) segcap = (segcap + 63) & ~63ULL;  // lookups: the value buffer is laid out in 64-group chunks
+    if constexpr (Pay::mode == kModeKeyed) {
+        if (tiles_per_wg > 16) return fail(PSK_EINVAL, "keyed lookup round of %llu keys needs %llu tiles per workgroup (max 16)",
+                                           (unsigned long long)n, (unsigned long long)tiles_per_wg);
+    }
     g->nwg = (uint32_t)nwg;
     g->segcap = (uint32_t)segcap;
     g->tile = (uint32_t)Tile::TILE;
@@ -198,14 +215,14 @@ static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, con
                           uint64_t n, hipStream_t st)
 {
     if constexpr (KT <= 8) {
-        // keyed probes carry (key index in tile << shift | bit in slice) in 32 bits, 0xFFFFFFFF being the pad: the tile must
-        // stay below 2^(32 - shift) keys (1024-thread tiles of k = 3, 4 are 5120 / 4096 keys: too many for 2^20-bit slices)
-        const bool ids_fit = Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, 1024>::TILE << g->shift) < (1ULL << 32);
+        // keyed probes carry (key index in tile << shift | bit in slice) in 31 bits (the top bit spells the tile ordinal): the
+        // tile must stay within 2^(31 - shift) keys (PayKeyId::max_kpt caps it at 2048 keys for 1024 threads)
+        const bool ids_fit = Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, 1024>::TILE << g->shift) <= (1ULL << 31);
         if (!(kBenchKnobs && (g->dbg & 16)) && ids_fit && scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget)
             return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st);
     }
-    static_assert(Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, kPartThreads>::TILE << 20) < (1ULL << 32),
-                  "512-thread tiles must keep keyed probes inside 32 bits for the largest slice (2^20 bits)");
+    static_assert(Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, kPartThreads>::TILE << 20) <= (1ULL << 31),
+                  "512-thread tiles must keep keyed probes inside 31 bits for the largest slice (2^20 bits)");
     return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, kPartThreads>(s, src, idxfn, pay, spill, g, n, st);
 }
 
@@ -334,5 +351,7 @@ PSK_HIDDEN int cms_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t
 PSK_HIDDEN int cms_remove_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);
 PSK_HIDDEN int cbf_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);
 // lookups (psk_lookup.hpp): query = psk_query; out_dev int32 (min / mean) or int64 (mean-min); kk = hashes per key
+PSK_HIDDEN int cbf_remove_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);  // unchecked decrement
+PSK_HIDDEN int flush_combined(psk_sketch *s, hipStream_t st);  // apply the write-combined CBF updates, if any (psk_capi.hip)
 PSK_HIDDEN int cms_check_partitioned(psk_sketch *s, const Batch &b, int query, int64_t els_added, void *out_dev, hipStream_t st, bool *done);
 PSK_HIDDEN int cbf_check_partitioned(psk_sketch *s, const Batch &b, uint32_t kk, uint32_t *out_dev, hipStream_t st, bool *done);

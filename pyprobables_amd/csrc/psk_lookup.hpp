@@ -42,7 +42,17 @@ struct SpillRaiseFlag {  // a lookup probe that found its segment full: the roun
 // ------------------------------------------------------------------------------------ pass 2
 constexpr int kGatherDepth = 8;
 
-// vals[group * 8 + e] = counter addressed by probe e of the group (pads: unspecified)
+// Value layout (shaped like the probe buffer, 32 bytes per group): a chunk of 64 consecutive groups of a segment is stored
+// as [64 x first four values][64 x last four values], so that both 16-byte stores of a lane are lane-contiguous (1 KiB per
+// wave-instruction instead of two half-filled 2 KiB strides).  Segments are sized in whole chunks (host).
+__device__ __forceinline__ uint64_t value_word(uint64_t seg_base_groups, uint32_t group_in_seg, uint32_t e)
+{
+    const uint64_t chunk = (seg_base_groups + (group_in_seg & ~63u)) * 8;  // in 32-bit words
+    const uint32_t l = group_in_seg & 63u;
+    return chunk + (e < 4 ? l * 4 + e : 256 + l * 4 + (e - 4));
+}
+
+// the counter addressed by every probe of every group (pads: unspecified)
 static __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const uint32_t *tab, uint64_t tab_cells, PartGeom g,
                                                                          const uint32_t *segcnt, const uint4 *buckets, uint4 *vals)
 {
@@ -72,9 +82,10 @@ static __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const u
         }
 #pragma unroll
         for (int d = 0; d < kGatherDepth; ++d) {
-            if (at[d] != ~0ULL) {
-                vals[2 * at[d]] = lo[d];
-                vals[2 * at[d] + 1] = hi[d];
+            if (at[d] != ~0ULL) {  // (a wave's lanes hold consecutive groups of one chunk: group_in_seg % 64 == lane)
+                const uint64_t chunk4 = 2 * (at[d] - (threadIdx.x & 63));
+                vals[chunk4 + (threadIdx.x & 63)] = lo[d];
+                vals[chunk4 + 64 + (threadIdx.x & 63)] = hi[d];
             }
         }
     });
@@ -145,7 +156,8 @@ constexpr int kCollectThreads = 1024;
 // dynamic LDS: runinfo[B] (uint2) | stage[stage_cap] (values in the tile's sorted order)
 template <class Query, int KT>
 __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query, PartGeom g, uint64_t n, const uint4 *perm, const uint2 *runinfo,
-                                                                    const uint32_t *vals, uint32_t stage_cap, typename Query::Out *out)
+                                                                    const uint32_t *vals, uint32_t stage_cap, uint32_t run_lanes,
+                                                                    typename Query::Out *out)
 {
     constexpr int GS = 8, P4 = (KT + 7) / 8;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -158,24 +170,28 @@ __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query,
         const uint32_t wg = (uint32_t)(tile % g.nwg);  // the pass-1 workgroup that owned this tile names the segments
         for (uint32_t b = threadIdx.x; b < B; b += kCollectThreads) info[b] = runinfo[tile * B + b];
         __syncthreads();
-        // ---- the tile's runs of values, back into the sorted order of pass 1's LDS stage: wave w takes slices w, w+16, ...;
-        // four runs are in flight per lane before LDS is written (one run is ~tile*k/B values: about one per lane)
-        for (uint32_t b0 = wave; b0 < B; b0 += 4 * (kCollectThreads / 64)) {
+        // ---- the tile's runs of values, back into the sorted order of pass 1's LDS stage.  A run is ~tile*k/B values, often
+        // far fewer than 64: `run_lanes` (a power of two, host's choice from that mean) lanes take one run, 64 / run_lanes
+        // runs ride one wave-instruction, four instructions are in flight per lane before LDS is written.
+        const uint32_t rl = run_lanes, per_wave = 64u / rl, sub = lane / rl, e0 = lane % rl;
+        const uint32_t stride = (kCollectThreads / 64) * per_wave;
+        for (uint32_t b0 = wave * per_wave + sub; b0 < B; b0 += 4 * stride) {
             uint32_t v[4], at[4];
             bool live[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const uint32_t b = b0 + (uint32_t)u * (kCollectThreads / 64);
+                const uint32_t b = b0 + (uint32_t)u * stride;
                 live[u] = false;
                 if (b < B) {
                     const uint2 ri = info[b];
                     const uint32_t cnt = ri.y & 0xFFFFu, off = ri.y >> 16;
-                    const uint64_t src = (seg_index(g, b, wg) * g.segcap + ri.x) * GS;
+                    const uint64_t seg = seg_index(g, b, wg) * g.segcap;
                     const uint32_t room = ri.x < g.segcap ? (g.segcap - ri.x) * GS : 0;  // (an overflowed run: the flag is up, the redo overwrites out[])
-                    at[u] = off + lane;
-                    live[u] = lane < cnt && lane < room;
-                    if (live[u]) v[u] = vals[src + lane];
-                    for (uint32_t e = lane + 64; e < cnt && e < room; e += 64) stage[off + e] = vals[src + e];  // long runs (skewed batches)
+                    const uint32_t lim = cnt < room ? cnt : room;
+                    at[u] = off + e0;
+                    live[u] = e0 < lim;
+                    if (live[u]) v[u] = vals[value_word(seg, ri.x + e0 / GS, e0 % GS)];
+                    for (uint32_t e = e0 + rl; e < lim; e += rl) stage[off + e] = vals[value_word(seg, ri.x + e / GS, e % GS)];  // longer runs
                 }
             }
 #pragma unroll

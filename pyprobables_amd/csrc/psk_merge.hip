@@ -170,6 +170,7 @@ extern "C" int psk_merge_sum(psk_sketch *s, void *nccl_comm, void *stream)
     if (nranks == 1 && !g_merge_single_rank) return PSK_OK;
     const bool is_signed = s->kind == PSK_KIND_CMS;
     const uint64_t cells = s->logical_bytes / 4;
+    PSK_TRY(flush_combined(s, st));  // write-combined CBF updates belong to this replica's table
     // 1. the ranks agree on the SUM of their bounds on |counter| (a 32-bit SUM wraps silently): one 8-byte read-back
     PSK_TRY(ensure(s->s_aux, 16));
     long long *bsum = (long long *)s->s_aux.p;

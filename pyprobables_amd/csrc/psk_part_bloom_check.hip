@@ -37,7 +37,10 @@ static bool check_geometry(psk_sketch *s, uint64_t n, PartGeom *g, uint64_t *rou
     if (!part_slices(s->m, 20, 7, g)) return false;
     g->k = s->k;
     uint64_t rk = part_round_keys(n, s->k, PayKeyId::group);
-    if (rk > 0xFFFFFFFFULL) rk = 0xFFFFFFFFULL;  // 32-bit key ids inside a round
+    // a keyed group spells the tile's ordinal inside its workgroup in 4 bits: at most 16 tiles per workgroup and round
+    // (256 workgroups x 16 x 2048-key tiles for k <= 8; 512-key tiles beyond)
+    const uint64_t cap = (uint64_t)PayKeyId::max_tiles_per_wg * 256 * (s->k <= 8 ? 2048 : 512);
+    if (rk > cap) rk = cap;
     *round_keys = rk;
     return true;
 }

@@ -69,8 +69,11 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
                 const uint64_t ntiles = (cnt + g.tile - 1) / g.tile;
                 auto kern = k_lookup_collect<Query, KT>;
                 PSK_TRY(set_dyn_lds(kern, lds3));
+                uint32_t run_lanes = 8;  // lanes that copy one (tile, slice) run of values: the power of two at or above the mean run
+                while (run_lanes < 64 && (uint64_t)run_lanes * g.nbuckets < (uint64_t)g.tile * kq) run_lanes *= 2;
                 hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(kCollectThreads), lds3, st, query, g, cnt,
-                                   (const uint4 *)s->s_perm.p, (const uint2 *)s->s_run.p, (const uint32_t *)s->s_vals.p, stage_cap, out_dev + start);
+                                   (const uint4 *)s->s_perm.p, (const uint2 *)s->s_run.p, (const uint32_t *)s->s_vals.p, stage_cap, run_lanes,
+                                   out_dev + start);
                 HIP_TRY(hipGetLastError());
                 return (int)PSK_OK;
             });

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Run one engine operation repeatedly (for rocprofv3 --kernel-trace --stats / --pmc):  prof_ops.py <op> [n] [iters]
+ops: bloom_add bloom_check bloom_check_fresh cms_add cms_add_unit cms_check cbf_add cbf_check cbf_remove cbf25_check cbf25_add"""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import pyprobables_amd as pa  # noqa: E402
+from pyprobables_amd import _native as N  # noqa: E402
+
+op = sys.argv[1]
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+st = lambda: torch.cuda.current_stream().cuda_stream or None  # noqa: E731
+
+
+def gen(n, start):
+    t = torch.empty((n, 16), dtype=torch.uint8, device="cuda")
+    N.check(N.lib().psk_gen_keys16(t.data_ptr(), start, n, 0x5EED, 0, st()))
+    return t
+
+
+keys = gen(n, 0)
+w = torch.empty(n, dtype=torch.int32, device="cuda")
+N.check(N.lib().psk_gen_weights(w.data_ptr(), 0, n, 0x5EED, 0, st()))
+if op.startswith("bloom"):
+    s = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    s.add_many(keys)
+    fresh = gen(n, 7 * n)
+    fn = {"bloom_add": lambda: s.add_many(keys), "bloom_check": lambda: s.check_many(keys), "bloom_check_fresh": lambda: s.check_many(fresh)}[op]
+elif op.startswith("cms"):
+    s = pa.CountMinSketch(width=2**20, depth=5)
+    s.add_many(keys, w)
+    fn = {"cms_add": lambda: s.add_many(keys, w), "cms_add_unit": lambda: s.add_many(keys), "cms_check": lambda: s.check_many(keys)}[op]
+else:
+    s = pa.CountingBloomFilter(est_elements=3_500_000, false_positive_rate=0.01) if op.startswith("cbf25") else \
+        pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    s.add_many(keys)
+    fn = {"add": lambda: s.add_many(keys), "check": lambda: s.check_many(keys), "remove": lambda: s.remove_many(keys)}[op.split("_", 1)[1]]
+for _ in range(2):
+    fn()
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(iters):
+    fn()
+b.record()
+torch.cuda.synchronize()
+ms = a.elapsed_time(b) / iters
+print(f"{op}: {ms * 1e3:.1f} us per {n} keys -> {n / ms / 1e3:.0f} M/s")

@@ -117,6 +117,26 @@ def test_cfg4_cbf_1GiB_mixed_stream(pa, oracle):
     assert np.array_equal(last, oc.check_keys(oracle.gen_keys16((nb - 1) * B, B)))
 
 
+def test_cfg4_cbf_1GiB_mixed_stream_write_combined(pa, oracle):
+    """the same 50-batch stream with combine_updates=True (what bench.py --config cfg4 runs): 1M-key batches wait on the
+    device and reach the 1 GiB table as a few large partitioned updates; compared with the oracle at three points"""
+    B, nb = 1_000_000, 50
+    cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, combine_updates=True)
+    oc = oracle.OracleCBF(2**28, 7)
+    for b in range(nb):
+        cbf.add_many(dev_keys(b * B, B))
+        oc.update_keys(oracle.gen_keys16(b * B, B))
+        if b >= 1:
+            cbf.remove_many(dev_keys((b - 1) * B, B // 2))
+            oc.update_keys(oracle.gen_keys16((b - 1) * B, B // 2), -np.ones(B // 2, dtype=np.int64))
+        if b in (17, 33, nb - 1):
+            want = torch.from_numpy(oc.bloom.view(np.int32)).cuda()
+            assert torch.equal(cbf.table_tensor[: want.numel()], want), f"table differs after batch {b}"
+            del want
+            assert cbf.elements_added == oc.els_added
+    assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+
+
 def test_cfg4_cbf_1GiB_large_batches_take_the_two_level_path(pa, oracle):
     """8192 slices: one 10 M-key batch brings enough probes for coarse buckets -> k_part_split -> per-slice fold"""
     n = 10_000_000

@@ -454,3 +454,83 @@ def test_two_level_cbf_add_vs_oracle(pa, oracle, force_partition):
     oc.update_keys(keys[:100_000], np.ones(100_000, dtype=np.int64))
     assert np.array_equal(np.frombuffer(bytes(cbf.bloom), dtype=np.uint32), oc.bloom)
     assert cbf.elements_added == oc.els_added
+
+
+# ------------------------------------------------------------------ write-combined CBF updates
+def test_cbf_combined_updates_vs_oracle(pa, oracle, force_partition):
+    """psk_cbf_update_combined: batches wait on the device and are applied list by list (adds, then removes as plain
+    decrements); small lists here so that several flushes, the weighted / unit switch, host and device batches, a key
+    length change and the read-triggered flush are all exercised"""
+    from pyprobables_amd import _native as N
+
+    old = N.get_option("combine_keys")
+    N.set_option("combine_keys", 150_000)
+    try:
+        B = 40_000
+        cbf = pa.CountingBloomFilter(est_elements=2_000_000, false_positive_rate=0.01, combine_updates=True)
+        oc = oracle.OracleCBF(cbf.number_bits, cbf.number_hashes)
+        for b in range(12):
+            keys = oracle.gen_keys16(b * B, B)
+            if b % 3 == 2:      # weighted batch (after unit ones: the earlier entries get their 1s)
+                w = oracle.gen_weights(b * B, B).astype(np.uint32)
+                cbf.add_many(_dev(keys), w)
+                oc.update_keys(keys, w.astype(np.int64))
+            elif b % 3 == 1:    # host batch
+                cbf.add_many(keys)
+                oc.update_keys(keys)
+            else:
+                cbf.add_many(_dev(keys))
+                oc.update_keys(keys)
+            if b >= 1 and b % 3 != 0:   # unit removes of keys that were added with weight >= 1
+                prev = oracle.gen_keys16((b - 1) * B, B // 2)
+                cbf.remove_many(_dev(prev))
+                oc.update_keys(prev, -np.ones(B // 2, dtype=np.int64))
+            if b in (4, 9):     # a read in the middle sees everything handed over so far
+                probe = oracle.gen_keys16(b * B, 1000)
+                assert np.array_equal(np.asarray(cbf.check_many(probe)).view(np.uint32), oc.check_keys(probe))
+        assert np.array_equal(np.frombuffer(bytes(cbf.bloom), dtype=np.uint32), oc.bloom)
+        assert cbf.elements_added == oc.els_added
+        assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+        # other key lengths flush what waits and start a new list
+        k8 = np.ascontiguousarray(oracle.gen_keys16(7, 30_000)[:, :8])
+        cbf.add_many(_dev(k8))
+        cbf.add_many(_dev(oracle.gen_keys16(900_000, 10)))
+        oc.update_keys(k8)
+        oc.update_keys(oracle.gen_keys16(900_000, 10))
+        assert torch.equal(cbf.table_tensor[: cbf.number_bits].cpu(), torch.from_numpy(oc.bloom.view(np.int32)))
+        # a remove of an absent key is a contract violation in this mode (tallied), not a no-op
+        cbf.remove_many(_dev(oracle.gen_keys16(5_000_000, 100)))
+        assert cbf.batch_diagnostics()["violations"] > 0
+        # clear drops what waits
+        cbf.clear()
+        cbf.add_many(_dev(oracle.gen_keys16(0, 1000)))
+        cbf.clear()
+        assert cbf.elements_added == 0 and cbf._cnt_number_bits_set() == 0
+    finally:
+        N.set_option("combine_keys", old)
+
+
+def test_cbf_unchecked_remove_direct_and_partitioned_agree(pa, oracle, force_partition):
+    """the decrement kernels behind the combined path: direct (CbfSub) and partitioned (k_counter_apply fold) forms, incl. a
+    frozen counter (2^32-1 stays) and weights too large for the inline probe (exact spill)"""
+    from pyprobables_amd import _native as N
+
+    n = 120_000
+    keys = oracle.gen_keys16(3, n)
+    w = (1 + (np.arange(n) % 5)).astype(np.uint32)
+    w[::1000] = 70_000
+    results = []
+    for part in (1, 0):
+        N.set_option("partition", part)
+        cbf = pa.CountingBloomFilter(est_elements=900_000, false_positive_rate=0.01, combine_updates=True)
+        cbf.add_many(_dev(keys), w)
+        cbf.add_many(_dev(keys[:10]), np.full(10, 2**32 - 1, dtype=np.uint32))   # saturate a few counters: they freeze
+        cbf.remove_many(_dev(keys[: n // 2]), w[: n // 2])
+        results.append((cbf.table_tensor.clone(), cbf.elements_added, cbf.batch_diagnostics()["violations"]))
+    N.set_option("partition", 1)
+    assert torch.equal(results[0][0], results[1][0]) and results[0][1:] == results[1][1:]
+    oc = oracle.OracleCBF(cbf.number_bits, cbf.number_hashes)
+    oc.update_keys(keys, w.astype(np.int64))
+    oc.update_keys(keys[:10], np.full(10, 2**32 - 1, dtype=np.int64))
+    oc.update_keys(keys[: n // 2], -w[: n // 2].astype(np.int64))
+    assert np.array_equal(results[0][0].cpu().numpy().view(np.uint32)[: oc.m], oc.bloom)
