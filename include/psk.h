@@ -152,7 +152,7 @@ int psk_cbf_check(psk_sketch *s, int layout, const void *data, const uint64_t *o
                   uint32_t key_len, int where, uint32_t *out, void *stream);
 /* Write-combined updates (opt-in).  The fold of a big counter table read-modify-writes the whole table whatever the batch
  * brings (1 GiB at BASELINE config 4), so small batches -- the config's 1M-key add / remove batches -- are collected on the
- * device and applied as ONE partitioned update per list once "combine_keys" keys (psk_set_option, default 2^24) are waiting:
+ * device and applied as ONE partitioned update per list once "combine_keys" keys (psk_set_option, default 2^25) are waiting:
  * first the adds (countingbloom.py:135-155), then the removes as plain decrements of every index by the key's weight
  * (countingbloom.py:203-206 with to_remove == num_els).  Exact for well-formed streams (every remove targets a key with at
  * least num_els live inserts at that point of the stream; nothing saturates) -- the contract of the unordered batch ops

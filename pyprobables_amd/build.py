@@ -15,19 +15,21 @@ from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
-SOURCES = [
-    "psk_capi.hip",
+# launcher translation units built twice (power-of-two / Barrett instantiations, see psk_host.hpp PSK_TU_POW2)
+VARIANT_SOURCES = [
     "psk_part_bloom_add.hip",
     "psk_part_bloom_check.hip",
     "psk_part_cms_add.hip",
     "psk_part_cms_remove.hip",
     "psk_part_cbf.hip",
-    "psk_index_ops.hip",
-    "psk_merge.hip",
+    "psk_part_cbf_remove.hip",
     "psk_part_cms_check.hip",
     "psk_part_cbf_check.hip",
-    "psk_part_cbf_remove.hip",
 ]
+PLAIN_SOURCES = ["psk_capi.hip", "psk_index_ops.hip", "psk_merge.hip", "psk_part_dispatch.hip"]
+# (source, object stem, extra flags); the heaviest units first so that the pool stays busy to the end
+SOURCES = [(f, Path(f).stem + f"_v{v}", [f"-DPSK_TU_POW2={v}"]) for f in VARIANT_SOURCES for v in (1, 0)] + \
+          [(f, Path(f).stem, []) for f in PLAIN_SOURCES]
 HEADERS = ["psk_device.hpp", "psk_partition.hpp", "psk_host.hpp", "psk_part_counter.hpp", "psk_lookup.hpp", "psk_part_lookup.hpp", "psk_digest.hpp",
            "../../include/psk.h"]
 OUT = CSRC / "libpsk_hip.so"
@@ -52,11 +54,13 @@ def needs_build() -> bool:
     if not OUT.exists():
         return True
     t = OUT.stat().st_mtime
-    return _newest_header() > t or any((CSRC / f).stat().st_mtime > t for f in SOURCES)
+    return _newest_header() > t or any((CSRC / f).stat().st_mtime > t for f, _, _ in SOURCES)
 
 
-def _compile(src: str, force: bool, verbose: bool, objdir: Path, extra: list) -> Path:
-    obj = objdir / (Path(src).stem + ".o")
+def _compile(item, force: bool, verbose: bool, objdir: Path, extra: list) -> Path:
+    src, stem, flags = item
+    extra = [*extra, *flags]
+    obj = objdir / (stem + ".o")
     dep = max((CSRC / src).stat().st_mtime, _newest_header())
     if force or not obj.exists() or obj.stat().st_mtime < dep:
         cmd = [hipcc(), *FLAGS, *extra, "-c", str(CSRC / src), "-o", str(obj)]

@@ -133,6 +133,7 @@ static inline int grid_for_keys(uint64_t n)  // direct kernels: 256 CUs x 16 blo
 // Tunables (psk_set_option): the partitioned path is taken when the batch has at least g_part_min_keys keys and
 // the table geometry allows it; g_part_mode 0 = never, 1 = auto.
 extern PSK_HIDDEN int64_t g_part_mode, g_part_min_keys, g_part_max_keys, g_part_cache_bytes, g_part_two_level_slices, g_part_debug;
+extern PSK_HIDDEN int64_t g_lookup_layout, g_lookup_run_lanes;  // A/B knobs of the counter lookups (value layout, lanes per run)
 
 // slices of a table of `cells` cells; max_shift = log2(cells one LDS slice may hold)
 static inline bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_shift, PartGeom *g,
@@ -294,6 +295,14 @@ static inline uint64_t part_round_keys(uint64_t n, uint32_t k, int group)
     return rk ? rk : 1;
 }
 
+// Rounds of the two-level path: every round ends in a fold that read-modify-writes the WHOLE table (0.5 ms for 1 GiB),
+// which dwarfs what a cache-sized bucket buffer saves -- as few rounds as `partition_max_keys` allows
+static inline uint64_t part_round_keys_two_level(uint64_t n)
+{
+    const uint64_t rk = (uint64_t)g_part_max_keys < n ? (uint64_t)g_part_max_keys : n;
+    return rk ? rk : 1;
+}
+
 // Two-level path (k_part_scatter by coarse bucket, then k_part_split by slice) for tables cut into more than
 // `partition_two_level_slices` slices.  Fills level 1 (g1: coarse buckets) from the final geometry g2; the caller runs
 // launch_scatter(..., g1, ...) with an inline-mode payload, then split_level2<OUT>(), then pass 2 on s_part2 / s_cnt2.
@@ -342,16 +351,29 @@ static inline Batch sub_batch(const Batch &b, uint64_t start, uint64_t cnt)
     return sub;
 }
 
-// the launchers (one translation unit each); *done = false when the batch / table is not eligible
-PSK_HIDDEN int bloom_add_partitioned(psk_sketch *s, const Batch &b, hipStream_t st, bool *done);
-PSK_HIDDEN int bloom_check_partitioned(psk_sketch *s, const Batch &b, uint8_t *out_dev, hipStream_t st, bool *done);
-PSK_HIDDEN int bloom_check_begin_partitioned(psk_sketch *s, const Batch &b, hipStream_t st);
-PSK_HIDDEN int bloom_check_finish_partitioned(psk_sketch *s, uint8_t *out_dev, hipStream_t st, bool *redo_flag_possible);
-PSK_HIDDEN int cms_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);
-PSK_HIDDEN int cms_remove_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);
-PSK_HIDDEN int cbf_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);
+// The launchers (one translation unit each, and each of those built TWICE: -DPSK_TU_POW2=1 holds the instantiations for
+// power-of-two tables, =0 the Barrett ones -- the ~1000 k_part_scatter instantiations then build in parallel and the
+// critical path of a full build halves); *done = false when the batch / table is not eligible.
+// psk_part_dispatch.hip picks the variant by s->pow2.
+#ifdef PSK_TU_POW2
+constexpr bool kTuPow2 = PSK_TU_POW2 != 0;
+#define PSK_VARIANT_CAT2(name, v) name##_v##v
+#define PSK_VARIANT_CAT(name, v) PSK_VARIANT_CAT2(name, v)
+#define PSK_VARIANT(name) PSK_VARIANT_CAT(name, PSK_TU_POW2)
+#endif
+#define PSK_DECLARE_VARIANTS(ret, name, args) \
+    PSK_HIDDEN ret name args;                 \
+    PSK_HIDDEN ret name##_v0 args;            \
+    PSK_HIDDEN ret name##_v1 args;
+PSK_DECLARE_VARIANTS(int, bloom_add_partitioned, (psk_sketch *s, const Batch &b, hipStream_t st, bool *done))
+PSK_DECLARE_VARIANTS(int, bloom_check_partitioned, (psk_sketch *s, const Batch &b, uint8_t *out_dev, hipStream_t st, bool *done))
+PSK_DECLARE_VARIANTS(int, bloom_check_begin_partitioned, (psk_sketch *s, const Batch &b, hipStream_t st))
+PSK_DECLARE_VARIANTS(int, bloom_check_finish_partitioned, (psk_sketch *s, uint8_t *out_dev, hipStream_t st, bool *redo_flag_possible))
+PSK_DECLARE_VARIANTS(int, cms_add_partitioned, (psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done))
+PSK_DECLARE_VARIANTS(int, cms_remove_partitioned, (psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done))
+PSK_DECLARE_VARIANTS(int, cbf_add_partitioned, (psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done))
+PSK_DECLARE_VARIANTS(int, cbf_remove_partitioned, (psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done))  // unchecked decrement
 // lookups (psk_lookup.hpp): query = psk_query; out_dev int32 (min / mean) or int64 (mean-min); kk = hashes per key
-PSK_HIDDEN int cbf_remove_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done);  // unchecked decrement
+PSK_DECLARE_VARIANTS(int, cms_check_partitioned, (psk_sketch *s, const Batch &b, int query, int64_t els_added, void *out_dev, hipStream_t st, bool *done))
+PSK_DECLARE_VARIANTS(int, cbf_check_partitioned, (psk_sketch *s, const Batch &b, uint32_t kk, uint32_t *out_dev, hipStream_t st, bool *done))
 PSK_HIDDEN int flush_combined(psk_sketch *s, hipStream_t st);  // apply the write-combined CBF updates, if any (psk_capi.hip)
-PSK_HIDDEN int cms_check_partitioned(psk_sketch *s, const Batch &b, int query, int64_t els_added, void *out_dev, hipStream_t st, bool *done);
-PSK_HIDDEN int cbf_check_partitioned(psk_sketch *s, const Batch &b, uint32_t kk, uint32_t *out_dev, hipStream_t st, bool *done);

@@ -45,8 +45,9 @@ constexpr int kGatherDepth = 8;
 // Value layout (shaped like the probe buffer, 32 bytes per group): a chunk of 64 consecutive groups of a segment is stored
 // as [64 x first four values][64 x last four values], so that both 16-byte stores of a lane are lane-contiguous (1 KiB per
 // wave-instruction instead of two half-filled 2 KiB strides).  Segments are sized in whole chunks (host).
-__device__ __forceinline__ uint64_t value_word(uint64_t seg_base_groups, uint32_t group_in_seg, uint32_t e)
+__device__ __forceinline__ uint64_t value_word(uint64_t seg_base_groups, uint32_t group_in_seg, uint32_t e, uint32_t layout = 1)
 {
+    if (layout == 0) return (seg_base_groups + group_in_seg) * 8 + e;  // natural: the 8 values of a group side by side
     const uint64_t chunk = (seg_base_groups + (group_in_seg & ~63u)) * 8;  // in 32-bit words
     const uint32_t l = group_in_seg & 63u;
     return chunk + (e < 4 ? l * 4 + e : 256 + l * 4 + (e - 4));
@@ -54,7 +55,7 @@ __device__ __forceinline__ uint64_t value_word(uint64_t seg_base_groups, uint32_
 
 // the counter addressed by every probe of every group (pads: unspecified)
 static __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const uint32_t *tab, uint64_t tab_cells, PartGeom g,
-                                                                         const uint32_t *segcnt, const uint4 *buckets, uint4 *vals)
+                                                                         const uint32_t *segcnt, const uint4 *buckets, uint4 *vals, uint32_t layout)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = blockIdx.x;
@@ -83,9 +84,14 @@ static __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const u
 #pragma unroll
         for (int d = 0; d < kGatherDepth; ++d) {
             if (at[d] != ~0ULL) {  // (a wave's lanes hold consecutive groups of one chunk: group_in_seg % 64 == lane)
-                const uint64_t chunk4 = 2 * (at[d] - (threadIdx.x & 63));
-                vals[chunk4 + (threadIdx.x & 63)] = lo[d];
-                vals[chunk4 + 64 + (threadIdx.x & 63)] = hi[d];
+                if (layout == 0) {
+                    vals[2 * at[d]] = lo[d];
+                    vals[2 * at[d] + 1] = hi[d];
+                } else {
+                    const uint64_t chunk4 = 2 * (at[d] - (threadIdx.x & 63));
+                    vals[chunk4 + (threadIdx.x & 63)] = lo[d];
+                    vals[chunk4 + 64 + (threadIdx.x & 63)] = hi[d];
+                }
             }
         }
     });
@@ -156,7 +162,7 @@ constexpr int kCollectThreads = 1024;
 // dynamic LDS: runinfo[B] (uint2) | stage[stage_cap] (values in the tile's sorted order)
 template <class Query, int KT>
 __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query, PartGeom g, uint64_t n, const uint4 *perm, const uint2 *runinfo,
-                                                                    const uint32_t *vals, uint32_t stage_cap, uint32_t run_lanes,
+                                                                    const uint32_t *vals, uint32_t stage_cap, uint32_t run_lanes, uint32_t layout,
                                                                     typename Query::Out *out)
 {
     constexpr int GS = 8, P4 = (KT + 7) / 8;
@@ -190,8 +196,8 @@ __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query,
                     const uint32_t lim = cnt < room ? cnt : room;
                     at[u] = off + e0;
                     live[u] = e0 < lim;
-                    if (live[u]) v[u] = vals[value_word(seg, ri.x + e0 / GS, e0 % GS)];
-                    for (uint32_t e = e0 + rl; e < lim; e += rl) stage[off + e] = vals[value_word(seg, ri.x + e / GS, e % GS)];  // longer runs
+                    if (live[u]) v[u] = vals[value_word(seg, ri.x + e0 / GS, e0 % GS, layout)];
+                    for (uint32_t e = e0 + rl; e < lim; e += rl) stage[off + e] = vals[value_word(seg, ri.x + e / GS, e % GS, layout)];  // longer runs
                 }
             }
 #pragma unroll

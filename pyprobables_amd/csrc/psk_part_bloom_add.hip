@@ -2,7 +2,7 @@
 #include "psk_host.hpp"
 
 // Bloom insert through the partitioned path; *done = false when this batch/table is not eligible
-int bloom_add_partitioned(psk_sketch *s, const Batch &b, hipStream_t st, bool *done)
+int PSK_VARIANT(bloom_add_partitioned)(psk_sketch *s, const Batch &b, hipStream_t st, bool *done)
 {
     *done = false;
     if (!part_wanted(b.n, s->k)) return PSK_OK;
@@ -13,7 +13,7 @@ int bloom_add_partitioned(psk_sketch *s, const Batch &b, hipStream_t st, bool *d
     uint32_t sub_bits = 0;
     if (two_level_geometry(g, &g1, &sub_bits)) {
         // more slices than one pass can bin well: coarse buckets first (inline 32-bit probes), then k_part_split
-        const uint64_t round_keys = part_round_keys(b.n, s->k, PayZero::group);
+        const uint64_t round_keys = part_round_keys_two_level(b.n);
         for (uint64_t start = 0; start < b.n; start += round_keys) {
             const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
             const Batch sub = sub_batch(b, start, cnt);
@@ -23,11 +23,8 @@ int bloom_add_partitioned(psk_sketch *s, const Batch &b, hipStream_t st, bool *d
                 using Src = decltype(src);
                 return with_kt<Src>(s->k, [&](auto kt) {
                     constexpr int KT = decltype(kt)::value;
-                    if (s->pow2)
-                        return launch_scatter<Src, IdxBloom<true>, PayZero, SpillBloomOr, KT>(s, src, IdxBloom<true>{s->md}, PayZero{},
+                    return launch_scatter<Src, IdxBloom<kTuPow2>, PayZero, SpillBloomOr, KT>(s, src, IdxBloom<kTuPow2>{s->md}, PayZero{},
                                                                                               spill, &g1, cnt, st);
-                    return launch_scatter<Src, IdxBloom<false>, PayZero, SpillBloomOr, KT>(s, src, IdxBloom<false>{s->md}, PayZero{},
-                                                                                           spill, &g1, cnt, st);
                 });
             }));
             if (!handled) return PSK_OK;
@@ -53,11 +50,8 @@ int bloom_add_partitioned(psk_sketch *s, const Batch &b, hipStream_t st, bool *d
             return with_kt<Src>(s->k, [&](auto kt) {
                 constexpr int KT = decltype(kt)::value;
                 SpillBloomOr spill{(uint32_t *)s->table};
-                if (s->pow2)
-                    return launch_scatter<Src, IdxBloom<true>, PayNone, SpillBloomOr, KT>(s, src, IdxBloom<true>{s->md}, PayNone{},
+                return launch_scatter<Src, IdxBloom<kTuPow2>, PayNone, SpillBloomOr, KT>(s, src, IdxBloom<kTuPow2>{s->md}, PayNone{},
                                                                                           spill, &g, cnt, st);
-                return launch_scatter<Src, IdxBloom<false>, PayNone, SpillBloomOr, KT>(s, src, IdxBloom<false>{s->md}, PayNone{},
-                                                                                       spill, &g, cnt, st);
             });
         }));
         if (!handled) return PSK_OK;  // layout without a partitioned instantiation: nothing was launched

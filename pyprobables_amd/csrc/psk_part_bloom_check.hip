@@ -11,11 +11,8 @@ static int check_round_scatter(psk_sketch *s, const Batch &sub, uint64_t cnt, ui
         return with_kt<Src>(s->k, [&](auto kt) {
             constexpr int KT = decltype(kt)::value;
             SpillBloomTest spill{(const uint32_t *)s->table, out, defer};
-            if (s->pow2)
-                return launch_scatter<Src, IdxBloom<true>, PayKeyId, SpillBloomTest, KT>(s, src, IdxBloom<true>{s->md}, PayKeyId{},
+            return launch_scatter<Src, IdxBloom<kTuPow2>, PayKeyId, SpillBloomTest, KT>(s, src, IdxBloom<kTuPow2>{s->md}, PayKeyId{},
                                                                                          spill, g, cnt, st);
-            return launch_scatter<Src, IdxBloom<false>, PayKeyId, SpillBloomTest, KT>(s, src, IdxBloom<false>{s->md}, PayKeyId{},
-                                                                                      spill, g, cnt, st);
         });
     });
 }
@@ -45,7 +42,7 @@ static bool check_geometry(psk_sketch *s, uint64_t n, PartGeom *g, uint64_t *rou
     return true;
 }
 
-int bloom_check_partitioned(psk_sketch *s, const Batch &b, uint8_t *out_dev, hipStream_t st, bool *done)
+int PSK_VARIANT(bloom_check_partitioned)(psk_sketch *s, const Batch &b, uint8_t *out_dev, hipStream_t st, bool *done)
 {
     *done = false;
     PartGeom g;
@@ -67,7 +64,7 @@ int bloom_check_partitioned(psk_sketch *s, const Batch &b, uint8_t *out_dev, hip
 
 // Split lookup, first half: hash + partition the first round now (this never reads the table), e.g. while a
 // multi-GPU merge of the table is still in flight on another stream.
-int bloom_check_begin_partitioned(psk_sketch *s, const Batch &b, hipStream_t st)
+int PSK_VARIANT(bloom_check_begin_partitioned)(psk_sketch *s, const Batch &b, hipStream_t st)
 {
     s->pend.active = true;
     s->pend.scattered = false;
@@ -85,7 +82,7 @@ int bloom_check_begin_partitioned(psk_sketch *s, const Batch &b, hipStream_t st)
 
 // second half: pass 2 of the first round, then the remaining rounds in full.  *redo_flag_possible tells the caller
 // to follow up with the flag-guarded direct check of the first round (an overflowed segment dropped probes).
-int bloom_check_finish_partitioned(psk_sketch *s, uint8_t *out_dev, hipStream_t st, bool *redo_flag_possible)
+int PSK_VARIANT(bloom_check_finish_partitioned)(psk_sketch *s, uint8_t *out_dev, hipStream_t st, bool *redo_flag_possible)
 {
     *redo_flag_possible = false;
     const Batch &b = s->pend.b;

@@ -2,21 +2,15 @@
 #include "psk_part_lookup.hpp"
 
 // countingbloom.py:166-174 check_alt: min over the kk supplied hashes (kk = k for key layouts)
-int cbf_check_partitioned(psk_sketch *s, const Batch &b, uint32_t kk, uint32_t *out_dev, hipStream_t st, bool *done)
+int PSK_VARIANT(cbf_check_partitioned)(psk_sketch *s, const Batch &b, uint32_t kk, uint32_t *out_dev, hipStream_t st, bool *done)
 {
     auto redo = [&](const uint32_t *flag, hipStream_t st2) {
         bool handled = false;
         return with_part_source(b, &handled, [&](auto src) {
             using Src = decltype(src);
-            if (s->pow2) {
-                using Op = CbfCheck<true>;
-                hipLaunchKernelGGL((k_apply_if<Src, Op>), dim3(grid_for_keys(b.n)), dim3(kBlock), 0, st2, flag, src,
-                                   Op{(const uint32_t *)s->table, s->md, kk, out_dev}, b.n);
-            } else {
-                using Op = CbfCheck<false>;
-                hipLaunchKernelGGL((k_apply_if<Src, Op>), dim3(grid_for_keys(b.n)), dim3(kBlock), 0, st2, flag, src,
-                                   Op{(const uint32_t *)s->table, s->md, kk, out_dev}, b.n);
-            }
+            using Op = CbfCheck<kTuPow2>;
+            hipLaunchKernelGGL((k_apply_if<Src, Op>), dim3(grid_for_keys(b.n)), dim3(kBlock), 0, st2, flag, src,
+                               Op{(const uint32_t *)s->table, s->md, kk, out_dev}, b.n);
             HIP_TRY(hipGetLastError());
             return (int)PSK_OK;
         });

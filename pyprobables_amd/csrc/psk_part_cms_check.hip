@@ -14,20 +14,18 @@ static int redo_direct(const Batch &b, const Op &op, const uint32_t *flag, hipSt
 }
 
 // countminsketch.py:332-340 check_alt under the min / mean (int32 out) or mean-min (int64 out) query
-int cms_check_partitioned(psk_sketch *s, const Batch &b, int query, int64_t els_added, void *out_dev, hipStream_t st, bool *done)
+int PSK_VARIANT(cms_check_partitioned)(psk_sketch *s, const Batch &b, int query, int64_t els_added, void *out_dev, hipStream_t st, bool *done)
 {
     const uint64_t cells = s->m * (uint64_t)s->k;
     if (query == PSK_Q_MEANMIN) {
         auto redo = [&](const uint32_t *flag, hipStream_t st2) {
-            if (s->pow2) return redo_direct(b, CmsCheckMeanMin<true>{(const int32_t *)s->table, s->md, s->k, els_added, (int64_t *)out_dev}, flag, st2);
-            return redo_direct(b, CmsCheckMeanMin<false>{(const int32_t *)s->table, s->md, s->k, els_added, (int64_t *)out_dev}, flag, st2);
+            return redo_direct(b, CmsCheckMeanMin<kTuPow2>{(const int32_t *)s->table, s->md, s->k, els_added, (int64_t *)out_dev}, flag, st2);
         };
         return counter_check_partitioned<IdxCms>(s, b, s->k, cells, QueryCmsMeanMin{els_added, (int64_t)s->m}, (int64_t *)out_dev, st, done, redo);
     }
     const bool mean = query == PSK_Q_MEAN;
     auto redo = [&](const uint32_t *flag, hipStream_t st2) {
-        if (s->pow2) return redo_direct(b, CmsCheck<true>{(const int32_t *)s->table, s->md, s->k, (int32_t *)out_dev, mean}, flag, st2);
-        return redo_direct(b, CmsCheck<false>{(const int32_t *)s->table, s->md, s->k, (int32_t *)out_dev, mean}, flag, st2);
+        return redo_direct(b, CmsCheck<kTuPow2>{(const int32_t *)s->table, s->md, s->k, (int32_t *)out_dev, mean}, flag, st2);
     };
     if (mean) return counter_check_partitioned<IdxCms>(s, b, s->k, cells, QueryCmsMean{}, (int32_t *)out_dev, st, done, redo);
     return counter_check_partitioned<IdxCms>(s, b, s->k, cells, QueryCmsMin{}, (int32_t *)out_dev, st, done, redo);

@@ -1,7 +1,7 @@
 // partitioned CountMinSketch remove launcher (own translation unit: parallel build)
 #include "psk_part_counter.hpp"
 
-int cms_remove_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done)
+int PSK_VARIANT(cms_remove_partitioned)(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done)
 {
     return counter_add_partitioned<IdxCms, true, true>(s, b, w_dev, s->m * (uint64_t)s->k, st, done);
 }

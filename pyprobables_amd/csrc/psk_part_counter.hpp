@@ -21,7 +21,7 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
         // Pass 2 read-modify-writes every slice of the table: only worth it when the batch brings enough probes
         // (direct atomics into a 1 GiB table run at ~20 G/s; the table RMW at ~4 TB/s)
         if (b.n * (uint64_t)s->k < cells / 8) return PSK_OK;
-        const uint64_t round_keys = part_round_keys(b.n, s->k, PayWeight::group);
+        const uint64_t round_keys = part_round_keys_two_level(b.n);
         SpillCounter<SIGNED> spill{(uint32_t *)s->table, w_dev == nullptr, NEG, sat2};
         for (uint64_t start = 0; start < b.n; start += round_keys) {
             const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
@@ -32,8 +32,7 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
                 using Src = decltype(src);
                 return with_kt<Src>(s->k, [&](auto kt) {
                     constexpr int KT = decltype(kt)::value;
-                    if (s->pow2) return launch_scatter<Src, IDX<true>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<true>{s->md}, pay, spill, &g1, cnt, st);
-                    return launch_scatter<Src, IDX<false>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<false>{s->md}, pay, spill, &g1, cnt, st);
+                    return launch_scatter<Src, IDX<kTuPow2>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<kTuPow2>{s->md}, pay, spill, &g1, cnt, st);
                 });
             }));
             if (!handled) return PSK_OK;
@@ -71,11 +70,9 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
                 SpillCounter<SIGNED> spill{(uint32_t *)s->table, w_dev == nullptr, NEG, sat};
                 if (w_dev) {
                     PayWeight pay{w_dev + start};
-                    if (s->pow2) return launch_scatter<Src, IDX<true>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<true>{s->md}, pay, spill, &g, cnt, st);
-                    return launch_scatter<Src, IDX<false>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<false>{s->md}, pay, spill, &g, cnt, st);
+                    return launch_scatter<Src, IDX<kTuPow2>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<kTuPow2>{s->md}, pay, spill, &g, cnt, st);
                 }
-                if (s->pow2) return launch_scatter<Src, IDX<true>, PayUnit, SpillCounter<SIGNED>, KT>(s, src, IDX<true>{s->md}, PayUnit{}, spill, &g, cnt, st);
-                return launch_scatter<Src, IDX<false>, PayUnit, SpillCounter<SIGNED>, KT>(s, src, IDX<false>{s->md}, PayUnit{}, spill, &g, cnt, st);
+                return launch_scatter<Src, IDX<kTuPow2>, PayUnit, SpillCounter<SIGNED>, KT>(s, src, IDX<kTuPow2>{s->md}, PayUnit{}, spill, &g, cnt, st);
             });
         }));
         if (!handled) return PSK_OK;

@@ -52,14 +52,13 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
                 PSK_TRY(ensure(s->s_run, max_tiles * g.nbuckets * 8));
                 PayUnitLookup pay{(uint4 *)s->s_perm.p, (uint2 *)s->s_run.p};
                 SpillRaiseFlag spill{flag};
-                if (s->pow2) PSK_TRY((launch_scatter<Src, IDX<true>, PayUnitLookup, SpillRaiseFlag, KT>(s, src, IDX<true>{s->md}, pay, spill, &g, cnt, st)));
-                else PSK_TRY((launch_scatter<Src, IDX<false>, PayUnitLookup, SpillRaiseFlag, KT>(s, src, IDX<false>{s->md}, pay, spill, &g, cnt, st)));
+                PSK_TRY((launch_scatter<Src, IDX<kTuPow2>, PayUnitLookup, SpillRaiseFlag, KT>(s, src, IDX<kTuPow2>{s->md}, pay, spill, &g, cnt, st)));
                 // pass 2: the counters behind every probe, in the probe buffer's shape
                 PSK_TRY(ensure(s->s_vals, (uint64_t)g.nbuckets * g.nwg * g.segcap * 32 + 256));
                 const size_t lds2 = (size_t)4 << g.shift;
                 PSK_TRY(set_dyn_lds(k_counter_gather, lds2));
                 hipLaunchKernelGGL(k_counter_gather, dim3(g.nbuckets), dim3(kApplyThreads), lds2, st, (const uint32_t *)s->table, cells, g,
-                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint4 *)s->s_vals.p);
+                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint4 *)s->s_vals.p, (uint32_t)g_lookup_layout);
                 HIP_TRY(hipGetLastError());
                 // pass 3: back to key order, query epilogue
                 const uint32_t kq = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
@@ -71,9 +70,10 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
                 PSK_TRY(set_dyn_lds(kern, lds3));
                 uint32_t run_lanes = 8;  // lanes that copy one (tile, slice) run of values: the power of two at or above the mean run
                 while (run_lanes < 64 && (uint64_t)run_lanes * g.nbuckets < (uint64_t)g.tile * kq) run_lanes *= 2;
+                if (g_lookup_run_lanes > 0) run_lanes = (uint32_t)g_lookup_run_lanes;
                 hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(kCollectThreads), lds3, st, query, g, cnt,
                                    (const uint4 *)s->s_perm.p, (const uint2 *)s->s_run.p, (const uint32_t *)s->s_vals.p, stage_cap, run_lanes,
-                                   out_dev + start);
+                                   (uint32_t)g_lookup_layout, out_dev + start);
                 HIP_TRY(hipGetLastError());
                 return (int)PSK_OK;
             });
