@@ -133,7 +133,7 @@ static inline int grid_for_keys(uint64_t n)  // direct kernels: 256 CUs x 16 blo
 // Tunables (psk_set_option): the partitioned path is taken when the batch has at least g_part_min_keys keys and
 // the table geometry allows it; g_part_mode 0 = never, 1 = auto.
 extern PSK_HIDDEN int64_t g_part_mode, g_part_min_keys, g_part_max_keys, g_part_cache_bytes, g_part_two_level_slices, g_part_debug;
-extern PSK_HIDDEN int64_t g_lookup_layout, g_lookup_run_lanes;  // A/B knobs of the counter lookups (value layout, lanes per run)
+extern PSK_HIDDEN int64_t g_lookup_run_lanes;  // bench knob of the counter lookups (lanes per run in pass 3; 0 = auto)
 
 // slices of a table of `cells` cells; max_shift = log2(cells one LDS slice may hold)
 static inline bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_shift, PartGeom *g,
@@ -191,7 +191,6 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
     const double mean = (double)tiles_per_wg * Tile::TILE * kk / (double)g->nbuckets;  // probes per segment
     // 16-byte groups per segment: mean/GS, + ~half a group of padding per (tile, slice) run, + 8 sigma
     uint64_t segcap = (uint64_t)(mean / Tile::GS + 0.5 * (double)tiles_per_wg + 8.0 * __builtin_sqrt(mean) / Tile::GS + 16.0);
-    if (pay_is_lookup<Pay>::value) segcap = (segcap + 63) & ~63ULL;  // lookups: the value buffer is laid out in 64-group chunks
     if constexpr (Pay::mode == kModeKeyed) {
         if (tiles_per_wg > 16) return fail(PSK_EINVAL, "keyed lookup round of %llu keys needs %llu tiles per workgroup (max 16)",
                                            (unsigned long long)n, (unsigned long long)tiles_per_wg);
@@ -293,6 +292,16 @@ static inline uint64_t part_round_keys(uint64_t n, uint32_t k, int group)
         }
     }
     return rk ? rk : 1;
+}
+
+// Big tables (>= 64 MiB): pass 2 reads (lookups) or read-modify-writes (updates) the WHOLE table once per round, which costs
+// more than what a cache-sized bucket buffer saves -- rounds as large as `partition_max_keys` allows
+static inline uint64_t part_round_keys_big_table(uint64_t n, uint32_t k, int group, uint64_t table_bytes)
+{
+    const uint64_t rk = part_round_keys(n, k, group);
+    if (table_bytes < (64ULL << 20)) return rk;
+    const uint64_t big = (uint64_t)g_part_max_keys < n ? (uint64_t)g_part_max_keys : n;
+    return big > rk ? big : rk;
 }
 
 // Rounds of the two-level path: every round ends in a fold that read-modify-writes the WHOLE table (0.5 ms for 1 GiB),

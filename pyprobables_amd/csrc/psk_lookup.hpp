@@ -42,20 +42,9 @@ struct SpillRaiseFlag {  // a lookup probe that found its segment full: the roun
 // ------------------------------------------------------------------------------------ pass 2
 constexpr int kGatherDepth = 8;
 
-// Value layout (shaped like the probe buffer, 32 bytes per group): a chunk of 64 consecutive groups of a segment is stored
-// as [64 x first four values][64 x last four values], so that both 16-byte stores of a lane are lane-contiguous (1 KiB per
-// wave-instruction instead of two half-filled 2 KiB strides).  Segments are sized in whole chunks (host).
-__device__ __forceinline__ uint64_t value_word(uint64_t seg_base_groups, uint32_t group_in_seg, uint32_t e, uint32_t layout = 1)
-{
-    if (layout == 0) return (seg_base_groups + group_in_seg) * 8 + e;  // natural: the 8 values of a group side by side
-    const uint64_t chunk = (seg_base_groups + (group_in_seg & ~63u)) * 8;  // in 32-bit words
-    const uint32_t l = group_in_seg & 63u;
-    return chunk + (e < 4 ? l * 4 + e : 256 + l * 4 + (e - 4));
-}
-
-// the counter addressed by every probe of every group (pads: unspecified)
+// vals[group * 8 + e] = the counter addressed by every probe of every group (pads: unspecified)
 static __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const uint32_t *tab, uint64_t tab_cells, PartGeom g,
-                                                                         const uint32_t *segcnt, const uint4 *buckets, uint4 *vals, uint32_t layout)
+                                                                         const uint32_t *segcnt, const uint4 *buckets, uint4 *vals)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = blockIdx.x;
@@ -83,15 +72,9 @@ static __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const u
         }
 #pragma unroll
         for (int d = 0; d < kGatherDepth; ++d) {
-            if (at[d] != ~0ULL) {  // (a wave's lanes hold consecutive groups of one chunk: group_in_seg % 64 == lane)
-                if (layout == 0) {
-                    vals[2 * at[d]] = lo[d];
-                    vals[2 * at[d] + 1] = hi[d];
-                } else {
-                    const uint64_t chunk4 = 2 * (at[d] - (threadIdx.x & 63));
-                    vals[chunk4 + (threadIdx.x & 63)] = lo[d];
-                    vals[chunk4 + 64 + (threadIdx.x & 63)] = hi[d];
-                }
+            if (at[d] != ~0ULL) {
+                vals[2 * at[d]] = lo[d];
+                vals[2 * at[d] + 1] = hi[d];
             }
         }
     });
@@ -162,7 +145,7 @@ constexpr int kCollectThreads = 1024;
 // dynamic LDS: runinfo[B] (uint2) | stage[stage_cap] (values in the tile's sorted order)
 template <class Query, int KT>
 __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query, PartGeom g, uint64_t n, const uint4 *perm, const uint2 *runinfo,
-                                                                    const uint32_t *vals, uint32_t stage_cap, uint32_t run_lanes, uint32_t layout,
+                                                                    const uint32_t *vals, uint32_t stage_cap, uint32_t run_lanes,
                                                                     typename Query::Out *out)
 {
     constexpr int GS = 8, P4 = (KT + 7) / 8;
@@ -172,13 +155,47 @@ __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query,
     const uint32_t B = g.nbuckets, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t k = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
     const uint64_t ntiles = (n + g.tile - 1) / g.tile;
+    // Software pipeline over tiles (a workgroup walks ~10 tiles; each tile used to be three dependent global round trips:
+    // runinfo -> runs of values -> perm): the NEXT tile's runinfo is fetched into registers while this tile's runs are
+    // copied, and this tile's perm[] entries are requested before the copy starts.
+    constexpr int kInfoRegs = kPartMaxBuckets / kCollectThreads;  // slices per thread (<= 2048 slices)
+    constexpr int kPre = 2;                                        // keys per thread whose perm[] is prefetched (tiles <= 2048 keys)
+    uint2 nxt[kInfoRegs];
+#pragma unroll
+    for (int r = 0; r < kInfoRegs; ++r) {
+        const uint32_t b = threadIdx.x + (uint32_t)r * kCollectThreads;
+        nxt[r] = (blockIdx.x < ntiles && b < B) ? runinfo[(uint64_t)blockIdx.x * B + b] : make_uint2(0, 0);
+    }
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t wg = (uint32_t)(tile % g.nwg);  // the pass-1 workgroup that owned this tile names the segments
-        for (uint32_t b = threadIdx.x; b < B; b += kCollectThreads) info[b] = runinfo[tile * B + b];
+        const uint64_t base = tile * g.tile;
+        const uint64_t end = base + g.tile < n ? base + g.tile : n;
+#pragma unroll
+        for (int r = 0; r < kInfoRegs; ++r) {
+            const uint32_t b = threadIdx.x + (uint32_t)r * kCollectThreads;
+            if (b < B) info[b] = nxt[r];
+        }
+        uint4 pw[kPre][P4];
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+            const uint64_t i = base + threadIdx.x + (uint64_t)q * kCollectThreads;
+#pragma unroll
+            for (int c = 0; c < P4; ++c) pw[q][c] = perm[(i < end ? i : base) * P4 + c];  // clamped, never branched around
+        }
         __syncthreads();
+        {
+            const uint64_t nt = tile + gridDim.x;
+#pragma unroll
+            for (int r = 0; r < kInfoRegs; ++r) {
+                const uint32_t b = threadIdx.x + (uint32_t)r * kCollectThreads;
+                nxt[r] = (nt < ntiles && b < B) ? runinfo[nt * B + b] : make_uint2(0, 0);
+            }
+        }
         // ---- the tile's runs of values, back into the sorted order of pass 1's LDS stage.  A run is ~tile*k/B values, often
         // far fewer than 64: `run_lanes` (a power of two, host's choice from that mean) lanes take one run, 64 / run_lanes
-        // runs ride one wave-instruction, four instructions are in flight per lane before LDS is written.
+        // runs ride one wave-instruction, four instructions are in flight per lane before LDS is written.  (Measured on
+        // MI355X: dword copies beat 16-byte pieces here -- 49 vs 64 us per 16.7 M values -- and a layout that makes pass 2's
+        // stores lane-contiguous costs pass 3 more than it saves pass 2.)
         const uint32_t rl = run_lanes, per_wave = 64u / rl, sub = lane / rl, e0 = lane % rl;
         const uint32_t stride = (kCollectThreads / 64) * per_wave;
         for (uint32_t b0 = wave * per_wave + sub; b0 < B; b0 += 4 * stride) {
@@ -191,13 +208,13 @@ __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query,
                 if (b < B) {
                     const uint2 ri = info[b];
                     const uint32_t cnt = ri.y & 0xFFFFu, off = ri.y >> 16;
-                    const uint64_t seg = seg_index(g, b, wg) * g.segcap;
+                    const uint64_t src = (seg_index(g, b, wg) * g.segcap + ri.x) * GS;
                     const uint32_t room = ri.x < g.segcap ? (g.segcap - ri.x) * GS : 0;  // (an overflowed run: the flag is up, the redo overwrites out[])
                     const uint32_t lim = cnt < room ? cnt : room;
                     at[u] = off + e0;
                     live[u] = e0 < lim;
-                    if (live[u]) v[u] = vals[value_word(seg, ri.x + e0 / GS, e0 % GS, layout)];
-                    for (uint32_t e = e0 + rl; e < lim; e += rl) stage[off + e] = vals[value_word(seg, ri.x + e / GS, e % GS, layout)];  // longer runs
+                    if (live[u]) v[u] = vals[src + e0];
+                    for (uint32_t e = e0 + rl; e < lim; e += rl) stage[off + e] = vals[src + e];  // longer runs
                 }
             }
 #pragma unroll
@@ -206,13 +223,11 @@ __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query,
         }
         __syncthreads();
         // ---- every key picks its k values through perm[]
-        const uint64_t base = tile * g.tile;
-        const uint64_t end = base + g.tile < n ? base + g.tile : n;
-        for (uint64_t i = base + threadIdx.x; i < end; i += kCollectThreads) {
+        auto finish_key = [&](uint64_t i, const uint4 (&w4)[P4]) {
             uint32_t p[8 * P4];
 #pragma unroll
             for (int c = 0; c < P4; ++c) {
-                const uint4 w = perm[i * P4 + c];
+                const uint4 w = w4[c];
                 p[8 * c + 0] = w.x & 0xFFFFu; p[8 * c + 1] = w.x >> 16; p[8 * c + 2] = w.y & 0xFFFFu; p[8 * c + 3] = w.y >> 16;
                 p[8 * c + 4] = w.z & 0xFFFFu; p[8 * c + 5] = w.z >> 16; p[8 * c + 6] = w.w & 0xFFFFu; p[8 * c + 7] = w.w >> 16;
             }
@@ -220,6 +235,17 @@ __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query,
 #pragma unroll
             for (int j = 0; j < KT; ++j) v[j] = (uint32_t)j < k ? stage[p[j] < stage_cap ? p[j] : 0] : 0u;
             out[i] = query.template operator()<KT>(v, k);
+        };
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+            const uint64_t i = base + threadIdx.x + (uint64_t)q * kCollectThreads;
+            if (i < end) finish_key(i, pw[q]);
+        }
+        for (uint64_t i = base + threadIdx.x + (uint64_t)kPre * kCollectThreads; i < end; i += kCollectThreads) {  // tiles beyond 2048 keys (k <= 4)
+            uint4 w4[P4];
+#pragma unroll
+            for (int c = 0; c < P4; ++c) w4[c] = perm[i * P4 + c];
+            finish_key(i, w4);
         }
         __syncthreads();
     }

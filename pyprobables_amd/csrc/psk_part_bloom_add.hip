@@ -40,7 +40,7 @@ int PSK_VARIANT(bloom_add_partitioned)(psk_sketch *s, const Batch &b, hipStream_
         return PSK_OK;
     }
     if (g.nbuckets > (uint32_t)kPartMaxBuckets) return PSK_OK;
-    const uint64_t round_keys = part_round_keys(b.n, s->k, PayNone::group);
+    const uint64_t round_keys = part_round_keys_big_table(b.n, s->k, PayNone::group, s->padded_bytes);
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
         const Batch sub = sub_batch(b, start, cnt);

@@ -33,7 +33,7 @@ static bool check_geometry(psk_sketch *s, uint64_t n, PartGeom *g, uint64_t *rou
     if (!part_wanted(n, s->k, 4)) return false;
     if (!part_slices(s->m, 20, 7, g)) return false;
     g->k = s->k;
-    uint64_t rk = part_round_keys(n, s->k, PayKeyId::group);
+    uint64_t rk = part_round_keys_big_table(n, s->k, PayKeyId::group, s->padded_bytes);
     // a keyed group spells the tile's ordinal inside its workgroup in 4 bits: at most 16 tiles per workgroup and round
     // (256 workgroups x 16 x 2048-key tiles for k <= 8; 512-key tiles beyond)
     const uint64_t cap = (uint64_t)PayKeyId::max_tiles_per_wg * 256 * (s->k <= 8 ? 2048 : 512);

@@ -57,7 +57,7 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
         return PSK_OK;
     }
     if (g.nbuckets > (uint32_t)kPartMaxBuckets) return PSK_OK;
-    const uint64_t round_keys = part_round_keys(b.n, s->k, w_dev ? PayWeight::group : PayUnit::group);
+    const uint64_t round_keys = part_round_keys_big_table(b.n, s->k, w_dev ? PayWeight::group : PayUnit::group, s->padded_bytes);
     unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;

@@ -4,21 +4,12 @@
 #include "psk_host.hpp"
 #include "psk_lookup.hpp"
 
-// keys per round such that what one round writes and reads back (probes 2 B, values 4 B, perm 16 B per 8 probes) stays
-// inside the Infinity Cache budget (`partition_cache_bytes`), like part_round_keys does for the update paths
-static inline uint64_t lookup_round_keys(uint64_t n, uint32_t k)
+// Keys per round.  Measured on MI355X (10 M CMS lookups): one round of 10 M keys 432 us, two 446, three cache-sized ones 464
+// -- the three kernels of a round stream ~50 B per key once and every round re-reads the table, so unlike the update
+// paths (part_round_keys) rounds are only cut at `partition_max_keys`.
+static inline uint64_t lookup_round_keys(uint64_t n, uint32_t)
 {
-    uint64_t rk = (uint64_t)g_part_max_keys < n ? (uint64_t)g_part_max_keys : n;
-    if (g_part_cache_bytes > 0 && n) {
-        const double per_key = (double)k * 6.0 * 1.2 + 16.0 * (double)((k + 7) / 8);
-        const double total = per_key * (double)n;
-        if (total > 1.25 * (double)g_part_cache_bytes) {
-            const uint64_t rounds = (uint64_t)(total / (double)g_part_cache_bytes) + 1;
-            uint64_t per = ((n + rounds - 1) / rounds + 4095) & ~4095ULL;
-            if (per < 1u << 20) per = 1u << 20;
-            if (per < rk) rk = per;
-        }
-    }
+    const uint64_t rk = (uint64_t)g_part_max_keys < n ? (uint64_t)g_part_max_keys : n;
     return rk ? rk : 1;
 }
 
@@ -58,7 +49,7 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
                 const size_t lds2 = (size_t)4 << g.shift;
                 PSK_TRY(set_dyn_lds(k_counter_gather, lds2));
                 hipLaunchKernelGGL(k_counter_gather, dim3(g.nbuckets), dim3(kApplyThreads), lds2, st, (const uint32_t *)s->table, cells, g,
-                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint4 *)s->s_vals.p, (uint32_t)g_lookup_layout);
+                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint4 *)s->s_vals.p);
                 HIP_TRY(hipGetLastError());
                 // pass 3: back to key order, query epilogue
                 const uint32_t kq = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
@@ -73,7 +64,7 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
                 if (g_lookup_run_lanes > 0) run_lanes = (uint32_t)g_lookup_run_lanes;
                 hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(kCollectThreads), lds3, st, query, g, cnt,
                                    (const uint4 *)s->s_perm.p, (const uint2 *)s->s_run.p, (const uint32_t *)s->s_vals.p, stage_cap, run_lanes,
-                                   (uint32_t)g_lookup_layout, out_dev + start);
+                                   out_dev + start);
                 HIP_TRY(hipGetLastError());
                 return (int)PSK_OK;
             });

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run one engine operation repeatedly (for rocprofv3 --kernel-trace --stats / --pmc):  prof_ops.py <op> [n] [iters]
-ops: bloom_add bloom_check bloom_check_fresh cms_add cms_add_unit cms_check cbf_add cbf_check cbf_remove cbf25_check cbf25_add"""
+ops: bloom_add bloom_check bloom_check_fresh bloom31_add bloom31_check cms_add cms_add_unit cms_check cbf_add cbf_check cbf_remove cbf25_check cbf25_add"""
 import sys
 from pathlib import Path
 
@@ -26,10 +26,10 @@ keys = gen(n, 0)
 w = torch.empty(n, dtype=torch.int32, device="cuda")
 N.check(N.lib().psk_gen_weights(w.data_ptr(), 0, n, 0x5EED, 0, st()))
 if op.startswith("bloom"):
-    s = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    s = pa.BloomFilter(est_elements=224044920 if op.startswith("bloom31") else 28005615, false_positive_rate=0.01)  # 2^31 / 2^28 bits
     s.add_many(keys)
     fresh = gen(n, 7 * n)
-    fn = {"bloom_add": lambda: s.add_many(keys), "bloom_check": lambda: s.check_many(keys), "bloom_check_fresh": lambda: s.check_many(fresh)}[op]
+    fn = {"add": lambda: s.add_many(keys), "check": lambda: s.check_many(keys), "check_fresh": lambda: s.check_many(fresh)}[op.split("_", 1)[1]]
 elif op.startswith("cms"):
     s = pa.CountMinSketch(width=2**20, depth=5)
     s.add_many(keys, w)
@@ -39,6 +39,7 @@ else:
         pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01)
     s.add_many(keys)
     fn = {"add": lambda: s.add_many(keys), "check": lambda: s.check_many(keys), "remove": lambda: s.remove_many(keys)}[op.split("_", 1)[1]]
+launches = 2 + iters + (1 if op in ("bloom_add", "bloom31_add", "cms_add", "cbf_add", "cbf25_add") else 0)  # the set-up insert runs the same kernels
 for _ in range(2):
     fn()
 torch.cuda.synchronize()
@@ -49,4 +50,4 @@ for _ in range(iters):
 b.record()
 torch.cuda.synchronize()
 ms = a.elapsed_time(b) / iters
-print(f"{op}: {ms * 1e3:.1f} us per {n} keys -> {n / ms / 1e3:.0f} M/s")
+print(f"{op}: {ms * 1e3:.1f} us per {n} keys -> {n / ms / 1e3:.0f} M/s  launches={launches} n={n}")
