@@ -180,8 +180,10 @@ class EventTimer:
 
 
 def timed_loop(torch, fn, iters, warm=2):
-    for _ in range(warm):
-        fn()
+    for _ in range(warm):  # synchronised warm-up calls: scratch buffers exist and the engine's adaptive choices (Bloom lookup
+        fn()               # scheme follows the previous call's miss tally) have settled before the clock starts
+        torch.cuda.synchronize()
+    fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()

@@ -146,6 +146,8 @@ extern "C" int psk_destroy(psk_sketch *s)
     (void)scope.enter(s->device);
     if (s->owns_table && s->table) hipFree(s->table);
     if (s->ctr) hipFree(s->ctr);
+    if (s->lk.dev) hipFree(s->lk.dev);
+    if (s->lk.pin) hipHostFree((void *)s->lk.pin);
     for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run,
                       &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w}) {
         if (b->p) hipFree(b->p);
@@ -424,7 +426,7 @@ int64_t g_part_cache_bytes = 240 << 20;  // bucket-buffer budget per round: the 
 int64_t g_part_two_level_slices = 2048;     // tables cut into more slices than this take the two-level path (0 = never)
 int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGeom::dbg); 0 in production
 extern int64_t g_combine_keys;       // defined with the write-combined CBF updates below
-int64_t g_lookup_run_lanes = 0;
+int64_t g_lookup_run_lanes = 0, g_bloom_lookup = 2;
 extern PSK_HIDDEN int64_t g_merge_single_rank;  // psk_merge.hip
 
 extern "C" int psk_set_option(const char *name, int64_t value)
@@ -439,6 +441,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "merge_single_rank")) g_merge_single_rank = value;
     else if (!strcmp(name, "combine_keys")) g_combine_keys = value;
     else if (!strcmp(name, "lookup_run_lanes")) g_lookup_run_lanes = value;
+    else if (!strcmp(name, "bloom_lookup")) g_bloom_lookup = value;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
 }

@@ -97,6 +97,14 @@ struct psk_sketch {
     DevBuf s_part2, s_cnt2;                    // two-level path: bucket buffer + fill counts after the second split
     DevBuf s_merge;                            // multi-GPU merge (psk_merge_or / _sum): exchange buffers
     DevBuf s_vals, s_perm, s_run;              // partitioned counter lookups: values, per-key stage positions, per-(tile, slice) runs
+    // Bloom lookups: which scheme the next large batch takes (g_bloom_lookup = 2, auto).  The kernels tally what they see
+    // (keyed: probes that missed; return trip: keys answered absent) into lk_dev; the tally is copied to a pinned host page
+    // when the call ends and read -- without any synchronisation, so possibly one call late -- when the next one starts.
+    struct {
+        unsigned long long *dev = nullptr;           // [0] misses of the call in flight
+        volatile unsigned long long *pin = nullptr;  // [0] misses, [1] units (probes or keys), [2] scheme that produced them
+        int mode = 0;                                // 0 keyed probes + miss stores, 1 return trip
+    } lk;
     // write-combined CBF updates (psk_cbf_update_combined): key batches wait here until a list is full, then each list is
     // applied as ONE partitioned update (the fold of a big table read-modify-writes the whole table whatever the batch size)
     struct PendList {
@@ -133,6 +141,7 @@ static inline int grid_for_keys(uint64_t n)  // direct kernels: 256 CUs x 16 blo
 // Tunables (psk_set_option): the partitioned path is taken when the batch has at least g_part_min_keys keys and
 // the table geometry allows it; g_part_mode 0 = never, 1 = auto.
 extern PSK_HIDDEN int64_t g_part_mode, g_part_min_keys, g_part_max_keys, g_part_cache_bytes, g_part_two_level_slices, g_part_debug;
+extern PSK_HIDDEN int64_t g_bloom_lookup;      // Bloom lookups: 0 keyed probes + miss stores, 1 return trip (psk_lookup.hpp), 2 (default) by the observed miss rate
 extern PSK_HIDDEN int64_t g_lookup_run_lanes;  // bench knob of the counter lookups (lanes per run in pass 3; 0 = auto)
 
 // slices of a table of `cells` cells; max_shift = log2(cells one LDS slice may hold)

@@ -34,6 +34,15 @@ struct PayUnitLookup {  // as PayUnit (8 x 16-bit cells per group) + the by-prod
     __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
 };
 
+struct PayBloomLookup {  // as PayNone (6 x 20-bit bit indices per group) + the by-products (Bloom lookups, below)
+    static constexpr int mode = kModePlain;
+    static constexpr int group = 6;
+    static constexpr bool lookup = true;
+    uint4 *perm;
+    uint2 *runinfo;
+    __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
+};
+
 struct SpillRaiseFlag {  // a lookup probe that found its segment full: the round is redone by the direct kernel
     uint32_t *flag;
     __device__ __forceinline__ void operator()(uint32_t, uint32_t) const { *flag = 1u; }
@@ -248,6 +257,169 @@ __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query,
             finish_key(i, w4);
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------ Bloom lookups, same three passes
+// The keyed lookup of psk_partition.hpp (k_bloom_test) pays one scattered byte store per CLEAR bit it meets: batches of keys
+// that were never inserted -- the common case of a Bloom lookup -- ran at half the rate of all-hit batches (21 vs 41 G
+// keys/s).  With the return trip of the counter lookups the cost does not depend on the answers: pass 2 writes ONE byte per
+// group of six probes (bit e = probe e's bit), pass 3 copies the tile's bytes (a few KB) into LDS and every key ANDs its k
+// bits (bloom.py:261-272).
+
+// bits[group] = the six tested bits of the group (slots past the run's end: unspecified)
+static __global__ __launch_bounds__(kApplyThreads) void k_bloom_gather(const uint32_t *tab, uint64_t tab_words, PartGeom g,
+                                                                       const uint32_t *segcnt, const uint4 *buckets, uint8_t *bits)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t b = blockIdx.x;
+    const uint32_t slice_words = 1u << (g.shift - 5);
+    const uint64_t w0 = (uint64_t)b * slice_words;
+    for (uint32_t w = threadIdx.x * 4; w < slice_words; w += kApplyThreads * 4) {
+        const uint64_t gw = w0 + w;
+        uint4 t = make_uint4(0, 0, 0, 0);
+        if (gw + 3 < tab_words) t = *reinterpret_cast<const uint4 *>(tab + gw);
+        else {
+            if (gw + 0 < tab_words) t.x = tab[gw + 0];
+            if (gw + 1 < tab_words) t.y = tab[gw + 1];
+            if (gw + 2 < tab_words) t.z = tab[gw + 2];
+        }
+        *reinterpret_cast<uint4 *>(smem + w) = t;
+    }
+    __syncthreads();
+    // (8 groups in flight per lane: 48 LDS words + the 8 groups stay inside the 128 VGPRs of a 1024-thread workgroup; with 12
+    // the kernel spilled and ran 3x slower)
+    constexpr int D = 8;
+    auto field = [](const uint4 &q, int e) -> uint32_t {  // slice-local bit index e of a group (two 64-bit halves of 3 x 20 bits)
+        const unsigned long long h = e < 3 ? (((unsigned long long)q.y << 32) | q.x) : (((unsigned long long)q.w << 32) | q.z);
+        return (uint32_t)(h >> (20 * (e % 3))) & 0xFFFFFu;
+    };
+    for_each_batch_at<D>(buckets, segcnt, g, b, make_uint4(0, 0, 0, 0), [&](const uint4 (&q)[D], const uint64_t (&at)[D], const uint32_t (&)[D]) {
+        uint32_t w[D][6];
+#pragma unroll
+        for (int d = 0; d < D; ++d)  // the LDS reads of the whole batch first (pads read a harmless in-slice word)
+#pragma unroll
+            for (int e = 0; e < 6; ++e) w[d][e] = smem[field(q[d], e) >> 5];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (at[d] != ~0ULL) {
+                uint32_t r = 0;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) r |= ((w[d][e] >> (field(q[d], e) & 31)) & 1u) << e;
+                bits[at[d]] = (uint8_t)r;
+            }
+        }
+    });
+}
+
+// dynamic LDS: runinfo[B] (uint2) | stage bytes (one per group of the tile's sorted stage)
+// (1024-thread workgroups: 256-thread ones -- more tiles in flight per CU -- measured slower, 84 vs 64 us per 10 M keys: the
+// kernel is bound by the 16 bytes of perm[] per key, not by per-tile latency)
+constexpr int kBloomCollectThreads = 1024;
+
+template <int KT>
+__global__ __launch_bounds__(kBloomCollectThreads) void k_bloom_collect(PartGeom g, uint64_t n, const uint4 *perm, const uint2 *runinfo, const uint8_t *bits,
+                                                                   uint32_t stage_groups, uint32_t run_lanes, uint8_t *out, unsigned long long *miss_ctr)
+{
+    uint32_t nmiss = 0;  // keys answered "absent" (feeds the host's choice of lookup scheme)
+    constexpr int GS = 6, P4 = (KT + 7) / 8;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint2 *info = reinterpret_cast<uint2 *>(smem);
+    uint8_t *stage = reinterpret_cast<uint8_t *>(smem + 2 * g.nbuckets);
+    const uint32_t B = g.nbuckets, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t k = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
+    const uint64_t ntiles = (n + g.tile - 1) / g.tile;
+    constexpr int kInfoRegs = kPartMaxBuckets / kBloomCollectThreads;
+    constexpr int kPre = 8 / P4;  // keys per thread whose perm[] is prefetched (8 = a 2048-key tile)
+    uint2 nxt[kInfoRegs];
+#pragma unroll
+    for (int r = 0; r < kInfoRegs; ++r) {
+        const uint32_t b = threadIdx.x + (uint32_t)r * kBloomCollectThreads;
+        nxt[r] = (blockIdx.x < ntiles && b < B) ? runinfo[(uint64_t)blockIdx.x * B + b] : make_uint2(0, 0);
+    }
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t wg = (uint32_t)(tile % g.nwg);
+        const uint64_t base = tile * g.tile;
+        const uint64_t end = base + g.tile < n ? base + g.tile : n;
+#pragma unroll
+        for (int r = 0; r < kInfoRegs; ++r) {
+            const uint32_t b = threadIdx.x + (uint32_t)r * kBloomCollectThreads;
+            if (b < B) info[b] = nxt[r];
+        }
+        uint4 pw[kPre][P4];
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+            const uint64_t i = base + threadIdx.x + (uint64_t)q * kBloomCollectThreads;
+#pragma unroll
+            for (int c = 0; c < P4; ++c) pw[q][c] = perm[(i < end ? i : base) * P4 + c];
+        }
+        __syncthreads();
+        {
+            const uint64_t nt = tile + gridDim.x;
+#pragma unroll
+            for (int r = 0; r < kInfoRegs; ++r) {
+                const uint32_t b = threadIdx.x + (uint32_t)r * kBloomCollectThreads;
+                nxt[r] = (nt < ntiles && b < B) ? runinfo[nt * B + b] : make_uint2(0, 0);
+            }
+        }
+        // ---- the tile's result bytes (one per group of six probes) into the order of pass 1's sorted stage
+        const uint32_t rl = run_lanes, per_wave = 64u / rl, sub = lane / rl, e0 = lane % rl;
+        const uint32_t stride = (kBloomCollectThreads / 64) * per_wave;
+        for (uint32_t b = wave * per_wave + sub; b < B; b += stride) {
+            const uint2 ri = info[b];
+            const uint32_t groups = ((ri.y & 0xFFFFu) + GS - 1) / GS, off_g = (ri.y >> 16) / GS;
+            const uint64_t src = seg_index(g, b, wg) * g.segcap + ri.x;
+            const uint32_t room = ri.x < g.segcap ? g.segcap - ri.x : 0;  // (an overflowed run: the flag is up, the redo overwrites out[])
+            const uint32_t lim = groups < room ? groups : room;
+            for (uint32_t e = e0; e < lim; e += rl) stage[off_g + e] = bits[src + e];
+        }
+        __syncthreads();
+        // ---- every key ANDs its k bits (bloom.py:269-271)
+        auto finish_key = [&](uint64_t i, const uint4 (&w4)[P4]) {
+            uint32_t p[8 * P4];
+#pragma unroll
+            for (int c = 0; c < P4; ++c) {
+                const uint4 w = w4[c];
+                p[8 * c + 0] = w.x & 0xFFFFu; p[8 * c + 1] = w.x >> 16; p[8 * c + 2] = w.y & 0xFFFFu; p[8 * c + 3] = w.y >> 16;
+                p[8 * c + 4] = w.z & 0xFFFFu; p[8 * c + 5] = w.z >> 16; p[8 * c + 6] = w.w & 0xFFFFu; p[8 * c + 7] = w.w >> 16;
+            }
+            uint32_t ok = 1;
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                if ((uint32_t)j < k) {
+                    const uint32_t gi = p[j] / GS, e = p[j] - gi * GS;
+                    ok &= ((uint32_t)stage[gi < stage_groups ? gi : 0] >> e) & 1u;
+                }
+            }
+            out[i] = (uint8_t)ok;
+            nmiss += ok ^ 1u;
+        };
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+            const uint64_t i = base + threadIdx.x + (uint64_t)q * kBloomCollectThreads;
+            if (i < end) finish_key(i, pw[q]);
+        }
+        for (uint64_t i = base + threadIdx.x + (uint64_t)kPre * kBloomCollectThreads; i < end; i += kBloomCollectThreads) {
+            uint4 w4[P4];
+#pragma unroll
+            for (int c = 0; c < P4; ++c) w4[c] = perm[i * P4 + c];
+            finish_key(i, w4);
+        }
+        __syncthreads();
+    }
+    if (miss_ctr) {
+        for (int o = 32; o > 0; o >>= 1) nmiss += __shfl_down(nmiss, o);
+        if ((threadIdx.x & 63) == 0 && nmiss) atomicAdd(miss_ctr, (unsigned long long)nmiss);
+    }
+}
+
+// the tally of a finished lookup -> the pinned host page the next call's choice of scheme reads (one consistent triple)
+static __global__ void k_lookup_publish(const unsigned long long *tally, volatile unsigned long long *pin, unsigned long long units, unsigned long long scheme)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        pin[1] = units;
+        pin[2] = scheme;
+        pin[0] = tally[0];
     }
 }
 

@@ -1,5 +1,6 @@
 // partitioned Bloom lookup launcher (own translation unit: parallel build)
 #include "psk_host.hpp"
+#include "psk_lookup.hpp"
 
 // pass 1 of one round: keyed probes of keys [0, cnt) of `sub` into the bucket buffer.  defer != nullptr: split lookup
 // (the table is not consulted; an overflowing segment raises *defer instead of testing its probes directly)
@@ -18,12 +19,12 @@ static int check_round_scatter(psk_sketch *s, const Batch &sub, uint64_t cnt, ui
 }
 
 // pass 2 of one round: any probe that finds its bit clear stores a 0 (out[] pre-set to 1 by the caller)
-static int check_round_test(psk_sketch *s, const PartGeom &g, uint8_t *out, hipStream_t st)
+static int check_round_test(psk_sketch *s, const PartGeom &g, uint8_t *out, hipStream_t st, unsigned long long *miss_ctr = nullptr)
 {
     const size_t lds = (size_t)1 << (g.shift - 3);
     PSK_TRY(set_dyn_lds(k_bloom_test, lds));
     hipLaunchKernelGGL(k_bloom_test, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (const uint32_t *)s->table, s->padded_bytes / 4, g,
-                       (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, out);
+                       (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, out, miss_ctr);
     HIP_TRY(hipGetLastError());
     return PSK_OK;
 }
@@ -42,8 +43,117 @@ static bool check_geometry(psk_sketch *s, uint64_t n, PartGeom *g, uint64_t *rou
     return true;
 }
 
+// Lookups with a return trip (psk_lookup.hpp): pass 1 with perm / runinfo, k_bloom_gather, k_bloom_collect.  The cost does not
+// depend on how many probes miss; option "bloom_lookup" = 0 selects the keyed kernels below instead (A/B, split lookups).
+static int bloom_check_return_trip(psk_sketch *s, const Batch &b, uint8_t *out_dev, hipStream_t st, bool *done)
+{
+    *done = false;
+    if (!part_wanted(b.n, s->k, 4)) return PSK_OK;
+    PartGeom g;
+    if (!part_slices(s->m, 20, 7, &g)) return PSK_OK;
+    g.k = s->k;
+    const uint64_t round_keys = (uint64_t)g_part_max_keys < b.n ? (uint64_t)g_part_max_keys : b.n;
+    PSK_TRY(ensure(s->s_flag, 8));
+    uint32_t *flag = (uint32_t *)s->s_flag.p;
+    HIP_TRY(hipMemsetAsync(flag, 0, 4, st));
+    for (uint64_t start = 0; start < b.n; start += round_keys) {
+        const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
+        const Batch sub = sub_batch(b, start, cnt);
+        bool handled = false;
+        PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
+            using Src = decltype(src);
+            return with_kt<Src>(s->k, [&](auto kt) {
+                constexpr int KT = decltype(kt)::value;
+                constexpr int P4 = (KT + 7) / 8;
+                using TileSmall = PartTile<PayBloomLookup, KT, kPartThreads>;
+                const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE;
+                PSK_TRY(ensure(s->s_perm, cnt * P4 * 16));
+                PSK_TRY(ensure(s->s_run, max_tiles * g.nbuckets * 8));
+                PayBloomLookup pay{(uint4 *)s->s_perm.p, (uint2 *)s->s_run.p};
+                SpillRaiseFlag spill{flag};
+                PSK_TRY((launch_scatter<Src, IdxBloom<kTuPow2>, PayBloomLookup, SpillRaiseFlag, KT>(s, src, IdxBloom<kTuPow2>{s->md}, pay, spill, &g, cnt, st)));
+                PSK_TRY(ensure(s->s_vals, (uint64_t)g.nbuckets * g.nwg * g.segcap + 256));  // one result byte per group
+                const size_t lds2 = (size_t)1 << (g.shift - 3);
+                PSK_TRY(set_dyn_lds(k_bloom_gather, lds2));
+                hipLaunchKernelGGL(k_bloom_gather, dim3(g.nbuckets), dim3(kApplyThreads), lds2, st, (const uint32_t *)s->table, s->padded_bytes / 4, g,
+                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint8_t *)s->s_vals.p);
+                HIP_TRY(hipGetLastError());
+                const uint32_t kq = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
+                const uint32_t stage_cap = (uint32_t)(((size_t)g.tile * kq + (size_t)5 * g.nbuckets + 3) & ~(size_t)3);
+                if (stage_cap > 0xFFFFu) return fail(PSK_EINVAL, "lookup tile of %u probes does not fit 16-bit stage positions", stage_cap);
+                const uint32_t stage_groups = stage_cap / 6 + 1;
+                const size_t lds3 = (size_t)8 * g.nbuckets + ((stage_groups + 15) & ~(size_t)15);
+                const uint64_t ntiles = (cnt + g.tile - 1) / g.tile;
+                auto kern = k_bloom_collect<KT>;
+                PSK_TRY(set_dyn_lds(kern, lds3));
+                uint32_t run_lanes = 2;  // lanes (one byte = one group of 6 probes each) per (tile, slice) run
+                while (run_lanes < 64 && (uint64_t)run_lanes * 6 * g.nbuckets < (uint64_t)g.tile * kq + 6ULL * g.nbuckets) run_lanes *= 2;
+                hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(kBloomCollectThreads), lds3, st, g, cnt, (const uint4 *)s->s_perm.p,
+                                   (const uint2 *)s->s_run.p, (const uint8_t *)s->s_vals.p, stage_groups, run_lanes, out_dev + start, s->lk.dev);
+                HIP_TRY(hipGetLastError());
+                return (int)PSK_OK;
+            });
+        }));
+        if (!handled) return PSK_OK;
+    }
+    // exact redo through the direct kernel, taken on the device only if a segment overflowed
+    bool handled = false;
+    PSK_TRY(with_part_source(b, &handled, [&](auto src) {
+        using Src = decltype(src);
+        using Op = BloomCheck<kTuPow2>;
+        hipLaunchKernelGGL((k_apply_if<Src, Op>), dim3(grid_for_keys(b.n)), dim3(kBlock), 0, st, (const uint32_t *)flag, src,
+                           Op{(const uint32_t *)s->table, s->md, s->k, out_dev}, b.n);
+        HIP_TRY(hipGetLastError());
+        return (int)PSK_OK;
+    }));
+    *done = true;
+    return PSK_OK;
+}
+
+// Which scheme?  Keyed probes cost ~240 us per 10 M all-hit keys but one scattered byte store per probe that misses (~450 us
+// when every key is absent); the return trip costs ~300 us whatever the answers.  Mode 2 follows what the previous large
+// lookups on this handle saw: the tally of the last finished call sits in a pinned page (no synchronisation: it may be one
+// call late, and the very first call is keyed).
+static int choose_scheme(psk_sketch *s, hipStream_t st)
+{
+    if (g_bloom_lookup != 2) return g_bloom_lookup != 0;
+    if (!s->lk.dev) {
+        HIP_TRY(hipMalloc((void **)&s->lk.dev, 8));
+        void *pin = nullptr;
+        HIP_TRY(hipHostMalloc(&pin, 32, hipHostMallocDefault));
+        s->lk.pin = (volatile unsigned long long *)pin;
+        s->lk.pin[0] = s->lk.pin[1] = s->lk.pin[2] = 0;
+    }
+    const unsigned long long miss = s->lk.pin[0], units = s->lk.pin[1], by = s->lk.pin[2];
+    if (units) {
+        const double f = (double)miss / (double)units;
+        if (by == 0) s->lk.mode = f > 0.22 ? 1 : 0;   // keyed: fraction of PROBES that missed; beyond ~1/4 the stores cost more than the return trip
+        else s->lk.mode = f < 0.12 ? 0 : 1;          // return trip: fraction of KEYS answered absent (each misses one probe or more)
+    }
+    HIP_TRY(hipMemsetAsync(s->lk.dev, 0, 8, st));
+    return s->lk.mode;
+}
+
+// the tally of this call -> the pinned page, by a one-thread kernel at the end of the call's work (stream-ordered, no host wait)
+static int publish_tally(psk_sketch *s, unsigned long long units, int scheme, hipStream_t st)
+{
+    if (g_bloom_lookup != 2 || !s->lk.dev) return PSK_OK;
+    hipLaunchKernelGGL(k_lookup_publish, dim3(1), dim3(1), 0, st, (const unsigned long long *)s->lk.dev, s->lk.pin, units, (unsigned long long)scheme);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
 int PSK_VARIANT(bloom_check_partitioned)(psk_sketch *s, const Batch &b, uint8_t *out_dev, hipStream_t st, bool *done)
 {
+    *done = false;
+    if (!part_wanted(b.n, s->k, 4)) return PSK_OK;
+    const int scheme = choose_scheme(s, st);
+    if (scheme < 0) return scheme;
+    if (scheme == 1) {
+        PSK_TRY(bloom_check_return_trip(s, b, out_dev, st, done));
+        if (*done) PSK_TRY(publish_tally(s, b.n, 1, st));
+        return PSK_OK;
+    }
     *done = false;
     PartGeom g;
     uint64_t round_keys;
@@ -56,8 +166,9 @@ int PSK_VARIANT(bloom_check_partitioned)(psk_sketch *s, const Batch &b, uint8_t 
         HIP_TRY(hipMemsetAsync(out, 1, cnt, st));
         PSK_TRY(check_round_scatter(s, sub, cnt, out, nullptr, &g, st, &handled));
         if (!handled) return PSK_OK;
-        PSK_TRY(check_round_test(s, g, out, st));
+        PSK_TRY(check_round_test(s, g, out, st, s->lk.dev));
     }
+    PSK_TRY(publish_tally(s, b.n * (uint64_t)s->k, 0, st));
     *done = true;
     return PSK_OK;
 }

@@ -858,9 +858,12 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *
 // Bloom lookup: the slice is loaded into LDS; a probe whose bit is clear zeroes its key's result byte
 // (out[] is pre-set to 1; every writer stores the same 0, so plain byte stores suffice).
 // group = 4 x (tile bit << 31 | key index in tile << shift | bit index in slice), see PayKeyId
+// miss_ctr (nullable): += the number of probes that found their bit clear (feeds the host's choice of lookup scheme)
 static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint32_t *tab, uint64_t tab_words, PartGeom g,
-                                                              const uint32_t *segcnt, const uint4 *buckets, uint8_t *out)
+                                                              const uint32_t *segcnt, const uint4 *buckets, uint8_t *out,
+                                                              unsigned long long *miss_ctr)
 {
+    uint32_t nmiss = 0;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = blockIdx.x;
     const uint32_t slice_words = 1u << (g.shift - 5);
@@ -896,6 +899,7 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint3
             const bool my = live && ((w[d].y >> (q[d].y & 31)) & 1u) == 0;
             const bool mz = live && ((w[d].z >> (q[d].z & 31)) & 1u) == 0;
             const bool mw = live && ((w[d].w >> (q[d].w & 31)) & 1u) == 0;
+            nmiss += (uint32_t)mx + (uint32_t)my + (uint32_t)mz + (uint32_t)mw;
             if (mx | my | mz | mw) {
                 const uint32_t ordinal = (q[d].x >> 31) | ((q[d].y >> 31) << 1) | ((q[d].z >> 31) << 2) | ((q[d].w >> 31) << 3);
                 const uint32_t kbase = (ordinal * g.nwg + wg[d]) * g.tile;
@@ -906,6 +910,10 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint3
             }
         }
     });
+    if (miss_ctr) {  // one atomic per wave
+        for (int o = 32; o > 0; o >>= 1) nmiss += __shfl_down(nmiss, o);
+        if ((threadIdx.x & 63) == 0 && nmiss) atomicAdd(miss_ctr, (unsigned long long)nmiss);
+    }
 }
 
 // Counter add (CMS / CBF fast path): accumulate the slice's weights into an LDS image with ds_add, then

@@ -534,3 +534,73 @@ def test_cbf_unchecked_remove_direct_and_partitioned_agree(pa, oracle, force_par
     oc.update_keys(keys[:10], np.full(10, 2**32 - 1, dtype=np.int64))
     oc.update_keys(keys[: n // 2], -w[: n // 2].astype(np.int64))
     assert np.array_equal(results[0][0].cpu().numpy().view(np.uint32)[: oc.m], oc.bloom)
+
+
+# ------------------------------------------------------------------ Bloom lookups: return trip vs keyed probes
+@pytest.mark.parametrize("mode", [1, 0])
+def test_bloom_lookup_modes_vs_oracle(pa, oracle, force_partition, mode):
+    """option bloom_lookup: 1 = pass 1 with perm / runinfo + k_bloom_gather + k_bloom_collect (default), 0 = keyed probes +
+    k_bloom_test; both against the oracle over hits, misses, k classes, table sizes, layouts, rounds and segment overflow"""
+    force_partition.set_option("bloom_lookup", mode)
+    try:
+        n = 160_000
+        keys = oracle.gen_keys16(21, n)
+        for est, fpr in [(28005615, 0.01), (5_000_000, 0.05), (2_000_000, 0.001), (1_000_000, 0.1), (300_000, 0.03), (1_000_000, 0.00001),
+                         (1160981, 0.0009653916676755292), (224044920, 0.01)]:
+            blm = pa.BloomFilter(est_elements=est, false_positive_rate=fpr)
+            ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+            blm.add_many(_dev(keys[: n // 2]))
+            ob.add_keys(keys[: n // 2])
+            want = ob.check_keys(keys)
+            assert np.array_equal(blm.check_many(_dev(keys)).cpu().numpy().astype(np.uint8), want), (est, fpr)
+            assert np.array_equal(np.asarray(blm.check_many(keys[50_000:90_000])).astype(np.uint8), want[50_000:90_000])
+        # several rounds, a partial last tile
+        blm = pa.BloomFilter(est_elements=3_000_000, false_positive_rate=0.01)
+        ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+        blm.add_many(_dev(keys[::3]))
+        ob.add_keys(keys[::3])
+        for max_keys in (1 << 25, 50_000, 4096 * 7 + 1):
+            force_partition.set_option("partition_max_keys", max_keys)
+            assert np.array_equal(blm.check_many(_dev(keys[:-3])).cpu().numpy().astype(np.uint8), ob.check_keys(keys[:-3]))
+        force_partition.set_option("partition_max_keys", 1 << 25)
+        # duplicate-heavy batch: segments overflow, the flagged redo keeps the answers exact
+        same = np.repeat(keys[5:6], 150_000, axis=0)
+        mix = np.concatenate([same, keys[:50_000]])
+        assert np.array_equal(blm.check_many(_dev(mix)).cpu().numpy().astype(np.uint8), ob.check_keys(mix))
+        fresh = oracle.gen_keys16(9_000_000, 120_000)   # (almost) all misses
+        assert np.array_equal(blm.check_many(_dev(fresh)).cpu().numpy().astype(np.uint8), ob.check_keys(fresh))
+        # ragged / wide-character keys and pre-hashed batches
+        words = [("ключ-%d-€" % i) * (1 + i % 3) for i in range(30_000)]
+        blm.add_many(words[:20_000])
+        hs = np.array([oracle.default_fnv_1a(w, blm.number_hashes) for w in words], dtype=np.uint64)
+        ob.add_hashes(hs[:20_000])
+        assert np.array_equal(np.asarray(blm.check_many(words)).astype(np.uint8), ob.check_hashes(hs))
+        assert np.array_equal(np.asarray(blm.check_alt_many(hs)).astype(np.uint8), ob.check_hashes(hs))
+    finally:
+        force_partition.set_option("bloom_lookup", 1)
+
+
+def test_bloom_lookup_auto_mode_follows_the_miss_rate_and_stays_exact(pa, oracle, force_partition):
+    """default option bloom_lookup = 2: the scheme of the next large lookup follows the tally of the previous ones (pinned page,
+    no synchronisation) -- whatever it picks, every answer equals the oracle's across alternating all-hit / all-miss batches"""
+    assert force_partition.get_option("partition") == 1
+    n = 300_000
+    keys = oracle.gen_keys16(0, n)
+    fresh = oracle.gen_keys16(50_000_000, n)
+    blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    blm.add_many(_dev(keys))
+    ob.add_keys(keys)
+    want_hit, want_miss = ob.check_keys(keys), ob.check_keys(fresh)
+    mixed = np.concatenate([keys[: n // 2], fresh[: n // 2]])
+    want_mixed = ob.check_keys(mixed)
+    dk, df, dm = _dev(keys), _dev(fresh), _dev(mixed)
+    for batch, want in [(dk, want_hit), (dk, want_hit), (df, want_miss), (df, want_miss), (df, want_miss), (dm, want_mixed), (dk, want_hit),
+                        (dk, want_hit), (dk, want_hit), (df, want_miss), (dm, want_mixed)]:
+        got = blm.check_many(batch)
+        torch.cuda.synchronize()   # the tally of this call is on the pinned page before the next call chooses
+        assert np.array_equal(got.cpu().numpy().astype(np.uint8), want)
+    # and without synchronisation in between (the choice may lag by a call)
+    outs = [blm.check_many(b) for b in (df, dk, df, dk, dm)]
+    for got, want in zip(outs, (want_miss, want_hit, want_miss, want_hit, want_mixed)):
+        assert np.array_equal(got.cpu().numpy().astype(np.uint8), want)
