@@ -407,19 +407,28 @@ __global__ __launch_bounds__(kBloomCollectThreads) void k_bloom_collect(PartGeom
         }
         __syncthreads();
     }
-    if (miss_ctr) {
+    if (miss_ctr) {  // ONE atomic per workgroup: same-address device atomics serialise (~11 ns each; one per wave cost 90 us here)
         for (int o = 32; o > 0; o >>= 1) nmiss += __shfl_down(nmiss, o);
-        if ((threadIdx.x & 63) == 0 && nmiss) atomicAdd(miss_ctr, (unsigned long long)nmiss);
+        uint32_t *part = smem;  // (the tile loop is over: LDS is free)
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = nmiss;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (int w = 0; w < kBloomCollectThreads / 64; ++w) t += part[w];
+            if (t) atomicAdd(miss_ctr, t);
+        }
     }
 }
 
 // the tally of a finished lookup -> the pinned host page the next call's choice of scheme reads (one consistent triple)
-static __global__ void k_lookup_publish(const unsigned long long *tally, volatile unsigned long long *pin, unsigned long long units, unsigned long long scheme)
+// (and zeroes the tally for the next call: no per-call memset)
+static __global__ void k_lookup_publish(unsigned long long *tally, volatile unsigned long long *pin, unsigned long long units, unsigned long long scheme)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         pin[1] = units;
         pin[2] = scheme;
         pin[0] = tally[0];
+        tally[0] = 0;
     }
 }
 

@@ -123,6 +123,7 @@ static int choose_scheme(psk_sketch *s, hipStream_t st)
         HIP_TRY(hipHostMalloc(&pin, 32, hipHostMallocDefault));
         s->lk.pin = (volatile unsigned long long *)pin;
         s->lk.pin[0] = s->lk.pin[1] = s->lk.pin[2] = 0;
+        HIP_TRY(hipMemsetAsync(s->lk.dev, 0, 8, st));  // once: k_lookup_publish re-zeroes the tally at the end of every call
     }
     const unsigned long long miss = s->lk.pin[0], units = s->lk.pin[1], by = s->lk.pin[2];
     if (units) {
@@ -130,7 +131,6 @@ static int choose_scheme(psk_sketch *s, hipStream_t st)
         if (by == 0) s->lk.mode = f > 0.22 ? 1 : 0;   // keyed: fraction of PROBES that missed; beyond ~1/4 the stores cost more than the return trip
         else s->lk.mode = f < 0.12 ? 0 : 1;          // return trip: fraction of KEYS answered absent (each misses one probe or more)
     }
-    HIP_TRY(hipMemsetAsync(s->lk.dev, 0, 8, st));
     return s->lk.mode;
 }
 
@@ -138,7 +138,7 @@ static int choose_scheme(psk_sketch *s, hipStream_t st)
 static int publish_tally(psk_sketch *s, unsigned long long units, int scheme, hipStream_t st)
 {
     if (g_bloom_lookup != 2 || !s->lk.dev) return PSK_OK;
-    hipLaunchKernelGGL(k_lookup_publish, dim3(1), dim3(1), 0, st, (const unsigned long long *)s->lk.dev, s->lk.pin, units, (unsigned long long)scheme);
+    hipLaunchKernelGGL(k_lookup_publish, dim3(1), dim3(1), 0, st, s->lk.dev, s->lk.pin, units, (unsigned long long)scheme);
     HIP_TRY(hipGetLastError());
     return PSK_OK;
 }

@@ -910,9 +910,16 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint3
             }
         }
     });
-    if (miss_ctr) {  // one atomic per wave
+    if (miss_ctr) {  // one atomic per workgroup (same-address device atomics serialise at ~11 ns each)
         for (int o = 32; o > 0; o >>= 1) nmiss += __shfl_down(nmiss, o);
-        if ((threadIdx.x & 63) == 0 && nmiss) atomicAdd(miss_ctr, (unsigned long long)nmiss);
+        __syncthreads();  // every wave is done with the slice image: reuse its first words
+        if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = nmiss;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (int w = 0; w < kApplyWaves; ++w) t += smem[w];
+            if (t) atomicAdd(miss_ctr, t);
+        }
     }
 }
 
