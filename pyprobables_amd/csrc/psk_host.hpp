@@ -142,6 +142,7 @@ static inline int grid_for_keys(uint64_t n)  // direct kernels: 256 CUs x 16 blo
 // the table geometry allows it; g_part_mode 0 = never, 1 = auto.
 extern PSK_HIDDEN int64_t g_part_mode, g_part_min_keys, g_part_max_keys, g_part_cache_bytes, g_part_two_level_slices, g_part_debug;
 extern PSK_HIDDEN int64_t g_bloom_lookup;      // Bloom lookups: 0 keyed probes + miss stores, 1 return trip (psk_lookup.hpp), 2 (default) by the observed miss rate
+extern PSK_HIDDEN int64_t g_lookup_split;        // bench knob: 0 = never share a slice between two pass-2 workgroups
 extern PSK_HIDDEN int64_t g_lookup_run_lanes;  // bench knob of the counter lookups (lanes per run in pass 3; 0 = auto)
 
 // slices of a table of `cells` cells; max_shift = log2(cells one LDS slice may hold)
@@ -158,6 +159,7 @@ static inline bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_
     g->nbuckets = (uint32_t)B;
     g->shift = (uint32_t)shift;
     g->dbg = (uint32_t)g_part_debug;
+    g->split = g->split_idx = 0;
     return true;
 }
 

@@ -51,15 +51,23 @@ struct SpillRaiseFlag {  // a lookup probe that found its segment full: the roun
 // ------------------------------------------------------------------------------------ pass 2
 constexpr int kGatherDepth = 8;
 
-// vals[group * 8 + e] = the counter addressed by every probe of every group (pads: unspecified)
+// The counter behind every probe of every group, in the probe buffer's shape (pads: unspecified).  Per SLICE the values are
+// written either as 8 x uint32 (32 bytes per group) or -- when every counter of the slice is below 2^16 (the usual case: a
+// pass over the slice while it is loaded tells) -- as 8 x uint16 (16 bytes per group, dense); fmt[slice] says which.
+// Grid: nbuckets * max(1, g.split) workgroups; with g.split > 1 the workgroups of a slice share its segments
+// (slice counts that do not fill the CUs -- CMS 5 x 2^20: 320 slices on 256 CUs -- left pass 2 unbalanced).
 static __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const uint32_t *tab, uint64_t tab_cells, PartGeom g,
-                                                                         const uint32_t *segcnt, const uint4 *buckets, uint4 *vals)
+                                                                         const uint32_t *segcnt, const uint4 *buckets, uint4 *vals, uint8_t *fmt)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t b = blockIdx.x;
+    __shared__ uint32_t wave_max[kApplyWaves];
+    const uint32_t S = g.split > 1 ? g.split : 1;
+    const uint32_t b = blockIdx.x / S;
+    g.split_idx = blockIdx.x % S;
     const uint32_t slice_cells = 1u << g.shift;
     const uint32_t mask = slice_cells - 1;
     const uint64_t c0 = (uint64_t)b * slice_cells;
+    uint32_t mx = 0;
     for (uint32_t w = threadIdx.x * 4; w < slice_cells; w += kApplyThreads * 4) {
         const uint64_t gc = c0 + w;
         uint4 t = make_uint4(0, 0, 0, 0);
@@ -70,9 +78,18 @@ static __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const u
             if (gc + 2 < tab_cells) t.z = tab[gc + 2];
         }
         *reinterpret_cast<uint4 *>(smem + w) = t;
+        mx |= t.x | t.y | t.z | t.w;  // (an OR is enough to tell whether any counter has a bit at or above 2^16; negative CMS bins do)
     }
+    for (int o = 32; o > 0; o >>= 1) mx |= __shfl_down(mx, o);
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = mx;
     __syncthreads();
-    for_each_batch_at<kGatherDepth>(buckets, segcnt, g, b, make_uint4(0, 0, 0, 0), [&](const uint4 (&q)[kGatherDepth], const uint64_t (&at)[kGatherDepth], const uint32_t (&)[kGatherDepth]) {
+    uint32_t all = 0;
+#pragma unroll
+    for (int w = 0; w < kApplyWaves; ++w) all |= wave_max[w];
+    const bool narrow = all < 65536u;
+    if (threadIdx.x == 0) fmt[b] = narrow ? 1 : 0;  // (every workgroup of the slice writes the same value)
+    for_each_batch_at<kGatherDepth>(buckets, segcnt, g, b, make_uint4(0, 0, 0, 0), [&](const uint4 (&q)[kGatherDepth], const uint64_t (&at)[kGatherDepth],
+                                                                                      const uint32_t (&wg)[kGatherDepth]) {
         uint4 lo[kGatherDepth], hi[kGatherDepth];
 #pragma unroll
         for (int d = 0; d < kGatherDepth; ++d) {  // the 8 LDS reads of every group first (a pad cell 0xFFFF reads a harmless in-slice word)
@@ -82,8 +99,13 @@ static __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const u
 #pragma unroll
         for (int d = 0; d < kGatherDepth; ++d) {
             if (at[d] != ~0ULL) {
-                vals[2 * at[d]] = lo[d];
-                vals[2 * at[d] + 1] = hi[d];
+                if (narrow) {  // the segment's groups packed at 16 bytes each from the segment's start
+                    const uint64_t seg4 = seg_index(g, b, wg[d]) * g.segcap;  // == at[d] - slot
+                    vals[2 * seg4 + (at[d] - seg4)] = make_uint4(lo[d].x | (lo[d].y << 16), lo[d].z | (lo[d].w << 16), hi[d].x | (hi[d].y << 16), hi[d].z | (hi[d].w << 16));
+                } else {
+                    vals[2 * at[d]] = lo[d];
+                    vals[2 * at[d] + 1] = hi[d];
+                }
             }
         }
     });
@@ -151,17 +173,19 @@ struct QueryCbfMin {   // countingbloom.py:166-174
 
 constexpr int kCollectThreads = 1024;
 
-// dynamic LDS: runinfo[B] (uint2) | stage[stage_cap] (values in the tile's sorted order)
+// dynamic LDS: runinfo[B] (uint2) | stage[stage_cap] (values in the tile's sorted order) | fmt[B] bytes
 template <class Query, int KT>
 __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query, PartGeom g, uint64_t n, const uint4 *perm, const uint2 *runinfo,
-                                                                    const uint32_t *vals, uint32_t stage_cap, uint32_t run_lanes,
+                                                                    const uint32_t *vals, const uint8_t *fmt, uint32_t stage_cap, uint32_t run_lanes,
                                                                     typename Query::Out *out)
 {
     constexpr int GS = 8, P4 = (KT + 7) / 8;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint2 *info = reinterpret_cast<uint2 *>(smem);
     uint32_t *stage = smem + 2 * g.nbuckets;
-    const uint32_t B = g.nbuckets, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint8_t *fmt_lds = reinterpret_cast<uint8_t *>(stage + stage_cap);  // the per-slice value format, read once (a global read per
+    const uint32_t B = g.nbuckets, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // run put a second round trip into the copy loop)
+    for (uint32_t b = threadIdx.x; b < B; b += kCollectThreads) fmt_lds[b] = fmt[b];
     const uint32_t k = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
     const uint64_t ntiles = (n + g.tile - 1) / g.tile;
     // Software pipeline over tiles (a workgroup walks ~10 tiles; each tile used to be three dependent global round trips:
@@ -209,26 +233,45 @@ __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query,
         const uint32_t stride = (kCollectThreads / 64) * per_wave;
         for (uint32_t b0 = wave * per_wave + sub; b0 < B; b0 += 4 * stride) {
             uint32_t v[4], at[4];
-            bool live[4];
+            bool live[4], two[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t b = b0 + (uint32_t)u * stride;
-                live[u] = false;
+                live[u] = two[u] = false;
                 if (b < B) {
                     const uint2 ri = info[b];
                     const uint32_t cnt = ri.y & 0xFFFFu, off = ri.y >> 16;
-                    const uint64_t src = (seg_index(g, b, wg) * g.segcap + ri.x) * GS;
+                    const uint64_t seg = seg_index(g, b, wg) * g.segcap;
                     const uint32_t room = ri.x < g.segcap ? (g.segcap - ri.x) * GS : 0;  // (an overflowed run: the flag is up, the redo overwrites out[])
                     const uint32_t lim = cnt < room ? cnt : room;
-                    at[u] = off + e0;
-                    live[u] = e0 < lim;
-                    if (live[u]) v[u] = vals[src + e0];
-                    for (uint32_t e = e0 + rl; e < lim; e += rl) stage[off + e] = vals[src + e];  // longer runs
+                    two[u] = fmt_lds[b] != 0;
+                    if (two[u]) {  // 16-bit values, the segment's groups packed at 16 bytes each: a lane moves TWO values (one dword);
+                        // the odd tail lands on the run's pad slots
+                        const uint32_t *src = vals + seg * GS + (uint64_t)ri.x * (GS / 2);
+                        const uint32_t lim2 = (lim + 1) / 2;
+                        at[u] = off + 2 * e0;
+                        live[u] = e0 < lim2;
+                        if (live[u]) v[u] = src[e0];
+                        for (uint32_t e = e0 + rl; e < lim2; e += rl) {  // longer runs
+                            const uint32_t x = src[e];
+                            *reinterpret_cast<uint2 *>(stage + off + 2 * e) = make_uint2(x & 0xFFFFu, x >> 16);
+                        }
+                    } else {
+                        const uint32_t *src = vals + (seg + ri.x) * GS;
+                        at[u] = off + e0;
+                        live[u] = e0 < lim;
+                        if (live[u]) v[u] = src[e0];
+                        for (uint32_t e = e0 + rl; e < lim; e += rl) stage[off + e] = src[e];
+                    }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (live[u]) stage[at[u]] = v[u];
+            for (int u = 0; u < 4; ++u) {
+                if (live[u]) {
+                    if (two[u]) *reinterpret_cast<uint2 *>(stage + at[u]) = make_uint2(v[u] & 0xFFFFu, v[u] >> 16);
+                    else stage[at[u]] = v[u];
+                }
+            }
         }
         __syncthreads();
         // ---- every key picks its k values through perm[]

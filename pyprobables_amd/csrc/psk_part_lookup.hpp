@@ -45,25 +45,32 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
                 SpillRaiseFlag spill{flag};
                 PSK_TRY((launch_scatter<Src, IDX<kTuPow2>, PayUnitLookup, SpillRaiseFlag, KT>(s, src, IDX<kTuPow2>{s->md}, pay, spill, &g, cnt, st)));
                 // pass 2: the counters behind every probe, in the probe buffer's shape
-                PSK_TRY(ensure(s->s_vals, (uint64_t)g.nbuckets * g.nwg * g.segcap * 32 + 256));
+                const uint64_t vals_bytes = (uint64_t)g.nbuckets * g.nwg * g.segcap * 32;
+                PSK_TRY(ensure(s->s_vals, vals_bytes + g.nbuckets + 256));  // values + one format byte per slice
+                uint8_t *fmt = (uint8_t *)s->s_vals.p + vals_bytes;
                 const size_t lds2 = (size_t)4 << g.shift;
                 PSK_TRY(set_dyn_lds(k_counter_gather, lds2));
-                hipLaunchKernelGGL(k_counter_gather, dim3(g.nbuckets), dim3(kApplyThreads), lds2, st, (const uint32_t *)s->table, cells, g,
-                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint4 *)s->s_vals.p);
+                // slice counts that do not fill the 256 CUs evenly: two workgroups share a slice's segments (each loads the slice)
+                PartGeom g2 = g;
+                g2.split = (g.nbuckets % 256 != 0 && g.nbuckets < 1024 && g_lookup_split != 0) ? 2 : 1;
+                hipLaunchKernelGGL(k_counter_gather, dim3(g.nbuckets * g2.split), dim3(kApplyThreads), lds2, st, (const uint32_t *)s->table, cells, g2,
+                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint4 *)s->s_vals.p, fmt);
                 HIP_TRY(hipGetLastError());
                 // pass 3: back to key order, query epilogue
                 const uint32_t kq = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
                 const uint32_t stage_cap = (uint32_t)(((size_t)g.tile * kq + (size_t)7 * g.nbuckets + 3) & ~(size_t)3);
                 if (stage_cap > 0xFFFFu) return fail(PSK_EINVAL, "lookup tile of %u probes does not fit 16-bit stage positions", stage_cap);
-                const size_t lds3 = ((size_t)2 * g.nbuckets + stage_cap) * 4;
+                const size_t lds3 = ((size_t)2 * g.nbuckets + stage_cap) * 4 + ((g.nbuckets + 15) & ~(size_t)15);
                 const uint64_t ntiles = (cnt + g.tile - 1) / g.tile;
                 auto kern = k_lookup_collect<Query, KT>;
                 PSK_TRY(set_dyn_lds(kern, lds3));
-                uint32_t run_lanes = 8;  // lanes that copy one (tile, slice) run of values: the power of two at or above the mean run
-                while (run_lanes < 64 && (uint64_t)run_lanes * g.nbuckets < (uint64_t)g.tile * kq) run_lanes *= 2;
+                // lanes that copy one (tile, slice) run of values: the power of two at or above HALF the mean run -- a lane moves two
+                // 16-bit values at a time, the usual format; runs of 32-bit values take a second trip through the loop
+                uint32_t run_lanes = 4;
+                while (run_lanes < 64 && (uint64_t)run_lanes * 2 * g.nbuckets < (uint64_t)g.tile * kq) run_lanes *= 2;
                 if (g_lookup_run_lanes > 0) run_lanes = (uint32_t)g_lookup_run_lanes;
                 hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(kCollectThreads), lds3, st, query, g, cnt,
-                                   (const uint4 *)s->s_perm.p, (const uint2 *)s->s_run.p, (const uint32_t *)s->s_vals.p, stage_cap, run_lanes,
+                                   (const uint4 *)s->s_perm.p, (const uint2 *)s->s_run.p, (const uint32_t *)s->s_vals.p, (const uint8_t *)fmt, stage_cap, run_lanes,
                                    out_dev + start);
                 HIP_TRY(hipGetLastError());
                 return (int)PSK_OK;

@@ -54,6 +54,8 @@ struct PartGeom {
     uint32_t k;             // hashes per key
     uint32_t tile;          // keys per pass-1 tile (keyed probes: key = tile id * tile + local index)
     uint32_t dbg;           // bench-only bits: 1 skip stores, 4 skip hashing, 8 one workgroup per CU, 32 phase profile
+    uint32_t split;         // read-only pass-2 kernels: workgroups per slice (0 / 1 = one); workgroup `split_idx` of a slice
+    uint32_t split_idx;     // walks segments split_idx, split_idx + split, ... (balances slice counts that do not fill the CUs)
 };
 
 // Where segment (slice b, workgroup wg) lives in the bucket buffer.  Workgroup-major: the B runs a workgroup
@@ -716,9 +718,11 @@ __device__ __forceinline__ void for_each_batch_at(const uint4 *buckets, const ui
                                                   const uint4 pad, Body body)
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t nseg = g.nwg > wave ? (g.nwg - wave + kApplyWaves - 1) / kApplyWaves : 0;  // <= 32
+    const uint32_t S = g.split > 1 ? g.split : 1, s0 = g.split > 1 ? g.split_idx : 0;
+    const uint32_t mine_total = g.nwg > s0 ? (g.nwg - s0 + S - 1) / S : 0;                     // segments this workgroup walks
+    const uint32_t nseg = mine_total > wave ? (mine_total - wave + kApplyWaves - 1) / kApplyWaves : 0;  // <= 32 per wave
     uint32_t mycnt = 0;
-    if (lane < nseg) mycnt = segcnt[(uint64_t)b * g.nwg + wave + kApplyWaves * lane];
+    if (lane < nseg) mycnt = segcnt[(uint64_t)b * g.nwg + s0 + S * (wave + kApplyWaves * lane)];
     const uint32_t chunks = (mycnt + 63) >> 6;
     const uint32_t incl = wave_inclusive_scan(chunks), excl = incl - chunks;
     const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -733,7 +737,7 @@ __device__ __forceinline__ void for_each_batch_at(const uint4 *buckets, const ui
             const uint32_t sl = seg < 64 ? seg : 63;
             const uint32_t v = (cc - (uint32_t)__builtin_amdgcn_readlane((int)excl, sl)) * 64 + lane;
             const uint32_t cnt = seg < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)mycnt, sl) : 0;
-            wg[d] = wave + kApplyWaves * sl;
+            wg[d] = s0 + S * (wave + kApplyWaves * sl);
             const uint64_t base = seg_index(g, b, wg[d]) * g.segcap;
             q[d] = pad;
             at[d] = ~0ULL;

@@ -169,3 +169,33 @@ def test_lookup_scratch_release_and_regrow(pa, oracle, force_partition):
     a = cms.check_many(_dev(keys)).cpu().numpy()
     cms._tab.release_scratch()
     assert np.array_equal(cms.check_many(_dev(keys)).cpu().numpy(), a)
+
+
+def test_lookup_value_formats_and_shared_slices(pa, oracle, force_partition):
+    """pass 2 writes a slice's values as uint16 when every counter of the slice is below 2^16 and as uint32 otherwise; both
+    formats in one table (big weights on a few keys, negative CMS bins), with and without two workgroups per slice"""
+    n = 200_000
+    keys = oracle.gen_keys16(77, n)
+    w = np.ones(n, dtype=np.uint32)
+    w[::997] = 3_000_000_000 // 7          # a few huge counters: their slices go wide
+    w[5::1013] = 70_000
+    cbf = pa.CountingBloomFilter(est_elements=437_000, false_positive_rate=0.01)
+    oc = oracle.OracleCBF(cbf.number_bits, cbf.number_hashes)
+    cbf.add_many(_dev(keys), w)
+    oc.update_keys(keys, w.astype(np.int64))
+    want = oc.check_keys(keys)
+    assert int(want.max()) > 2**16 and int((want < 2**16).sum()) > n // 2
+    cms = pa.CountMinSketch(width=100_003, depth=3)      # 10 slices of 2^15 (not a multiple of the CU count: shared slices)
+    ocm = oracle.OracleCMS(100_003, 3)
+    wi = w.astype(np.int64).clip(max=2**31 - 1).astype(np.int32)
+    cms.add_many(_dev(keys), _dev(wi))
+    ocm.add_keys(keys, wi)
+    cms.remove_many(_dev(keys[:5000]), _dev(np.full(5000, 100_000, dtype=np.int32)))   # negative bins
+    ocm.remove_keys(keys[:5000], np.full(5000, 100_000, dtype=np.int32))
+    wantc = ocm.check_keys(keys).astype(np.int32)
+    assert int(wantc.min()) < 0
+    for split in (1, 0):
+        force_partition.set_option("lookup_split", split)
+        assert np.array_equal(cbf.check_many(_dev(keys)).cpu().numpy().view(np.uint32), want)
+        assert np.array_equal(cms.check_many(_dev(keys)).cpu().numpy(), wantc)
+    force_partition.set_option("lookup_split", 1)
