@@ -83,7 +83,10 @@ int psk_device_count(int *count);
  * 240 MiB: batches whose buffer would exceed 1.5x this are cut into equal rounds so that pass 2 reads pass 1's output from
  * the 256 MB Infinity Cache instead of HBM; 0 disables), "partition_two_level_slices" (default 2048: tables cut into more
  * LDS-sized slices than this are partitioned in two levels -- coarse buckets, then slices; 0 = such tables use the direct
- * kernels) */
+ * kernels), "combine_keys" (keys per write-combining list of psk_cbf_update_combined, default 2^25), "bloom_lookup" (large Bloom
+ * lookups: 0 = keyed probes + one store per missing probe, 1 = return trip with a cost independent of the answers, 2 (default) =
+ * chosen per call from the miss tally of the previous lookups on the handle), "merge_single_rank" (1: psk_merge_* run the
+ * collective path on a one-rank communicator); bench knobs: "lookup_split", "lookup_run_lanes" */
 int psk_set_option(const char *name, int64_t value);
 int psk_get_option(const char *name, int64_t *value);
 /* bench-only: s_memtime totals per phase of the last partition pass 1 (option part_debug & 32) */

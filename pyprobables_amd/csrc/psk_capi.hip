@@ -468,6 +468,9 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "partition_cache_bytes")) *value = g_part_cache_bytes;
     else if (!strcmp(name, "partition_two_level_slices")) *value = g_part_two_level_slices;
     else if (!strcmp(name, "combine_keys")) *value = g_combine_keys;
+    else if (!strcmp(name, "bloom_lookup")) *value = g_bloom_lookup;
+    else if (!strcmp(name, "lookup_split")) *value = g_lookup_split;
+    else if (!strcmp(name, "lookup_run_lanes")) *value = g_lookup_run_lanes;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
 }

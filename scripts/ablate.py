@@ -4,6 +4,10 @@ import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from _common import gen_keys, gen_weights, timed_loop, use_knobs_build  # noqa: E402
+
+use_knobs_build()  # the part_debug bits exist only in the -DPSK_BENCH_KNOBS=1 build
 import torch
 
 import bench
@@ -11,11 +15,11 @@ import pyprobables_amd as pa
 from pyprobables_amd import _native as N
 
 n = 10_000_000
-keys = bench.gen_keys(n, 0, 0)
+keys = gen_keys(n, 0, 0)
 blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01, device=0)
 for dbg, label in [(0, "full"), (1, "no stores"), (4, "no hashing"), (5, "skeleton only"), (2, "hashing only (+ key loads)"), (10, "hashing only, 1 WG/CU"), (8, "1 WG/CU")]:
     N.set_option("part_debug", dbg)
-    ms = bench.timed_loop(lambda: blm.add_many(keys), 10, warm=3)
+    ms = timed_loop(lambda: blm.add_many(keys), 10, warm=3)
     print(f"dbg={dbg} {label:28s} insert {ms*1e3:8.1f} us  -> {n/ms/1e3:9.0f} Mkeys/s", flush=True)
 N.set_option("part_debug", 0)
 

@@ -5,13 +5,15 @@ import time
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from _common import gen_keys, gen_weights, timed_loop  # noqa: E402
 import torch
 
 import bench
 import pyprobables_amd as pa
 
 n = 10_000_000
-keys = bench.gen_keys(n, 0, 0)
+keys = gen_keys(n, 0, 0)
 blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01, device=0)
 res = {}
 

@@ -5,6 +5,10 @@ import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from _common import gen_keys, gen_weights, timed_loop, use_knobs_build  # noqa: E402
+
+use_knobs_build()  # the part_debug bits exist only in the -DPSK_BENCH_KNOBS=1 build
 import torch
 
 import bench
@@ -12,14 +16,14 @@ import pyprobables_amd as pa
 from pyprobables_amd import _native as N
 
 n = 10_000_000
-keys = bench.gen_keys(n, 0, 0)
+keys = gen_keys(n, 0, 0)
 blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01, device=0)
 blm.add_many(keys)
 for extra, label in ((0, "scatter"),):
     for which, fn in (("insert", lambda: blm.add_many(keys)), ("check", lambda: blm.check_many(keys))):
         for dbg, tag in ((0, "full"), (4, "no hashing"), (1, "no stores"), (2, "hash only")):
             N.set_option("part_debug", dbg | extra)
-            ms = bench.timed_loop(fn, 10, warm=3)
+            ms = timed_loop(fn, 10, warm=3)
             print(f"{label} {which:6s} {tag:10s} {ms*1e3:8.1f} us", flush=True)
         N.set_option("part_debug", 32 | extra)
         fn(); torch.cuda.synchronize()

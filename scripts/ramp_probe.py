@@ -3,7 +3,7 @@ sys.path.insert(0, '/root/repo')
 import torch, bench
 import pyprobables_amd as pa
 n = 10_000_000
-keys = bench.gen_keys(n, 0, 0)
+keys = gen_keys(n, 0, 0)
 blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01, device=0)
 def step():
     blm.clear(); blm.add_many(keys); return blm.check_many(keys)
