@@ -148,7 +148,7 @@ extern "C" int psk_destroy(psk_sketch *s)
     if (s->ctr) hipFree(s->ctr);
     if (s->lk.dev) hipFree(s->lk.dev);
     if (s->lk.pin) hipHostFree((void *)s->lk.pin);
-    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run,
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
                       &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w}) {
         if (b->p) hipFree(b->p);
         if (b->pin) hipHostFree(b->pin);
@@ -640,6 +640,29 @@ static int account_weights(psk_sketch *s, const W *w_dev, uint64_t n, int which,
     return PSK_OK;
 }
 
+// Accounting of a weighted batch, fused into pass 1 when the partitioned path takes it (PayWeight::tally): post the request,
+// try the partitioned launcher, settle what it did not take over with the stand-alone pass over the weights.
+template <class W>
+static int post_acct(psk_sketch *s, const W *w_dev, uint64_t n, int which, long long bound_mult, hipStream_t st, bool grow_bound, bool weights_signed)
+{
+    s->acct.pending = false;
+    if (!w_dev || n == 0) return account_weights(s, w_dev, n, which, bound_mult, st, grow_bound);  // unit weights: a one-thread kernel
+    s->acct.pending = true;
+    s->acct.which = which;
+    s->acct.bound_mult = bound_mult;
+    s->acct.grow_bound = grow_bound;
+    s->acct.weights_signed = weights_signed;
+    return PSK_OK;
+}
+
+template <class W>
+static int settle_acct(psk_sketch *s, const W *w_dev, uint64_t n, hipStream_t st)
+{
+    if (!s->acct.pending) return PSK_OK;
+    s->acct.pending = false;
+    return account_weights(s, w_dev, n, s->acct.which, s->acct.bound_mult, st, s->acct.grow_bound);
+}
+
 // ----------------------------------------------------- CountingBloomFilter
 int64_t g_combine_keys = 1 << 25;  // keys per write-combining list (psk_set_option "combine_keys")
 
@@ -647,10 +670,11 @@ int64_t g_combine_keys = 1 << 25;  // keys per write-combining list (psk_set_opt
 static int cbf_apply_device(psk_sketch *s, const Batch &b, const uint32_t *w, bool remove, hipStream_t st)
 {
     if (b.n == 0) return PSK_OK;
-    PSK_TRY(account_weights(s, w, b.n, remove ? PSK_CTR_REMOVED : PSK_CTR_ADDED, (long long)s->k, st, !remove));
+    PSK_TRY(post_acct(s, w, b.n, remove ? PSK_CTR_REMOVED : PSK_CTR_ADDED, (long long)s->k, st, !remove, false));
     unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
     bool done = false;
     PSK_TRY(remove ? cbf_remove_partitioned(s, b, w, st, &done) : cbf_add_partitioned(s, b, w, st, &done));
+    PSK_TRY(settle_acct(s, w, b.n, st));
     if (done) return PSK_OK;
     return with_source(b, [&](auto src) {
         if (remove) {
@@ -739,11 +763,12 @@ extern "C" int psk_cbf_add(psk_sketch *s, int layout, const void *data, const ui
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
     const uint32_t *w;
     PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
-    PSK_TRY(account_weights(s, w, n, PSK_CTR_ADDED, (long long)s->k, st));
+    PSK_TRY(post_acct(s, w, n, PSK_CTR_ADDED, (long long)s->k, st, true, false));
     unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
     {
         bool done = false;
         PSK_TRY(cbf_add_partitioned(s, b, w, st, &done));
+        PSK_TRY(settle_acct(s, w, n, st));
         if (done) return finish(where, nullptr, st);
     }
     PSK_TRY(with_source(b, [&](auto src) {
@@ -797,9 +822,10 @@ static int cbf_remove_composed(psk_sketch *s, const Batch &b, const uint32_t *w,
     hipLaunchKernelGGL(k_cbf_to_remove, dim3(grid_for(b.n) > 1024 ? 1024 : grid_for(b.n)), dim3(kBlock), 0, st, (const uint32_t *)mins, w, b.n, amount,
                        (unsigned long long *)(s->ctr + PSK_CTR_VIOLATIONS));
     HIP_TRY(hipGetLastError());
-    PSK_TRY(account_weights(s, (const uint32_t *)amount, b.n, PSK_CTR_REMOVED, (long long)s->k, st, false));
+    PSK_TRY(post_acct(s, (const uint32_t *)amount, b.n, PSK_CTR_REMOVED, (long long)s->k, st, false, false));
     bool dec = false;
     PSK_TRY(cbf_remove_partitioned(s, b, amount, st, &dec));
+    PSK_TRY(settle_acct(s, (const uint32_t *)amount, b.n, st));
     if (!dec) {  // not eligible after all: the same decrement through the direct kernel
         unsigned long long *viol = (unsigned long long *)(s->ctr + PSK_CTR_VIOLATIONS);
         PSK_TRY(with_source(b, [&](auto src) {
@@ -917,11 +943,12 @@ static int cms_update(psk_sketch *s, int layout, const void *data, const uint64_
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
     const int32_t *w;
     PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
-    PSK_TRY(account_weights(s, w, n, NEG ? PSK_CTR_REMOVED : PSK_CTR_ADDED, 1LL, st));
+    PSK_TRY(post_acct(s, w, n, NEG ? PSK_CTR_REMOVED : PSK_CTR_ADDED, 1LL, st, true, true));
     unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
     {
         bool done = false;
         PSK_TRY(NEG ? cms_remove_partitioned(s, b, (const uint32_t *)w, st, &done) : cms_add_partitioned(s, b, (const uint32_t *)w, st, &done));
+        PSK_TRY(settle_acct(s, w, n, st));
         if (done) return finish(where, nullptr, st);
     }
     PSK_TRY(with_source(b, [&](auto src) {
@@ -1241,7 +1268,7 @@ extern "C" int psk_release_scratch(psk_sketch *s)
     if (s->pend.active) return fail(PSK_EINVAL, "a split lookup is pending: finish it before releasing the scratch buffers");
     PSK_TRY(flush_combined(s, nullptr));
     HIP_TRY(hipDeviceSynchronize());
-    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run,
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
                       &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w}) {
         if (b->p) HIP_TRY(hipFree(b->p));
         b->p = nullptr;

@@ -96,7 +96,17 @@ struct psk_sketch {
     DevBuf s_flag;                             // split lookup: "a segment overflowed" flag
     DevBuf s_part2, s_cnt2;                    // two-level path: bucket buffer + fill counts after the second split
     DevBuf s_merge;                            // multi-GPU merge (psk_merge_or / _sum): exchange buffers
+    DevBuf s_tally;                            // weighted pass 1: (sum w, sum |w|) per workgroup, folded by k_tally_fold
     DevBuf s_vals, s_perm, s_run;              // partitioned counter lookups: values, per-key stage positions, per-(tile, slice) runs
+    // Weighted counter updates: the caller (psk_capi.hip) posts what has to be accounted for the batch; a partitioned launcher
+    // that scatters the weights takes the request over (PayWeight::tally sums them inside pass 1) and clears `pending`;
+    // otherwise the caller runs the stand-alone pass over the weights (k_weight_sum).
+    struct {
+        bool pending = false;
+        int which = -1;          // PSK_CTR_ADDED / PSK_CTR_REMOVED
+        long long bound_mult = 1;
+        bool grow_bound = true, weights_signed = false;
+    } acct;
     // Bloom lookups: which scheme the next large batch takes (g_bloom_lookup = 2, auto).  The kernels tally what they see
     // (keyed: probes that missed; return trip: keys answered absent) into lk_dev; the tally is copied to a pinned host page
     // when the call ends and read -- without any synchronisation, so possibly one call late -- when the next one starts.

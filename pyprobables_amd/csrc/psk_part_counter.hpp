@@ -3,6 +3,28 @@
 #include "psk_host.hpp"
 
 // account_weights(), so ctr[6] holds this batch's sum|w| for the wrap check inside pass 2.
+// the weights of keys [start, ...) + the fused accounting request posted by the caller (psk_sketch::acct), if any
+static inline int pay_weights(psk_sketch *s, const uint32_t *w_dev, uint64_t start, PayWeight *pay)
+{
+    *pay = PayWeight{w_dev ? w_dev + start : nullptr};
+    if (w_dev && s->acct.pending) {
+        PSK_TRY(ensure(s->s_tally, 1024 * sizeof(ulonglong2)));  // one slot per pass-1 workgroup (<= 512)
+        pay->tally = (ulonglong2 *)s->s_tally.p;
+        pay->weights_signed = s->acct.weights_signed ? 1 : 0;
+    }
+    return PSK_OK;
+}
+
+// after a weighted pass 1 of `nwg` workgroups: its slots -> the device counters
+static inline int fold_tally(psk_sketch *s, const PayWeight &pay, uint32_t nwg, hipStream_t st)
+{
+    if (!pay.tally) return PSK_OK;
+    hipLaunchKernelGGL(k_tally_fold, dim3(1), dim3(256), 0, st, (const ulonglong2 *)pay.tally, nwg, s->ctr, s->acct.which, s->acct.bound_mult,
+                       s->acct.grow_bound ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
 template <template <bool> class IDX, bool SIGNED, bool NEG>
 static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, uint64_t cells, hipStream_t st,
                                    bool *done)
@@ -27,7 +49,8 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
             const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
             const Batch sub = sub_batch(b, start, cnt);
             bool handled = false;
-            PayWeight pay{w_dev ? w_dev + start : nullptr};  // level 1 is always inline: weight (or 1) << shift1 | index in the coarse bucket
+            PayWeight pay;  // level 1 is always inline: weight (or 1) << shift1 | index in the coarse bucket
+            PSK_TRY(pay_weights(s, w_dev, start, &pay));
             PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
                 using Src = decltype(src);
                 return with_kt<Src>(s->k, [&](auto kt) {
@@ -36,6 +59,7 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
                 });
             }));
             if (!handled) return PSK_OK;
+            PSK_TRY(fold_tally(s, pay, g1.nwg, st));
             PartGeom g2 = g;
             const size_t lds = (size_t)4 << g2.shift;
             if (w_dev) {
@@ -53,6 +77,7 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
             }
             HIP_TRY(hipGetLastError());
         }
+        if (w_dev) s->acct.pending = false;  // pass 1 summed the weights
         *done = true;
         return PSK_OK;
     }
@@ -63,19 +88,22 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
         const Batch sub = sub_batch(b, start, cnt);
         bool handled = false;
+        PayWeight payw;
+        PSK_TRY(pay_weights(s, w_dev, start, &payw));
         PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
             using Src = decltype(src);
             return with_kt<Src>(s->k, [&](auto kt) {
                 constexpr int KT = decltype(kt)::value;
                 SpillCounter<SIGNED> spill{(uint32_t *)s->table, w_dev == nullptr, NEG, sat};
                 if (w_dev) {
-                    PayWeight pay{w_dev + start};
+                    const PayWeight pay = payw;
                     return launch_scatter<Src, IDX<kTuPow2>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<kTuPow2>{s->md}, pay, spill, &g, cnt, st);
                 }
                 return launch_scatter<Src, IDX<kTuPow2>, PayUnit, SpillCounter<SIGNED>, KT>(s, src, IDX<kTuPow2>{s->md}, PayUnit{}, spill, &g, cnt, st);
             });
         }));
         if (!handled) return PSK_OK;
+        PSK_TRY(fold_tally(s, payw, g.nwg, st));
         const size_t lds = (size_t)4 << g.shift;
         if (w_dev) {
             auto kern = k_counter_apply<SIGNED, true, NEG>;
@@ -90,6 +118,7 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
         }
         HIP_TRY(hipGetLastError());
     }
+    if (w_dev) s->acct.pending = false;  // pass 1 summed the weights
     *done = true;
     return PSK_OK;
 }

@@ -93,6 +93,10 @@ struct pay_max_kpt { static constexpr int value = 1 << 20; };
 template <class Pay>
 struct pay_max_kpt<Pay, decltype((void)Pay::max_kpt)> { static constexpr int value = Pay::max_kpt; };
 template <class Pay, class = void>
+struct pay_has_tally { static constexpr bool value = false; };
+template <class Pay>
+struct pay_has_tally<Pay, decltype((void)&Pay::tally)> { static constexpr bool value = true; };
+template <class Pay, class = void>
 struct pay_is_lookup { static constexpr bool value = false; };
 template <class Pay>
 struct pay_is_lookup<Pay, decltype((void)Pay::lookup)> { static constexpr bool value = Pay::lookup; };
@@ -112,6 +116,12 @@ struct PayWeight {
     static constexpr int group = 4;
     static constexpr int mode = kModeInline;
     const uint32_t *w;  // int32 / uint32 bit patterns; null = unit weights (level 1 of the two-level path)
+    // Fused accounting (round 2; it used to be a separate pass over the weights, k_weight_sum: 18 us per 10 M): pass 1 reads
+    // every weight anyway, so every workgroup also leaves (sum w, sum |w|) of its keys in tally[blockIdx.x] -- plain stores,
+    // no atomics: 768 same-address atomics at the kernel's end cost as much as the pass they replaced -- and the one-block
+    // k_tally_fold between pass 1 and pass 2 adds the slots into the handle's device counters.  null: nothing to account.
+    ulonglong2 *tally = nullptr;
+    int weights_signed = 0;
     __device__ __forceinline__ uint32_t operator()(uint64_t i, uint64_t) const { return w ? w[i] : 1u; }
 };
 struct PayZero {   // level 1 of the two-level Bloom insert: 4 x 32-bit (0 << shift | bit index inside the coarse bucket)
@@ -351,6 +361,8 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     }
     if ((dbg & 32) && threadIdx.x == 0) t_prev = __builtin_readcyclecounter();
 
+    long long tally_s = 0;            // fused weight accounting (PayWeight::tally)
+    unsigned long long tally_a = 0;
     uint32_t ordinal = ~0u;  // of the tile inside this workgroup's sequence (keyed probes carry it)
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         ++ordinal;
@@ -495,6 +507,15 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
             const uint64_t i = base + (uint64_t)q * NT + threadIdx.x;
             if (i < n) {
                 uint32_t pos[LOOKUP ? 8 * ((KT + 7) / 8) : 1] = {};  // lookups: where each of my probes sits in the sorted stage
+                if constexpr (pay_has_tally<Pay>::value) {
+                    // (here, not where the weight is loaded: the sum would pin the load's latency into the hash phase --
+                    // measured +19 us per 10 M keys -- while this phase consumes the weight anyway)
+                    if (pay.tally) {
+                        const long long v = pay.weights_signed ? (long long)(int32_t)payload[q] : (long long)payload[q];
+                        tally_s += v;
+                        tally_a += (unsigned long long)(v < 0 ? -v : v);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     if ((uint32_t)j < k) {
@@ -559,10 +580,61 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         atomicAdd(prof, 1ULL);
     }
 #undef PSK_TICK
+    if constexpr (pay_has_tally<Pay>::value) {
+        if (pay.tally) {  // block reduction through the (now idle) stage, one 16-byte store per workgroup
+            for (int o = 32; o > 0; o >>= 1) {
+                tally_s += __shfl_down(tally_s, o);
+                tally_a += __shfl_down(tally_a, o);
+            }
+            unsigned long long *red = reinterpret_cast<unsigned long long *>(stage);
+            if ((threadIdx.x & 63) == 0) {
+                red[2 * (threadIdx.x >> 6)] = (unsigned long long)tally_s;
+                red[2 * (threadIdx.x >> 6) + 1] = tally_a;
+            }
+            lds_barrier();
+            if (threadIdx.x == 0) {
+                unsigned long long ss = 0, aa = 0;
+                for (int w = 0; w < NT / 64; ++w) { ss += red[2 * w]; aa += red[2 * w + 1]; }
+                pay.tally[blockIdx.x] = make_ulonglong2(ss, aa);
+            }
+        }
+    }
     // publish how many groups of each of my segments are valid (the kernel boundary orders it before pass 2)
     for (uint32_t b = threadIdx.x; b < B; b += NT) {
         const uint32_t c = cur[b];
         segcnt[(uint64_t)b * g.nwg + blockIdx.x] = c < g.segcap ? c : g.segcap;
+    }
+}
+
+// The per-workgroup (sum w, sum |w|) slots of a weighted pass 1 -> the handle's device counters: ctr[which] += sum w
+// (elements_added terms), ctr[6] = sum |w| * bound_mult of THIS round (pass 2's wrap check), and, when grow_bound, the
+// saturating bound on |counter| ctr[4].  One block; the stream orders it between pass 1 and pass 2.
+static __global__ __launch_bounds__(256) void k_tally_fold(const ulonglong2 *slots, uint32_t nslots, long long *ctr, int which, long long bound_mult,
+                                                           int grow_bound)
+{
+    __shared__ unsigned long long ps[4], pa[4];
+    unsigned long long ss = 0, aa = 0;
+    for (uint32_t i = threadIdx.x; i < nslots; i += 256) {
+        const ulonglong2 v = slots[i];
+        ss += v.x;
+        aa += v.y;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        ss += __shfl_down(ss, o);
+        aa += __shfl_down(aa, o);
+    }
+    if ((threadIdx.x & 63) == 0) { ps[threadIdx.x >> 6] = ss; pa[threadIdx.x >> 6] = aa; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ss = ps[0] + ps[1] + ps[2] + ps[3];
+        aa = pa[0] + pa[1] + pa[2] + pa[3];
+        if (which >= 0) ctr[which] += (long long)ss;
+        const unsigned long long add = aa * (unsigned long long)bound_mult;
+        ctr[6] = (long long)(add >> 63 ? (1ULL << 62) : add);
+        if (grow_bound) {
+            const unsigned long long nb = (unsigned long long)ctr[4] + add;
+            ctr[4] = (nb < add || nb > (1ULL << 62)) ? (1LL << 62) : (long long)nb;
+        }
     }
 }
 
