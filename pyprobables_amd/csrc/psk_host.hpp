@@ -152,16 +152,22 @@ static inline int grid_for_keys(uint64_t n)  // direct kernels: 256 CUs x 16 blo
 // the table geometry allows it; g_part_mode 0 = never, 1 = auto.
 extern PSK_HIDDEN int64_t g_part_mode, g_part_min_keys, g_part_max_keys, g_part_cache_bytes, g_part_two_level_slices, g_part_debug;
 extern PSK_HIDDEN int64_t g_bloom_lookup;      // Bloom lookups: 0 keyed probes + miss stores, 1 return trip (psk_lookup.hpp), 2 (default) by the observed miss rate
+extern PSK_HIDDEN int64_t g_part_slice_bias;     // bench knob: added to log2(cells per slice)
+extern PSK_HIDDEN int64_t g_part_tile_threads;   // pass 1 workgroup size for k <= 8: 0 = 1024 when the LDS stage fits (one per CU), 512 = two 512-thread workgroups per CU
 extern PSK_HIDDEN int64_t g_lookup_split;        // bench knob: 0 = never share a slice between two pass-2 workgroups
 extern PSK_HIDDEN int64_t g_lookup_run_lanes;  // bench knob of the counter lookups (lanes per run in pass 3; 0 = auto)
 
 // slices of a table of `cells` cells; max_shift = log2(cells one LDS slice may hold)
+// target_lg: aim at 2^target_lg .. 2^(target_lg+1)-1 slices.  8 (one slice per CU or more) for the Bloom tables; the counter
+// tables take 7: measured on MI355X (scripts/ab_slices.py, CMS 2^20 x 5) 160 slices of 2^15 counters beat 320 of 2^14 --
+// pass 1 sorts into half as many bins with runs twice as long (weighted add 211 -> 193 us, lookups 314 -> 302 us), which
+// outweighs pass 2 running on 160 of the 256 CUs.
 static inline bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_shift, PartGeom *g,
-                               uint64_t max_buckets = kPartMaxBuckets)
+                               uint64_t max_buckets = kPartMaxBuckets, int target_lg = 8)
 {
     if (cells >= (1ULL << 32) || cells < (1ULL << 16)) return false;  // cell index 0xFFFFFFFF is the pad marker
     const uint32_t lg = 63 - __builtin_clzll(cells);  // floor(log2 cells)
-    int shift = (int)lg - 8;                          // aim at 256..511 slices: one per CU
+    int shift = (int)lg - target_lg + (int)g_part_slice_bias;  // (bias: bench knob)
     if (shift > (int)max_shift) shift = max_shift;
     if (shift < (int)min_shift) shift = min_shift;
     const uint64_t B = (cells + (1ULL << shift) - 1) >> shift;
@@ -239,7 +245,7 @@ static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, con
         // keyed probes carry (key index in tile << shift | bit in slice) in 31 bits (the top bit spells the tile ordinal): the
         // tile must stay within 2^(31 - shift) keys (PayKeyId::max_kpt caps it at 2048 keys for 1024 threads)
         const bool ids_fit = Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, 1024>::TILE << g->shift) <= (1ULL << 31);
-        if (!(kBenchKnobs && (g->dbg & 16)) && ids_fit && scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget)
+        if (!(kBenchKnobs && (g->dbg & 16)) && g_part_tile_threads != 512 && ids_fit && scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget)
             return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st);
     }
     static_assert(Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, kPartThreads>::TILE << 20) <= (1ULL << 31),

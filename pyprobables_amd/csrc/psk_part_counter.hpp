@@ -34,7 +34,7 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
     // unit-weight batches cannot wrap a 32-bit partial sum when n*k < 2^31 (weighted ones are checked on the device)
     if (!w_dev && b.n * (uint64_t)s->k >= (1ULL << 31)) return PSK_OK;
     PartGeom g;
-    if (!part_slices(cells, 15, 5, &g, 16384)) return PSK_OK;  // 2^15 counters = 128 KiB per slice
+    if (!part_slices(cells, 15, 5, &g, 16384, 7)) return PSK_OK;  // 2^15 counters = 128 KiB per slice
     g.k = s->k;
     unsigned long long *sat2 = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
     PartGeom g1;

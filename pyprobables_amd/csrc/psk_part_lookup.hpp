@@ -22,7 +22,7 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
     *done = false;
     if (!part_wanted(b.n, kk, 4)) return PSK_OK;
     PartGeom g;
-    if (!part_slices(cells, 15, 5, &g)) return PSK_OK;  // 2^15 counters = 128 KiB per slice; beyond 2048 slices: direct kernels
+    if (!part_slices(cells, 15, 5, &g, kPartMaxBuckets, 7)) return PSK_OK;  // 2^15 counters = 128 KiB per slice; beyond 2048 slices: direct kernels
     g.k = kk;
     const uint64_t round_keys = lookup_round_keys(b.n, kk);
     PSK_TRY(ensure(s->s_flag, 8));
