@@ -20,7 +20,25 @@ constexpr int kGroup = 8;                                // hash chains interlea
 
 // ------------------------------------------------------------------ hashing
 // hashes.py:99-102  hval ^= e; hval *= prime (mod 2^64)
-__device__ __forceinline__ uint64_t fnv_step(uint64_t h, uint32_t e) { return (h ^ (uint64_t)e) * kFnvPrime; }
+// prime = 2^40 + 0x1B3 and e < 2^32, so with x = lo ^ e:  lo' = low32(x * 0x1B3),  hi' = hi * 0x1B3 + high32(x * 0x1B3) + (x << 8).
+// Four VALU instructions: v_xor_b32, v_mad_u64_u32 (lo' and the carry at once), v_lshl_add_u32, and a second
+// v_mad_u64_u32 as a 32-bit multiply-add (only the low word of its sum is used; the addend's high word is left undefined).
+// hipcc's own expansion of the 64-bit multiply is five (bitop3, lshlrev, mad_u64_u32, mul_lo_u32, add3_u32; 9.4 ns against
+// 7.5 ns per wave64 step and SIMD in scripts/ubench/alu.hip) -- the chains of a non-power-of-two table are VALU bound.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint64_t fnv_step(uint64_t h, uint32_t e)
+{
+    const uint32_t x = (uint32_t)h ^ e;
+    const uint64_t t = (uint64_t)x * 0x1B3u;
+    u32x2_t addend;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+    addend.x = (x << 8) + (uint32_t)(t >> 32);
+    uint64_t u;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(u) : "v"((uint32_t)(h >> 32)), "s"(0x1B3u), "v"(__builtin_bit_cast(uint64_t, addend)) : "vcc");
+#pragma clang diagnostic pop
+    return ((uint64_t)(uint32_t)u << 32) | (uint32_t)t;
+}
 
 // hashes.py:96  seeded offset basis
 __device__ __forceinline__ uint64_t fnv_seed(uint32_t seed) { return kFnvBasis + 31ULL * (uint64_t)seed; }
@@ -37,7 +55,8 @@ __device__ __forceinline__ void fnv_word(uint64_t (&h)[G], uint32_t w)
 {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const uint32_t e = (w >> (8 * b)) & 0xFFu;
+        uint32_t e = (w >> (8 * b)) & 0xFFu;
+        asm volatile("" : "+v"(e));  // the byte once per key byte in a VGPR (see fnv_word32)
 #pragma unroll
         for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e);
     }

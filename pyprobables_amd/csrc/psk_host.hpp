@@ -154,6 +154,7 @@ extern PSK_HIDDEN int64_t g_part_mode, g_part_min_keys, g_part_max_keys, g_part_
 extern PSK_HIDDEN int64_t g_bloom_lookup;      // Bloom lookups: 0 keyed probes + miss stores, 1 return trip (psk_lookup.hpp), 2 (default) by the observed miss rate
 extern PSK_HIDDEN int64_t g_part_slice_bias;     // bench knob: added to log2(cells per slice)
 extern PSK_HIDDEN int64_t g_part_tile_threads;   // pass 1 workgroup size for k <= 8: 0 = 1024 when the LDS stage fits (one per CU), 512 = two 512-thread workgroups per CU
+extern PSK_HIDDEN int64_t g_part_wgs;            // bench knob: pass 1 workgroups (0 = auto: one or two per CU)
 extern PSK_HIDDEN int64_t g_lookup_split;        // bench knob: 0 = never share a slice between two pass-2 workgroups
 extern PSK_HIDDEN int64_t g_lookup_run_lanes;  // bench knob of the counter lookups (lanes per run in pass 3; 0 = auto)
 
@@ -204,7 +205,7 @@ static size_t scatter_lds_bytes(const PartGeom *g)
 
 template <class Src, class IdxFn, class Pay, class Spill, int KT, int NT>
 static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, PartGeom *g,
-                             uint64_t n, hipStream_t st)
+                             uint64_t n, hipStream_t st, uint32_t want_wgs)
 {
     using Tile = PartTile<Pay, KT, NT>;
     const uint64_t ntiles = (n + Tile::TILE - 1) / Tile::TILE;
@@ -213,6 +214,8 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
     uint64_t per_cu = NT > 512 ? 1 : (lds > 76 * 1024 ? 1 : 2);
     if (kBenchKnobs && (g->dbg & 8)) per_cu = 1;  // ablation: one workgroup per CU
     uint64_t nwg = 256 * per_cu;
+    if (want_wgs) nwg = want_wgs;  // caller's choice (keyed lookups into big tables: twice the keys per round)
+    if (g_part_wgs > 0) nwg = (uint64_t)g_part_wgs;
     if (nwg > ntiles) nwg = ntiles;
     const uint64_t tiles_per_wg = (ntiles + nwg - 1) / nwg;
     const double mean = (double)tiles_per_wg * Tile::TILE * kk / (double)g->nbuckets;  // probes per segment
@@ -239,18 +242,18 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
 constexpr size_t kScatterLdsBudget = 160 * 1024;
 template <class Src, class IdxFn, class Pay, class Spill, int KT>
 static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, PartGeom *g,
-                          uint64_t n, hipStream_t st)
+                          uint64_t n, hipStream_t st, uint32_t want_wgs = 0)
 {
     if constexpr (KT <= 8) {
         // keyed probes carry (key index in tile << shift | bit in slice) in 31 bits (the top bit spells the tile ordinal): the
         // tile must stay within 2^(31 - shift) keys (PayKeyId::max_kpt caps it at 2048 keys for 1024 threads)
         const bool ids_fit = Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, 1024>::TILE << g->shift) <= (1ULL << 31);
         if (!(kBenchKnobs && (g->dbg & 16)) && g_part_tile_threads != 512 && ids_fit && scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget)
-            return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st);
+            return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st, want_wgs);
     }
     static_assert(Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, kPartThreads>::TILE << 20) <= (1ULL << 31),
                   "512-thread tiles must keep keyed probes inside 31 bits for the largest slice (2^20 bits)");
-    return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, kPartThreads>(s, src, idxfn, pay, spill, g, n, st);
+    return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, kPartThreads>(s, src, idxfn, pay, spill, g, n, st, want_wgs);
 }
 
 // compile-time hash count: exact for the common small k on the 16-byte fast layout, rounded up otherwise

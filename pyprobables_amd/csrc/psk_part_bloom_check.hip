@@ -4,6 +4,11 @@
 
 // pass 1 of one round: keyed probes of keys [0, cnt) of `sub` into the bucket buffer.  defer != nullptr: split lookup
 // (the table is not consulted; an overflowing segment raises *defer instead of testing its probes directly)
+// Pass 1 workgroups of the keyed lookups.  A round holds 16 tiles per workgroup (PayKeyId) and pass 2 reads the whole table
+// once per round: with 2048 slices (m = 2^31: 256 MiB per round) twice the workgroups -- twice the keys per round -- is worth
+// +7 % (21.0 -> 22.6 G keys/s, scripts/ab_wgs.py); at 1024 slices and below it measures the same or slightly worse.
+static inline uint32_t keyed_wgs(const PartGeom &g) { return g.nbuckets >= 2048 ? 512u : 0u; }  // 0: launch_scatter's default
+
 static int check_round_scatter(psk_sketch *s, const Batch &sub, uint64_t cnt, uint8_t *out, uint32_t *defer, PartGeom *g,
                                hipStream_t st, bool *handled)
 {
@@ -13,7 +18,7 @@ static int check_round_scatter(psk_sketch *s, const Batch &sub, uint64_t cnt, ui
             constexpr int KT = decltype(kt)::value;
             SpillBloomTest spill{(const uint32_t *)s->table, out, defer};
             return launch_scatter<Src, IdxBloom<kTuPow2>, PayKeyId, SpillBloomTest, KT>(s, src, IdxBloom<kTuPow2>{s->md}, PayKeyId{},
-                                                                                         spill, g, cnt, st);
+                                                                                         spill, g, cnt, st, keyed_wgs(*g));
         });
     });
 }
@@ -37,7 +42,8 @@ static bool check_geometry(psk_sketch *s, uint64_t n, PartGeom *g, uint64_t *rou
     uint64_t rk = part_round_keys_big_table(n, s->k, PayKeyId::group, s->padded_bytes);
     // a keyed group spells the tile's ordinal inside its workgroup in 4 bits: at most 16 tiles per workgroup and round
     // (256 workgroups x 16 x 2048-key tiles for k <= 8; 512-key tiles beyond)
-    const uint64_t cap = (uint64_t)PayKeyId::max_tiles_per_wg * 256 * (s->k <= 8 ? 2048 : 512);
+    const uint64_t cap = (uint64_t)PayKeyId::max_tiles_per_wg * (g_part_wgs > 0 ? (uint64_t)g_part_wgs : (keyed_wgs(*g) ? keyed_wgs(*g) : 256u)) *
+                         (s->k <= 8 ? (g_part_tile_threads == 512 ? 1024 : 2048) : 512);
     if (rk > cap) rk = cap;
     *round_keys = rk;
     return true;

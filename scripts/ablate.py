@@ -14,9 +14,13 @@ import bench
 import pyprobables_amd as pa
 from pyprobables_amd import _native as N
 
-n = 10_000_000
+# usage: ablate.py [est_elements [n_keys [slices]]]  (defaults: the cfg-2 filter, 10 M keys, 256 slices)
+est = int(sys.argv[1]) if len(sys.argv) > 1 else 28005615
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+nslices = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 keys = gen_keys(n, 0, 0)
-blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01, device=0)
+blm = pa.BloomFilter(est_elements=est, false_positive_rate=0.01, device=0)
+print("m =", blm.number_bits, "k =", blm.number_hashes, "n =", n)
 for dbg, label in [(0, "full"), (1, "no stores"), (4, "no hashing"), (5, "skeleton only"), (2, "hashing only (+ key loads)"), (10, "hashing only, 1 WG/CU"), (8, "1 WG/CU")]:
     N.set_option("part_debug", dbg)
     ms = timed_loop(lambda: blm.add_many(keys), 10, warm=3)
@@ -28,11 +32,11 @@ import ctypes as C
 N.set_option("part_debug", 32)
 blm.add_many(keys); torch.cuda.synchronize()
 buf = (C.c_uint64 * 12)()
-N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 256, buf))   # clear whatever warm-up left
+N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, nslices, 256, buf))   # clear whatever warm-up left
 for _ in range(3):
     blm.add_many(keys)
 torch.cuda.synchronize()
-N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 256, buf))
+N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, nslices, 256, buf))
 names = ["(wgs)", "zero+bar", "hash+hist+bar", "scan+bar", "sort+bar", "writeout(+bar)"]
 tot = sum(buf[1:12])
 names += ["  scan: read hist+zero", "  scan: wave scan", "  scan: cursor+pads", "  hash+hist (own work)"]
@@ -44,11 +48,11 @@ N.set_option("part_debug", 0)
 # same phase profile for the lookup (keyed) variant
 N.set_option("part_debug", 32)
 blm.check_many(keys); torch.cuda.synchronize()
-N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 256, buf))
+N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, nslices, 256, buf))
 for _ in range(3):
     blm.check_many(keys)
 torch.cuda.synchronize()
-N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 256, buf))
+N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, nslices, 256, buf))
 tot = sum(buf[1:12])
 for i in [1, 9, 2, 6, 7, 8, 3, 4, 5]:
     print(f"check phase {names[i]:24s} {buf[i]/buf[0]/3:10.0f} ticks per WG per launch  ({100.0*buf[i]/tot:5.1f} %)")

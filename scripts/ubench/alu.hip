@@ -21,6 +21,9 @@ __global__ void k(uint32_t *out, uint32_t seed)
             if (OP == 6) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(e));
             if (OP == 7) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(e));
             if (OP == 8) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(a[i]));
+            if (OP == 9) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 10) asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x78" : "+v"(a[i]) : "v"(e));
+            if (OP == 11) asm volatile("v_lshlrev_b32 %0, 8, %0" : "+v"(a[i]));
         }
     }
     uint32_t s = 0;
@@ -60,7 +63,7 @@ static void run(const char *name, F launch, int waves_per_simd)
 int main()
 {
     uint32_t *o; hipMalloc(&o, 256 * 4 * 8 * 1024 * 8);
-    const char *names[] = {"v_mul_lo_u32", "v_xor_b32", "v_lshl_add_u32", "v_xor_b32_sdwa", "v_mul_u32_u24", "v_mad_u32_u24", "v_add_u32", "v_mul_hi_u32", "v_bfe_u32"};
+    const char *names[] = {"v_mul_lo_u32", "v_xor_b32", "v_lshl_add_u32", "v_xor_b32_sdwa", "v_mul_u32_u24", "v_mad_u32_u24", "v_add_u32", "v_mul_hi_u32", "v_bfe_u32", "v_add3_u32", "v_bitop3_b32", "v_lshlrev_b32"};
     for (int wps : {1, 4}) {
         dim3 grid(256 * wps), block(256);  // 256 CUs x wps blocks of 4 waves = wps waves per SIMD
         run(names[0], [&] { k<0><<<grid, block>>>(o, 1); }, wps);
@@ -72,6 +75,9 @@ int main()
         run(names[6], [&] { k<6><<<grid, block>>>(o, 1); }, wps);
         run(names[7], [&] { k<7><<<grid, block>>>(o, 1); }, wps);
         run(names[8], [&] { k<8><<<grid, block>>>(o, 1); }, wps);
+        run(names[9], [&] { k<9><<<grid, block>>>(o, 1); }, wps);
+        run(names[10], [&] { k<10><<<grid, block>>>(o, 1); }, wps);
+        run(names[11], [&] { k<11><<<grid, block>>>(o, 1); }, wps);
         run("v_mad_u64_u32", [&] { k64<0><<<grid, block>>>((uint64_t *)o, 1); }, wps);
         run("v_lshl_add_u64", [&] { k64<1><<<grid, block>>>((uint64_t *)o, 1); }, wps);
     }
