@@ -23,7 +23,7 @@ int PSK_VARIANT(bloom_add_partitioned)(psk_sketch *s, const Batch &b, hipStream_
                 using Src = decltype(src);
                 return with_kt<Src>(s->k, [&](auto kt) {
                     constexpr int KT = decltype(kt)::value;
-                    return launch_scatter<Src, IdxBloom<kTuPow2>, PayZero, SpillBloomOr, KT>(s, src, IdxBloom<kTuPow2>{s->md}, PayZero{},
+                    return launch_scatter<Src, IdxBloomWide<kTuPow2>, PayZero, SpillBloomOr, KT>(s, src, IdxBloomWide<kTuPow2>{s->md}, PayZero{},
                                                                                               spill, &g1, cnt, st);
                 });
             }));

@@ -65,8 +65,20 @@ __device__ __forceinline__ uint64_t seg_index(const PartGeom &g, uint32_t b, uin
 
 // idx functors: which table cell does hash j of a key address?
 // lo32: the index needs only the low 32 bits of the hash (power-of-two modulus <= 2^32)
+// The modulus of IdxBloom / IdxCms is at most 2^31 (single-level geometry: <= 2048 slices of <= 2^20 cells; counter tables
+// <= 2^29 cells): non-power-of-two ones reduce with reduce_small.  IdxBloomWide serves the two-level Bloom insert (m < 2^32).
 template <bool POW2>
 struct IdxBloom {  // bloom.py:247 / countingbloom.py:145:  h % m
+    static constexpr bool lo32 = POW2 && kPartHash32;
+    Mod md;
+    __device__ __forceinline__ uint32_t operator()(uint32_t, uint64_t h) const
+    {
+        return POW2 ? (uint32_t)reduce<true>(md, h) : reduce_small(md, h);
+    }
+    __device__ __forceinline__ uint32_t from32(uint32_t, uint32_t h) const { return h & (uint32_t)md.mask; }
+};
+template <bool POW2>
+struct IdxBloomWide {
     static constexpr bool lo32 = POW2 && kPartHash32;
     Mod md;
     __device__ __forceinline__ uint32_t operator()(uint32_t, uint64_t h) const { return (uint32_t)reduce<POW2>(md, h); }
@@ -78,7 +90,7 @@ struct IdxCms {  // countminsketch.py:275:  (h % width) + i*width
     Mod md;
     __device__ __forceinline__ uint32_t operator()(uint32_t j, uint64_t h) const
     {
-        return (uint32_t)(reduce<POW2>(md, h) + (uint64_t)j * md.m);
+        return (POW2 ? (uint32_t)reduce<true>(md, h) : reduce_small(md, h)) + j * (uint32_t)md.m;
     }
     __device__ __forceinline__ uint32_t from32(uint32_t j, uint32_t h) const
     {
