@@ -447,7 +447,7 @@ int64_t g_part_cache_bytes = 240 << 20;  // bucket-buffer budget per round: the 
 int64_t g_part_two_level_slices = 2048;     // tables cut into more slices than this take the two-level path (0 = never)
 int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGeom::dbg); 0 in production
 extern int64_t g_combine_keys;       // defined with the write-combined CBF updates below
-int64_t g_lookup_run_lanes = 0, g_bloom_lookup = 2, g_lookup_split = 1, g_part_tile_threads = 0, g_part_slice_bias = 0, g_part_wgs = 0;
+int64_t g_lookup_run_lanes = 0, g_bloom_lookup = 2, g_lookup_split = 1, g_part_tile_threads = 0, g_part_slice_bias = 0, g_part_wgs = 0, g_part_even_tiles = 1;
 extern PSK_HIDDEN int64_t g_merge_single_rank;  // psk_merge.hip
 
 extern "C" int psk_set_option(const char *name, int64_t value)
@@ -467,6 +467,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "tile_threads")) g_part_tile_threads = value;
     else if (!strcmp(name, "slice_bias")) g_part_slice_bias = value;
     else if (!strcmp(name, "scatter_workgroups")) g_part_wgs = value;
+    else if (!strcmp(name, "even_tiles")) g_part_even_tiles = value;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
 }

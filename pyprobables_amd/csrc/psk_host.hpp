@@ -154,6 +154,7 @@ extern PSK_HIDDEN int64_t g_part_mode, g_part_min_keys, g_part_max_keys, g_part_
 extern PSK_HIDDEN int64_t g_bloom_lookup;      // Bloom lookups: 0 keyed probes + miss stores, 1 return trip (psk_lookup.hpp), 2 (default) by the observed miss rate
 extern PSK_HIDDEN int64_t g_part_slice_bias;     // bench knob: added to log2(cells per slice)
 extern PSK_HIDDEN int64_t g_part_tile_threads;   // pass 1 workgroup size for k <= 8: 0 = 1024 when the LDS stage fits (one per CU), 512 = two 512-thread workgroups per CU
+extern PSK_HIDDEN int64_t g_part_even_tiles;     // 1 (default): pass 1 evens the tile size out over the workgroups
 extern PSK_HIDDEN int64_t g_part_wgs;            // bench knob: pass 1 workgroups (0 = auto: one or two per CU)
 extern PSK_HIDDEN int64_t g_lookup_split;        // bench knob: 0 = never share a slice between two pass-2 workgroups
 extern PSK_HIDDEN int64_t g_lookup_run_lanes;  // bench knob of the counter lookups (lanes per run in pass 3; 0 = auto)
@@ -218,7 +219,15 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
     if (g_part_wgs > 0) nwg = (uint64_t)g_part_wgs;
     if (nwg > ntiles) nwg = ntiles;
     const uint64_t tiles_per_wg = (ntiles + nwg - 1) / nwg;
-    const double mean = (double)tiles_per_wg * Tile::TILE * kk / (double)g->nbuckets;  // probes per segment
+    // Even tiles: 10 M keys are 4883 tiles of 2048, i.e. 19 rounds of all 256 workgroups and a 20th of only 19 of them --
+    // every workgroup takes ceil(tiles / workgroups) tiles of the same, slightly smaller size instead (a multiple of 64 keys:
+    // whole waves), the last one short.  Pass 2 and the lookups' pass 3 read the tile size from the geometry.
+    uint64_t tk = Tile::TILE;
+    if (g_part_even_tiles != 0 && nwg * tiles_per_wg > ntiles) {
+        tk = ((n + nwg * tiles_per_wg - 1) / (nwg * tiles_per_wg) + 63) & ~63ULL;
+        if (tk > (uint64_t)Tile::TILE) tk = Tile::TILE;
+    }
+    const double mean = (double)tiles_per_wg * (double)tk * kk / (double)g->nbuckets;  // probes per segment
     // 16-byte groups per segment: mean/GS, + ~half a group of padding per (tile, slice) run, + 8 sigma
     uint64_t segcap = (uint64_t)(mean / Tile::GS + 0.5 * (double)tiles_per_wg + 8.0 * __builtin_sqrt(mean) / Tile::GS + 16.0);
     if constexpr (Pay::mode == kModeKeyed) {
@@ -227,7 +236,7 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
     }
     g->nwg = (uint32_t)nwg;
     g->segcap = (uint32_t)segcap;
-    g->tile = (uint32_t)Tile::TILE;
+    g->tile = (uint32_t)tk;
     PSK_TRY(ensure(s->s_part, (uint64_t)g->nbuckets * nwg * segcap * 16 + 256));
     PSK_TRY(ensure(s->s_cnt, (uint64_t)g->nbuckets * nwg * 4 + 128));  // + 12 x u64 of phase profile (dbg & 32)
     auto kern = k_part_scatter<Src, IdxFn, Pay, Spill, KT, NT>;

@@ -72,7 +72,7 @@ static int bloom_check_return_trip(psk_sketch *s, const Batch &b, uint8_t *out_d
                 constexpr int KT = decltype(kt)::value;
                 constexpr int P4 = (KT + 7) / 8;
                 using TileSmall = PartTile<PayBloomLookup, KT, kPartThreads>;
-                const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE;
+                const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE + 512;  // (+: evened tiles, launch_scatter_nt)
                 PSK_TRY(ensure(s->s_perm, cnt * P4 * 16));
                 PSK_TRY(ensure(s->s_run, max_tiles * g.nbuckets * 8));
                 PayBloomLookup pay{(uint4 *)s->s_perm.p, (uint2 *)s->s_run.p};

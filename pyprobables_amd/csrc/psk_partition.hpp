@@ -343,7 +343,9 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     constexpr bool kExactK = KT != 8 && KT != 16 && KT != 32;
     const uint32_t k = kExactK ? (uint32_t)KT : g.k;
     const uint32_t mask = (1u << g.shift) - 1;
-    const uint64_t ntiles = (n + TILE - 1) / TILE;
+    // keys per tile: TILE, or fewer when the host evened the tiles out over the workgroups (launch_scatter_nt); a multiple of 64
+    const uint32_t tk = g.tile;
+    const uint64_t ntiles = (n + tk - 1) / tk;
 
     for (uint32_t b = threadIdx.x; b < B; b += NT) cur[b] = 0;
     for (uint32_t b = threadIdx.x; b < 2 * B; b += NT) hist0[b] = 0;
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     if (kPartPipeline) {
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
-            const uint64_t i = (uint64_t)blockIdx.x * TILE + (uint64_t)q * NT + threadIdx.x;
+            const uint64_t i = (uint64_t)blockIdx.x * tk + (uint64_t)q * NT + threadIdx.x;
             kcur[q] = src.load(i < n ? i : n - 1);  // coalesced; clamped, never branched around (a conditional load
         }                                           // makes hipcc wait vmcnt(0) per element: serial round trips)
     }
@@ -386,11 +388,12 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         // ---- hash + histogram: rank = my position among this tile's probes of the same slice
         uint32_t idx[KPT][KT], rank[KPT][KT], payload[KPT];
         uint32_t fold = 0;
-        const uint64_t base = tile * TILE;
+        const uint64_t base = tile * tk;
+        const uint64_t tile_end = base + tk < n ? base + tk : n;
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
             const uint64_t i = base + (uint64_t)q * NT + threadIdx.x;
-            if (i < n) {
+            if (i < tile_end) {
                 const typename Src::Key key = kPartPipeline ? kcur[q] : src.load(i);
                 if (PAIR) payload[q] = pay(i, base);
                 if constexpr (IdxFn::lo32) {  // 32-bit chains (power-of-two table: the upper hash halves are dead)
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         if (dbg & 2) {  // bench-only: keep the hashes alive, skip the rest of the tile (uniform)
             if (fold == 0x12345u) segcnt[0] = fold;
             if (kPartPipeline) {
-                const uint64_t nbase = (tile + gridDim.x) * TILE;
+                const uint64_t nbase = (tile + gridDim.x) * tk;
 #pragma unroll
                 for (int q = 0; q < KPT; ++q) {
                     const uint64_t i = nbase + (uint64_t)q * NT + threadIdx.x;
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
 
         // ---- prefetch the next tile's keys (consumed -- pinned -- before the write-out below)
         if (kPartPipeline) {
-            const uint64_t nbase = (tile + gridDim.x) * TILE;
+            const uint64_t nbase = (tile + gridDim.x) * tk;
 #pragma unroll
             for (int q = 0; q < KPT; ++q) {
                 const uint64_t i = nbase + (uint64_t)q * NT + threadIdx.x;
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
             const uint64_t i = base + (uint64_t)q * NT + threadIdx.x;
-            if (i < n) {
+            if (i < tile_end) {
                 uint32_t pos[LOOKUP ? 8 * ((KT + 7) / 8) : 1] = {};  // lookups: where each of my probes sits in the sorted stage
                 if constexpr (pay_has_tally<Pay>::value) {
                     // (here, not where the weight is loaded: the sum would pin the load's latency into the hash phase --
