@@ -234,6 +234,9 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
         if (tiles_per_wg > 16) return fail(PSK_EINVAL, "keyed lookup round of %llu keys needs %llu tiles per workgroup (max 16)",
                                            (unsigned long long)n, (unsigned long long)tiles_per_wg);
     }
+    // (pass 1 addresses a group as wg_base + slice * segcap + slot with a 24-bit multiply and a 32-bit sum)
+    if (segcap >= (1u << 24) || (uint64_t)g->nbuckets * segcap >= (1ULL << 32))
+        return fail(PSK_EINVAL, "partition round of %llu keys is too large (segments of %llu groups)", (unsigned long long)n, (unsigned long long)segcap);
     g->nwg = (uint32_t)nwg;
     g->segcap = (uint32_t)segcap;
     g->tile = (uint32_t)tk;

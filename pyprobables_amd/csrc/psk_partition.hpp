@@ -244,8 +244,11 @@ struct PartTile {
 // real (pads trail), so it names the slice.  delta[b] turns the stage group index into the slot of my segment.
 template <class Pay, class Spill>
 __device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t *gb, const uint32_t *delta, const PartGeom &g, uint32_t mask,
-                                           uint32_t gi, uint64_t tile, uint64_t base, const Spill &spill, uint4 *buckets)
+                                           uint32_t gi, uint64_t tile, uint64_t base, const Spill &spill, uint4 *wg_buckets)
 {
+    // wg_buckets: this workgroup's nbuckets segments (seg_index(g, 0, blockIdx.x) * segcap groups into the buffer); slice and
+    // segment capacity are both < 2^24 and a workgroup's share of the buffer is far below 2^32 groups: 24-bit multiply-add,
+    // 32-bit group index (the 64-bit (wg * B + b) * segcap + slot cost nine VALU instructions per group)
     constexpr int GS = Pay::group;
     if constexpr (Pay::mode == kModePlain) {
         // the LDS stage holds full cell indices (the first one names the slice); HBM gets them packed
@@ -266,9 +269,8 @@ __device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t
             uint4 o;
             if constexpr (GS == 6) {
                 // two 64-bit halves: 3 x 20-bit local indices + the number of valid ones in bits 60..63
-                uint32_t nv = 0;
-#pragma unroll
-                for (int e = 0; e < 6; ++e) nv += c[e] != kPadProbe;  // pads trail
+                // (cells are < 2^31 and the pad is all ones: the sign bits of c[1..5] count the pads -- no compare / carry chains)
+                const uint32_t nv = 6u - ((c[1] >> 31) + (c[2] >> 31) + (c[3] >> 31) + (c[4] >> 31) + (c[5] >> 31));
                 const uint32_t n0 = nv < 3 ? nv : 3, n1 = nv - n0;
                 const unsigned long long h0 = (unsigned long long)(c[0] & mask) | ((unsigned long long)(c[1] & mask) << 20) |
                                               ((unsigned long long)(c[2] & mask) << 40) | ((unsigned long long)n0 << 60);
@@ -276,11 +278,11 @@ __device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t
                                               ((unsigned long long)(c[5] & mask) << 40) | ((unsigned long long)n1 << 60);
                 o = make_uint4((uint32_t)h0, (uint32_t)(h0 >> 32), (uint32_t)h1, (uint32_t)(h1 >> 32));
             } else {
-                auto h16 = [&](uint32_t x) -> uint32_t { return x == kPadProbe ? 0xFFFFu : (x & mask); };
+                auto h16 = [&](uint32_t x) -> uint32_t { return (x & mask) | ((uint32_t)((int32_t)x >> 31) & 0xFFFFu); };  // pad (all ones) -> 0xFFFF
                 o = make_uint4(h16(c[0]) | (h16(c[1]) << 16), h16(c[2]) | (h16(c[3]) << 16),
                                h16(c[4]) | (h16(c[5]) << 16), h16(c[6]) | (h16(c[7]) << 16));
             }
-            buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = o;
+            wg_buckets[__umul24(b, g.segcap) + slot] = o;
         } else {  // segment full: exact fallback, probe by probe
 #pragma unroll
             for (int e = 0; e < GS; ++e)
@@ -291,7 +293,7 @@ __device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t
         const uint32_t b = gb[gi];
         const uint32_t slot = delta[b] + gi;
         if (slot < g.segcap) {
-            buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = e;
+            wg_buckets[__umul24(b, g.segcap) + slot] = e;
         } else {  // segment full: exact saturating add on the table, probe by probe
             const uint32_t w[4] = {e.x, e.y, e.z, e.w};
 #pragma unroll
@@ -307,7 +309,8 @@ __device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t
             uint32_t o[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x) o[x] = (w[x] == kPadProbe ? w[0] : w[x]) | ((((uint32_t)tile >> x) & 1u) << 31);
-            buckets[seg_index(g, b, blockIdx.x) * g.segcap + slot] = make_uint4(o[0], o[1], o[2], o[3]);
+            // (v_cmp + v_cndmask + v_or per word; the branch-free sign-mask form compiles to max / ashr / and / or3 and measured slower)
+            wg_buckets[__umul24(b, g.segcap) + slot] = make_uint4(o[0], o[1], o[2], o[3]);
         } else {
 #pragma unroll
             for (int x = 0; x < 4; ++x)
@@ -346,6 +349,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     // keys per tile: TILE, or fewer when the host evened the tiles out over the workgroups (launch_scatter_nt); a multiple of 64
     const uint32_t tk = g.tile;
     const uint64_t ntiles = (n + tk - 1) / tk;
+    uint4 *wg_buckets = buckets + seg_index(g, 0, blockIdx.x) * g.segcap;  // my segment of slice 0; slice b: + b * segcap
 
     for (uint32_t b = threadIdx.x; b < B; b += NT) cur[b] = 0;
     for (uint32_t b = threadIdx.x; b < 2 * B; b += NT) hist0[b] = 0;
@@ -531,10 +535,15 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
                         tally_a += (unsigned long long)(v < 0 ? -v : v);
                     }
                 }
+                // the k offsets first, then the k stores: written as one loop hipcc waits for every off[] read before the stage[]
+                // store in front of the next one (they may alias for all it knows) -- k dependent LDS round trips per key
+                uint32_t pp[KT];
+#pragma unroll
+                for (int j = 0; j < KT; ++j) pp[j] = (uint32_t)j < k ? off[idx[q][j] >> g.shift] + rank[q][j] : 0u;
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     if ((uint32_t)j < k) {
-                        const uint32_t p = off[idx[q][j] >> g.shift] + rank[q][j];
+                        const uint32_t p = pp[j];
                         if constexpr (LOOKUP) pos[j] = p;
                         if constexpr (PAIR) {
                             // final word (payload << shift | index in the slice); the slice of every group is kept
@@ -580,7 +589,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         if (!(dbg & 1)) {
             const uint32_t ngroups = tile_probes / GS;
             for (uint32_t gi = threadIdx.x; gi < ngroups; gi += NT) {
-                emit_group<Pay, Spill>(stage, gb, delta, g, mask, gi, Pay::mode == kModeKeyed ? (uint64_t)ordinal : tile, base, spill, buckets);
+                emit_group<Pay, Spill>(stage, gb, delta, g, mask, gi, Pay::mode == kModeKeyed ? (uint64_t)ordinal : tile, base, spill, wg_buckets);
             }
         }
         // (pipelined form) no barrier needed here: the next iteration touches only hist (last read two barriers

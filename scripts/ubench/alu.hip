@@ -24,6 +24,24 @@ __global__ void k(uint32_t *out, uint32_t seed)
             if (OP == 9) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(e));
             if (OP == 10) asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x78" : "+v"(a[i]) : "v"(e));
             if (OP == 11) asm volatile("v_lshlrev_b32 %0, 8, %0" : "+v"(a[i]));
+            if (OP == 12) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 13) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 14) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(e));
+            if (OP == 15) asm volatile("v_cmp_ne_u32 vcc, %0, %1" : : "v"(a[i]), "v"(e) : "vcc");
+            if (OP == 16) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 17) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 18) asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(a[i]));
+            if (OP == 19) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(a[i]));
+            if (OP == 20) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 21) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 22) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 23) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 24) asm volatile("v_or3_b32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(e));
+            if (OP == 25) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[i]) : "v"(e) : "vcc");
+            if (OP == 26) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a[i]) : "v"(e) : "vcc");
+            if (OP == 27) asm volatile("v_xor_b32 %0, 0x1b3, %0" : "+v"(a[i]));
+            if (OP == 28) asm volatile("v_mul_lo_u32 %0, %0, s4" : "+v"(a[i]) : : "s4");
+            if (OP == 29) asm volatile("v_and_b32 %0, 0xff, %0" : "+v"(a[i]));
         }
     }
     uint32_t s = 0;
@@ -63,8 +81,8 @@ static void run(const char *name, F launch, int waves_per_simd)
 int main()
 {
     uint32_t *o; hipMalloc(&o, 256 * 4 * 8 * 1024 * 8);
-    const char *names[] = {"v_mul_lo_u32", "v_xor_b32", "v_lshl_add_u32", "v_xor_b32_sdwa", "v_mul_u32_u24", "v_mad_u32_u24", "v_add_u32", "v_mul_hi_u32", "v_bfe_u32", "v_add3_u32", "v_bitop3_b32", "v_lshlrev_b32"};
-    for (int wps : {1, 4}) {
+    const char *names[] = {"v_mul_lo_u32", "v_xor_b32", "v_lshl_add_u32", "v_xor_b32_sdwa", "v_mul_u32_u24", "v_mad_u32_u24", "v_add_u32", "v_mul_hi_u32", "v_bfe_u32", "v_add3_u32", "v_bitop3_b32", "v_lshlrev_b32", "v_and_b32", "v_or_b32", "v_cndmask_b32", "v_cmp_ne_u32", "v_sub_u32", "v_min_u32", "v_ashrrev_i32", "v_lshrrev_b32", "v_mov_b32", "v_bfi_b32", "v_and_or_b32", "v_lshl_or_b32", "v_or3_b32", "v_addc_co_u32", "v_add_co_u32", "v_xor_b32 literal", "v_mul_lo_u32 sgpr", "v_and_b32 literal"};
+    for (int wps : {4}) {
         dim3 grid(256 * wps), block(256);  // 256 CUs x wps blocks of 4 waves = wps waves per SIMD
         run(names[0], [&] { k<0><<<grid, block>>>(o, 1); }, wps);
         run(names[1], [&] { k<1><<<grid, block>>>(o, 1); }, wps);
@@ -78,6 +96,8 @@ int main()
         run(names[9], [&] { k<9><<<grid, block>>>(o, 1); }, wps);
         run(names[10], [&] { k<10><<<grid, block>>>(o, 1); }, wps);
         run(names[11], [&] { k<11><<<grid, block>>>(o, 1); }, wps);
+#define RUN(i) run(names[i], [&] { k<i><<<grid, block>>>(o, 1); }, wps)
+        RUN(12); RUN(13); RUN(14); RUN(15); RUN(16); RUN(17); RUN(18); RUN(19); RUN(20); RUN(21); RUN(22); RUN(23); RUN(24); RUN(25); RUN(26); RUN(27); RUN(28); RUN(29);
         run("v_mad_u64_u32", [&] { k64<0><<<grid, block>>>((uint64_t *)o, 1); }, wps);
         run("v_lshl_add_u64", [&] { k64<1><<<grid, block>>>((uint64_t *)o, 1); }, wps);
     }
