@@ -5,9 +5,10 @@
 // pass 1 of one round: keyed probes of keys [0, cnt) of `sub` into the bucket buffer.  defer != nullptr: split lookup
 // (the table is not consulted; an overflowing segment raises *defer instead of testing its probes directly)
 // Pass 1 workgroups of the keyed lookups.  A round holds 16 tiles per workgroup (PayKeyId) and pass 2 reads the whole table
-// once per round: with 2048 slices (m = 2^31: 256 MiB per round) twice the workgroups -- twice the keys per round -- is worth
-// +7 % (21.0 -> 22.6 G keys/s, scripts/ab_wgs.py); at 1024 slices and below it measures the same or slightly worse.
-static inline uint32_t keyed_wgs(const PartGeom &g) { return g.nbuckets >= 2048 ? 512u : 0u; }  // 0: launch_scatter's default
+// once per round: with 2048 slices (m = 2^31: 256 MiB per round) four times the workgroups -- 33.5 M keys per round -- is worth
+// +13 % (256 workgroups 21.0, 512: 22.7, 1024: 23.8 G keys/s; scripts/ab_wgs.py, scripts/ab_2p31_lookup.py); at 1024 slices and
+// below it measures the same or slightly worse.
+static inline uint32_t keyed_wgs(const PartGeom &g) { return g.nbuckets >= 2048 ? 1024u : 0u; }  // 0: launch_scatter's default
 
 static int check_round_scatter(psk_sketch *s, const Batch &sub, uint64_t cnt, uint8_t *out, uint32_t *defer, PartGeom *g,
                                hipStream_t st, bool *handled)
