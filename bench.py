@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-detail", action="store_true", help="skip the CMS / CBF / GUPS side measurements")
     ap.add_argument("--no-combine", action="store_true", help="cfg4: apply every 1M-key batch at once (no write-combining of update batches)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="psk_set_option before the run (A/B of engine tunables)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: merge, then look up (no lookup pass 1 under the merge)")
     args = ap.parse_args()
     ds, dw = DEFAULT_STEPS[args.config]
@@ -548,7 +549,7 @@ class Cfg4:
                        "batch_keys": self.B, "batches": self.nb, "ops_per_step": self.ops_per_step, "parallelism": "single GPU",
                        "combine_updates": not self.args.no_combine,
                        "note": "combine_updates: the 1M-key batches are collected on the device (D2D copy of the keys) and applied as one "
-                               "partitioned update per 2^25 keys, all inside the timed step (the stream ends with a flush); removes are "
+                               "partitioned update per 2^26 keys, all inside the timed step (the stream ends with a flush); removes are "
                                "decrements, exact for this well-formed stream"},
             "roofline": roofline("cbf_add", "CBF stream = per fold: k_part_scatter (coarse) + k_part_split + k_counter_apply over the 1 GiB table",
                                  self.ops_per_step, ms, "the fold read-modify-writes the whole 1 GiB table; batches are combined before it"),
@@ -639,6 +640,10 @@ def main():
     self_launch(args)
     ctx = Ctx(args)
     torch = ctx.torch
+    for opt in args.option:
+        from pyprobables_amd import _native as _n
+        name, _, value = opt.partition("=")
+        _n.set_option(name, int(value, 0))
     wl = WORKLOADS[args.config](ctx, args)
 
     # clock ramp: a fresh process starts at idle clocks and the first tens of milliseconds after a fence run slow; spin

@@ -83,7 +83,7 @@ int psk_device_count(int *count);
  * 240 MiB: batches whose buffer would exceed 1.5x this are cut into equal rounds so that pass 2 reads pass 1's output from
  * the 256 MB Infinity Cache instead of HBM; 0 disables), "partition_two_level_slices" (default 2048: tables cut into more
  * LDS-sized slices than this are partitioned in two levels -- coarse buckets, then slices; 0 = such tables use the direct
- * kernels), "combine_keys" (keys per write-combining list of psk_cbf_update_combined, default 2^25), "bloom_lookup" (large Bloom
+ * kernels), "combine_keys" (keys per write-combining list of psk_cbf_update_combined, default 2^26), "bloom_lookup" (large Bloom
  * lookups: 0 = keyed probes + one store per missing probe, 1 = return trip with a cost independent of the answers, 2 (default) =
  * chosen per call from the miss tally of the previous lookups on the handle), "merge_single_rank" (1: psk_merge_* run the
  * collective path on a one-rank communicator); bench knobs: "lookup_split", "lookup_run_lanes" */
@@ -155,7 +155,7 @@ int psk_cbf_check(psk_sketch *s, int layout, const void *data, const uint64_t *o
                   uint32_t key_len, int where, uint32_t *out, void *stream);
 /* Write-combined updates (opt-in).  The fold of a big counter table read-modify-writes the whole table whatever the batch
  * brings (1 GiB at BASELINE config 4), so small batches -- the config's 1M-key add / remove batches -- are collected on the
- * device and applied as ONE partitioned update per list once "combine_keys" keys (psk_set_option, default 2^25) are waiting:
+ * device and applied as ONE partitioned update per list once "combine_keys" keys (psk_set_option, default 2^26) are waiting:
  * first the adds (countingbloom.py:135-155), then the removes as plain decrements of every index by the key's weight
  * (countingbloom.py:203-206 with to_remove == num_els).  Exact for well-formed streams (every remove targets a key with at
  * least num_els live inserts at that point of the stream; nothing saturates) -- the contract of the unordered batch ops

@@ -39,7 +39,7 @@ class CountingBloomFilter(BloomFilter):
     def __init__(self, est_elements=None, false_positive_rate=None, filepath=None, hex_string=None, hash_function=None,
                  device=None, combine_updates: bool = False):
         """``combine_updates`` (extra, off by default): ``add_many`` / ``remove_many`` batches are collected on the device
-        and applied as one partitioned update per 2^25 keys (``psk_cbf_update_combined``): folding a big table costs a
+        and applied as one partitioned update per 2^26 keys (``psk_cbf_update_combined``): folding a big table costs a
         pass over the WHOLE table whatever the batch size, so streams of small batches (BASELINE config 4: 1M-key
         batches into 1 GiB) only run fast when combined.  Removes are then plain decrements -- exact for well-formed
         streams (every remove targets a key with enough live inserts), the contract of the unordered batch ops; a remove
@@ -148,7 +148,7 @@ class CountingBloomFilter(BloomFilter):
     def _update_batch(self, remove: bool, b: KeyBatch, num_els) -> None:
         keep: list = []
         w_addr, _ = weights_arg(num_els, b.n, np.uint32, b.where, keep, 0, _U32_MAX, self._tab.device)
-        if getattr(self, "_combine", False):  # write-combined: collected on the device, applied per 2^25 keys
+        if getattr(self, "_combine", False):  # write-combined: collected on the device, applied per 2^26 keys
             N.check(N.lib().psk_cbf_update_combined(self._tab.handle, *b.args(), w_addr, int(remove), b.where, self._tab.stream))
         else:
             fn = N.lib().psk_cbf_remove if remove else N.lib().psk_cbf_add

@@ -442,7 +442,8 @@ static int finish(int where, const OutBuf *o, hipStream_t st)
 // ------------------------------------------------- partitioned (large-batch) path: options
 int64_t g_part_mode = 1;
 int64_t g_part_min_keys = 1 << 16;   // x1 for Bloom inserts, x4 for lookups / counter adds (part_wanted)
-int64_t g_part_max_keys = 1 << 25;   // keys per partition round (bounds the bucket buffer)
+int64_t g_part_max_keys = 1 << 26;   // keys per partition round (bounds the bucket buffer: ~2 GB of scratch at k = 7; sized for 288 GB of HBM --
+                                     // every round into a big table ends in a pass over the whole table, so fewer, larger rounds)
 int64_t g_part_cache_bytes = 240 << 20;  // bucket-buffer budget per round: the part of the 256 MB MALL we count on
 int64_t g_part_two_level_slices = 2048;     // tables cut into more slices than this take the two-level path (0 = never)
 int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGeom::dbg); 0 in production
@@ -690,7 +691,7 @@ static int settle_acct(psk_sketch *s, const W *w_dev, uint64_t n, hipStream_t st
 }
 
 // ----------------------------------------------------- CountingBloomFilter
-int64_t g_combine_keys = 1 << 25;  // keys per write-combining list (psk_set_option "combine_keys")
+int64_t g_combine_keys = 1 << 26;  // keys per write-combining list (psk_set_option "combine_keys"): 1 GiB of 16-byte keys per list
 
 // one unordered CBF update over a DEVICE-resident batch: add (countingbloom.py:135-155) or the unchecked decrement
 static int cbf_apply_device(psk_sketch *s, const Batch &b, const uint32_t *w, bool remove, hipStream_t st)
