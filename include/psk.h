@@ -79,14 +79,15 @@ const char *psk_last_error(void);         /* thread-local text of the last failu
 int psk_version(void);
 int psk_device_count(int *count);
 /* process-wide tunables: "partition" (0 = direct kernels only, 1 = auto), "partition_min_keys" (Bloom inserts with
- * at least this many keys -- 4x as many for lookups and counter adds -- take the partitioned path), "partition_max_keys" (keys per partition round), "partition_cache_bytes" (bucket-buffer budget per round, default
+ * at least this many keys -- 4x as many for lookups and counter adds -- take the partitioned path), "partition_max_keys" (keys per partition round, default 2^26), "partition_cache_bytes" (bucket-buffer budget per round, default
  * 240 MiB: batches whose buffer would exceed 1.5x this are cut into equal rounds so that pass 2 reads pass 1's output from
  * the 256 MB Infinity Cache instead of HBM; 0 disables), "partition_two_level_slices" (default 2048: tables cut into more
  * LDS-sized slices than this are partitioned in two levels -- coarse buckets, then slices; 0 = such tables use the direct
  * kernels), "combine_keys" (keys per write-combining list of psk_cbf_update_combined, default 2^26), "bloom_lookup" (large Bloom
  * lookups: 0 = keyed probes + one store per missing probe, 1 = return trip with a cost independent of the answers, 2 (default) =
  * chosen per call from the miss tally of the previous lookups on the handle), "merge_single_rank" (1: psk_merge_* run the
- * collective path on a one-rank communicator); bench knobs: "lookup_split", "lookup_run_lanes" */
+ * collective path on a one-rank communicator), "even_tiles" (default 1: pass 1 gives every workgroup the same number of equally
+ * sized tiles); bench knobs: "lookup_split", "lookup_run_lanes", "tile_threads", "scatter_workgroups", "slice_bias" */
 int psk_set_option(const char *name, int64_t value);
 int psk_get_option(const char *name, int64_t *value);
 /* bench-only: s_memtime totals per phase of the last partition pass 1 (option part_debug & 32) */

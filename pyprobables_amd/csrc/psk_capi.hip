@@ -498,6 +498,9 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "lookup_split")) *value = g_lookup_split;
     else if (!strcmp(name, "tile_threads")) *value = g_part_tile_threads;
     else if (!strcmp(name, "lookup_run_lanes")) *value = g_lookup_run_lanes;
+    else if (!strcmp(name, "even_tiles")) *value = g_part_even_tiles;
+    else if (!strcmp(name, "scatter_workgroups")) *value = g_part_wgs;
+    else if (!strcmp(name, "slice_bias")) *value = g_part_slice_bias;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
 }

@@ -1,6 +1,8 @@
 """Seeded differential fuzzing of the HIP engine against the C oracle: random table geometries, key layouts,
 batch sizes and both kernel families (direct / partitioned).  Bit-exact or it fails."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -18,12 +20,15 @@ def pa():
     return pyprobables_amd
 
 
+EXTRA = int(os.environ.get("PSK_FUZZ_EXTRA", "0"))  # soak runs: PSK_FUZZ_EXTRA=500 python -m pytest tests/test_gpu_fuzz.py -m gpu
+
+
 @pytest.fixture()
 def engine_options():
     from pyprobables_amd import _native as N
 
     old = {k: N.get_option(k) for k in ("partition", "partition_min_keys", "partition_max_keys", "partition_cache_bytes", "partition_two_level_slices",
-                                        "bloom_lookup", "lookup_split")}
+                                        "bloom_lookup", "lookup_split", "even_tiles")}
     yield N
     for k, v in old.items():
         N.set_option(k, v)
@@ -53,7 +58,7 @@ def _random_keys(rng, n):
     return ks, [k.encode("latin-1") for k in ks]
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 + EXTRA))
 def test_fuzz_bloom(pa, oracle, engine_options, seed):
     rng = np.random.default_rng(1000 + seed)
     engine_options.set_option("partition", int(rng.integers(0, 2)))
@@ -62,6 +67,7 @@ def test_fuzz_bloom(pa, oracle, engine_options, seed):
     engine_options.set_option("partition_cache_bytes", int(rng.choice([0, 1 << 16, 240 << 20])))
     engine_options.set_option("partition_two_level_slices", int(rng.choice([0, 2, 512])))
     engine_options.set_option("bloom_lookup", int(seed % 3))   # keyed probes / return trip / chosen per call
+    engine_options.set_option("even_tiles", int(seed // 3 % 2))
     est = int(rng.choice([50, 3000, 40_000, 200_000, 1_000_000]))
     fpr = float(rng.choice([0.3, 0.05, 0.01, 0.001, 1e-6]))
     blm = pa.BloomFilter(est_elements=est, false_positive_rate=fpr)
@@ -84,7 +90,7 @@ def test_fuzz_bloom(pa, oracle, engine_options, seed):
     assert blm._cnt_number_bits_set() == ob.bits_set()
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 + EXTRA))
 def test_fuzz_cms(pa, oracle, engine_options, seed):
     rng = np.random.default_rng(2000 + seed)
     engine_options.set_option("partition", int(rng.integers(0, 2)))
@@ -122,7 +128,7 @@ def test_fuzz_cms(pa, oracle, engine_options, seed):
         cms.query_type, oc.query = "min", oracle.Q_MIN
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 + EXTRA))
 def test_fuzz_cbf(pa, oracle, engine_options, seed):
     rng = np.random.default_rng(3000 + seed)
     engine_options.set_option("partition", int(rng.integers(0, 2)))
@@ -157,7 +163,7 @@ def test_fuzz_cbf(pa, oracle, engine_options, seed):
 
 
 # large tables: 2^20-bit Bloom slices / 2^15-cell counter slices at their maximum, every k class, both partition levels
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(20 + EXTRA))
 def test_fuzz_big_tables(pa, oracle, engine_options, seed):
     rng = np.random.default_rng(5000 + seed)
     engine_options.set_option("partition", 1)
