@@ -169,6 +169,45 @@ def test_bloom_4gbit_takes_the_two_level_path(pa, oracle):
     assert np.array_equal(blm.check_many(torch.from_numpy(probe).cuda()).cpu().numpy().astype(np.uint8), ob.check_keys(probe))
 
 
+def test_cms_large_non_pow2_width_two_level(pa, oracle):
+    """width 10^8 + 7 x depth 5 (2 GB of bins, 15259 slices: coarse buckets + k_part_split) with a non power-of-two modulus:
+    all 5 x (10^8 + 7) bins against the oracle after 14 M weighted updates (13 M in one call: the two-level path is taken from
+    cells / 8 probes per call; 1 M through the direct kernels), then lookups of inserted and fresh keys"""
+    width, depth, n = 100_000_007, 5, 14_000_000
+    cms = pa.CountMinSketch(width=width, depth=depth)
+    oc = oracle.OracleCMS(width, depth)
+    keys = oracle.gen_keys16(5, n)
+    w = oracle.gen_weights(5, n)
+    dk, dw = torch.from_numpy(keys).cuda(), torch.from_numpy(w).cuda()
+    cms.add_many(dk[:13_000_000], dw[:13_000_000])
+    cms.add_many(dk[13_000_000:], dw[13_000_000:])
+    oc.add_keys(keys, w)
+    assert np.array_equal(cms.table_tensor.cpu().numpy()[: oc.bins.size], oc.bins)
+    assert cms.elements_added == oc.els_added
+    probe = oracle.gen_keys16(5 + n - 250_000, 500_000)
+    assert np.array_equal(cms.check_many(torch.from_numpy(probe).cuda()).cpu().numpy().astype(np.int64), oc.check_keys(probe))
+
+
+def test_bloom_non_pow2_just_below_2p31_bits(pa, oracle):
+    """the largest single-level geometry with a non power-of-two modulus (2039 slices of 2^20 bits): the 32-bit remainder of
+    the partitioned path (reduce_small: r = h - q*m < 2m, just below 2^32 here) against the oracle's plain h % m"""
+    n = 3_000_000
+    blm = pa.BloomFilter(est_elements=223_000_000, false_positive_rate=0.01)
+    m = blm.number_bits
+    assert 2**31 - 2**24 < m < 2**31 and m & (m - 1) and blm.number_hashes == 7
+    ob = oracle.OracleBloom(m, 7)
+    keys = oracle.gen_keys16(99, n)
+    dk = torch.from_numpy(keys).cuda()
+    blm.add_many(dk[: n // 2])
+    blm.add_many(dk[n // 3:])
+    ob.add_keys(keys)
+    nb = ob.bloom.size // 4 * 4
+    assert torch.equal(blm.table_tensor.cpu().view(torch.uint8)[:nb], torch.from_numpy(ob.bloom[:nb]))
+    assert blm._cnt_number_bits_set() == ob.bits_set()
+    probe = oracle.gen_keys16(99 + n - 300_000, 600_000)     # half inserted, half fresh; large enough for the partitioned lookup
+    assert np.array_equal(blm.check_many(torch.from_numpy(probe).cuda()).cpu().numpy().astype(np.uint8), ob.check_keys(probe))
+
+
 def test_bloom_beyond_2p32_bits_uses_64bit_indices(pa, oracle):
     """m > 2^32: bit indices no longer fit 32 bits, the partitioned path steps aside, the direct kernels carry on"""
     n = 1_000_000
