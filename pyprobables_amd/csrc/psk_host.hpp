@@ -217,6 +217,7 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
     uint64_t nwg = 256 * per_cu;
     if (want_wgs) nwg = want_wgs;  // caller's choice (keyed lookups into big tables: twice the keys per round)
     if (g_part_wgs > 0) nwg = (uint64_t)g_part_wgs;
+    if (nwg > 64u * kApplyWaves) nwg = 64u * kApplyWaves;  // pass 2: a wave walks at most one segment per lane (for_each_batch_at)
     if (nwg > ntiles) nwg = ntiles;
     const uint64_t tiles_per_wg = (ntiles + nwg - 1) / nwg;
     // Even tiles: 10 M keys are 4883 tiles of 2048, i.e. 19 rounds of all 256 workgroups and a 20th of only 19 of them --

@@ -43,7 +43,7 @@ static bool check_geometry(psk_sketch *s, uint64_t n, PartGeom *g, uint64_t *rou
     uint64_t rk = part_round_keys_big_table(n, s->k, PayKeyId::group, s->padded_bytes);
     // a keyed group spells the tile's ordinal inside its workgroup in 4 bits: at most 16 tiles per workgroup and round
     // (256 workgroups x 16 x 2048-key tiles for k <= 8; 512-key tiles beyond)
-    const uint64_t cap = (uint64_t)PayKeyId::max_tiles_per_wg * (g_part_wgs > 0 ? (uint64_t)g_part_wgs : (keyed_wgs(*g) ? keyed_wgs(*g) : 256u)) *
+    const uint64_t cap = (uint64_t)PayKeyId::max_tiles_per_wg * (g_part_wgs > 0 ? (uint64_t)(g_part_wgs < 1024 ? g_part_wgs : 1024) : (keyed_wgs(*g) ? keyed_wgs(*g) : 256u)) *
                          (s->k <= 8 ? (g_part_tile_threads == 512 ? 1024 : 2048) : 512);
     if (rk > cap) rk = cap;
     *round_keys = rk;
@@ -73,7 +73,7 @@ static int bloom_check_return_trip(psk_sketch *s, const Batch &b, uint8_t *out_d
                 constexpr int KT = decltype(kt)::value;
                 constexpr int P4 = (KT + 7) / 8;
                 using TileSmall = PartTile<PayBloomLookup, KT, kPartThreads>;
-                const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE + 512;  // (+: evened tiles, launch_scatter_nt)
+                const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE + 1024;  // (+ workgroups: evened tiles, launch_scatter_nt)
                 PSK_TRY(ensure(s->s_perm, cnt * P4 * 16));
                 PSK_TRY(ensure(s->s_run, max_tiles * g.nbuckets * 8));
                 PayBloomLookup pay{(uint4 *)s->s_perm.p, (uint2 *)s->s_run.p};

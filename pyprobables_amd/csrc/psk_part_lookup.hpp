@@ -38,7 +38,7 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
                 constexpr int KT = decltype(kt)::value;
                 constexpr int P4 = (KT + 7) / 8;
                 using TileSmall = PartTile<PayUnitLookup, KT, kPartThreads>;  // the smaller of the two tile sizes bounds the tile count
-                const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE + 512;  // (+: evened tiles, launch_scatter_nt)
+                const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE + 1024;  // (+ workgroups: evened tiles, launch_scatter_nt)
                 PSK_TRY(ensure(s->s_perm, cnt * P4 * 16));
                 PSK_TRY(ensure(s->s_run, max_tiles * g.nbuckets * 8));
                 PayUnitLookup pay{(uint4 *)s->s_perm.p, (uint2 *)s->s_run.p};
