@@ -153,7 +153,7 @@ static inline int grid_for_keys(uint64_t n)  // direct kernels: 256 CUs x 16 blo
 extern PSK_HIDDEN int64_t g_part_mode, g_part_min_keys, g_part_max_keys, g_part_cache_bytes, g_part_two_level_slices, g_part_debug;
 extern PSK_HIDDEN int64_t g_bloom_lookup;      // Bloom lookups: 0 keyed probes + miss stores, 1 return trip (psk_lookup.hpp), 2 (default) by the observed miss rate
 extern PSK_HIDDEN int64_t g_part_slice_bias;     // bench knob: added to log2(cells per slice)
-extern PSK_HIDDEN int64_t g_part_tile_threads;   // pass 1 workgroup size for k <= 8: 0 = 1024 when the LDS stage fits (one per CU), 512 = two 512-thread workgroups per CU
+extern PSK_HIDDEN int64_t g_part_tile_threads;   // pass 1 workgroup shape for k <= 8: 0 = auto (launch_scatter), 512 / 1024 = forced
 extern PSK_HIDDEN int64_t g_part_even_tiles;     // 1 (default): pass 1 evens the tile size out over the workgroups
 extern PSK_HIDDEN int64_t g_part_wgs;            // bench knob: pass 1 workgroups (0 = auto: one or two per CU)
 extern PSK_HIDDEN int64_t g_lookup_split;        // bench knob: 0 = never share a slice between two pass-2 workgroups
@@ -204,6 +204,8 @@ static size_t scatter_lds_bytes(const PartGeom *g)
     return (5 * (size_t)g->nbuckets + 16 + 24 + stage_words) * 4;
 }
 
+constexpr size_t kScatterLdsBudget = 160 * 1024;
+constexpr size_t kScatterLdsTwoPerCu = 78 * 1024;  // two workgroups' dynamic LDS per CU
 template <class Src, class IdxFn, class Pay, class Spill, int KT, int NT>
 static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, PartGeom *g,
                              uint64_t n, hipStream_t st, uint32_t want_wgs)
@@ -212,7 +214,7 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
     const uint64_t ntiles = (n + Tile::TILE - 1) / Tile::TILE;
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
     const size_t lds = scatter_lds_bytes<Pay, KT, NT>(g);
-    uint64_t per_cu = NT > 512 ? 1 : (lds > 76 * 1024 ? 1 : 2);
+    uint64_t per_cu = NT > 512 ? 1 : (lds > kScatterLdsTwoPerCu ? 1 : 2);
     if (kBenchKnobs && (g->dbg & 8)) per_cu = 1;  // ablation: one workgroup per CU
     uint64_t nwg = 256 * per_cu;
     if (want_wgs) nwg = want_wgs;  // caller's choice (keyed lookups into big tables: twice the keys per round)
@@ -251,21 +253,27 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
     return PSK_OK;
 }
 
-// workgroup size: 1024 threads for small k when the (twice as large) LDS stage fits, else 512 (see PartTile::NT)
-constexpr size_t kScatterLdsBudget = 160 * 1024;
+// Workgroup shape (PartTile): k <= 8 takes one 1024-thread workgroup per CU; the Bloom insert (Pay::fat512) two 512-thread
+// workgroups per CU with 32 probes per thread when two LDS stages fit (tables of up to ~512 slices); larger k runs 512 threads
+// with one key per thread.
+// Option "tile_threads": 0 = this rule, 512 / 1024 = force the shape (A/B).
 template <class Src, class IdxFn, class Pay, class Spill, int KT>
 static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, PartGeom *g,
                           uint64_t n, hipStream_t st, uint32_t want_wgs = 0)
 {
-    if constexpr (KT <= 8) {
-        // keyed probes carry (key index in tile << shift | bit in slice) in 31 bits (the top bit spells the tile ordinal): the
-        // tile must stay within 2^(31 - shift) keys (PayKeyId::max_kpt caps it at 2048 keys for 1024 threads)
-        const bool ids_fit = Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, 1024>::TILE << g->shift) <= (1ULL << 31);
-        if (!(kBenchKnobs && (g->dbg & 16)) && g_part_tile_threads != 512 && ids_fit && scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget)
-            return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st, want_wgs);
-    }
     static_assert(Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, kPartThreads>::TILE << 20) <= (1ULL << 31),
                   "512-thread tiles must keep keyed probes inside 31 bits for the largest slice (2^20 bits)");
+    if constexpr (KT <= 8) {
+        // keyed probes carry (key index in tile << shift | bit in slice) in 31 bits (the top bit spells the tile ordinal): the
+        // tile must stay within 2^(31 - shift) keys (PayKeyId::max_tile caps it at 2048 keys)
+        static_assert(Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, 1024>::TILE << 20) <= (1ULL << 31), "keyed tile too large");
+        const bool fits1024 = scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget;
+        const bool two_per_cu = pay_fat512<Pay>::value && scatter_lds_bytes<Pay, KT, kPartThreads>(g) <= kScatterLdsTwoPerCu;
+        bool use1024 = fits1024 && !two_per_cu;
+        if (g_part_tile_threads == 1024) use1024 = fits1024;
+        if (g_part_tile_threads == 512 || (kBenchKnobs && (g->dbg & 16))) use1024 = false;
+        if (use1024) return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st, want_wgs);
+    }
     return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, kPartThreads>(s, src, idxfn, pay, spill, g, n, st, want_wgs);
 }
 

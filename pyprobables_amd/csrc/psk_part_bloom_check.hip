@@ -44,7 +44,7 @@ static bool check_geometry(psk_sketch *s, uint64_t n, PartGeom *g, uint64_t *rou
     // a keyed group spells the tile's ordinal inside its workgroup in 4 bits: at most 16 tiles per workgroup and round
     // (256 workgroups x 16 x 2048-key tiles for k <= 8; 512-key tiles beyond)
     const uint64_t cap = (uint64_t)PayKeyId::max_tiles_per_wg * (g_part_wgs > 0 ? (uint64_t)(g_part_wgs < 1024 ? g_part_wgs : 1024) : (keyed_wgs(*g) ? keyed_wgs(*g) : 256u)) *
-                         (s->k <= 8 ? (g_part_tile_threads == 512 ? 1024 : 2048) : 512);
+                         (s->k <= 8 ? 2048 : 512);
     if (rk > cap) rk = cap;
     *round_keys = rk;
     return true;

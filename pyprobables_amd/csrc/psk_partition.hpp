@@ -101,9 +101,13 @@ struct IdxCms {  // countminsketch.py:275:  (h % width) + i*width
 // (a payload functor with `static constexpr bool lookup = true` asks pass 1 for the by-products the partitioned
 // lookups need -- psk_lookup.hpp: perm[] and runinfo[])
 template <class Pay, class = void>
-struct pay_max_kpt { static constexpr int value = 1 << 20; };
+struct pay_max_tile { static constexpr int value = 1 << 30; };
 template <class Pay>
-struct pay_max_kpt<Pay, decltype((void)Pay::max_kpt)> { static constexpr int value = Pay::max_kpt; };
+struct pay_max_tile<Pay, decltype((void)Pay::max_tile)> { static constexpr int value = Pay::max_tile; };
+template <class Pay, class = void>
+struct pay_fat512 { static constexpr bool value = false; };
+template <class Pay>
+struct pay_fat512<Pay, decltype((void)Pay::fat512)> { static constexpr bool value = Pay::fat512; };
 template <class Pay, class = void>
 struct pay_has_tally { static constexpr bool value = false; };
 template <class Pay>
@@ -117,6 +121,7 @@ struct pay_is_lookup<Pay, decltype((void)Pay::lookup)> { static constexpr bool v
 struct PayNone {   // Bloom insert: 6 probes per group, 20-bit slice-local bit indices
     static constexpr int mode = kModePlain;
     static constexpr int group = 6;
+    static constexpr bool fat512 = true;  // PartTile: two 512-thread workgroups per CU with 32 probes per thread (measured: -3.5 %)
     __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
 };
 struct PayUnit {   // unit-weight counter adds: 8 probes per group, 16-bit slice-local cell indices (slices <= 2^15 cells)
@@ -144,12 +149,12 @@ struct PayZero {   // level 1 of the two-level Bloom insert: 4 x 32-bit (0 << sh
 // Bloom lookups: 4 probes per group, word = tile bit << 31 | key index within the tile << shift | bit index within the slice.
 // The four top bits of a group spell the tile's ordinal inside its workgroup's sequence (tile = ordinal * nwg + wg, wg = the
 // segment's workgroup), so a round holds at most 16 tiles per workgroup; the tile is at most 2^(31 - shift) keys
-// (max_kpt = 2: 2048 keys with 1024 threads).  Trailing slots of a run's last group repeat its first probe (a lookup
+// (max_tile = 2048 keys: slices of 2^20 bits).  Trailing slots of a run's last group repeat its first probe (a lookup
 // probe may be tested twice), so there is no pad marker in HBM.
 struct PayKeyId {
     static constexpr int group = 4;
     static constexpr int mode = kModeKeyed;
-    static constexpr int max_kpt = 2;
+    static constexpr int max_tile = 2048;
     static constexpr uint32_t max_tiles_per_wg = 16;
     __device__ __forceinline__ uint32_t operator()(uint64_t i, uint64_t base) const { return (uint32_t)(i - base); }
 };
@@ -229,13 +234,23 @@ struct PartTile {
     static constexpr bool pair = Pay::mode != kModePlain;           // probes carry a payload (weight / key id): the stage holds
                                                                     // the final 32-bit word and a per-group slice id (gb[])
     static constexpr int GS = Pay::group;                           // probes per 16-byte output group
-    static constexpr int PP = kPartProbes / 2;                      // 16 probes per thread: <= 100 VGPRs, 2 workgroups per CU
-    static constexpr int KPT0 = PP / KT >= 1 ? PP / KT : 1;
-    static constexpr int KPT = KPT0 < pay_max_kpt<Pay>::value ? KPT0 : pay_max_kpt<Pay>::value;  // keys per thread per tile
-    // Threads per workgroup: 512, or (host's choice, small k, when the LDS stage fits) 1024 = one workgroup per CU: the
-    // per-tile fixed costs (scan, barriers) are then paid once per 14 K probes instead of per 7 K; measured +5 % over
-    // two 512-thread workgroups per CU.  Large k stays at 512: 32-probe threads need more than the 128 VGPRs a
-    // 1024-thread workgroup can have.
+    // Probes per thread and tile.  k <= 8 comes in two shapes with the same tile (2048 keys for k = 7: 14 K probes, so the
+    // per-tile fixed costs -- scan, barriers -- are paid equally often): 1024 threads x 16 probes, one workgroup per CU, and
+    // 512 threads x 32 probes (113 VGPRs), TWO workgroups per CU when two LDS stages fit (the host's choice, launch_scatter).
+    // With one workgroup per CU the VALU-bound hash phase and the LDS / latency-bound scan, sort and write-out phases run
+    // strictly one after the other (ablation: hashing alone 94 us, everything else 138 us, both 203 us per 10 M keys); two
+    // workgroups drift out of phase and overlap them: insert 185 -> 178 us.  (Two 512-thread workgroups with 16 probes per
+    // thread -- 1024-key tiles, twice the tiles -- gave that gain back in fixed costs: round 1.)  Large k: 512 threads, 16
+    // or 32 probes, one key per thread.
+    // (Pay::fat512: the Bloom insert only.  Keyed lookups and weighted adds measured the same either way, unit counter adds
+    // 2 % and the counter lookups -- more registers per key: perm[] positions -- 5 % worse: they keep 16 probes per thread;
+    // scripts/ab_shape.py.)
+    static constexpr int PP = (NT_ == 512 && KT <= 8 && pay_fat512<Pay>::value) ? kPartProbes : kPartProbes / 2;
+    static constexpr int KPT_CAP = NT_ == 512 ? 6 : 1 << 20;        // registers: 2 words per probe + 4 per prefetched key
+    static constexpr int KPT1 = PP / KT >= 1 ? PP / KT : 1;
+    static constexpr int KPT0 = KPT1 < KPT_CAP ? KPT1 : KPT_CAP;
+    static constexpr int KPT_PAY = pay_max_tile<Pay>::value / NT_;  // (keyed probes: the key index inside the tile has 11 bits)
+    static constexpr int KPT = KPT0 < KPT_PAY ? KPT0 : KPT_PAY;     // keys per thread per tile
     static constexpr int NT = NT_;
     static constexpr int TILE = NT * KPT;                           // keys per tile
 };
