@@ -383,6 +383,28 @@ def test_split_lookup_segment_overflow_is_redone_exactly(pa, oracle, force_parti
     assert got[1] == 1 and got.sum() >= 150_000 - 300
 
 
+def test_split_lookup_overflow_in_later_rounds(pa, oracle, force_partition):
+    # six rounds; the duplicate-heavy stretch sits in rounds 1 and 2 (begin scatters round 0 only: the later rounds run in full
+    # at finish, their overflowing probes take the exact direct test), and the table changes while the lookup is pending
+    n = 260_000
+    keys = oracle.gen_keys16(77, n)
+    keys[60_000:140_000] = oracle.gen_keys16(9, 1)
+    dk = _dev(keys)
+    blm = pa.BloomFilter(est_elements=2_000_000, false_positive_rate=0.01)
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    blm.add_many(dk[:30_000])
+    ob.add_keys(keys[:30_000])
+    force_partition.set_option("partition_max_keys", 50_000)  # 6 rounds
+    blm.check_many_begin(dk)
+    blm.add_many(dk[60_000:60_001])     # the repeated key and a stretch of the last rounds go in while the lookup is pending
+    blm.add_many(dk[230_000:240_000])
+    ob.add_keys(keys[60_000:60_001])
+    ob.add_keys(keys[230_000:240_000])
+    got = blm.check_many_finish().cpu().numpy().astype(np.uint8)
+    assert np.array_equal(got, ob.check_keys(keys))
+    assert got[60_000:140_000].all() and got[230_000:240_000].all()
+
+
 # ------------------------------------------------------------------ two-level path (coarse buckets, then k_part_split)
 @pytest.mark.parametrize("est,fpr,n", [
     (28005615, 0.01, 700_000),    # 256 slices -> 128 coarse buckets x 2
