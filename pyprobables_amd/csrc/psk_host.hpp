@@ -155,6 +155,7 @@ extern PSK_HIDDEN int64_t g_bloom_lookup;      // Bloom lookups: 0 keyed probes 
 extern PSK_HIDDEN int64_t g_part_slice_bias;     // bench knob: added to log2(cells per slice)
 extern PSK_HIDDEN int64_t g_part_tile_threads;   // pass 1 workgroup shape for k <= 8: 0 = auto (launch_scatter), 512 / 1024 = forced
 extern PSK_HIDDEN int64_t g_part_even_tiles;     // 1 (default): pass 1 evens the tile size out over the workgroups
+extern PSK_HIDDEN int64_t g_part_dense_groups;   // pass 2 walks a wave's segments end to end when a segment holds fewer groups than this on average (0 = never)
 extern PSK_HIDDEN int64_t g_part_wgs;            // bench knob: pass 1 workgroups (0 = auto: one or two per CU)
 extern PSK_HIDDEN int64_t g_lookup_split;        // bench knob: 0 = never share a slice between two pass-2 workgroups
 extern PSK_HIDDEN int64_t g_lookup_run_lanes;  // bench knob of the counter lookups (lanes per run in pass 3; 0 = auto)
@@ -178,6 +179,7 @@ static inline bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_
     g->shift = (uint32_t)shift;
     g->dbg = (uint32_t)g_part_debug;
     g->split = g->split_idx = 0;
+    g->dense = 0;
     return true;
 }
 
@@ -243,6 +245,8 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
     g->nwg = (uint32_t)nwg;
     g->segcap = (uint32_t)segcap;
     g->tile = (uint32_t)tk;
+    // pass 2's walk (for_each_batch_at): segments much shorter than a 64-lane load are walked end to end
+    g->dense = (mean / Tile::GS + 0.5 * (double)tiles_per_wg) < (double)g_part_dense_groups ? 1u : 0u;
     PSK_TRY(ensure(s->s_part, (uint64_t)g->nbuckets * nwg * segcap * 16 + 256));
     PSK_TRY(ensure(s->s_cnt, (uint64_t)g->nbuckets * nwg * 4 + 128));  // + 12 x u64 of phase profile (dbg & 32)
     auto kern = k_part_scatter<Src, IdxFn, Pay, Spill, KT, NT>;

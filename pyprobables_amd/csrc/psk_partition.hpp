@@ -56,6 +56,7 @@ struct PartGeom {
     uint32_t dbg;           // bench-only bits: 1 skip stores, 4 skip hashing, 8 one workgroup per CU, 32 phase profile
     uint32_t split;         // read-only pass-2 kernels: workgroups per slice (0 / 1 = one); workgroup `split_idx` of a slice
     uint32_t split_idx;     // walks segments split_idx, split_idx + split, ... (balances slice counts that do not fill the CUs)
+    uint32_t dense;         // pass 2: 1 = short segments, a wave walks its segments end to end (for_each_batch_at); set by pass 1's launcher
 };
 
 // Where segment (slice b, workgroup wg) lives in the bucket buffer.  Workgroup-major: the B runs a workgroup
@@ -816,14 +817,23 @@ __global__ __launch_bounds__(kSplitThreads) void k_part_split(PartGeom g1, const
 constexpr int kApplyThreads = 1024;
 constexpr int kApplyWaves = kApplyThreads / 64;
 
-// Walk the groups of slice `b`: wave w takes segments w, w+16, ... (<= 32 of them: one count per lane).
+// Walk the groups of slice `b`: wave w takes segments w, w+16, ... (<= 64 of them: one count per lane).
 // A segment is a few hundred probes, so walking segment by segment is a chain of dependent HBM latencies
-// (count -> data -> next count ...) and leaves most loads of the last 64-group chunk of every segment empty.
-// Instead the wave's segments are cut into 64-group chunks, the chunks are numbered across segments (DPP prefix
-// sum of the per-segment chunk counts) and D chunks -- whichever segments they fall in -- are kept in flight per
-// lane before LDS is touched.  chunk -> (segment, offset) is scalar work: ballot + popcount + two readlanes.
-// `body` gets the D groups of a batch; absent ones hold `pad`.
-// body(q, at, wg): the D groups, their flat index in the bucket buffer (~0 = absent) and the pass-1 workgroup of their segment
+// (count -> data -> next count ...).  Two ways of keeping D 16-byte loads per lane in flight whatever segments they fall in:
+//   chunked (g.dense == 0, long segments)  every segment is cut into 64-group chunks, the chunks are numbered across the
+//       wave's segments (DPP prefix sum of the per-segment chunk counts); chunk -> (segment, offset) is scalar work: ballot +
+//       popcount + two readlanes, the lanes of a load share one segment base.  The last chunk of a segment fills only
+//       (groups mod 64) lanes: nothing for the 178-group segments of the headline configuration, but the 9-group segments
+//       of a 10 M-key lookup into 2048 slices used 14 % of the lanes of every load.
+//   dense (g.dense == 1, short segments)  the wave's segments are laid end to end: a prefix sum of the per-segment GROUP
+//       counts numbers the wave's groups 0 .. T-1 and lane l of load d takes group G0 + 64 d + l.  The first segment of a row
+//       of 64 groups is scalar work as before; the segment boundaries INSIDE the row are walked with one readlane + compare +
+//       two selects each, and every lane computes its own segment base.  m = 2^31: lookups of 10 M keys 665 -> 559 us, of
+//       2^25 keys 1415 -> 1382 us; on segments of ~40 groups and more it costs 1-2 % (178-group segments of the headline
+//       configuration: check 41.5 -> 40.7 G keys/s), hence the switch (launch_scatter_nt: mean groups per segment below
+//       the option `dense_walk_groups`, default 40).
+// body(q, at, wg): the D groups, their flat index in the bucket buffer (~0 = absent) and the pass-1 workgroup of their
+// segment (per lane in the dense walk); absent ones hold `pad`.
 template <int D, class Body>
 __device__ __forceinline__ void for_each_batch_at(const uint4 *buckets, const uint32_t *segcnt, const PartGeom &g, uint32_t b,
                                                   const uint4 pad, Body body)
@@ -831,9 +841,45 @@ __device__ __forceinline__ void for_each_batch_at(const uint4 *buckets, const ui
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t S = g.split > 1 ? g.split : 1, s0 = g.split > 1 ? g.split_idx : 0;
     const uint32_t mine_total = g.nwg > s0 ? (g.nwg - s0 + S - 1) / S : 0;                     // segments this workgroup walks
-    const uint32_t nseg = mine_total > wave ? (mine_total - wave + kApplyWaves - 1) / kApplyWaves : 0;  // <= 32 per wave
+    const uint32_t nseg = mine_total > wave ? (mine_total - wave + kApplyWaves - 1) / kApplyWaves : 0;  // <= 64 per wave
     uint32_t mycnt = 0;
     if (lane < nseg) mycnt = segcnt[(uint64_t)b * g.nwg + s0 + S * (wave + kApplyWaves * lane)];
+    if (g.dense) {
+        const uint32_t incl = wave_inclusive_scan(mycnt), excl = incl - mycnt;
+        const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        for (uint32_t G0 = 0; G0 < T; G0 += 64u * D) {
+            uint4 q[D];
+            uint64_t at[D];
+            uint32_t wg[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const uint32_t row = G0 + 64u * (uint32_t)d;  // uniform: first group of this load
+                const uint32_t G = row + lane;
+                uint32_t t = (uint32_t)__builtin_popcountll(__ballot(incl <= row));  // uniform: segments that end at or before `row`
+                const uint32_t sl = t < 64 ? t : 63;
+                uint32_t seg = sl;                                                      // per lane: my group's segment ...
+                uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)excl, sl);    // ... and the number of its first group
+                for (; t < 64; ++t) {  // the boundaries inside this row (uniform trip count)
+                    const uint32_t end_t = (uint32_t)__builtin_amdgcn_readlane((int)incl, t);
+                    if (end_t > row + 63u) break;
+                    const bool past = G >= end_t;
+                    seg = past ? t + 1 : seg;
+                    first = past ? end_t : first;
+                }
+                seg = seg < 64 ? seg : 63;
+                wg[d] = s0 + S * (wave + kApplyWaves * seg);
+                q[d] = pad;
+                at[d] = ~0ULL;
+                if (G < T) {
+                    const uint64_t idx = seg_index(g, b, wg[d]) * g.segcap + (G - first);
+                    q[d] = buckets[idx];
+                    at[d] = idx;
+                }
+            }
+            body(q, at, wg);
+        }
+        return;
+    }
     const uint32_t chunks = (mycnt + 63) >> 6;
     const uint32_t incl = wave_inclusive_scan(chunks), excl = incl - chunks;
     const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -866,9 +912,37 @@ __device__ __forceinline__ void for_each_batch(const uint4 *buckets, const uint3
                                                const uint4 pad, Body body)
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t nseg = g.nwg > wave ? (g.nwg - wave + kApplyWaves - 1) / kApplyWaves : 0;  // <= 32
+    const uint32_t nseg = g.nwg > wave ? (g.nwg - wave + kApplyWaves - 1) / kApplyWaves : 0;  // <= 64
     uint32_t mycnt = 0;
     if (lane < nseg) mycnt = segcnt[(uint64_t)b * g.nwg + wave + kApplyWaves * lane];
+    if (g.dense) {  // see for_each_batch_at
+        const uint32_t incl = wave_inclusive_scan(mycnt), excl = incl - mycnt;
+        const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        for (uint32_t G0 = 0; G0 < T; G0 += 64u * D) {
+            uint4 q[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const uint32_t row = G0 + 64u * (uint32_t)d;
+                const uint32_t G = row + lane;
+                uint32_t t = (uint32_t)__builtin_popcountll(__ballot(incl <= row));
+                const uint32_t sl = t < 64 ? t : 63;
+                uint32_t seg = sl;
+                uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)excl, sl);
+                for (; t < 64; ++t) {
+                    const uint32_t end_t = (uint32_t)__builtin_amdgcn_readlane((int)incl, t);
+                    if (end_t > row + 63u) break;
+                    const bool past = G >= end_t;
+                    seg = past ? t + 1 : seg;
+                    first = past ? end_t : first;
+                }
+                seg = seg < 64 ? seg : 63;
+                q[d] = pad;
+                if (G < T) q[d] = buckets[seg_index(g, b, wave + kApplyWaves * seg) * g.segcap + (G - first)];
+            }
+            body(q);
+        }
+        return;
+    }
     const uint32_t chunks = (mycnt + 63) >> 6;
     const uint32_t incl = wave_inclusive_scan(chunks), excl = incl - chunks;
     const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);

@@ -28,7 +28,7 @@ def engine_options():
     from pyprobables_amd import _native as N
 
     old = {k: N.get_option(k) for k in ("partition", "partition_min_keys", "partition_max_keys", "partition_cache_bytes", "partition_two_level_slices",
-                                        "bloom_lookup", "lookup_split", "even_tiles")}
+                                        "bloom_lookup", "lookup_split", "even_tiles", "dense_walk_groups")}
     yield N
     for k, v in old.items():
         N.set_option(k, v)
@@ -68,6 +68,7 @@ def test_fuzz_bloom(pa, oracle, engine_options, seed):
     engine_options.set_option("partition_two_level_slices", int(rng.choice([0, 2, 512])))
     engine_options.set_option("bloom_lookup", int(seed % 3))   # keyed probes / return trip / chosen per call
     engine_options.set_option("even_tiles", int(seed // 3 % 2))
+    engine_options.set_option("dense_walk_groups", (0, 40, 1 << 30)[seed // 2 % 3])  # pass 2: chunked walk / by segment length / end-to-end walk
     est = int(rng.choice([50, 3000, 40_000, 200_000, 1_000_000]))
     fpr = float(rng.choice([0.3, 0.05, 0.01, 0.001, 1e-6]))
     blm = pa.BloomFilter(est_elements=est, false_positive_rate=fpr)
@@ -97,6 +98,7 @@ def test_fuzz_cms(pa, oracle, engine_options, seed):
     engine_options.set_option("partition_min_keys", int(rng.choice([1, 1, 4096])))
     engine_options.set_option("partition_two_level_slices", int(rng.choice([0, 2, 512])))
     engine_options.set_option("lookup_split", int(seed % 2))
+    engine_options.set_option("dense_walk_groups", (0, 40, 1 << 30)[seed // 2 % 3])
     width = int(rng.choice([7, 1000, 4096, 65_536, 100_003, 1 << 18]))
     depth = int(rng.choice([1, 3, 5, 8, 11]))
     cms = pa.CountMinSketch(width=width, depth=depth)
@@ -134,6 +136,7 @@ def test_fuzz_cbf(pa, oracle, engine_options, seed):
     engine_options.set_option("partition", int(rng.integers(0, 2)))
     engine_options.set_option("partition_min_keys", int(rng.choice([1, 4096])))
     engine_options.set_option("partition_two_level_slices", int(rng.choice([0, 2, 512])))
+    engine_options.set_option("dense_walk_groups", (0, 40, 1 << 30)[seed % 3])
     est = int(rng.choice([200, 5000, 30_000, 300_000]))
     fpr = float(rng.choice([0.1, 0.01, 0.001]))
     cbf = pa.CountingBloomFilter(est_elements=est, false_positive_rate=fpr)
@@ -168,6 +171,7 @@ def test_fuzz_big_tables(pa, oracle, engine_options, seed):
     rng = np.random.default_rng(5000 + seed)
     engine_options.set_option("partition", 1)
     engine_options.set_option("partition_min_keys", 1)
+    engine_options.set_option("dense_walk_groups", (1 << 30, 40, 0)[seed // 2 % 3])
     engine_options.set_option("partition_two_level_slices", int(rng.choice([2048, 64, 256])))
     k_fpr = {3: 0.12, 4: 0.06, 5: 0.03, 6: 0.016, 7: 0.008, 8: 0.004, 10: 0.001, 13: 0.00012}
     k = int(rng.choice(list(k_fpr)))

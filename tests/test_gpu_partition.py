@@ -405,6 +405,52 @@ def test_split_lookup_overflow_in_later_rounds(pa, oracle, force_partition):
     assert got[60_000:140_000].all() and got[230_000:240_000].all()
 
 
+# ------------------------------------------------------------------ pass 2: chunked and end-to-end segment walks
+@pytest.mark.parametrize("dense_groups", [0, 1 << 30])
+def test_pass2_segment_walks_agree_with_the_oracle(pa, oracle, force_partition, dense_groups):
+    """option dense_walk_groups: 0 = every segment cut into its own 64-group chunks, huge = a wave walks its segments end to
+    end (the default picks by the mean segment length).  Inserts, both lookup schemes and the counter kernels under either."""
+    old = force_partition.get_option("dense_walk_groups")
+    force_partition.set_option("dense_walk_groups", dense_groups)
+    try:
+        n = 700_000
+        keys = oracle.gen_keys16(123, n)
+        fresh = oracle.gen_keys16(90_000_000, n // 2)
+        dk, df = _dev(keys), _dev(fresh)
+        for est, fpr in ((28005615, 0.01), (3_000_000, 0.02), (224044920 // 4, 0.01)):  # 256 slices, general m, 512 slices
+            blm = pa.BloomFilter(est_elements=est, false_positive_rate=fpr)
+            ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+            blm.add_many(dk[: n // 2])
+            blm.add_many(dk[n // 3:])
+            ob.add_keys(keys)
+            assert np.array_equal(_table(blm), ob.bloom)
+            for scheme in (0, 1):
+                force_partition.set_option("bloom_lookup", scheme)
+                assert np.array_equal(blm.check_many(dk).cpu().numpy().astype(np.uint8), ob.check_keys(keys))
+                assert np.array_equal(blm.check_many(df).cpu().numpy().astype(np.uint8), ob.check_keys(fresh))
+            force_partition.set_option("bloom_lookup", 2)
+        w = (np.arange(n, dtype=np.int32) % 7) + 1
+        cms = pa.CountMinSketch(width=2**20, depth=5)
+        oc = oracle.OracleCMS(2**20, 5)
+        cms.add_many(dk, torch.from_numpy(w).cuda())
+        cms.add_many(dk[: n // 2])
+        oc.add_keys(keys, w)
+        oc.add_keys(keys[: n // 2])
+        assert np.array_equal(cms.table_tensor.cpu().numpy()[: oc.bins.size], oc.bins)
+        assert np.array_equal(cms.check_many(dk).cpu().numpy(), oc.check_keys(keys))
+        cbf = pa.CountingBloomFilter(est_elements=3_000_000, false_positive_rate=0.01)
+        ocb = oracle.OracleCBF(cbf.number_bits, cbf.number_hashes)
+        cbf.add_many(dk)
+        ocb.update_keys(keys)
+        assert np.array_equal(cbf.check_many(dk).cpu().numpy().astype(np.uint32), ocb.check_keys(keys))
+        cbf.remove_many(dk[: n // 2])
+        ocb.update_keys(keys[: n // 2], -np.ones(n // 2, dtype=np.int64))
+        assert np.array_equal(_table(cbf, np.uint32), ocb.bloom)
+    finally:
+        force_partition.set_option("dense_walk_groups", old)
+        force_partition.set_option("bloom_lookup", 2)
+
+
 # ------------------------------------------------------------------ two-level path (coarse buckets, then k_part_split)
 @pytest.mark.parametrize("est,fpr,n", [
     (28005615, 0.01, 700_000),    # 256 slices -> 128 coarse buckets x 2
