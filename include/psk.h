@@ -88,7 +88,8 @@ int psk_device_count(int *count);
  * chosen per call from the miss tally of the previous lookups on the handle), "merge_single_rank" (1: psk_merge_* run the
  * collective path on a one-rank communicator), "even_tiles" (default 1: pass 1 gives every workgroup the same number of equally
  * sized tiles), "dense_walk_groups" (default 40: pass 2 walks a wave's segments end to end -- every lane of a load busy -- when a
- * (slice, workgroup) segment holds fewer 16-byte groups than this on average, e.g. small batches into 2048-slice tables); bench knobs: "lookup_split", "lookup_run_lanes", "tile_threads", "scatter_workgroups", "slice_bias" */
+ * (slice, workgroup) segment holds fewer 16-byte groups than this on average, e.g. small batches into 2048-slice tables), "lookup_half_slices" (default 1: CMS / CBF lookups into tables of 2^26 .. 2^27
+ * counters run partitioned over slices of 2^16 counters held as 16-bit values; 0 = such tables use the direct kernels); bench knobs: "lookup_split", "lookup_run_lanes", "tile_threads", "scatter_workgroups", "slice_bias" */
 int psk_set_option(const char *name, int64_t value);
 int psk_get_option(const char *name, int64_t *value);
 /* bench-only: s_memtime totals per phase of the last partition pass 1 (option part_debug & 32) */

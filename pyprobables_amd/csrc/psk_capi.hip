@@ -449,6 +449,7 @@ int64_t g_part_two_level_slices = 2048;     // tables cut into more slices than 
 int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGeom::dbg); 0 in production
 extern int64_t g_combine_keys;       // defined with the write-combined CBF updates below
 int64_t g_lookup_run_lanes = 0, g_bloom_lookup = 2, g_lookup_split = 1, g_part_tile_threads = 0, g_part_slice_bias = 0, g_part_wgs = 0, g_part_even_tiles = 1;
+int64_t g_lookup_half = 1;
 int64_t g_part_dense_groups = 40;   // pass 2: segments of fewer groups (mean) are walked end to end (for_each_batch_at); 0 = never
 extern PSK_HIDDEN int64_t g_merge_single_rank;  // psk_merge.hip
 
@@ -471,6 +472,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "scatter_workgroups")) g_part_wgs = value;
     else if (!strcmp(name, "even_tiles")) g_part_even_tiles = value;
     else if (!strcmp(name, "dense_walk_groups")) g_part_dense_groups = value;
+    else if (!strcmp(name, "lookup_half_slices")) g_lookup_half = value;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
 }
@@ -502,6 +504,7 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "lookup_run_lanes")) *value = g_lookup_run_lanes;
     else if (!strcmp(name, "even_tiles")) *value = g_part_even_tiles;
     else if (!strcmp(name, "dense_walk_groups")) *value = g_part_dense_groups;
+    else if (!strcmp(name, "lookup_half_slices")) *value = g_lookup_half;
     else if (!strcmp(name, "scatter_workgroups")) *value = g_part_wgs;
     else if (!strcmp(name, "slice_bias")) *value = g_part_slice_bias;
     else return fail(PSK_EINVAL, "unknown option %s", name);

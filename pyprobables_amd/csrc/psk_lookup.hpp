@@ -56,8 +56,13 @@ constexpr int kGatherDepth = 8;
 // pass over the slice while it is loaded tells) -- as 8 x uint16 (16 bytes per group, dense); fmt[slice] says which.
 // Grid: nbuckets * max(1, g.split) workgroups; with g.split > 1 the workgroups of a slice share its segments
 // (slice counts that do not fill the CUs -- CMS 5 x 2^20: 320 slices on 256 CUs -- left pass 2 unbalanced).
-static __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const uint32_t *tab, uint64_t tab_cells, PartGeom g,
-                                                                         const uint32_t *segcnt, const uint4 *buckets, uint4 *vals, uint8_t *fmt)
+// HALF (tables of more than 2048 x 2^15 counters, up to 2^27): slices of 2^16 counters whose LDS image holds 16-BIT values
+// (128 KiB); the values always leave in the 16-bit format.  A slice with a counter at or above 2^16 (or a negative CMS bin)
+// cannot be held that way: it raises *flag and the host's flag-guarded direct kernel redoes the batch (exact, slow, rare --
+// the counters of a CountingBloomFilter are small; a CBF for 10 M elements at 1 % already has 9.6e7 of them).
+template <bool HALF>
+__global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const uint32_t *tab, uint64_t tab_cells, PartGeom g,
+                                                                  const uint32_t *segcnt, const uint4 *buckets, uint4 *vals, uint8_t *fmt, uint32_t *flag)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t wave_max[kApplyWaves];
@@ -67,6 +72,7 @@ static __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const u
     const uint32_t slice_cells = 1u << g.shift;
     const uint32_t mask = slice_cells - 1;
     const uint64_t c0 = (uint64_t)b * slice_cells;
+    const uint16_t *smem16 = reinterpret_cast<const uint16_t *>(smem);
     uint32_t mx = 0;
     for (uint32_t w = threadIdx.x * 4; w < slice_cells; w += kApplyThreads * 4) {
         const uint64_t gc = c0 + w;
@@ -77,7 +83,8 @@ static __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const u
             if (gc + 1 < tab_cells) t.y = tab[gc + 1];
             if (gc + 2 < tab_cells) t.z = tab[gc + 2];
         }
-        *reinterpret_cast<uint4 *>(smem + w) = t;
+        if (HALF) *reinterpret_cast<uint2 *>(smem + w / 2) = make_uint2((t.x & 0xFFFFu) | (t.y << 16), (t.z & 0xFFFFu) | (t.w << 16));
+        else *reinterpret_cast<uint4 *>(smem + w) = t;
         mx |= t.x | t.y | t.z | t.w;  // (an OR is enough to tell whether any counter has a bit at or above 2^16; negative CMS bins do)
     }
     for (int o = 32; o > 0; o >>= 1) mx |= __shfl_down(mx, o);
@@ -86,15 +93,19 @@ static __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const u
     uint32_t all = 0;
 #pragma unroll
     for (int w = 0; w < kApplyWaves; ++w) all |= wave_max[w];
-    const bool narrow = all < 65536u;
-    if (threadIdx.x == 0) fmt[b] = narrow ? 1 : 0;  // (every workgroup of the slice writes the same value)
+    const bool narrow = HALF || all < 65536u;
+    if (threadIdx.x == 0) {
+        fmt[b] = narrow ? 1 : 0;  // (every workgroup of the slice writes the same value)
+        if (HALF && all >= 65536u) *flag = 1u;
+    }
+    auto cell = [&](uint32_t i) -> uint32_t { return HALF ? (uint32_t)smem16[i & mask] : smem[i & mask]; };
     for_each_batch_at<kGatherDepth>(buckets, segcnt, g, b, make_uint4(0, 0, 0, 0), [&](const uint4 (&q)[kGatherDepth], const uint64_t (&at)[kGatherDepth],
                                                                                       const uint32_t (&wg)[kGatherDepth]) {
         uint4 lo[kGatherDepth], hi[kGatherDepth];
 #pragma unroll
         for (int d = 0; d < kGatherDepth; ++d) {  // the 8 LDS reads of every group first (a pad cell 0xFFFF reads a harmless in-slice word)
-            lo[d] = make_uint4(smem[q[d].x & 0xFFFFu & mask], smem[(q[d].x >> 16) & mask], smem[q[d].y & 0xFFFFu & mask], smem[(q[d].y >> 16) & mask]);
-            hi[d] = make_uint4(smem[q[d].z & 0xFFFFu & mask], smem[(q[d].z >> 16) & mask], smem[q[d].w & 0xFFFFu & mask], smem[(q[d].w >> 16) & mask]);
+            lo[d] = make_uint4(cell(q[d].x & 0xFFFFu), cell(q[d].x >> 16), cell(q[d].y & 0xFFFFu), cell(q[d].y >> 16));
+            hi[d] = make_uint4(cell(q[d].z & 0xFFFFu), cell(q[d].z >> 16), cell(q[d].w & 0xFFFFu), cell(q[d].w >> 16));
         }
 #pragma unroll
         for (int d = 0; d < kGatherDepth; ++d) {

@@ -22,7 +22,14 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
     *done = false;
     if (!part_wanted(b.n, kk, 4)) return PSK_OK;
     PartGeom g;
-    if (!part_slices(cells, 15, 5, &g, kPartMaxBuckets, 7)) return PSK_OK;  // 2^15 counters = 128 KiB per slice; beyond 2048 slices: direct kernels
+    // 2^15 counters = 128 KiB per slice.  Beyond 2048 such slices (2^26 counters: a CBF for 7 M elements at 1 %) and up to 2^27
+    // counters: slices of 2^16 counters held as 16-bit values (k_counter_gather<true>; a counter at or above 2^16 raises the redo
+    // flag).  Larger tables: direct kernels.
+    bool half = false;
+    if (!part_slices(cells, 15, 5, &g, kPartMaxBuckets, 7)) {
+        if (g_lookup_half == 0 || !part_slices(cells, 16, 16, &g, kPartMaxBuckets, 7)) return PSK_OK;
+        half = true;
+    }
     g.k = kk;
     const uint64_t round_keys = lookup_round_keys(b.n, kk);
     PSK_TRY(ensure(s->s_flag, 8));
@@ -48,13 +55,14 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
                 const uint64_t vals_bytes = (uint64_t)g.nbuckets * g.nwg * g.segcap * 32;
                 PSK_TRY(ensure(s->s_vals, vals_bytes + g.nbuckets + 256));  // values + one format byte per slice
                 uint8_t *fmt = (uint8_t *)s->s_vals.p + vals_bytes;
-                const size_t lds2 = (size_t)4 << g.shift;
-                PSK_TRY(set_dyn_lds(k_counter_gather, lds2));
+                const size_t lds2 = (size_t)(half ? 2 : 4) << g.shift;
+                auto gather = half ? k_counter_gather<true> : k_counter_gather<false>;
+                PSK_TRY(set_dyn_lds(gather, lds2));
                 // slice counts that do not fill the 256 CUs evenly: two workgroups share a slice's segments (each loads the slice)
                 PartGeom g2 = g;
                 g2.split = (g.nbuckets % 256 != 0 && g.nbuckets < 1024 && g_lookup_split != 0) ? 2 : 1;
-                hipLaunchKernelGGL(k_counter_gather, dim3(g.nbuckets * g2.split), dim3(kApplyThreads), lds2, st, (const uint32_t *)s->table, cells, g2,
-                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint4 *)s->s_vals.p, fmt);
+                hipLaunchKernelGGL(gather, dim3(g.nbuckets * g2.split), dim3(kApplyThreads), lds2, st, (const uint32_t *)s->table, cells, g2,
+                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint4 *)s->s_vals.p, fmt, flag);
                 HIP_TRY(hipGetLastError());
                 // pass 3: back to key order, query epilogue
                 const uint32_t kq = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;

@@ -199,3 +199,62 @@ def test_lookup_value_formats_and_shared_slices(pa, oracle, force_partition):
         assert np.array_equal(cbf.check_many(_dev(keys)).cpu().numpy().view(np.uint32), want)
         assert np.array_equal(cms.check_many(_dev(keys)).cpu().numpy(), wantc)
     force_partition.set_option("lookup_split", 1)
+
+
+# ------------------------------------------------------------------ 2^26 .. 2^27 counters: slices of 2^16 counters held as 16-bit values
+def test_cbf_lookups_between_2p26_and_2p27_counters_take_half_slices(pa, oracle, force_partition):
+    """a CountingBloomFilter for 10 M elements at 1 % has 9.6e7 counters = 2925 slices of 2^15: beyond the one-level lookup, which
+    used to mean the direct gathers.  k_counter_gather<true> keeps 2^16 counters per slice as 16-bit values; check / remove
+    (validated: lookup + decrement) against the oracle, the direct kernels, and with the option off"""
+    n = 400_000
+    keys = oracle.gen_keys16(11, n)
+    probe = np.concatenate([keys[: n // 2], oracle.gen_keys16(99_000_000, n // 2)])
+    dk, dp = _dev(keys), _dev(probe)
+    cbf = pa.CountingBloomFilter(est_elements=10_000_000, false_positive_rate=0.01)
+    assert 2**26 < cbf.number_bits <= 2**27
+    oc = oracle.OracleCBF(cbf.number_bits, cbf.number_hashes)
+    w = (np.arange(n, dtype=np.int64) % 5) + 1
+    cbf.add_many(dk, w.astype(np.uint32))
+    oc.update_keys(keys, w)
+    want = oc.check_keys(probe)
+    got = cbf.check_many(dp).cpu().numpy().astype(np.uint32)
+    assert np.array_equal(got, want)
+    assert np.array_equal(_direct(force_partition, lambda: cbf.check_many(dp).cpu().numpy().astype(np.uint32)), want)
+    force_partition.set_option("lookup_half_slices", 0)
+    try:
+        assert np.array_equal(cbf.check_many(dp).cpu().numpy().astype(np.uint32), want)
+    finally:
+        force_partition.set_option("lookup_half_slices", 1)
+    # validated remove = the same lookup + the partitioned decrement
+    cbf.remove_many(dk[: n // 4])
+    oc.update_keys(keys[: n // 4], -np.ones(n // 4, dtype=np.int64))
+    assert np.array_equal(np.frombuffer(bytes(cbf.bloom), dtype=np.uint32), oc.bloom)
+    assert cbf.elements_added == oc.els_added
+    # a counter at or above 2^16 cannot live in a 16-bit slice image: the device flag sends the batch through the direct kernel
+    big = oracle.gen_keys16(5_000_000, 1)
+    cbf.add_many(_dev(big), 70_000)
+    oc.update_keys(big, np.array([70_000], dtype=np.int64))
+    probe2 = np.concatenate([big, probe])
+    assert np.array_equal(cbf.check_many(_dev(probe2)).cpu().numpy().astype(np.uint32), oc.check_keys(probe2))
+
+
+def test_cms_2p27_bins_half_slices_and_negative_bins(pa, oracle, force_partition):
+    """CountMinSketch 2^24 x 8 = 2^27 bins (2048 slices of 2^16): min / mean lookups; a negative bin (remove) has bits above 2^16
+    as a uint32, so its slice raises the redo flag and the answers still equal the oracle's"""
+    n = 300_000
+    keys = oracle.gen_keys16(21, n)
+    w = oracle.gen_weights(3, n)
+    cms = pa.CountMinSketch(width=2**24, depth=8)
+    oc = oracle.OracleCMS(2**24, 8)
+    cms.add_many(_dev(keys), _dev(w))
+    oc.add_keys(keys, w)
+    probe = np.concatenate([keys[: n // 2], oracle.gen_keys16(77_000_000, n // 2)])
+    for query in ("min", "mean"):
+        cms.query_type = query
+        oq = oracle.OracleCMS(2**24, 8, query)
+        oq.add_keys(keys, w)
+        assert np.array_equal(cms.check_many(_dev(probe)).cpu().numpy().astype(np.int64), oq.check_keys(probe)), query
+    cms.query_type = "min"
+    cms.remove_many(_dev(keys[:1000]), _dev(w[:1000]) * 2)   # those bins go negative
+    oc.remove_keys(keys[:1000], w[:1000] * 2)
+    assert np.array_equal(cms.check_many(_dev(probe)).cpu().numpy().astype(np.int64), oc.check_keys(probe))
