@@ -167,9 +167,16 @@ def weights_arg(w, n: int, np_dtype, where: int, keep: list, lo: int, hi: int, d
             if device is not None and w.device.index != device:
                 raise ValueError(f"weights live on cuda:{w.device.index}, the sketch on cuda:{device}")
             want = torch.int32 if np_dtype in (np.int32, np.uint32) else torch.int64
-            t = w.to(want).contiguous()
-            if t.numel() != n:
+            if w.numel() != n:
                 raise ValueError("weights length differs from the number of keys")
+            if w.is_floating_point() or w.dtype == torch.bool:
+                raise TypeError("num_els must be integers")
+            if want == torch.int32 and w.element_size() > 4 and n:
+                # a 64-bit device tensor would be narrowed silently: check its range like the host path does (one small reduction)
+                mn, mx = int(w.min().item()), int(w.max().item())
+                if mn < lo or mx > hi:
+                    raise OverflowError(f"num_els outside [{lo}, {hi}]")
+            t = w.to(want).contiguous()
             keep.append(t)
             return t.data_ptr(), None
         w = w.numpy()

@@ -258,3 +258,20 @@ def test_cms_2p27_bins_half_slices_and_negative_bins(pa, oracle, force_partition
     cms.remove_many(_dev(keys[:1000]), _dev(w[:1000]) * 2)   # those bins go negative
     oc.remove_keys(keys[:1000], w[:1000] * 2)
     assert np.array_equal(cms.check_many(_dev(probe)).cpu().numpy().astype(np.int64), oc.check_keys(probe))
+
+
+def test_wide_device_weights_are_range_checked(pa, oracle):
+    """a 64-bit device tensor of counts is narrowed to the engine's 32-bit weights: values outside the range raise like the host
+    path does (they used to wrap silently); in-range 64-bit counts are accepted"""
+    keys = oracle.gen_keys16(0, 1000)
+    dk = _dev(keys)
+    cms = pa.CountMinSketch(width=4096, depth=4)
+    with pytest.raises(OverflowError):
+        cms.add_many(dk, torch.full((1000,), 2**40, dtype=torch.int64, device="cuda"))
+    with pytest.raises(TypeError):
+        cms.add_many(dk, torch.ones(1000, dtype=torch.float32, device="cuda"))
+    cms.add_many(dk, torch.full((1000,), 3, dtype=torch.int64, device="cuda"))
+    oc = oracle.OracleCMS(4096, 4)
+    oc.add_keys(keys, np.full(1000, 3, dtype=np.int32))
+    assert np.array_equal(cms.table_tensor.cpu().numpy()[: oc.bins.size], oc.bins)
+    assert cms.elements_added == 3000
