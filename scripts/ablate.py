@@ -18,6 +18,9 @@ from pyprobables_amd import _native as N
 est = int(sys.argv[1]) if len(sys.argv) > 1 else 28005615
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
 nslices = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+# pass-1 workgroups of the insert (the phase counters sit behind the slices x workgroups segment counts): 512 since the insert
+# runs two 512-thread workgroups per CU (256 for tables whose LDS stage does not fit twice, e.g. 2048 slices); lookups: 256
+nwg_insert = int(sys.argv[4]) if len(sys.argv) > 4 else (512 if nslices <= 512 else 256)
 keys = gen_keys(n, 0, 0)
 blm = pa.BloomFilter(est_elements=est, false_positive_rate=0.01, device=0)
 print("m =", blm.number_bits, "k =", blm.number_hashes, "n =", n)
@@ -32,11 +35,11 @@ import ctypes as C
 N.set_option("part_debug", 32)
 blm.add_many(keys); torch.cuda.synchronize()
 buf = (C.c_uint64 * 12)()
-N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, nslices, 256, buf))   # clear whatever warm-up left
+N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, nslices, nwg_insert, buf))   # clear whatever warm-up left
 for _ in range(3):
     blm.add_many(keys)
 torch.cuda.synchronize()
-N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, nslices, 256, buf))
+N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, nslices, nwg_insert, buf))
 names = ["(wgs)", "zero+bar", "hash+hist+bar", "scan+bar", "sort+bar", "writeout(+bar)"]
 tot = sum(buf[1:12])
 names += ["  scan: read hist+zero", "  scan: wave scan", "  scan: cursor+pads", "  hash+hist (own work)"]
