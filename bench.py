@@ -21,6 +21,17 @@ stream) BEFORE the timed region, i.e. they are resident in HBM when the clock st
   cfg5  BloomFilter(224044920, 0.01) -> m = 2^31 bits (256 MiB per replica).  N_total keys (default 10^9) are split by
         key range over the ranks; STEP = clear + insert the shard + allreduce(OR) + check the shard.  Strong scaling.
 
+The default run (--gpus 1, cfg2) ALSO executes short steps of cfg3 (as written: 100M updates in 10 passes), cfg4 and cfg5
+(N = 1) after the headline's timed region and reports them under `configs.cfg3|cfg4|cfg5` (own ms_per_step, roofline,
+parity flags), so that the driver's one line covers the whole of BASELINE.json's metric (--no-extra-configs skips them).
+
+Failure handling: every rank arms a watchdog (--timeout seconds); a rank that fails or hangs still makes rank 0 (or the
+self-launching parent) print ONE JSON line with `"rc" != 0` and `"error"`, never a silent hang.
+
+Per-rank memory, `--config cfg5 --gpus 8`: 125M keys x 16 B = 2.0 GB of resident keys + the 256 MiB replica + ~2.6 GB of
+partition scratch per 2^25-key chunk (bucket buffer ~1.1 GB insert / ~1.9 GB lookup, segment counts) + 0.5 GB of merge
+buffers: < 6 GB of the 288 GB.  At N = 1 the 10^9 keys are 16 GB.
+
 Every line carries
   roofline      the dominant kernel of the configuration (cfg2: the Bloom insert launch = k_part_scatter + k_bloom_apply):
                 ALGORITHMIC bytes (72 B per inserted key, 45 per Bloom lookup, 60 per CMS update, ...) divided
@@ -39,18 +50,26 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
+import traceback
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+# dmabuf IPC: RCCL across processes needs it on this driver.  Set here, before torch / the HSA runtime start, so that BOTH launch
+# forms (python bench.py --gpus N, and python -m torch.distributed.run ... bench.py) run their ranks with the same environment.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SEED = 0x5EED
 # algorithmic bytes per unit of work (L = 16-byte key, k = 7, d = 5)
 BYTES = {"bloom_insert": 72, "bloom_check": 45, "cms_add": 60, "cms_check": 40, "cbf_add": 76, "cbf_remove": 76, "cbf_check": 48}
 DEFAULT_STEPS = {"cfg2": (200, 20), "cfg3": (20, 3), "cfg4": (10, 2), "cfg5": (5, 1)}
-PMC_FILE = ROOT / "profiles" / "r02_pmc_traffic.json"
+PMC_FILE = next((f for f in (ROOT / "profiles" / "r03_pmc_traffic.json", ROOT / "profiles" / "r02_pmc_traffic.json") if f.exists()),
+                ROOT / "profiles" / "r03_pmc_traffic.json")
+L2_FILE = ROOT / "profiles" / "r03_l2_hit.json"
+METRIC_CFG2 = "million keys/sec insert+lookup (Bloom m=2^28 k=7, CMS 2^20x5)"
 
 
 def parse():
@@ -69,6 +88,9 @@ def parse():
     ap.add_argument("--no-combine", action="store_true", help="cfg4: apply every 1M-key batch at once (no write-combining of update batches)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="psk_set_option before the run (A/B of engine tunables)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: merge, then look up (no lookup pass 1 under the merge)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="default run: skip the short cfg3 / cfg4 / cfg5 steps reported under `configs`")
+    ap.add_argument("--timeout", type=float, default=900.0, help="watchdog: seconds after which a rank gives up (JSON error line, rc 124)")
+    ap.add_argument("--init-timeout", type=float, default=180.0, help="N > 1: seconds allowed for the process-group rendezvous / RCCL init")
     args = ap.parse_args()
     ds, dw = DEFAULT_STEPS[args.config]
     args.steps = ds if args.steps is None else args.steps
@@ -76,8 +98,15 @@ def parse():
     return args
 
 
+def error_line(args, rc: int, error: str) -> str:
+    """the JSON line of a run that failed: same keys as a good line, value null, rc != 0"""
+    return json.dumps({"metric": METRIC_CFG2 if args.config == "cfg2" else f"bench {args.config}", "value": None, "unit": None, "n_gpus": args.gpus,
+                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "rc": rc, "error": error[-2000:]})
+
+
 def self_launch(args) -> None:
-    """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start the N ranks ourselves"""
+    """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start the N ranks ourselves.  The ranks' stdout
+    is passed through; if they fail, hang past --timeout or end without a JSON line, ONE JSON error line is printed."""
     if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
         return
     with socket.socket() as s:
@@ -86,8 +115,19 @@ def self_launch(args) -> None:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
-    sys.exit(subprocess.call(cmd, env=env))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    timer = threading.Timer(args.timeout + 60.0, lambda: os.killpg(proc.pid, 9))  # (the ranks' own watchdogs fire first)
+    timer.daemon = True
+    timer.start()
+    out = proc.stdout.read()
+    rc = proc.wait()
+    timer.cancel()
+    sys.stdout.write(out)
+    last = out.strip().splitlines()[-1] if out.strip() else ""
+    has_json = last.startswith("{") and last.endswith("}")
+    if rc != 0 and not has_json:
+        print(error_line(args, rc, f"the ranks ended with rc {rc} and no result line" + (" (killed by the launcher's watchdog)" if rc in (-9, 137) else "")), flush=True)
+    sys.exit(rc if rc >= 0 else 128 - rc)
 
 
 # ----------------------------------------------------------------------------------------------- plumbing
@@ -124,10 +164,13 @@ class Ctx:
                 os.environ.setdefault("WORLD_SIZE", "1")
                 os.environ["PSK_FORCE_MERGE_PATH"] = "1"
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            from datetime import timedelta
+
+            tmo = timedelta(seconds=args.init_timeout)  # rendezvous + every collective: a dead rank raises instead of hanging
             if self.single_device:
-                dist.init_process_group("gloo")
+                dist.init_process_group("gloo", timeout=tmo)
             else:
-                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=tmo)
             self.dist = dist
 
     def fence(self):
@@ -197,14 +240,27 @@ def timed_loop(torch, fn, iters, warm=2):
 
 def pmc_traffic(op: str, n: int):
     """HBM-side bytes per launch of `op` from the committed PMC profile of the same workload and kernels
-    (scripts/profile.sh -> profiles/r02_pmc_traffic.json); None when there is no matching record"""
+    (scripts/profile_r03.sh -> profiles/r03_pmc_traffic.json); None when there is no matching record.  A record measured
+    on chunks of the same kernels (`per_key_scalable`: cfg 5 inserts its shard in 2^25-key calls) is scaled by the key count."""
     try:
         pmc = json.loads(PMC_FILE.read_text())
-        if pmc["keys"] == n and op in pmc:
-            return pmc[op]["hbm_bytes_per_launch"]
+        rec = pmc[op]
+        if rec.get("keys", pmc.get("keys")) == n:
+            return rec["hbm_bytes_per_launch"]
+        if rec.get("per_key_scalable"):
+            return int(rec["bytes_per_key"] * n)
     except Exception:
         pass
     return None
+
+
+def l2_hit(op: str):
+    """L2 hit rate TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum) of the launch's kernels (profiles/r03_l2_hit.json,
+    scripts/profile_r03.sh: its own rocprofv3 --pmc pass); None when there is no record"""
+    try:
+        return json.loads(L2_FILE.read_text())[op]["l2_hit"]
+    except Exception:
+        return None
 
 
 def roofline(op: str, kernel: str, units: int, ms: float, limiter: str, traffic_op: str | None = None):
@@ -215,6 +271,7 @@ def roofline(op: str, kernel: str, units: int, ms: float, limiter: str, traffic_
         "bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": None if ach is None else ach / HBM_PEAK_GBS, "traffic": traffic,
         "traffic_source": f"{PMC_FILE.relative_to(ROOT)} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; bytes per launch)" if traffic else None,
+        "l2_hit": l2_hit(traffic_op or op),
         "algorithmic_bytes_per_launch": units * BYTES[op], "algorithmic_bytes_per_unit": BYTES[op], "avg_kernel_ms": ms,
         "limiter": limiter,
     }
@@ -250,6 +307,13 @@ def cpu_baseline(n_sample: int, reps: int = 3):
     t_mt = obm.mt_seconds                          # the three phases; replica allocation / first touch is outside the clock
     allc = {"value": 2 * n_mt / t_mt / 1e6, "unit": "Mkeys/s", "cores": cores, "kind": "port", "seconds": t_mt, "all_found": found == n_mt,
             "sample": f"insert {n_mt} + check {n_mt} keys, {cores} threads: per-thread 32 MiB replica, OR merge, lookups (oracle/psk_oracle.c, key generation included)"}
+    # -- C port, all cores, ONE shared table with relaxed atomic ORs (no replicas, no merge): the honest "all cores" figure
+    obs = oracle.OracleBloom(m, k)
+    found_s = obs.insert_check_mt_shared(0, n_mt, cores)
+    t_sh = obs.mt_seconds
+    shared = {"value": 2 * n_mt / t_sh / 1e6, "unit": "Mkeys/s", "cores": cores, "kind": "port", "seconds": t_sh, "all_found": found_s == n_mt,
+              "table_equals_replica_variant": bool((obs.bloom == obm.bloom).all()),
+              "sample": f"insert {n_mt} + check {n_mt} keys, {cores} threads on ONE shared 32 MiB table (__atomic_fetch_or, relaxed), lookups (oracle/psk_oracle.c, key generation included)"}
     # -- pure-Python mirror (what the reference's interpreted loop costs here; never the reference itself)
     n_py = 100_000
     mb = pymirror.MirrorBloom(m, k)
@@ -261,7 +325,7 @@ def cpu_baseline(n_sample: int, reps: int = 3):
     t_py = time.perf_counter() - t0
     py = {"value": 2 * n_py / t_py / 1e6, "unit": "Mkeys/s", "cores": 1, "kind": "python-mirror", "seconds": t_py, "all_found": ok,
           "sample": f"insert {n_py} + check {n_py} keys through oracle/pymirror.py (interpreted per-key FNV-1a + add_alt/check_alt, bigint arithmetic like the reference)"}
-    return {**one, "legs": {"port_1core": dict(one), "port_allcores": allc, "python_mirror": py}}
+    return {**one, "legs": {"port_1core": dict(one), "port_allcores": allc, "port_allcores_shared_table": shared, "python_mirror": py}}
 
 
 # ----------------------------------------------------------------------------------------------- cfg2
@@ -342,7 +406,7 @@ class Cfg2:
             detail.update(side)
             rooflines.update(rl)
         line = {
-            "metric": "million keys/sec insert+lookup (Bloom m=2^28 k=7)",
+            "metric": METRIC_CFG2,
             "config": {
                 "workload": "cfg2: BloomFilter(est_elements=28005615, fpr=0.01): m=2^28 bits, k=7, default_fnv_1a; per rank per step: "
                             "clear + insert 10M x 16B keys + (merge) + check the same 10M",
@@ -385,7 +449,7 @@ def side_measurements(ctx: Ctx, n, blm, keys):
     cms = pa.CountMinSketch(width=2**20, depth=5, device=dev)
     ms = timed_loop(torch, lambda: cms.add_many(keys, w), 5)
     out["cms_add_Mupd_s"] = n / ms / 1e3
-    rl["cms_add"] = roofline("cms_add", "CMS weighted add = k_weight_sum + k_part_scatter<...,IdxCms<pow2>,PayWeight,...,5> + k_counter_apply",
+    rl["cms_add"] = roofline("cms_add", "CMS weighted add = k_part_scatter<...,IdxCms<pow2>,PayWeight,...,5> (sums the weights) + k_tally_fold + k_counter_apply",
                              n, ms, "pass 1 (5 FNV-1a chains + LDS counting sort), pass 2 folds 2^15-cell slices", "cms_add_weighted")
     ms = timed_loop(torch, lambda: cms.check_many(keys), 5)
     out["cms_check_Mkeys_s"] = n / ms / 1e3
@@ -486,7 +550,7 @@ class Cfg3:
                                    "(10 passes over 10M 16-byte keys, weights 1..7) + (SUM merge)",
                        "keys_per_rank": n, "passes": self.PASSES, "width": 2**20, "depth": 5,
                        "parallelism": f"key-range x{ctx.world}, replica per GPU, allreduce(SUM)" if ctx.world > 1 else "single GPU"},
-            "roofline": roofline("cms_add", "CMS weighted add = k_weight_sum + k_part_scatter<...,IdxCms<pow2>,PayWeight,...,5> + k_counter_apply "
+            "roofline": roofline("cms_add", "CMS weighted add = k_part_scatter<...,IdxCms<pow2>,PayWeight,...,5> (sums the weights) + k_tally_fold + k_counter_apply "
                                  "(one pass of 10M updates between two HIP events)", n, add_ms,
                                  "pass 1 (5 FNV-1a chains + LDS counting sort), pass 2 folds 2^15-cell slices", "cms_add_weighted"),
             "rooflines": {"cms_check": roofline("cms_check", "CMS lookup (min over 5 rows)", n, chk_ms, "see DESIGN.md 3.2")},
@@ -552,7 +616,7 @@ class Cfg4:
                                "partitioned update per 2^26 keys, all inside the timed step (the stream ends with a flush); removes are "
                                "decrements, exact for this well-formed stream"},
             "roofline": roofline("cbf_add", "CBF stream = per fold: k_part_scatter (coarse) + k_part_split + k_counter_apply over the 1 GiB table",
-                                 self.ops_per_step, ms, "the fold read-modify-writes the whole 1 GiB table; batches are combined before it"),
+                                 self.ops_per_step, ms, "the fold read-modify-writes the whole 1 GiB table; batches are combined before it", "cfg4_stream"),
             "rooflines": {},
             "detail": {"elements_added": els, "expected_elements": expect, "sum_counters_equals_k_x_live": total == 7 * expect, "diagnostics": diag},
         }
@@ -616,8 +680,8 @@ class Cfg5:
                        "keys_total": self.args.n_total, "keys_per_rank": self.n, "m_bits": 2**31, "k": 7,
                        "parallelism": f"key-range x{ctx.world}, replica per GPU, allreduce(OR) = all_to_all + OR kernel + all_gather"},
             "roofline": roofline("bloom_insert", "Bloom insert, m=2^31 (2048 slices): k_part_scatter + k_bloom_apply per 32M-key chunk", self.n, ins,
-                                 "short (tile, slice) runs at 2048 slices: pass 1 is write-out bound"),
-            "rooflines": {"bloom_check": roofline("bloom_check", "Bloom lookup, m=2^31", self.n, chk, "as the insert")},
+                                 "short (tile, slice) runs at 2048 slices: pass 1 is write-out bound", "bloom31_insert"),
+            "rooflines": {"bloom_check": roofline("bloom_check", "Bloom lookup, m=2^31", self.n, chk, "as the insert", "bloom31_check")},
             "detail": {"insert_ms": ins, "merge_ms": None if mrg != mrg else mrg, "check_ms": chk,
                        "insert_Mkeys_s_per_gpu": self.n / ins / 1e3, "check_Mkeys_s_per_gpu": self.n / chk / 1e3,
                        "merge_GBs_per_gpu": None if mrg != mrg else 2**28 / mrg / 1e6,
@@ -635,53 +699,123 @@ WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5}
 DTYPES = {"cfg2": "u64", "cfg3": "i32", "cfg4": "u32", "cfg5": "u64"}  # arithmetic type of the path (hash chains / counters)
 
 
+UNITS = {"cfg2": "Mkeys/s", "cfg3": "Mupdates/s", "cfg4": "Mops/s", "cfg5": "Mkeys/s"}
+EXTRA_STEPS = {"cfg3": (5, 1), "cfg4": (3, 1), "cfg5": (2, 1)}  # (steps, warmup) of the extra configurations on the default line
+
+
+def run_workload(ctx: Ctx, args, name: str, steps: int, warmup: int, spinup: float):
+    """spin-up, `warmup` untimed steps, EXACTLY `steps` timed steps between two fences, per-phase pass, parity.
+    -> (workload, body, fails, seconds per step (max over ranks), untimed spin-up steps)"""
+    torch = ctx.torch
+    wl = WORKLOADS[name](ctx, args)
+    # clock ramp: a fresh process starts at idle clocks and the first tens of milliseconds after a fence run slow; spin
+    # the same step untimed first so that short runs (the driver's --steps 20) measure the steady state
+    t_spin = time.perf_counter()
+    spun = 0
+    while time.perf_counter() - t_spin < spinup:
+        wl.step(False)
+        spun += 1
+        if spun % 8 == 0:
+            torch.cuda.synchronize()
+    for _ in range(warmup):
+        wl.step(False)
+    ctx.fence()
+    t0 = time.perf_counter()
+    sample_every = max(1, min(20, steps // 3))  # the dominant launch is event-timed on every sample_every-th step (>= 3 samples)
+    for it in range(steps):
+        wl.step(it % sample_every == 0)
+    ctx.fence()
+    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    wl.instrumented()  # per-phase HIP-event times (not part of `value`)
+    ctx.fence()
+    body, fails = wl.finish(elapsed / steps * 1e3)
+    return wl, body, fails, elapsed / steps, spun
+
+
+def extra_config(ctx: Ctx, args, name: str):
+    """one of cfg3 / cfg4 / cfg5 (N = 1) as written, a few steps: the object reported under `configs.<name>`"""
+    steps, warmup = EXTRA_STEPS[name]
+    wl, body, fails, sec, spun = run_workload(ctx, args, name, steps, warmup, min(args.spinup, 0.3))
+    obj = {"metric": body.pop("metric"), "value": wl.ops_per_step / sec / 1e6, "unit": UNITS[name], "ms_per_step": sec * 1e3, "steps": steps,
+           "warmup": warmup, "scaling": body.pop("scaling", "weak"), "dtype": DTYPES[name], "parity_ok": not fails, "parity_failures": fails}
+    obj.update(body)
+    del wl
+    ctx.torch.cuda.empty_cache()
+    return obj, fails
+
+
 def main():
     args = parse()
     self_launch(args)
+    rank = int(os.environ.get("RANK", 0))
+
+    def give_up():  # a hang (a rank that died inside a collective, a wedged rendezvous): say so in the result line, then leave
+        if rank == 0:
+            os.write(1, ("\n" + error_line(args, 124, f"watchdog: no result after {args.timeout:g} s (a rank failed or a collective hangs)") + "\n").encode())
+        os._exit(124)
+
+    dog = threading.Timer(args.timeout, give_up)
+    dog.daemon = True
+    dog.start()
+    try:
+        rc = run(args)
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001  -- the line must exist whatever happened (rank 0 reports; the others just fail)
+        if rank == 0:
+            sys.stdout.flush()
+            print(error_line(args, 1, f"{type(e).__name__}: {e} | " + traceback.format_exc(limit=4)), flush=True)
+        os._exit(1)  # (not sys.exit: a failed rank must not wait in atexit handlers for collectives that will never complete)
+    dog.cancel()
+    if rc:
+        raise SystemExit(rc)
+
+
+def run(args):
+    inject = os.environ.get("PSK_BENCH_INJECT")  # test hook for the failure paths: "raise" / "hang" (optionally ":<rank>")
+    if inject:
+        kind, _, who = inject.partition(":")
+        if not who or int(who) == int(os.environ.get("RANK", 0)):
+            if kind == "hang":
+                time.sleep(1e6)
+            raise RuntimeError("injected failure (PSK_BENCH_INJECT)")
     ctx = Ctx(args)
     torch = ctx.torch
     for opt in args.option:
         from pyprobables_amd import _native as _n
         name, _, value = opt.partition("=")
         _n.set_option(name, int(value, 0))
-    wl = WORKLOADS[args.config](ctx, args)
-
-    # clock ramp: a fresh process starts at idle clocks and the first tens of milliseconds after a fence run slow; spin
-    # the same step untimed first so that short runs (the driver's --steps 20) measure the steady state
-    t_spin = time.perf_counter()
-    spun = 0
-    while time.perf_counter() - t_spin < args.spinup:
-        wl.step(False)
-        spun += 1
-        if spun % 8 == 0:
-            torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        wl.step(False)
-    ctx.fence()
-    t0 = time.perf_counter()
-    sample_every = max(1, min(20, args.steps // 3))  # the dominant launch is event-timed on every sample_every-th step (>= 3 samples)
-    for it in range(args.steps):
-        wl.step(it % sample_every == 0)
-    ctx.fence()
-    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
-    wl.instrumented()  # per-phase HIP-event times (not part of `value`)
-    ctx.fence()
-    body, fails = wl.finish(elapsed / args.steps * 1e3)
+    wl, body, fails, sec, spun = run_workload(ctx, args, args.config, args.steps, args.warmup, args.spinup)
 
     line = {
         "metric": body.pop("metric"),
-        "value": wl.ops_per_step / (elapsed / args.steps) / 1e6,
-        "unit": "Mkeys/s" if args.config in ("cfg2", "cfg5") else ("Mupdates/s" if args.config == "cfg3" else "Mops/s"),
-        "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "value": wl.ops_per_step / sec / 1e6,
+        "unit": UNITS[args.config],
+        "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
         "higher_is_better": True, "scaling": body.pop("scaling", "weak"), "vs_baseline": None, "dtype": DTYPES[args.config],
-        "data": "synthetic",
+        "data": "synthetic", "rc": 0,
     }
     body["config"]["clock_spinup"] = f"{spun} untimed steps (~{args.spinup:g} s) before the {args.warmup} warm-up steps"
     line.update(body)
+    if args.config == "cfg2" and ctx.world == 1 and not ctx.distributed and not args.no_extra_configs and not args.no_detail:
+        # the rest of BASELINE.json's metric on the same line: cfg3 as written (CMS 2^20 x 5, 100M weighted updates), and short
+        # cfg4 / cfg5 (N = 1) steps -- after, and outside, the headline's timed region
+        del wl
+        torch.cuda.empty_cache()
+        line["configs"] = {}
+        for name in ("cfg3", "cfg4", "cfg5"):
+            obj, f2 = extra_config(ctx, args, name)
+            line["configs"][name] = obj
+            fails += [f"{name}: {x}" for x in f2]
+        c3 = line["configs"]["cfg3"]
+        line["cms"] = {"insert_Mupdates_s": c3["value"], "lookup_Mkeys_s": c3["detail"]["check_Mkeys_s"], "source": "configs.cfg3 (100M weighted updates in 10 passes; lookups of the 10M keys)"}
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(min(args.n, 10_000_000))
     elif ctx.rank == 0:
         line["cpu_baseline"] = None
+    if fails:
+        line["rc"] = 2
+        line["error"] = "; ".join(fails)
     if ctx.dist is not None:
         ctx.dist.destroy_process_group()
     if ctx.rank == 0:
@@ -696,7 +830,9 @@ def main():
             pass
         print(json.dumps(line), flush=True)
     if fails:
-        raise SystemExit("; ".join(fails))
+        print("; ".join(fails), file=sys.stderr)
+        return 2
+    return 0
 
 
 if __name__ == "__main__":

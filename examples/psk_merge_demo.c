@@ -11,6 +11,10 @@
  * key's estimate is >= 1 on every rank and psk_get_counters reports elements_added == N (countminsketch.py:380-391).
  * With a single GPU the communicator has one rank; the option "merge_single_rank" still drives the whole collective
  * path (ncclSend / ncclRecv to self, the OR-reduce kernel, ncclAllGather).
+ * Wrap-and-clamp: a third, small sketch whose per-rank bounds on |counter| sum past the int32 rail takes the widened
+ * (64-bit) reduction: every rank holds 2^30 in the three bins of one key (add, remove, add: the bound is 3 * 2^30), so
+ * with R >= 2 ranks the summed bins clamp at INT32_MAX exactly like join (countminsketch.py:386-391) and the merge's
+ * saturation tally is `depth` on EVERY rank -- not R x depth.
  * The merge entry points are called from one thread per rank and never inside an outer ncclGroupStart / ncclGroupEnd. */
 #include <pthread.h>
 #include <stdint.h>
@@ -31,7 +35,7 @@ typedef struct {
     int rank, nranks;
     ncclComm_t comm;
     int ok;
-    char msg[256];
+    char msg[512];
 } job;
 
 static uint64_t splitmix64(uint64_t x)
@@ -83,13 +87,32 @@ static void *rank_main(void *arg)
     }
     int64_t ctr[PSK_CTR_COUNT];
     TRY(psk_get_counters(cms, ctr, NULL));
+    /* wrap-and-clamp: bins of key 0 hold 2^30 on every rank, the bound on |counter| is 3 * 2^30 > INT32_MAX */
+    psk_sketch *big = NULL;
+    const int32_t w30 = 1 << 30;
+    int32_t merged = 0;
+    int64_t bctr[PSK_CTR_COUNT];
+    TRY(psk_cms_create(4096, 3, j->rank, NULL, &big));
+    TRY(psk_cms_add(big, PSK_KEYS_FIXED, keys, NULL, 1, 16, &w30, PSK_HOST, NULL));
+    TRY(psk_cms_remove(big, PSK_KEYS_FIXED, keys, NULL, 1, 16, &w30, PSK_HOST, NULL));
+    TRY(psk_cms_add(big, PSK_KEYS_FIXED, keys, NULL, 1, 16, &w30, PSK_HOST, NULL));
+    TRY(psk_merge_sum(big, j->comm, NULL));
+    TRY(psk_cms_check(big, PSK_KEYS_FIXED, keys, NULL, 1, 16, PSK_HOST, PSK_Q_MIN, &merged, NULL));
+    TRY(psk_get_counters(big, bctr, NULL));
+    const int64_t sum30 = (int64_t)j->nranks << 30;
+    const int32_t want = sum30 > 2147483647LL ? 2147483647 : (int32_t)sum30;
+    const int64_t want_sat = sum30 > 2147483647LL ? 3 : 0;  /* one clamped cell per row, counted once */
+    const int clamp_ok = merged == want && bctr[PSK_CTR_SATURATED] == want_sat && bctr[PSK_CTR_ADDED] == 2 * sum30 &&
+                         bctr[PSK_CTR_REMOVED] == sum30;
+    TRY(psk_destroy(big));
     TRY(psk_destroy(blm));
     TRY(psk_destroy(cms));
     free(keys); free(hits); free(est);
-    j->ok = found == N_KEYS && counted == N_KEYS && ctr[PSK_CTR_ADDED] == (int64_t)N_KEYS;
-    snprintf(j->msg, sizeof j->msg, "rank %d/%d: inserted [%llu, %llu), found %llu of %llu, cms >= 1 for %llu, elements_added %lld",
+    j->ok = found == N_KEYS && counted == N_KEYS && ctr[PSK_CTR_ADDED] == (int64_t)N_KEYS && clamp_ok;
+    snprintf(j->msg, sizeof j->msg, "rank %d/%d: inserted [%llu, %llu), found %llu of %llu, cms >= 1 for %llu, elements_added %lld; "
+             "clamped merge: bin %d (want %d), saturated %lld (want %lld)",
              j->rank, j->nranks, (unsigned long long)lo, (unsigned long long)hi, (unsigned long long)found, (unsigned long long)N_KEYS,
-             (unsigned long long)counted, (long long)ctr[PSK_CTR_ADDED]);
+             (unsigned long long)counted, (long long)ctr[PSK_CTR_ADDED], merged, want, (long long)bctr[PSK_CTR_SATURATED], (long long)want_sat);
     return NULL;
 }
 

@@ -235,7 +235,10 @@ int psk_or_reduce_slices(void *dst, const void *src, uint32_t nslices, uint64_t 
  *   psk_merge_sum  CMS / CBF: allreduce(SUM) of the counters -- 32-bit while the summed per-rank bounds prove that no counter
  *                  reaches a rail, else 64-bit and clamped like join (countminsketch.py:380-391; CBF at 2^32-1,
  *                  countingbloom.py:149-151); the tallies of psk_get_counters (added / removed / violations / saturated)
- *                  become global totals.  Synchronises `stream` once (8-byte read-back of the summed bound).
+ *                  become global totals (cells the merge itself clamps are counted once, not once per rank).  ONE-SHOT per
+ *                  stream segment: replicas and tallies are per-rank deltas going in, global totals coming out -- merging
+ *                  the same replicas twice counts everything again.  Synchronises `stream` once (8-byte read-back of the
+ *                  summed bound; each rank's bound is capped at 2^40 first so the sum cannot wrap).
  * One-rank communicators return at once (option "merge_single_rank" = 1 runs the collective path anyway: tests). */
 int psk_merge_or(psk_sketch *s, void *nccl_comm, void *stream);
 int psk_merge_sum(psk_sketch *s, void *nccl_comm, void *stream);

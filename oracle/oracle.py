@@ -120,6 +120,8 @@ def lib():
         L.psk_o_cbf_nonzero.argtypes = [vp, u64]
         L.psk_o_bloom_insert_check_mt.restype = u64
         L.psk_o_bloom_insert_check_mt.argtypes = [vp, u64, u32, u64, u64, u64, u32, C.POINTER(C.c_double)]
+        L.psk_o_bloom_insert_check_mt_shared.restype = u64
+        L.psk_o_bloom_insert_check_mt_shared.argtypes = [vp, u64, u32, u64, u64, u64, u32, C.POINTER(C.c_double)]
         L.psk_o_splitmix64.restype = u64
         L.psk_o_splitmix64.argtypes = [u64]
         L.psk_o_gen_keys16.restype = None
@@ -273,6 +275,13 @@ class OracleBloom:
         (``self.mt_seconds``: wall time of the three phases, replicas allocated and touched beforehand)"""
         sec = C.c_double(0.0)
         found = int(lib().psk_o_bloom_insert_check_mt(_ptr(self.bloom), self.m, self.k, start, n, seed, nthreads, C.byref(sec)))
+        self.mt_seconds = sec.value
+        return found
+
+    def insert_check_mt_shared(self, start: int, n: int, nthreads: int, seed: int = 0x5EED) -> int:
+        """all-cores baseline leg, the shape one would ship on a CPU: ONE shared table, relaxed atomic OR per bit, then lookups"""
+        sec = C.c_double(0.0)
+        found = int(lib().psk_o_bloom_insert_check_mt_shared(_ptr(self.bloom), self.m, self.k, start, n, seed, nthreads, C.byref(sec)))
         self.mt_seconds = sec.value
         return found
 

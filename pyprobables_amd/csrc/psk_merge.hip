@@ -105,6 +105,14 @@ __global__ __launch_bounds__(kBlock) void k_narrow_clamp(const long long *src, u
     if ((threadIdx.x & 63) == 0 && sat) atomicAdd(sat_ctr, sat);
 }
 
+// this rank's bound on |counter|, capped so that the SUM over any number of ranks cannot wrap 64 bits (the engine saturates
+// the bound at 2^62: four such ranks sum to 0 mod 2^64 and the plain 32-bit reduction would be chosen)
+__global__ void k_capped_bound(const long long *ctr_bound, long long *out)
+{
+    const long long b = *ctr_bound;
+    *out = (b < 0 || b > (1LL << 40)) ? (1LL << 40) : b;
+}
+
 int launch_grid(uint64_t n)
 {
     uint64_t g = (n + kBlock - 1) / kBlock;
@@ -174,17 +182,24 @@ extern "C" int psk_merge_sum(psk_sketch *s, void *nccl_comm, void *stream)
     // 1. the ranks agree on the SUM of their bounds on |counter| (a 32-bit SUM wraps silently): one 8-byte read-back
     PSK_TRY(ensure(s->s_aux, 16));
     long long *bsum = (long long *)s->s_aux.p;
-    HIP_TRY(hipMemcpyAsync(bsum, s->ctr + PSK_CTR_ABS_BOUND, 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_capped_bound, dim3(1), dim3(1), 0, st, (const long long *)(s->ctr + PSK_CTR_ABS_BOUND), bsum);
+    HIP_TRY(hipGetLastError());
     NCCL_TRY(R, R->AllReduce(bsum, bsum, 1, ncclInt64, ncclSum, comm, st));
     long long bound = 0;
     HIP_TRY(hipMemcpyAsync(&bound, bsum, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const long long rail = is_signed ? (long long)INT32_MAX : 0xFFFFFFFFLL;
+    // 2. the tallies (added / removed / violations / saturated) become global totals: psk_get_counters then reports the
+    //    merged sketch's elements_added terms on every rank.  BEFORE the clamp below adds its count: every rank clamps the
+    //    same summed table, so that count is already global (summing it would report nranks x the true number).
+    //    The merge is ONE-SHOT per stream segment: tables and tallies are per-rank deltas going in and global totals coming
+    //    out; merging the same replicas twice would count everything again.
+    NCCL_TRY(R, R->AllReduce(s->ctr, s->ctr, 4, ncclInt64, ncclSum, comm, st));
     if (bound >= 0 && bound <= rail) {
-        // 2a. no global counter can reach a rail: the plain 32-bit reduction is exact
+        // 3a. no global counter can reach a rail: the plain 32-bit reduction is exact
         NCCL_TRY(R, R->AllReduce(s->table, s->table, cells, is_signed ? ncclInt32 : ncclUint32, ncclSum, comm, st));
     } else {
-        // 2b. widen, sum in 64 bits, clamp like join (countminsketch.py:380-391 / countingbloom.py:149-151)
+        // 3b. widen, sum in 64 bits, clamp like join (countminsketch.py:380-391 / countingbloom.py:149-151)
         PSK_TRY(ensure(s->s_merge, cells * 8));
         long long *wide = (long long *)s->s_merge.p;
         hipLaunchKernelGGL(k_widen, dim3(launch_grid(cells)), dim3(kBlock), 0, st, (const uint32_t *)s->table, wide, cells, (int)is_signed);
@@ -194,9 +209,6 @@ extern "C" int psk_merge_sum(psk_sketch *s, void *nccl_comm, void *stream)
                            (int)is_signed, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED));
         HIP_TRY(hipGetLastError());
     }
-    // 3. the tallies (added / removed / violations / saturated) become global totals: psk_get_counters then reports the
-    //    merged sketch's elements_added terms on every rank
-    NCCL_TRY(R, R->AllReduce(s->ctr, s->ctr, 4, ncclInt64, ncclSum, comm, st));
     // 4. the wrap-free bound describes the table: re-derive it from the merged counters
     return psk_rescan_bound(s, stream);
 }

@@ -18,6 +18,7 @@ replica equal to the table one filter fed the whole stream would hold (SURVEY.md
 from __future__ import annotations
 
 import os
+import weakref
 
 from . import _native as N
 
@@ -47,19 +48,26 @@ def hip_or_reduce(dst, src, nslices: int, slice_words: int) -> None:
 _merge_bufs: dict = {}
 
 
-def _merge_buffers(table, world: int, slice_words: int):
-    """(work | None, recv, mine) for one (table, world): allocated once, reused by every merge of that table -- the
-    collective sits inside timed loops and two table-sized allocations per call are not free"""
-    key = (table.data_ptr(), table.numel(), world, str(table.device))
+def _merge_buffers(table, world: int, slice_words: int, lane: str = "sync"):
+    """(work | None, recv, mine) for one (table, world, lane): allocated once, reused by every merge of that table -- the
+    collective sits inside timed loops and two table-sized allocations per call are not free.  ``lane`` keeps the
+    buffers of ``merge_bloom_async`` (side stream) apart from those of the synchronous merge, so that a synchronous
+    merge issued before an async handle's ``wait()`` cannot race on them.  The entry is dropped when the table tensor
+    is freed (the buffers are about 2x the table)."""
+    key = (table.data_ptr(), table.numel(), str(table.dtype), world, str(table.device), lane)
     bufs = _merge_bufs.get(key)
     if bufs is None:
         padded = slice_words * world
         work = None if padded == table.numel() else torch.zeros(padded, dtype=table.dtype, device=table.device)
         recv = torch.empty(padded, dtype=table.dtype, device=table.device)
         mine = torch.empty(slice_words, dtype=table.dtype, device=table.device)
-        if len(_merge_bufs) >= 8:  # tables come and go (tests): keep the cache small
+        if len(_merge_bufs) >= 8:  # views of tables come and go (tests): keep the cache small
             _merge_bufs.pop(next(iter(_merge_bufs)))
         bufs = _merge_bufs[key] = (work, recv, mine)
+        try:
+            weakref.finalize(table, _merge_bufs.pop, key, None)
+        except TypeError:  # pragma: no cover  (an object that cannot be weakly referenced: the size cap above still holds)
+            pass
     return bufs
 
 
@@ -68,7 +76,7 @@ def release_merge_buffers() -> None:
     _merge_bufs.clear()
 
 
-def allreduce_or_(table, group=None, or_reduce=hip_or_reduce):
+def allreduce_or_(table, group=None, or_reduce=hip_or_reduce, lane: str = "sync"):
     """in-place bitwise-OR all-reduce of a 1-D int32 tensor (all_to_all -> OR kernel -> all_gather)"""
     world = dist.get_world_size(group)
     if world == 1 and not os.environ.get("PSK_FORCE_MERGE_PATH"):  # (the env knob lets a 1-GPU test drive RCCL)
@@ -76,7 +84,7 @@ def allreduce_or_(table, group=None, or_reduce=hip_or_reduce):
     n = table.numel()
     slice_words = -(-n // world)
     slice_words = (slice_words + 3) & ~3  # 16-byte slices for the uint4 kernel
-    work, recv, mine = _merge_buffers(table, world, slice_words)
+    work, recv, mine = _merge_buffers(table, world, slice_words, lane)
     src = table
     if work is not None:  # n is not a multiple of 4 * world words: exchange a zero-padded copy
         work[:n].copy_(table)
@@ -192,5 +200,5 @@ def merge_bloom_async(blm, group=None, or_reduce=hip_or_reduce) -> MergeHandle:
         side = _merge_streams[dev.index] = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
-        allreduce_or_(t, group, or_reduce)
+        allreduce_or_(t, group, or_reduce, lane="async")
     return MergeHandle(side, dev)

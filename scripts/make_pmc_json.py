@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
-"""gpurun_out/r02/pmc_<op>.json (scripts/pmc_op.sh) -> profiles/r02_pmc_traffic.json, the file bench.py reads `roofline.traffic` from"""
+"""gpurun_out/<round>/pmc_<op>.json (scripts/pmc_op.sh) -> profiles/<round>_pmc_traffic.json and profiles/<round>_l2_hit.json, the files
+bench.py reads `roofline.traffic` and `roofline.l2_hit` from.   make_pmc_json.py [dir] [round tag, default r03]"""
 import json
 import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-src = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / "r02"
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r03"
+src = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / TAG
 names = {"bloom_add": "bloom_insert", "bloom_check": "bloom_check", "bloom_check_fresh": "bloom_check_all_fresh", "cms_add": "cms_add_weighted",
-         "cms_check": "cms_check", "cbf_add": "cbf_add", "cbf_check": "cbf_check", "cbf_remove": "cbf_remove"}
+         "cms_check": "cms_check", "cbf_add": "cbf_add", "cbf_check": "cbf_check", "cbf_remove": "cbf_remove", "cfg4_stream": "cfg4_stream",
+         "bloom31_add": "bloom31_insert", "bloom31_check": "bloom31_check"}
+SCALABLE = {"bloom31_add", "bloom31_check"}  # measured on one 2^25-key call; cfg 5 makes ceil(n / 2^25) such calls per step
 out = {
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over scripts/prof_ops.py <op> (scripts/pmc_op.sh, "
               "scripts/profile_r02.sh); counters in KiB; FETCH_SIZE doubled (MI355X_MICROARCH.md HBM section: on gfx950 it reports half of a wide "
@@ -16,6 +20,10 @@ out = {
               "L2 -> fabric requests include Infinity Cache hits: upper bound of the HBM bytes.",
     "keys": None,
 }
+l2 = {"source": "rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum over scripts/prof_ops.py <op> (scripts/pmc_op.sh): L2 hit rate = "
+                "TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum) over the kernels of one launch (MI355X_MICROARCH.md, L2 section)"}
+
+
 def factor(kernel: str) -> int:
     """FETCH_SIZE correction: 2 for the streaming kernels (16 B per lane, coalesced), 1 for the direct kernels, whose random
     4-byte gathers are one 64-byte request each (round 1: TCC_EA0_RDREQ == probe count)"""
@@ -24,8 +32,16 @@ def factor(kernel: str) -> int:
 
 for f in sorted(src.glob("pmc_*.json")):
     d = json.loads(f.read_text())
-    out["keys"] = d["keys"]
+    if d["keys"] == 10_000_000:
+        out["keys"] = d["keys"]
     hbm = int(sum(factor(k) * v["fetch_KiB_per_launch"] + v["write_KiB_per_launch"] for k, v in d["kernels"].items()) * 1024)
-    out[names.get(d["op"], d["op"])] = {"kernels": d["kernels"], "hbm_bytes_per_launch": hbm, "bytes_per_key": round(hbm / d["keys"], 1)}
-(ROOT / "profiles" / "r02_pmc_traffic.json").write_text(json.dumps(out, indent=1) + "\n")
-print("wrote profiles/r02_pmc_traffic.json:", {k: v["bytes_per_key"] for k, v in out.items() if isinstance(v, dict)})
+    rec = {"keys": d["keys"], "kernels": d["kernels"], "hbm_bytes_per_launch": hbm, "bytes_per_key": round(hbm / d["keys"], 1), "l2_hit": d.get("l2_hit")}
+    if d["op"] in SCALABLE:
+        rec["per_key_scalable"] = True
+    out[names.get(d["op"], d["op"])] = rec
+    l2[names.get(d["op"], d["op"])] = {"l2_hit": d.get("l2_hit"), "keys": d["keys"],
+                                        "kernels": {k: {"l2_hit": v.get("l2_hit"), "l2_requests_per_launch": v.get("l2_requests_per_launch")} for k, v in d["kernels"].items()}}
+(ROOT / "profiles" / f"{TAG}_pmc_traffic.json").write_text(json.dumps(out, indent=1) + "\n")
+(ROOT / "profiles" / f"{TAG}_l2_hit.json").write_text(json.dumps(l2, indent=1) + "\n")
+print(f"wrote profiles/{TAG}_pmc_traffic.json:", {k: v["bytes_per_key"] for k, v in out.items() if isinstance(v, dict)})
+print(f"wrote profiles/{TAG}_l2_hit.json:", {k: v["l2_hit"] for k, v in l2.items() if isinstance(v, dict)})

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Run one engine operation repeatedly (for rocprofv3 --kernel-trace --stats / --pmc):  prof_ops.py <op> [n] [iters]
-ops: bloom_add bloom_check bloom_check_fresh bloom31_add bloom31_check cms_add cms_add_unit cms_check cbf_add cbf_check cbf_remove cbf25_check cbf25_add"""
+ops: bloom_add bloom_check bloom_check_fresh bloom31_add bloom31_check cms_add cms_add_unit cms_check cbf_add cbf_check cbf_remove cbf25_check cbf25_add
+     cfg4_stream (n = keys per batch, 50 batches: BASELINE cfg 4's add / remove stream, write-combined, flush included)"""
 import sys
 from pathlib import Path
 
@@ -22,6 +23,32 @@ def gen(n, start):
     return t
 
 
+if op == "cfg4_stream":
+    B, NB = n, 50
+    allk = gen(B * NB, 0)
+    s = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, combine_updates=True)
+
+    def fn():
+        s.clear()
+        for b in range(NB):
+            s.add_many(allk[b * B:(b + 1) * B])
+            if b >= 1:
+                s.remove_many(allk[(b - 1) * B:(b - 1) * B + B // 2])
+        s.synchronize()
+
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b_.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b_) / iters
+    ops = B * NB + (NB - 1) * (B // 2)
+    print(f"{op}: {ms * 1e3:.1f} us per {ops} ops -> {ops / ms / 1e3:.0f} M/s  launches={2 + iters} n={ops}")
+    sys.exit(0)
 keys = gen(n, 0)
 w = torch.empty(n, dtype=torch.int32, device="cuda")
 N.check(N.lib().psk_gen_weights(w.data_ptr(), 0, n, 0x5EED, 0, st()))

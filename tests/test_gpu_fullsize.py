@@ -5,7 +5,7 @@ cfg 2  BloomFilter m = 2^28, k = 7: insert 10M keys, check them + 10M fresh keys
 cfg 3  CountMinSketch 2^20 x 5: 100M weighted adds                                       (full compare)
 cfg 4  CountingBloomFilter m = 2^28 (1 GiB): 50M-op add/remove stream in 1M batches      (full compare after every batch)
 cfg 5  BloomFilter m = 2^31: two rank-shards merged by OR == single-stream filter        (20M keys compared; the collective
-       form -- all_to_all + OR kernel + all_gather with two ranks -- is tests/test_gpu_bench_multi.py and test_gpu_merge_abi.py)
+       form -- all_to_all + OR kernel + all_gather with two ranks -- is tests/test_gpu_bench_multi.py, and over real RCCL tests/test_gpu_rccl_multi.py and examples/psk_merge_demo.c)
 """
 
 import numpy as np
