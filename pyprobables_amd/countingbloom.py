@@ -38,13 +38,17 @@ class CountingBloomFilter(BloomFilter):
 
     def __init__(self, est_elements=None, false_positive_rate=None, filepath=None, hex_string=None, hash_function=None,
                  device=None, combine_updates: bool = False):
-        """``combine_updates`` (extra, off by default): ``add_many`` / ``remove_many`` batches are collected on the device
-        and applied as one partitioned update per 2^26 keys (``psk_cbf_update_combined``): folding a big table costs a
-        pass over the WHOLE table whatever the batch size, so streams of small batches (BASELINE config 4: 1M-key
-        batches into 1 GiB) only run fast when combined.  Removes are then plain decrements -- exact for well-formed
-        streams (every remove targets a key with enough live inserts), the contract of the unordered batch ops; a remove
-        of an absent key is tallied in ``batch_diagnostics()['violations']`` instead of being a no-op.  Reads
-        (``check*``, ``bloom``, ``export``, ``elements_added`` ...) always see every update handed over."""
+        """Small unit-weight ``add_many`` batches into big tables (more than 2^26 counters) are write-combined by the engine
+        on its own: adds commute, so each batch is hashed and partitioned when it is handed over and the probes are folded
+        into the table together with their successors -- exact, no opt-in (``psk_set_option("auto_combine", 0)`` turns it
+        off).  Reads and removes always see every update handed over.
+
+        ``combine_updates`` (extra, off by default) also defers ``remove_many``: folding a big table costs a pass over the
+        WHOLE table whatever the batch size, so streams that interleave small add and remove batches (BASELINE config 4:
+        1M-key batches into 1 GiB) only run fast when the removes wait as well.  They are then plain decrements applied
+        after the window's adds -- exact for well-formed streams (every remove targets a key with enough live inserts), the
+        contract of the unordered batch ops; a remove of an absent key is tallied in ``batch_diagnostics()['violations']``
+        instead of being a no-op (countingbloom.py:200-201)."""
         self._combine = bool(combine_updates)
         super().__init__(est_elements, false_positive_rate, filepath, hex_string, hash_function, device)
 
@@ -60,7 +64,7 @@ class CountingBloomFilter(BloomFilter):
 
     def _flush(self) -> None:
         super()._flush()
-        if self._tab is not None and getattr(self, "_combine", False):
+        if self._tab is not None:  # write-combined updates (automatic for small add batches into big tables) reach the table
             self._tab.flush()
 
     def _table_len(self, n_bits: int) -> int:

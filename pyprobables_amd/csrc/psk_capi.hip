@@ -2,6 +2,7 @@
 // Host side: handle bookkeeping, host<->device staging for PSK_HOST buffers, launch geometry.
 #include "psk_host.hpp"
 #include "psk_digest.hpp"
+#include "psk_nibble.hpp"
 
 #include <map>
 #include <mutex>
@@ -149,10 +150,11 @@ extern "C" int psk_destroy(psk_sketch *s)
     if (s->lk.dev) hipFree(s->lk.dev);
     if (s->lk.pin) hipHostFree((void *)s->lk.pin);
     for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
-                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w}) {
+                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt}) {
         if (b->p) hipFree(b->p);
         if (b->pin) hipHostFree(b->pin);
     }
+    if (s->scat.ev) hipEventDestroy(s->scat.ev);
     delete s;
     return PSK_OK;
 }
@@ -181,12 +183,15 @@ static __global__ __launch_bounds__(kBlock) void k_clear(uint4 *tab, uint64_t nv
     if (blockIdx.x == 0 && threadIdx.x < PSK_CTR_COUNT) ctr[threadIdx.x] = 0;
 }
 
+static int scat_drop(psk_sketch *s, hipStream_t st);  // forget the scattered write-combined updates (defined with them below)
+
 extern "C" int psk_clear(psk_sketch *s, void *stream)
 {
     CHECK_HANDLE(s, -1);
     hipStream_t st = (hipStream_t)stream;
     s->comb.add.n = s->comb.rem.n = 0;  // write-combined updates that have not reached the table are cleared with it
     s->comb.add.unit = s->comb.rem.unit = true;
+    PSK_TRY(scat_drop(s, st));
     // one launch for the table AND the counter block (two fills are two ~5 us launches; clear sits in every bench step)
     const uint64_t nvec = s->padded_bytes / 16;
     uint64_t grid = (nvec + kBlock * 4 - 1) / (kBlock * 4);
@@ -232,6 +237,7 @@ extern "C" int psk_write_table(psk_sketch *s, const void *src_host, uint64_t nby
     hipStream_t st = (hipStream_t)stream;
     s->comb.add.n = s->comb.rem.n = 0;  // the table is replaced: pending updates go with the old contents
     s->comb.add.unit = s->comb.rem.unit = true;
+    PSK_TRY(scat_drop(s, st));
     HIP_TRY(hipMemsetAsync(s->table, 0, s->padded_bytes, st));
     HIP_TRY(hipMemcpyAsync(s->table, src_host, nbytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(s->ctr, 0, sizeof(long long) * PSK_CTR_COUNT, st));
@@ -447,9 +453,13 @@ int64_t g_part_max_keys = 1 << 26;   // keys per partition round (bounds the buc
 int64_t g_part_cache_bytes = 240 << 20;  // bucket-buffer budget per round: the part of the 256 MB MALL we count on
 int64_t g_part_two_level_slices = 2048;     // tables cut into more slices than this take the two-level path (0 = never)
 int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGeom::dbg); 0 in production
-extern int64_t g_combine_keys;       // defined with the write-combined CBF updates below
 int64_t g_lookup_run_lanes = 0, g_bloom_lookup = 2, g_lookup_split = 1, g_part_tile_threads = 0, g_part_slice_bias = 0, g_part_wgs = 0, g_part_even_tiles = 1;
 int64_t g_lookup_half = 1;
+int64_t g_lookup_nibble = 1;   // CBF lookups into 2^25 .. 2^29 counters: 4-bit slice images (psk_nibble.hpp) from cells / 16 probes on; 2 = always; 0 = the 32-bit / 16-bit slices or direct
+int64_t g_nib_nt = 1;   // nontemporal table loads in k_nib_gather (1 GiB lookups 710 -> 656 us per 10 M keys); the fold of k_nib_apply re-writes what it
+                        // reads and measured slower with them (795 -> 984 us): never there
+int64_t g_nib_update_layout = 1;   // see psk_nibble.hpp (bench A/B)
+int64_t g_update_nibble = 1;   // CBF unit-weight adds / decrements into 2^26 .. 2^29 counters: 4-bit delta images, one level; 0 = two-level 32-bit path
 int64_t g_part_dense_groups = 40;   // pass 2: segments of fewer groups (mean) are walked end to end (for_each_batch_at); 0 = never
 extern PSK_HIDDEN int64_t g_merge_single_rank;  // psk_merge.hip
 
@@ -464,6 +474,9 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "part_debug")) g_part_debug = value;
     else if (!strcmp(name, "merge_single_rank")) g_merge_single_rank = value;
     else if (!strcmp(name, "combine_keys")) g_combine_keys = value;
+    else if (!strcmp(name, "auto_combine")) g_auto_combine = value;
+    else if (!strcmp(name, "combine_scatter")) g_combine_scatter = value;
+    else if (!strcmp(name, "auto_combine_keys")) g_auto_combine_keys = value;
     else if (!strcmp(name, "lookup_run_lanes")) g_lookup_run_lanes = value;
     else if (!strcmp(name, "bloom_lookup")) g_bloom_lookup = value;
     else if (!strcmp(name, "lookup_split")) g_lookup_split = value;
@@ -473,6 +486,10 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "even_tiles")) g_part_even_tiles = value;
     else if (!strcmp(name, "dense_walk_groups")) g_part_dense_groups = value;
     else if (!strcmp(name, "lookup_half_slices")) g_lookup_half = value;
+    else if (!strcmp(name, "lookup_nibble_slices")) g_lookup_nibble = value;
+    else if (!strcmp(name, "update_nibble_slices")) g_update_nibble = value;
+    else if (!strcmp(name, "nibble_update_layout")) g_nib_update_layout = value;
+    else if (!strcmp(name, "nibble_nt_loads")) g_nib_nt = value;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
 }
@@ -498,6 +515,9 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "partition_cache_bytes")) *value = g_part_cache_bytes;
     else if (!strcmp(name, "partition_two_level_slices")) *value = g_part_two_level_slices;
     else if (!strcmp(name, "combine_keys")) *value = g_combine_keys;
+    else if (!strcmp(name, "auto_combine")) *value = g_auto_combine;
+    else if (!strcmp(name, "combine_scatter")) *value = g_combine_scatter;
+    else if (!strcmp(name, "auto_combine_keys")) *value = g_auto_combine_keys;
     else if (!strcmp(name, "bloom_lookup")) *value = g_bloom_lookup;
     else if (!strcmp(name, "lookup_split")) *value = g_lookup_split;
     else if (!strcmp(name, "tile_threads")) *value = g_part_tile_threads;
@@ -505,6 +525,10 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "even_tiles")) *value = g_part_even_tiles;
     else if (!strcmp(name, "dense_walk_groups")) *value = g_part_dense_groups;
     else if (!strcmp(name, "lookup_half_slices")) *value = g_lookup_half;
+    else if (!strcmp(name, "lookup_nibble_slices")) *value = g_lookup_nibble;
+    else if (!strcmp(name, "update_nibble_slices")) *value = g_update_nibble;
+    else if (!strcmp(name, "nibble_update_layout")) *value = g_nib_update_layout;
+    else if (!strcmp(name, "nibble_nt_loads")) *value = g_nib_nt;
     else if (!strcmp(name, "scatter_workgroups")) *value = g_part_wgs;
     else if (!strcmp(name, "slice_bias")) *value = g_part_slice_bias;
     else return fail(PSK_EINVAL, "unknown option %s", name);
@@ -688,6 +712,7 @@ static int post_acct(psk_sketch *s, const W *w_dev, uint64_t n, int which, long 
     s->acct.bound_mult = bound_mult;
     s->acct.grow_bound = grow_bound;
     s->acct.weights_signed = weights_signed;
+    s->acct.weights01 = false;
     return PSK_OK;
 }
 
@@ -722,22 +747,142 @@ static int cbf_apply_device(psk_sketch *s, const Batch &b, const uint32_t *w, bo
     });
 }
 
+// ---- write-combined updates as scattered probes (psk_sketch::scat, psk_nibble.hpp)
+int64_t g_combine_scatter = 0;         // psk_cbf_update_combined: 1 = unit-weight batches wait as scattered probes instead of key lists (see there)
+int64_t g_auto_combine = 1;            // psk_cbf_add: small unit-weight batches into big tables wait as scattered probes (adds commute: exact)
+int64_t g_auto_combine_keys = 1 << 24; // keys per list in that mode (~0.8 GB of segments for k = 7, allocated on first use)
+
+// a flush (or drop) on another stream than the last append must not overtake it
+// (the event is recorded only when a second stream shows up: one per append put a barrier packet -- ~5 us of dispatch bubble --
+// behind every 1 M-key batch of BASELINE cfg 4, 0.45 ms per step)
+static int comb_order(psk_sketch *s, hipStream_t st)
+{
+    if (!s->scat.appended || st == s->scat.last) return PSK_OK;
+    if (!s->scat.ev) HIP_TRY(hipEventCreateWithFlags(&s->scat.ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(s->scat.ev, s->scat.last));  // the tail of the stream that appended last: behind all of its appends
+    HIP_TRY(hipStreamWaitEvent(st, s->scat.ev, 0));
+    s->scat.last = st;  // (what follows on `st` is ordered behind it)
+    return PSK_OK;
+}
+
+static int comb_appended(psk_sketch *s, hipStream_t st)
+{
+    s->scat.last = st;
+    s->scat.appended = true;
+    return PSK_OK;
+}
+
+static int scat_zero(psk_sketch *s, bool add, bool rem, hipStream_t st)
+{
+    const uint64_t nseg = (uint64_t)s->scat.g.nbuckets * s->scat.g.nwg;
+    uint32_t *a = add ? (uint32_t *)s->scat.add.cnt.p : nullptr, *b = rem ? (uint32_t *)s->scat.rem.cnt.p : nullptr;
+    if (!a && !b) return PSK_OK;
+    hipLaunchKernelGGL(k_zero_u32, dim3(256), dim3(256), 0, st, a ? a : b, nseg, (a && b) ? b : nullptr, (a && b) ? nseg : 0ULL);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
+static int scat_drop(psk_sketch *s, hipStream_t st)
+{
+    if (!s->scat.ready || (s->scat.add.n == 0 && s->scat.rem.n == 0)) return PSK_OK;
+    PSK_TRY(comb_order(s, st));
+    PSK_TRY(scat_zero(s, s->scat.add.n != 0, s->scat.rem.n != 0, st));
+    s->scat.add.n = s->scat.rem.n = 0;
+    return PSK_OK;
+}
+
+// apply the scattered lists: adds, then decrements (a remove whose add waits in the same window must find it applied).
+// Enough probes: one pass over the table (k_nib_apply; both lists in ONE launch when both are due); few: a drain with atomics.
+static int scat_flush(psk_sketch *s, hipStream_t st)
+{
+    if (!s->scat.ready || (s->scat.add.n == 0 && s->scat.rem.n == 0)) return PSK_OK;
+    PSK_TRY(comb_order(s, st));
+    const uint64_t na = s->scat.add.n, nr = s->scat.rem.n;
+    s->scat.add.n = s->scat.rem.n = 0;  // (cleared first: a failure must not re-apply the lists on the next call)
+    PartGeom g = s->scat.g;
+    const uint64_t per_seg = (uint64_t)g.nbuckets * g.nwg * 6;
+    g.dense = ((na > nr ? na : nr) * s->k / per_seg) < (uint64_t)g_part_dense_groups ? 1u : 0u;
+    const size_t lds = (size_t)1 << (g.shift - 1);
+    unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
+    const bool pass_a = na * s->k >= s->m / 8, pass_r = nr * s->k >= s->m / 8;
+    auto launch = [&](auto kern, const psk_sketch::ScatList *la, const psk_sketch::ScatList *lb, uint32_t direct) {
+        PSK_TRY(set_dyn_lds(kern, lds));
+        hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint32_t *)la->cnt.p, (const uint4 *)la->part.p,
+                           (const uint32_t *)(lb ? lb->cnt.p : nullptr), (const uint4 *)(lb ? lb->part.p : nullptr), sat, direct);
+        HIP_TRY(hipGetLastError());
+        return (int)PSK_OK;
+    };
+    const bool blocks = g_nib_update_layout != 0;
+    if (na && nr && pass_a && pass_r) {
+        PSK_TRY(blocks ? launch(k_nib_apply<2, true>, &s->scat.add, &s->scat.rem, 0u) : launch(k_nib_apply<2, false>, &s->scat.add, &s->scat.rem, 0u));
+    } else {
+        if (na) PSK_TRY(blocks ? launch(k_nib_apply<0, true>, &s->scat.add, nullptr, pass_a ? 0u : 1u) : launch(k_nib_apply<0, false>, &s->scat.add, nullptr, pass_a ? 0u : 1u));
+        if (nr) PSK_TRY(blocks ? launch(k_nib_apply<1, true>, &s->scat.rem, nullptr, pass_r ? 0u : 1u) : launch(k_nib_apply<1, false>, &s->scat.rem, nullptr, pass_r ? 0u : 1u));
+    }
+    return scat_zero(s, na != 0, nr != 0, st);
+}
+
+// Hand a unit-weight batch over as scattered probes.  cap: keys per list; *done = false: not eligible (nothing was launched / changed).
+static int scat_append(psk_sketch *s, const Batch &b, bool neg, uint64_t cap, hipStream_t st, bool *done)
+{
+    *done = false;
+    if (s->kind != PSK_KIND_CBF || g_update_nibble == 0 || b.n == 0 || b.n > cap || s->k > 32) return PSK_OK;
+    if (b.layout == PSK_KEYS_HASHES && b.key_len < s->k) return PSK_OK;
+    if (!s->scat.ready || s->scat.cap != cap) {
+        PartGeom g;
+        if (!scat_geometry(s, cap, &g)) return PSK_OK;
+        PSK_TRY(scat_flush(s, st));  // (a list sized for another capacity)
+        s->scat.g = g;
+        s->scat.cap = cap;
+        s->scat.ready = true;
+    }
+    psk_sketch::ScatList &l = neg ? s->scat.rem : s->scat.add;
+    if (l.n + b.n > cap) PSK_TRY(flush_combined(s, st));
+    const PartGeom &g = s->scat.g;
+    const uint64_t part_bytes = (uint64_t)g.nbuckets * g.nwg * g.segcap * 16 + 256, cnt_bytes = (uint64_t)g.nbuckets * g.nwg * 4 + 128;
+    if (l.part.cap < part_bytes || l.cnt.cap < cnt_bytes) {  // first use (or released): allocate, counts start at zero
+        PSK_TRY(ensure(l.part, part_bytes));
+        PSK_TRY(ensure(l.cnt, cnt_bytes));
+        HIP_TRY(hipMemsetAsync(l.cnt.p, 0, cnt_bytes, st));
+        l.n = 0;
+    }
+    PSK_TRY(comb_order(s, st));  // (appends are ordered among themselves too: two streams must not race on the cursors)
+    bool appended = false;
+    PSK_TRY(cbf_scat_append(s, b, neg ? 1 : 0, st, &appended));
+    if (!appended) return PSK_OK;  // layout without a partitioned instantiation
+    l.n += b.n;
+    PSK_TRY(comb_appended(s, st));
+    *done = true;
+    return PSK_OK;
+}
+
 int flush_combined(psk_sketch *s, hipStream_t st)
 {
-    if (s->kind != PSK_KIND_CBF || (s->comb.add.n == 0 && s->comb.rem.n == 0)) return PSK_OK;
-    // adds first: a remove whose add waits in the same window must find it applied
-    for (int pass = 0; pass < 2; ++pass) {
+    if (s->kind != PSK_KIND_CBF) return PSK_OK;
+    const bool keys_pending = s->comb.add.n != 0 || s->comb.rem.n != 0;
+    const bool scat_pending = s->scat.ready && (s->scat.add.n != 0 || s->scat.rem.n != 0);
+    if (!keys_pending && !scat_pending) return PSK_OK;
+    PSK_TRY(comb_order(s, st));
+    // adds first: a remove whose add waits in the same window must find it applied.  Two mechanisms may hold updates -- key lists
+    // (weighted batches, tables below the nibble geometry) and scattered probes: all adds of both, then all removes of both.
+    auto key_list = [&](int pass) {
         psk_sketch::PendList &l = pass == 0 ? s->comb.add : s->comb.rem;
-        if (l.n == 0) continue;
+        if (l.n == 0) return (int)PSK_OK;
         Batch b{PSK_KEYS_FIXED, l.keys.p, nullptr, l.n, s->comb.key_len};
-        const uint64_t n = l.n;
         l.n = 0;  // (cleared first: a failure must not re-apply the list on the next call)
         const bool unit = l.unit;
         l.unit = true;
-        (void)n;
-        PSK_TRY(cbf_apply_device(s, b, unit ? nullptr : (const uint32_t *)l.w.p, pass == 1, st));
+        return cbf_apply_device(s, b, unit ? nullptr : (const uint32_t *)l.w.p, pass == 1, st);
+    };
+    PSK_TRY(key_list(0));
+    if (scat_pending && s->comb.rem.n != 0 && s->scat.add.n != 0) {  // key-list removes wait: the scattered adds must land before them
+        const uint64_t nr = s->scat.rem.n;
+        s->scat.rem.n = 0;
+        PSK_TRY(scat_flush(s, st));
+        s->scat.rem.n = nr;
     }
-    return PSK_OK;
+    PSK_TRY(key_list(1));
+    return scat_flush(s, st);
 }
 
 extern "C" int psk_flush(psk_sketch *s, void *stream)
@@ -755,6 +900,20 @@ extern "C" int psk_cbf_update_combined(psk_sketch *s, int layout, const void *da
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) return PSK_OK;
     const uint64_t cap = g_combine_keys > 0 ? (uint64_t)g_combine_keys : 0;
+    // Scattered probes instead of key lists (option "combine_scatter", off): pass 1 per batch saves the key copy and the second read
+    // of the keys, but measured on BASELINE cfg 4 (99 batches of 0.5-1 M keys) it costs more than it saves -- a 1 M-key pass 1 runs
+    // two tiles per workgroup and pays its fixed costs (1024 cursors read and written per workgroup, pipeline fill) every time:
+    // 45 us per batch against 7 us for the copy plus 21 us per 1 M keys of a 50 M-key pass 1; the step took 6.7 ms instead of 3.9.
+    if (!weights && cap && g_combine_scatter != 0) {
+        Batch b;
+        PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+        bool taken = false;
+        PSK_TRY(scat_append(s, b, remove != 0, cap, st, &taken));
+        if (taken) {
+            PSK_TRY(account_weights(s, (const uint32_t *)nullptr, n, remove ? PSK_CTR_REMOVED : PSK_CTR_ADDED, (long long)s->k, st, !remove));
+            return finish(where, nullptr, st);
+        }
+    }
     const bool combinable = layout == PSK_KEYS_FIXED && key_len > 0 && data && n < cap;
     if (!combinable || (s->comb.key_len && s->comb.key_len != key_len) || (s->comb.cap && s->comb.cap != cap)) {
         PSK_TRY(flush_combined(s, st));
@@ -772,7 +931,8 @@ extern "C" int psk_cbf_update_combined(psk_sketch *s, int layout, const void *da
     s->comb.key_len = key_len;
     s->comb.cap = cap;
     PSK_TRY(ensure(l.keys, cap * (uint64_t)key_len));  // full capacity at once: growing would drop the pending keys
-    PSK_TRY(ensure(l.w, cap * 4));
+    if (weights || !l.unit) PSK_TRY(ensure(l.w, cap * 4));  // the weight list only once a non-unit batch has arrived
+    PSK_TRY(comb_order(s, st));
     const hipMemcpyKind kind = where == PSK_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     HIP_TRY(hipMemcpyAsync((uint8_t *)l.keys.p + l.n * (uint64_t)key_len, data, n * (uint64_t)key_len, kind, st));
     uint32_t *wdst = (uint32_t *)l.w.p + l.n;
@@ -784,6 +944,7 @@ extern "C" int psk_cbf_update_combined(psk_sketch *s, int layout, const void *da
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)wdst, 1, n, st));
     }
     l.n += n;
+    PSK_TRY(comb_appended(s, st));
     if (where == PSK_HOST) HIP_TRY(hipStreamSynchronize(st));  // the caller may reuse its buffers on return
     return PSK_OK;
 }
@@ -794,9 +955,21 @@ extern "C" int psk_cbf_add(psk_sketch *s, int layout, const void *data, const ui
     CHECK_HANDLE(s, PSK_KIND_CBF);
     PSK_TRY(check_hashes_width(s, layout, key_len));
     hipStream_t st = (hipStream_t)stream;
-    PSK_TRY(flush_combined(s, st));  // write-combined updates reach the table before anything else touches it
     Batch b;
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
+    // Automatic write-combining (no opt-in): a unit-weight batch too small to pay for a pass over a big table would take one
+    // fabric atomic per probe.  Adds commute (countingbloom.py:135-155; the clamp at 2^32-1 is applied by the fold just the
+    // same), so the batch is scattered now and folded with its successors; every entry point that reads or removes flushes first.
+    if (!weights && g_auto_combine != 0 && s->comb.rem.n == 0 && s->scat.rem.n == 0 && (int64_t)n >= g_part_min_keys &&
+        n * (uint64_t)s->k < s->m / 8 && g_auto_combine_keys > 0) {
+        bool taken = false;
+        PSK_TRY(scat_append(s, b, false, (uint64_t)g_auto_combine_keys, st, &taken));
+        if (taken) {
+            PSK_TRY(account_weights(s, (const uint32_t *)nullptr, n, PSK_CTR_ADDED, (long long)s->k, st, true));
+            return finish(where, nullptr, st);
+        }
+    }
+    PSK_TRY(flush_combined(s, st));  // write-combined updates reach the table before anything else touches it
     const uint32_t *w;
     PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
     PSK_TRY(post_acct(s, w, n, PSK_CTR_ADDED, (long long)s->k, st, true, false));
@@ -859,8 +1032,10 @@ static int cbf_remove_composed(psk_sketch *s, const Batch &b, const uint32_t *w,
                        (unsigned long long *)(s->ctr + PSK_CTR_VIOLATIONS));
     HIP_TRY(hipGetLastError());
     PSK_TRY(post_acct(s, (const uint32_t *)amount, b.n, PSK_CTR_REMOVED, (long long)s->k, st, false, false));
+    s->acct.weights01 = w == nullptr;  // unit removes: every amount is 0 or 1
     bool dec = false;
     PSK_TRY(cbf_remove_partitioned(s, b, amount, st, &dec));
+    s->acct.weights01 = false;
     PSK_TRY(settle_acct(s, (const uint32_t *)amount, b.n, st));
     if (!dec) {  // not eligible after all: the same decrement through the direct kernel
         unsigned long long *viol = (unsigned long long *)(s->ctr + PSK_CTR_VIOLATIONS);
@@ -1305,11 +1480,12 @@ extern "C" int psk_release_scratch(psk_sketch *s)
     PSK_TRY(flush_combined(s, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
-                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w}) {
+                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt}) {
         if (b->p) HIP_TRY(hipFree(b->p));
         b->p = nullptr;
         b->cap = 0;
     }
+    s->scat.ready = false;
     return PSK_OK;
 }
 

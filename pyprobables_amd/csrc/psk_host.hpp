@@ -106,6 +106,7 @@ struct psk_sketch {
         int which = -1;          // PSK_CTR_ADDED / PSK_CTR_REMOVED
         long long bound_mult = 1;
         bool grow_bound = true, weights_signed = false;
+        bool weights01 = false;  // the weights are 0 / 1 flags (amounts of a validated unit-weight CBF remove): masked unit probes may serve
     } acct;
     // Bloom lookups: which scheme the next large batch takes (g_bloom_lookup = 2, auto).  The kernels tally what they see
     // (keyed: probes that missed; return trip: keys answered absent) into lk_dev; the tally is copied to a pinned host page
@@ -127,6 +128,22 @@ struct psk_sketch {
         uint64_t cap = 0;    // keys per list
         PendList add, rem;
     } comb;
+    // Write-combined unit-weight CBF updates kept as SCATTERED PROBES (round 3): pass 1 runs when a batch is handed over and
+    // appends to persistent (slice, workgroup) segments; a flush is pass 2 alone (psk_nibble.hpp: one level of 2^18-counter
+    // slices), or -- few probes -- a drain with atomics.  No key copies, the keys are read once.
+    struct ScatList {
+        DevBuf part, cnt;    // bucket buffer (nbuckets x nwg segments of segcap 16-byte groups) + groups per segment
+        uint64_t n = 0;      // keys behind the probes
+    };
+    struct {
+        bool ready = false;
+        PartGeom g{};        // the fixed geometry of both lists (nbuckets, shift, nwg, segcap, k; append = 1)
+        uint64_t cap = 0;    // keys per list the segments were sized for
+        ScatList add, rem;
+        hipEvent_t ev = nullptr;       // recorded behind the last append (either mechanism): a flush on ANOTHER stream waits for it
+        hipStream_t last = nullptr;
+        bool appended = false;
+    } scat;
     // split lookup (psk_bloom_check_begin / _finish): pass 1 of the first round has run, the rest waits for the table
     struct {
         bool active = false, scattered = false;
@@ -156,6 +173,9 @@ extern PSK_HIDDEN int64_t g_part_slice_bias;     // bench knob: added to log2(ce
 extern PSK_HIDDEN int64_t g_part_tile_threads;   // pass 1 workgroup shape for k <= 8: 0 = auto (launch_scatter), 512 / 1024 = forced
 extern PSK_HIDDEN int64_t g_part_even_tiles;     // 1 (default): pass 1 evens the tile size out over the workgroups
 extern PSK_HIDDEN int64_t g_lookup_half;           // 1 (default): counter lookups into 2^26 .. 2^27 counters use 2^16-counter slices of 16-bit values
+extern PSK_HIDDEN int64_t g_nib_nt;             // nontemporal table loads in the nibble-slice kernels (bench A/B)
+extern PSK_HIDDEN int64_t g_nib_update_layout;  // delta-image layout of k_nib_apply: 0 pieces, 1 blocks (psk_nibble.hpp)
+extern PSK_HIDDEN int64_t g_lookup_nibble, g_update_nibble;  // CBF tables beyond one level of 32-bit slices: 4-bit slice images (psk_nibble.hpp)
 extern PSK_HIDDEN int64_t g_part_dense_groups;   // pass 2 walks a wave's segments end to end when a segment holds fewer groups than this on average (0 = never)
 extern PSK_HIDDEN int64_t g_part_wgs;            // bench knob: pass 1 workgroups (0 = auto: one or two per CU)
 extern PSK_HIDDEN int64_t g_lookup_split;        // bench knob: 0 = never share a slice between two pass-2 workgroups
@@ -181,6 +201,24 @@ static inline bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_
     g->dbg = (uint32_t)g_part_debug;
     g->split = g->split_idx = 0;
     g->dense = 0;
+    g->append = 0;
+    return true;
+}
+
+// The fixed geometry of a handle's persistent lists for `cap` keys per list (psk_sketch::scat); false: the table is not eligible.
+static inline bool scat_geometry(const psk_sketch *s, uint64_t cap, PartGeom *g)
+{
+    if (s->m <= (1ULL << 26) || !part_slices(s->m, kNibShift, kNibShift, g, kPartMaxBuckets, 7)) return false;
+    g->k = s->k;
+    g->nwg = 256;
+    g->append = 1;
+    g->tile = 0;
+    const double tile_keys = 2048.0 * 7.0 / (double)(s->k < 1 ? 1 : s->k);             // keys per pass-1 tile, roughly (14 K probes)
+    const double mean = (double)cap * s->k / ((double)g->nbuckets * g->nwg);           // probes per segment when the list is full
+    const double runs = 2.0 * (double)cap / (tile_keys * g->nwg) + 64.0;               // (tile, slice) runs per segment: small batches bring short tiles
+    const double segcap = mean / 6.0 + 0.5 * runs + 8.0 * __builtin_sqrt(mean) / 6.0 + 16.0;
+    if (segcap >= (double)(1u << 24) || (double)g->nbuckets * segcap >= 4294967296.0) return false;
+    g->segcap = (uint32_t)segcap;
     return true;
 }
 
@@ -207,16 +245,39 @@ static size_t scatter_lds_bytes(const PartGeom *g)
     return (5 * (size_t)g->nbuckets + 16 + 24 + stage_words) * 4;
 }
 
+// append mode (PartGeom::append): the caller's persistent segments; g->nwg / g->segcap are the caller's and stay as they are
+struct ScatterTarget {
+    uint32_t *cnt;
+    uint4 *part;
+};
+
 constexpr size_t kScatterLdsBudget = 160 * 1024;
 constexpr size_t kScatterLdsTwoPerCu = 78 * 1024;  // two workgroups' dynamic LDS per CU
 template <class Src, class IdxFn, class Pay, class Spill, int KT, int NT>
 static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, PartGeom *g,
-                             uint64_t n, hipStream_t st, uint32_t want_wgs)
+                             uint64_t n, hipStream_t st, uint32_t want_wgs, const ScatterTarget *fixed = nullptr)
 {
     using Tile = PartTile<Pay, KT, NT>;
     const uint64_t ntiles = (n + Tile::TILE - 1) / Tile::TILE;
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
     const size_t lds = scatter_lds_bytes<Pay, KT, NT>(g);
+    if (fixed) {  // append behind what the segments already hold: the first min(nwg, tiles) workgroups each take their share of tiles
+        if (Pay::mode != kModePlain) return fail(PSK_EINVAL, "persistent segments carry payload-free probes");
+        const uint64_t grid = g->nwg < ntiles ? g->nwg : ntiles;
+        if (grid == 0) return PSK_OK;
+        const uint64_t per_wg = (ntiles + grid - 1) / grid;
+        uint64_t tk = Tile::TILE;
+        if (g_part_even_tiles != 0 && grid * per_wg > ntiles) {
+            tk = ((n + grid * per_wg - 1) / (grid * per_wg) + 63) & ~63ULL;
+            if (tk > (uint64_t)Tile::TILE) tk = Tile::TILE;
+        }
+        g->tile = (uint32_t)tk;
+        auto kern = k_part_scatter<Src, IdxFn, Pay, Spill, KT, NT>;
+        PSK_TRY(set_dyn_lds(kern, lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, src, idxfn, pay, spill, *g, n, fixed->cnt, fixed->part);
+        HIP_TRY(hipGetLastError());
+        return PSK_OK;
+    }
     uint64_t per_cu = NT > 512 ? 1 : (lds > kScatterLdsTwoPerCu ? 1 : 2);
     if (kBenchKnobs && (g->dbg & 8)) per_cu = 1;  // ablation: one workgroup per CU
     uint64_t nwg = 256 * per_cu;
@@ -264,22 +325,24 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
 // Option "tile_threads": 0 = this rule, 512 / 1024 = force the shape (A/B).
 template <class Src, class IdxFn, class Pay, class Spill, int KT>
 static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, PartGeom *g,
-                          uint64_t n, hipStream_t st, uint32_t want_wgs = 0)
+                          uint64_t n, hipStream_t st, uint32_t want_wgs = 0, const ScatterTarget *fixed = nullptr)
 {
-    static_assert(Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, kPartThreads>::TILE << 20) <= (1ULL << 31),
-                  "512-thread tiles must keep keyed probes inside 31 bits for the largest slice (2^20 bits)");
+    if constexpr (Pay::mode == kModeKeyed)
+        static_assert(((uint64_t)PartTile<Pay, KT, kPartThreads>::TILE << Pay::slice_shift) <= (1ULL << 31),
+                      "512-thread tiles must keep keyed probes inside 31 bits for the largest slice");
     if constexpr (KT <= 8) {
         // keyed probes carry (key index in tile << shift | bit in slice) in 31 bits (the top bit spells the tile ordinal): the
         // tile must stay within 2^(31 - shift) keys (PayKeyId::max_tile caps it at 2048 keys)
-        static_assert(Pay::mode != kModeKeyed || ((uint64_t)PartTile<Pay, KT, 1024>::TILE << 20) <= (1ULL << 31), "keyed tile too large");
+        if constexpr (Pay::mode == kModeKeyed)
+            static_assert(((uint64_t)PartTile<Pay, KT, 1024>::TILE << Pay::slice_shift) <= (1ULL << 31), "keyed tile too large");
         const bool fits1024 = scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget;
         const bool two_per_cu = pay_fat512<Pay>::value && scatter_lds_bytes<Pay, KT, kPartThreads>(g) <= kScatterLdsTwoPerCu;
         bool use1024 = fits1024 && !two_per_cu;
         if (g_part_tile_threads == 1024) use1024 = fits1024;
         if (g_part_tile_threads == 512 || (kBenchKnobs && (g->dbg & 16))) use1024 = false;
-        if (use1024) return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st, want_wgs);
+        if (use1024) return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st, want_wgs, fixed);
     }
-    return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, kPartThreads>(s, src, idxfn, pay, spill, g, n, st, want_wgs);
+    return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, kPartThreads>(s, src, idxfn, pay, spill, g, n, st, want_wgs, fixed);
 }
 
 // compile-time hash count: exact for the common small k on the 16-byte fast layout, rounded up otherwise
@@ -442,3 +505,7 @@ PSK_DECLARE_VARIANTS(int, cbf_remove_partitioned, (psk_sketch *s, const Batch &b
 PSK_DECLARE_VARIANTS(int, cms_check_partitioned, (psk_sketch *s, const Batch &b, int query, int64_t els_added, void *out_dev, hipStream_t st, bool *done))
 PSK_DECLARE_VARIANTS(int, cbf_check_partitioned, (psk_sketch *s, const Batch &b, uint32_t kk, uint32_t *out_dev, hipStream_t st, bool *done))
 PSK_HIDDEN int flush_combined(psk_sketch *s, hipStream_t st);  // apply the write-combined CBF updates, if any (psk_capi.hip)
+// pass 1 of a unit-weight CBF batch, appended to the handle's persistent add (neg = 0) / decrement (neg = 1) list; *done = false:
+// the batch / table is not eligible (nothing was launched)
+PSK_DECLARE_VARIANTS(int, cbf_scat_append, (psk_sketch *s, const Batch &b, int neg, hipStream_t st, bool *done))
+extern PSK_HIDDEN int64_t g_auto_combine, g_auto_combine_keys, g_combine_keys, g_combine_scatter;

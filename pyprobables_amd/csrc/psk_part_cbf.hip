@@ -5,3 +5,17 @@ int PSK_VARIANT(cbf_add_partitioned)(psk_sketch *s, const Batch &b, const uint32
 {
     return counter_add_partitioned<IdxBloom, false, false>(s, b, w_dev, s->m, st, done);
 }
+
+// Write-combined unit-weight updates as scattered probes (psk_sketch::scat): pass 1 of this batch, appended to the add / decrement
+// list.  The caller (psk_capi.hip) has set up the geometry and the buffers and flushes a full list first.
+int PSK_VARIANT(cbf_scat_append)(psk_sketch *s, const Batch &b, int neg, hipStream_t st, bool *done)
+{
+    *done = false;
+    psk_sketch::ScatList &l = neg ? s->scat.rem : s->scat.add;
+    const ScatterTarget target{(uint32_t *)l.cnt.p, (uint4 *)l.part.p};
+    PartGeom g = s->scat.g;
+    bool handled = false;
+    PSK_TRY(nib_scatter<false>(s, b, nullptr, neg != 0, &g, st, &handled, &target));
+    *done = handled;
+    return PSK_OK;
+}

@@ -15,5 +15,7 @@ int PSK_VARIANT(cbf_check_partitioned)(psk_sketch *s, const Batch &b, uint32_t k
             return (int)PSK_OK;
         });
     };
+    PSK_TRY(cbf_check_nibble(s, b, kk, out_dev, st, done, redo));  // big tables: 4-bit slice images (psk_nibble.hpp)
+    if (*done) return PSK_OK;
     return counter_check_partitioned<IdxBloom>(s, b, kk, s->m, QueryCbfMin{}, out_dev, st, done, redo);
 }

@@ -1,6 +1,7 @@
 // psk_part_counter.hpp -- launcher template of the partitioned counter adds (CMS add / remove, CBF add)
 #pragma once
 #include "psk_host.hpp"
+#include "psk_nibble.hpp"
 
 // account_weights(), so ctr[6] holds this batch's sum|w| for the wrap check inside pass 2.
 // the weights of keys [start, ...) + the fused accounting request posted by the caller (psk_sketch::acct), if any
@@ -25,12 +26,74 @@ static inline int fold_tally(psk_sketch *s, const PayWeight &pay, uint32_t nwg, 
     return PSK_OK;
 }
 
+// One round of pass 1 for the NIBBLE update path (psk_nibble.hpp): 6 x 20-bit probe groups of the keys of `sub` (all of them, or -- mask
+// != nullptr, decrements only -- those with mask[i] != 0) into the handle's bucket buffer, or (fixed) appended to persistent segments.
+template <bool MASKABLE>
+static inline int nib_scatter(psk_sketch *s, const Batch &sub, const uint32_t *mask, bool neg, PartGeom *g, hipStream_t st, bool *handled,
+                              const ScatterTarget *fixed = nullptr)
+{
+    SpillCounter<false> spill{(uint32_t *)s->table, true, neg, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED)};
+    return with_part_source(sub, handled, [&](auto src) {
+        using Src = decltype(src);
+        return with_kt<Src>(s->k, [&](auto kt) {
+            constexpr int KT = decltype(kt)::value;
+            if constexpr (MASKABLE) {  // (masked batches only exist for decrements: instantiated in that translation unit only)
+                if (mask) return launch_scatter<Src, IdxBloom<kTuPow2>, PayUnitMasked, SpillCounter<false>, KT>(s, src, IdxBloom<kTuPow2>{s->md}, PayUnitMasked{mask}, spill, g, sub.n, st, 0, fixed);
+            }
+            return launch_scatter<Src, IdxBloom<kTuPow2>, PayNone, SpillCounter<false>, KT>(s, src, IdxBloom<kTuPow2>{s->md}, PayNone{}, spill, g, sub.n, st, 0, fixed);
+        });
+    });
+}
+
+template <bool NEG>
+static inline int nib_apply(psk_sketch *s, const PartGeom &g, const void *cnt, const void *part, hipStream_t st)
+{
+    const size_t lds = (size_t)1 << (g.shift - 1);
+    auto kern = g_nib_update_layout ? k_nib_apply<NEG ? 1 : 0, true> : k_nib_apply<NEG ? 1 : 0, false>;
+    PSK_TRY(set_dyn_lds(kern, lds));
+    hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint32_t *)cnt, (const uint4 *)part,
+                       (const uint32_t *)nullptr, (const uint4 *)nullptr, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED), 0u);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
+// CountingBloomFilter unit-weight adds / decrements into 2^26 .. 2^29 counters: ONE level of 2^18-counter slices with 4-bit delta
+// images (the 32-bit images need the two-level path there).  w01: the per-key weights are known to be 0 or 1 (the amounts of the
+// validated remove): keys with 0 send no probes.  Eligible when the batch brings enough probes to pay for the pass over the table.
+template <bool NEG>
+static inline int cbf_unit_nibble(psk_sketch *s, const Batch &b, const uint32_t *w01, hipStream_t st, bool *done)
+{
+    *done = false;
+    const uint64_t cells = s->m;
+    if (g_update_nibble == 0 || cells <= (1ULL << 26) || !part_wanted(b.n, s->k, 4)) return PSK_OK;
+    if (b.n * (uint64_t)s->k < cells / 8) return PSK_OK;
+    PartGeom g;
+    if (!part_slices(cells, kNibShift, kNibShift, &g, kPartMaxBuckets, 7)) return PSK_OK;
+    g.k = s->k;
+    const uint64_t round_keys = part_round_keys_two_level(b.n);
+    for (uint64_t start = 0; start < b.n; start += round_keys) {
+        const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
+        bool handled = false;
+        PSK_TRY(nib_scatter<NEG>(s, sub_batch(b, start, cnt), w01 ? w01 + start : nullptr, NEG, &g, st, &handled));
+        if (!handled) return PSK_OK;  // (first round: nothing was launched)
+        PSK_TRY(nib_apply<NEG>(s, g, s->s_cnt.p, s->s_part.p, st));
+    }
+    *done = true;
+    return PSK_OK;
+}
+
 template <template <bool> class IDX, bool SIGNED, bool NEG>
 static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, uint64_t cells, hipStream_t st,
                                    bool *done)
 {
     *done = false;
     if (!part_wanted(b.n, s->k, 4)) return PSK_OK;
+    if constexpr (!SIGNED) {  // CountingBloomFilter: unit weights (or 0 / 1 amounts) into a big table -> nibble deltas, one level
+        if (!w_dev || s->acct.weights01) {
+            PSK_TRY(cbf_unit_nibble<NEG>(s, b, w_dev, st, done));
+            if (*done) return PSK_OK;  // (weights, if any, stay to be accounted by the caller's stand-alone pass: acct.pending is untouched)
+        }
+    }
     // unit-weight batches cannot wrap a 32-bit partial sum when n*k < 2^31 (weighted ones are checked on the device)
     if (!w_dev && b.n * (uint64_t)s->k >= (1ULL << 31)) return PSK_OK;
     PartGeom g;

@@ -19,3 +19,4 @@ PSK_DISPATCH(cbf_remove_partitioned, (psk_sketch *s, const Batch &b, const uint3
 PSK_DISPATCH(cms_check_partitioned, (psk_sketch *s, const Batch &b, int query, int64_t els, void *out_dev, hipStream_t st, bool *done),
              (s, b, query, els, out_dev, st, done))
 PSK_DISPATCH(cbf_check_partitioned, (psk_sketch *s, const Batch &b, uint32_t kk, uint32_t *out_dev, hipStream_t st, bool *done), (s, b, kk, out_dev, st, done))
+PSK_DISPATCH(cbf_scat_append, (psk_sketch *s, const Batch &b, int neg, hipStream_t st, bool *done), (s, b, neg, st, done))

@@ -3,6 +3,7 @@
 #pragma once
 #include "psk_host.hpp"
 #include "psk_lookup.hpp"
+#include "psk_nibble.hpp"
 
 // Keys per round.  Measured on MI355X (10 M CMS lookups): one round of 10 M keys 432 us, two 446, three cache-sized ones 464
 // -- the three kernels of a round stream ~50 B per key once and every round re-reads the table, so unlike the update
@@ -87,6 +88,75 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
         if (!handled) return PSK_OK;  // layout without a partitioned instantiation: nothing was launched (first round)
     }
     PSK_TRY(redo(flag, st));  // runs only if a segment overflowed (device-side flag): exact for any input
+    *done = true;
+    return PSK_OK;
+}
+
+// CountingBloomFilter lookups through NIBBLE slices (psk_nibble.hpp): tables of 2^25 .. 2^29 counters -- beyond 1024 of the 32-bit
+// slices above the three passes below win (fewer, longer runs in pass 1 and pass 3), and beyond 2^27 counters they are the only
+// partitioned form (BASELINE cfg 4's 1 GiB table: 1024 slices of 2^18 counters).  countingbloom.py:166-174.
+template <class Redo>
+static inline int cbf_check_nibble(psk_sketch *s, const Batch &b, uint32_t kk, uint32_t *out_dev, hipStream_t st, bool *done, Redo &&redo)
+{
+    *done = false;
+    const uint64_t cells = s->m;
+    if (g_lookup_nibble == 0 || cells < (1ULL << 25) || !part_wanted(b.n, kk, 4)) return PSK_OK;
+    // pass 2 reads the WHOLE table (4 B per counter at ~4.4 TB/s: 0.25 ms for 2^28 counters) where the direct kernel fetches one
+    // 64-byte line per probe (52 G probes/s): worth it from about cells / 16 probes on (measured on the 1 GiB table: a 0.5 M-key
+    // lookup 67 us direct, 0.4 ms through the slices)
+    if (g_lookup_nibble != 2 && b.n * (uint64_t)kk < cells / 16) return PSK_OK;  // (2: always -- tests)
+    PartGeom g;
+    if (!part_slices(cells, kNibShift, kNibShift, &g, kPartMaxBuckets, 7)) return PSK_OK;
+    g.k = kk;
+    const uint64_t round_keys = lookup_round_keys(b.n, kk);
+    PSK_TRY(ensure(s->s_flag, 8));
+    uint32_t *flag = (uint32_t *)s->s_flag.p;
+    HIP_TRY(hipMemsetAsync(flag, 0, 4, st));
+    for (uint64_t start = 0; start < b.n; start += round_keys) {
+        const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
+        const Batch sub = sub_batch(b, start, cnt);
+        bool handled = false, fits = true;
+        PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
+            using Src = decltype(src);
+            return with_kt<Src>(kk, [&](auto kt) {
+                constexpr int KT = decltype(kt)::value;
+                constexpr int P4 = (KT + 7) / 8;
+                using TileSmall = PartTile<PayBloomLookup, KT, kPartThreads>;
+                using TileBig = PartTile<PayBloomLookup, KT, 1024>;
+                const uint32_t kq = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
+                // 16-bit stage positions (perm[]): the largest tile pass 1 may choose must fit -- else not eligible, nothing launched
+                const size_t tile_max = TileBig::TILE > TileSmall::TILE ? TileBig::TILE : TileSmall::TILE;
+                if (tile_max * kq + (size_t)5 * g.nbuckets + 3 > 0xFFFFu) { fits = false; return (int)PSK_OK; }
+                const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE + 1024;  // (+ workgroups: evened tiles, launch_scatter_nt)
+                PSK_TRY(ensure(s->s_perm, cnt * P4 * 16));
+                PSK_TRY(ensure(s->s_run, max_tiles * g.nbuckets * 8));
+                PayBloomLookup pay{(uint4 *)s->s_perm.p, (uint2 *)s->s_run.p};
+                SpillRaiseFlag spill{flag};
+                PSK_TRY((launch_scatter<Src, IdxBloom<kTuPow2>, PayBloomLookup, SpillRaiseFlag, KT>(s, src, IdxBloom<kTuPow2>{s->md}, pay, spill, &g, cnt, st)));
+                PSK_TRY(ensure(s->s_vals, (uint64_t)g.nbuckets * g.nwg * g.segcap * 4 + 256));  // one dword (six nibbles) per group
+                const size_t lds2 = (size_t)1 << (g.shift - 1);
+                PSK_TRY(set_dyn_lds(k_nib_gather, lds2));
+                hipLaunchKernelGGL(k_nib_gather, dim3(g.nbuckets), dim3(kApplyThreads), lds2, st, (const uint32_t *)s->table, cells, g,
+                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint32_t *)s->s_vals.p, (uint32_t)(g_nib_nt != 0));
+                HIP_TRY(hipGetLastError());
+                const uint32_t stage_cap = (uint32_t)(((size_t)g.tile * kq + (size_t)5 * g.nbuckets + 3) & ~(size_t)3);
+                const uint32_t stage_groups = stage_cap / 6 + 1;
+                const size_t lds3 = (size_t)8 * g.nbuckets + (size_t)4 * ((stage_groups + 3) & ~3u);
+                const uint64_t ntiles = (cnt + g.tile - 1) / g.tile;
+                auto kern = k_nib_collect<KT>;
+                PSK_TRY(set_dyn_lds(kern, lds3));
+                uint32_t run_lanes = 2;  // lanes (one dword = one group of 6 probes each) per (tile, slice) run
+                while (run_lanes < 64 && (uint64_t)run_lanes * 6 * g.nbuckets < (uint64_t)g.tile * kq + 6ULL * g.nbuckets) run_lanes *= 2;
+                if (g_lookup_run_lanes > 0) run_lanes = (uint32_t)g_lookup_run_lanes;
+                hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(kBloomCollectThreads), lds3, st, g, cnt, (const uint4 *)s->s_perm.p,
+                                   (const uint2 *)s->s_run.p, (const uint32_t *)s->s_vals.p, stage_groups, run_lanes, out_dev + start, flag);
+                HIP_TRY(hipGetLastError());
+                return (int)PSK_OK;
+            });
+        }));
+        if (!handled || !fits) return PSK_OK;  // (only ever on the first round: nothing was launched)
+    }
+    PSK_TRY(redo(flag, st));  // a segment overflowed, or a key's counters are all 15 or more: exact redo by the direct kernel
     *done = true;
     return PSK_OK;
 }

@@ -42,6 +42,7 @@ constexpr int kPartMaxBuckets = 2048;
 constexpr int kPartScanPerThread = 4;   // slices per lane of a scanning thread: 64 x 4 = one wave covers 256 slices
 constexpr bool kPartPipeline = true;   // prefetch the next tile's keys under the current tile (see k_part_scatter)
 constexpr bool kPartHash32 = true;     // explicit 32-bit FNV chains for power-of-two tables
+constexpr uint32_t kNibShift = 18;           // log2(counters per 4-bit slice image): psk_nibble.hpp (CountingBloomFilter tables beyond 2^26 cells)
 constexpr uint32_t kPadProbe = 0xFFFFFFFFu;  // filler that pads every run to whole groups; pass 2 skips it
 
 enum PartMode { kModePlain = 0, kModeInline = 1, kModeKeyed = 2 };
@@ -57,6 +58,8 @@ struct PartGeom {
     uint32_t split;         // read-only pass-2 kernels: workgroups per slice (0 / 1 = one); workgroup `split_idx` of a slice
     uint32_t split_idx;     // walks segments split_idx, split_idx + split, ... (balances slice counts that do not fill the CUs)
     uint32_t dense;         // pass 2: 1 = short segments, a wave walks its segments end to end (for_each_batch_at); set by pass 1's launcher
+    uint32_t append;        // pass 1: 1 = my segments already hold segcnt[] groups from earlier launches with the SAME geometry -- append behind
+                            // them (write-combined updates: every batch is scattered when it is handed over, pass 2 runs once per flush)
 };
 
 // Where segment (slice b, workgroup wg) lives in the bucket buffer.  Workgroup-major: the B runs a workgroup
@@ -114,6 +117,10 @@ struct pay_has_tally { static constexpr bool value = false; };
 template <class Pay>
 struct pay_has_tally<Pay, decltype((void)&Pay::tally)> { static constexpr bool value = true; };
 template <class Pay, class = void>
+struct pay_has_keep { static constexpr bool value = false; };
+template <class Pay>
+struct pay_has_keep<Pay, decltype((void)&Pay::keep)> { static constexpr bool value = true; };
+template <class Pay, class = void>
 struct pay_is_lookup { static constexpr bool value = false; };
 template <class Pay>
 struct pay_is_lookup<Pay, decltype((void)Pay::lookup)> { static constexpr bool value = Pay::lookup; };
@@ -124,6 +131,13 @@ struct PayNone {   // Bloom insert: 6 probes per group, 20-bit slice-local bit i
     static constexpr int group = 6;
     static constexpr bool fat512 = true;  // PartTile: two 512-thread workgroups per CU with 32 probes per thread (measured: -3.5 %)
     __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
+};
+struct PayUnitMasked {  // PayNone's probes, for the keys with amount[i] != 0 only: the decrement of the validated CBF remove, whose
+    static constexpr int mode = kModePlain;  // per-key amounts are 0 (absent / frozen: countingbloom.py:198-201) or 1
+    static constexpr int group = 6;
+    const uint32_t *amount;
+    __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
+    __device__ __forceinline__ uint32_t keep(uint64_t i) const { return amount[i]; }
 };
 struct PayUnit {   // unit-weight counter adds: 8 probes per group, 16-bit slice-local cell indices (slices <= 2^15 cells)
     static constexpr int mode = kModePlain;
@@ -156,6 +170,7 @@ struct PayKeyId {
     static constexpr int group = 4;
     static constexpr int mode = kModeKeyed;
     static constexpr int max_tile = 2048;
+    static constexpr int slice_shift = 20;  // largest slice (log2 bits) these probes address: max_tile << slice_shift <= 2^31
     static constexpr uint32_t max_tiles_per_wg = 16;
     __device__ __forceinline__ uint32_t operator()(uint64_t i, uint64_t base) const { return (uint32_t)(i - base); }
 };
@@ -347,6 +362,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t dbg = kBenchKnobs ? g.dbg : 0u;  // folds to 0 in the shipped build
     const uint32_t B = g.nbuckets;
+    const uint64_t last = n ? n - 1 : 0;       // index the clamped prefetches fall back to (the key buffer holds at least one key)
     uint32_t *hist0 = smem;  // two copies: tile t counts in one while the scan phase of tile t zeroes the other
     uint32_t *off = hist0 + 2 * B;
     uint32_t *delta = off + B;
@@ -367,7 +383,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     const uint64_t ntiles = (n + tk - 1) / tk;
     uint4 *wg_buckets = buckets + seg_index(g, 0, blockIdx.x) * g.segcap;  // my segment of slice 0; slice b: + b * segcap
 
-    for (uint32_t b = threadIdx.x; b < B; b += NT) cur[b] = 0;
+    for (uint32_t b = threadIdx.x; b < B; b += NT) cur[b] = g.append ? segcnt[(uint64_t)b * g.nwg + blockIdx.x] : 0u;
     for (uint32_t b = threadIdx.x; b < 2 * B; b += NT) hist0[b] = 0;
     uint32_t parity = 0;
     lds_barrier();
@@ -380,7 +396,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
             const uint64_t i = (uint64_t)blockIdx.x * tk + (uint64_t)q * NT + threadIdx.x;
-            kcur[q] = src.load(i < n ? i : n - 1);  // coalesced; clamped, never branched around (a conditional load
+            kcur[q] = src.load(i < n ? i : last);  // coalesced; clamped, never branched around (a conditional load
         }                                           // makes hipcc wait vmcnt(0) per element: serial round trips)
     }
 
@@ -410,6 +426,18 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         uint32_t fold = 0;
         const uint64_t base = tile * tk;
         const uint64_t tile_end = base + tk < n ? base + tk : n;
+        // Pay::keep (masked batches): a key whose flag is 0 sends no probes.  The flags are requested up front and first consumed
+        // behind the key's hash chains, which hides the load.
+        constexpr bool KEEP = pay_has_keep<Pay>::value;
+        uint32_t kw[KEEP ? KPT : 1];
+        if constexpr (KEEP) {
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                const uint64_t i = base + (uint64_t)q * NT + threadIdx.x;
+                kw[q] = pay.keep(i < n ? i : last);
+            }
+        }
+        auto kept = [&](int q) -> bool { if constexpr (KEEP) return kw[q] != 0; else return true; };
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
             const uint64_t i = base + (uint64_t)q * NT + threadIdx.x;
@@ -436,7 +464,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
                         if ((uint32_t)j < k) {
                             idx[q][j] = idxfn.from32((uint32_t)j, h[j]);
                             if (dbg & 2) { fold ^= idx[q][j]; continue; }  // bench-only: hashing alone
-                            rank[q][j] = atomicAdd(&hist[idx[q][j] >> g.shift], 1u);  // ds_add_rtn_u32
+                            if (kept(q)) rank[q][j] = atomicAdd(&hist[idx[q][j] >> g.shift], 1u);  // ds_add_rtn_u32
                         }
                     }
                 } else {
@@ -458,7 +486,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
                     for (int j = 0; j < KT; ++j) {
                         if ((uint32_t)j < k) {
                             idx[q][j] = idxfn((uint32_t)j, h[j]);
-                            rank[q][j] = atomicAdd(&hist[idx[q][j] >> g.shift], 1u);  // ds_add_rtn_u32
+                            if (kept(q)) rank[q][j] = atomicAdd(&hist[idx[q][j] >> g.shift], 1u);  // ds_add_rtn_u32
                         }
                     }
                 }
@@ -471,7 +499,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
 #pragma unroll
                 for (int q = 0; q < KPT; ++q) {
                     const uint64_t i = nbase + (uint64_t)q * NT + threadIdx.x;
-                    kcur[q] = src.load(i < n ? i : n - 1);
+                    kcur[q] = src.load(i < n ? i : last);
                 }
             }
             continue;
@@ -486,7 +514,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
 #pragma unroll
             for (int q = 0; q < KPT; ++q) {
                 const uint64_t i = nbase + (uint64_t)q * NT + threadIdx.x;
-                kcur[q] = src.load(i < n ? i : n - 1);  // unconditional (clamped) on purpose, see above
+                kcur[q] = src.load(i < n ? i : last);  // unconditional (clamped) on purpose, see above
             }
         }
 
@@ -540,7 +568,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
             const uint64_t i = base + (uint64_t)q * NT + threadIdx.x;
-            if (i < tile_end) {
+            if (i < tile_end && kept(q)) {
                 uint32_t pos[LOOKUP ? 8 * ((KT + 7) / 8) : 1] = {};  // lookups: where each of my probes sits in the sorted stage
                 if constexpr (pay_has_tally<Pay>::value) {
                     // (here, not where the weight is loaded: the sum would pin the load's latency into the hash phase --

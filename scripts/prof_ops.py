@@ -11,6 +11,11 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import pyprobables_amd as pa  # noqa: E402
 from pyprobables_amd import _native as N  # noqa: E402
 
+import os  # noqa: E402
+
+for kv in os.environ.get("PSK_OPTS", "").split(","):  # engine options for this run, e.g. PSK_OPTS=bloom_lookup=3
+    if "=" in kv:
+        N.set_option(kv.split("=")[0], int(kv.split("=")[1], 0))
 op = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
@@ -65,7 +70,7 @@ else:
     s = pa.CountingBloomFilter(est_elements=3_500_000, false_positive_rate=0.01) if op.startswith("cbf25") else \
         pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01)
     s.add_many(keys)
-    fn = {"add": lambda: s.add_many(keys), "check": lambda: s.check_many(keys), "remove": lambda: s.remove_many(keys)}[op.split("_", 1)[1]]
+    fn = {"add": lambda: s.add_many(keys), "check": lambda: s.check_many(keys), "remove": lambda: (s.add_many(keys), s.remove_many(keys))}[op.split("_", 1)[1]]  # (remove: the keys go back in first, so that every remove finds its key)
 launches = 2 + iters + (1 if op in ("bloom_add", "bloom31_add", "cms_add", "cbf_add", "cbf25_add") else 0)  # the set-up insert runs the same kernels
 for _ in range(2):
     fn()

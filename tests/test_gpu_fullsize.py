@@ -94,6 +94,8 @@ def test_cfg3_cms_100M_weighted_full(pa, oracle):
 def test_cfg4_cbf_1GiB_mixed_stream(pa, oracle):
     """all 50 batches of the cfg-4 stream, the whole 1 GiB table compared with the oracle after EVERY batch (on the device:
     the oracle's table is uploaded, 1 GiB over PCIe per batch)"""
+    from pyprobables_amd import _native as N
+
     B, nb = 1_000_000, 50
     cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01)
     assert (cbf.number_bits, cbf.number_hashes) == (2**28, 7)
@@ -108,6 +110,19 @@ def test_cfg4_cbf_1GiB_mixed_stream(pa, oracle):
         assert torch.equal(cbf.table_tensor[: want.numel()], want), f"table differs after batch {b}"
         del want
         assert cbf.elements_added == oc.els_added
+        # lookups after every batch (the 1 GiB table's partitioned lookup: nibble slices): this batch's keys -- present --, the keys
+        # just removed -- mostly back to 0 -- and keys of the next batch -- absent
+        starts = [max(b - 1, 0) * B, b * B, (b + 1) * B]
+        got = cbf.check_many(torch.cat([dev_keys(s0, 100_000) for s0 in starts])).cpu().numpy().view(np.uint32)
+        want_c = oc.check_keys(np.concatenate([oracle.gen_keys16(s0, 100_000) for s0 in starts]))
+        assert np.array_equal(got, want_c), f"lookups differ after batch {b}"
+        if b % 8 == 7:  # (0.3 M keys sit below the crossover of the nibble-slice lookup: force it now and then)
+            N.set_option("lookup_nibble_slices", 2)
+            try:
+                got = cbf.check_many(torch.cat([dev_keys(s0, 100_000) for s0 in starts])).cpu().numpy().view(np.uint32)
+            finally:
+                N.set_option("lookup_nibble_slices", 1)
+            assert np.array_equal(got, want_c), f"nibble-slice lookups differ after batch {b}"
     expect = nb * B - (nb - 1) * (B // 2)
     assert cbf.elements_added == expect
     assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}

@@ -1,0 +1,222 @@
+"""CountingBloomFilter tables beyond one level of 32-bit LDS slices -- BASELINE cfg 4's 2^28 counters (1 GiB) -- through the
+4-bit slice images of psk_nibble.hpp: lookups (k_nib_gather + k_nib_collect; countingbloom.py:166-174), unit-weight adds
+(k_nib_apply; :135-155) and the validated remove (lookup -> amounts -> masked decrement; :186-208), bit-exact against the
+oracle, against the direct kernels and with the options off; the cases the 4-bit images cannot hold (a key whose counters are
+all 15 or more; a counter hit 16 times or more in one round) must come out exact through their redo / fallback."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def pa():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import pyprobables_amd
+
+    return pyprobables_amd
+
+
+@pytest.fixture()
+def force_partition():
+    from pyprobables_amd import _native as N
+
+    names = ("partition", "partition_min_keys", "lookup_nibble_slices", "update_nibble_slices")
+    old = [N.get_option(k) for k in names]
+    N.set_option("partition", 1)
+    N.set_option("partition_min_keys", 1)
+    N.set_option("lookup_nibble_slices", 2)   # also below the crossover (cells / 16 probes)
+    yield N
+    for k, v in zip(names, old):
+        N.set_option(k, v)
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _table(cbf):
+    return cbf.table_tensor.cpu().numpy().view(np.uint32)[: cbf.number_bits]
+
+
+@pytest.mark.parametrize("est", [28005615, 10_000_000, 3_600_000])
+def test_cbf_lookups_through_nibble_slices(pa, oracle, force_partition, est):
+    """2^28 counters (1024 slices of 2^18), 9.6e7 (366 slices, Barrett) and 3.45e7 (132 slices): min over k counters"""
+    N = force_partition
+    cbf = pa.CountingBloomFilter(est_elements=est, false_positive_rate=0.01)
+    m, k = cbf.number_bits, cbf.number_hashes
+    assert m >= 2**25
+    n = 600_000
+    keys = oracle.gen_keys16(5, n)
+    w = (np.arange(n, dtype=np.int64) % 4) + 1
+    oc = oracle.OracleCBF(m, k)
+    cbf.add_many(_dev(keys), w.astype(np.uint32))
+    oc.update_keys(keys, w)
+    probe = np.concatenate([keys[: n // 2], oracle.gen_keys16(900_000_000, n // 2)])  # half of them were never added
+    dp = _dev(probe)
+    want = oc.check_keys(probe)
+    assert 0 < int((want == 0).sum()) < probe.shape[0]
+    got = cbf.check_many(dp).cpu().numpy().astype(np.uint32)
+    assert np.array_equal(got, want)
+    N.set_option("lookup_nibble_slices", 0)
+    assert np.array_equal(cbf.check_many(dp).cpu().numpy().astype(np.uint32), want)
+    N.set_option("lookup_nibble_slices", 2)
+    # check_alt: the min runs over ALL supplied hashes (countingbloom.py:174), here 9 per key
+    hs = np.array([oracle.default_fnv_1a(bytes(kx), 9) for kx in probe[:3000]], dtype=np.uint64)
+    hs = np.tile(hs, (100, 1))  # 300 k rows: a batch large enough for the partitioned path
+    want_alt = np.tile(np.array([oc.check_alt(row) for row in hs[:3000]], dtype=np.uint32), 100)
+    assert np.array_equal(np.asarray(cbf.check_alt_many(hs)).view(np.uint32), want_alt)
+    # a key whose counters are all 15 or more: the 4-bit image says "15", the flag-guarded direct kernel gives the exact answer
+    heavy = oracle.gen_keys16(123_456_789, 3)
+    cbf.add_many(_dev(heavy), np.array([15, 16, 40_000], dtype=np.uint32))
+    oc.update_keys(heavy, np.array([15, 16, 40_000], dtype=np.int64))
+    probe2 = np.concatenate([heavy, probe[:200_000]])
+    want2 = oc.check_keys(probe2)
+    assert want2[:3].tolist() == [15, 16, 40_000]
+    assert np.array_equal(cbf.check_many(_dev(probe2)).cpu().numpy().astype(np.uint32), want2)
+
+
+def test_cbf_1GiB_unit_adds_and_validated_removes_through_nibble_deltas(pa, oracle, force_partition):
+    """2^28 counters: a 5.2 M-key unit add brings more than cells / 8 probes -> one level of nibble-delta slices (no k_part_split);
+    the validated remove = nibble lookup -> amounts (0 for absent keys) -> masked decrement.  One key repeated 40 times in the
+    add batch carries past 15 in its slices: those workgroups fall back to exact atomics."""
+    N = force_partition
+    n = 5_200_000
+    cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    assert cbf.number_bits == 2**28
+    oc = oracle.OracleCBF(2**28, 7)
+    keys = oracle.gen_keys16(0, n)
+    keys[1000:1040] = keys[7]            # 41 copies of key 7 in one batch
+    cbf.add_many(_dev(keys))
+    oc.update_keys(keys)
+    assert np.array_equal(_table(cbf), oc.bloom), "unit add (nibble deltas)"
+    assert cbf.elements_added == oc.els_added
+    assert int(oc.check_keys(keys[7:8])[0]) >= 41
+    # the same batch through the two-level 32-bit path must agree
+    N.set_option("update_nibble_slices", 0)
+    c2 = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    c2.add_many(_dev(keys))
+    assert torch.equal(c2.table_tensor, cbf.table_tensor)
+    del c2
+    N.set_option("update_nibble_slices", 1)
+    # validated remove: distinct present keys + keys that were never added (no-ops: countingbloom.py:200-201)
+    present = oracle.gen_keys16(2_000_000, 3_000_000)            # keys [2M, 5M) of the stream: each present once
+    absent = oracle.gen_keys16(800_000_000, 2_200_000)
+    absent = absent[oc.check_keys(absent) == 0]                  # (a false positive would be "removed" by the reference too, and then the
+    rm = np.concatenate([present, absent])                       # result depends on the order inside the batch: not a well-formed stream)
+    cbf.remove_many(_dev(rm))
+    oc.update_keys(rm, -np.ones(rm.shape[0], dtype=np.int64))
+    assert np.array_equal(_table(cbf), oc.bloom), "validated remove (nibble lookup + masked decrement)"
+    assert cbf.elements_added == oc.els_added
+    assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+    # lookups afterwards, present / removed / never seen
+    probe = np.concatenate([keys[:300_000], present[:300_000], absent[:300_000]])
+    assert np.array_equal(cbf.check_many(_dev(probe)).cpu().numpy().astype(np.uint32), oc.check_keys(probe))
+
+
+def test_cbf_nibble_paths_non_power_of_two_table(pa, oracle, force_partition):
+    """9.6e7 counters (Barrett reduction, the last slice is partial): unit add + validated remove + lookups"""
+    cbf = pa.CountingBloomFilter(est_elements=10_000_000, false_positive_rate=0.01)
+    m, k = cbf.number_bits, cbf.number_hashes
+    assert 2**26 < m < 2**27
+    n = 2_000_000  # 14 M probes >= cells / 8
+    keys = oracle.gen_keys16(31, n)
+    oc = oracle.OracleCBF(m, k)
+    cbf.add_many(_dev(keys))
+    oc.update_keys(keys)
+    assert np.array_equal(_table(cbf), oc.bloom)
+    absent = oracle.gen_keys16(700_000_000, n // 2 + 300_000)
+    rm = np.concatenate([keys[: n // 2], absent[oc.check_keys(absent) == 0]])  # (no false positives: see above)
+    cbf.remove_many(_dev(rm))
+    oc.update_keys(rm, -np.ones(rm.shape[0], dtype=np.int64))
+    assert np.array_equal(_table(cbf), oc.bloom)
+    assert cbf.elements_added == oc.els_added
+    probe = np.concatenate([keys[-200_000:], rm[-200_000:]])
+    assert np.array_equal(cbf.check_many(_dev(probe)).cpu().numpy().astype(np.uint32), oc.check_keys(probe))
+
+
+def test_small_add_batches_into_a_big_table_are_write_combined_automatically(pa, oracle):
+    """no opt-in: unit-weight add_many batches too small to pay for a pass over the 1 GiB table are scattered when they are
+    handed over and folded together later (adds commute: countingbloom.py:135-155); every read sees them"""
+    from pyprobables_amd import _native as N
+
+    assert N.get_option("auto_combine") == 1
+    B = 400_000
+    cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    oc = oracle.OracleCBF(2**28, 7)
+    for b in range(14):                                  # 5.6 M keys in 14 batches: the flush takes the pass over the table
+        keys = oracle.gen_keys16(b * B, B)
+        cbf.add_many(_dev(keys))
+        oc.update_keys(keys)
+    assert cbf.elements_added == oc.els_added            # (get_counters flushes)
+    assert np.array_equal(_table(cbf), oc.bloom)
+    # a few more batches, then a lookup: too few probes for a table pass -> drained with atomics; the lookup sees them
+    for b in range(14, 17):
+        keys = oracle.gen_keys16(b * B, B)
+        cbf.add_many(_dev(keys))
+        oc.update_keys(keys)
+    probe = np.concatenate([oracle.gen_keys16(16 * B, 100_000), oracle.gen_keys16(900_000_000, 100_000)])
+    assert np.array_equal(cbf.check_many(_dev(probe)).cpu().numpy().astype(np.uint32), oc.check_keys(probe))
+    assert np.array_equal(_table(cbf), oc.bloom)
+    # pending adds, then a validated remove of some of them and of absent keys: the remove flushes first
+    keys = oracle.gen_keys16(17 * B, B)
+    cbf.add_many(_dev(keys))
+    oc.update_keys(keys)
+    absent = oracle.gen_keys16(700_000_000, 50_000)
+    rm = np.concatenate([keys[: B // 2], absent[oc.check_keys(absent) == 0]])
+    cbf.remove_many(_dev(rm))
+    oc.update_keys(rm, -np.ones(rm.shape[0], dtype=np.int64))
+    assert np.array_equal(_table(cbf), oc.bloom)
+    assert cbf.elements_added == oc.els_added
+    assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+    # clear drops what waits; host batches and a non-16-byte key length go the same way
+    cbf.add_many(_dev(oracle.gen_keys16(0, B)))
+    cbf.clear()
+    assert int(cbf.table_tensor.abs().sum().item()) == 0 and cbf.elements_added == 0
+    oc = oracle.OracleCBF(2**28, 7)
+    k12 = np.ascontiguousarray(oracle.gen_keys16(5, 300_000)[:, :12])
+    cbf.add_many(k12)                                    # host buffer, 12-byte keys
+    oc.update_keys(k12)
+    cbf.add_many(_dev(k12[:100_000]))
+    oc.update_keys(k12[:100_000])
+    assert np.array_equal(_table(cbf), oc.bloom)
+    # the option off: the same batches take the direct kernels
+    N.set_option("auto_combine", 0)
+    try:
+        c2 = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01)
+        c2.add_many(k12)
+        c2.add_many(_dev(k12[:100_000]))
+        assert torch.equal(c2.table_tensor, cbf.table_tensor)
+    finally:
+        N.set_option("auto_combine", 1)
+
+
+def test_opt_in_combining_mixes_scattered_and_key_lists(pa, oracle, request):
+    """combine_updates=True: unit-weight batches wait as scattered probes, weighted ones as key lists; at the flush all adds
+    of both land before all removes of both (well-formed stream)"""
+    from pyprobables_amd import _native as N
+
+    B = 300_000
+    N.set_option("combine_scatter", 1)   # (off by default: measured slower on BASELINE cfg 4's 1 M-key batches)
+    request.addfinalizer(lambda: N.set_option("combine_scatter", 0))
+    cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, combine_updates=True)
+    oc = oracle.OracleCBF(2**28, 7)
+    k0, k1, k2 = (oracle.gen_keys16(i * B, B) for i in range(3))
+    w = (np.arange(B, dtype=np.int64) % 3) + 1
+    cbf.add_many(_dev(k0))                                # scattered
+    cbf.add_many(_dev(k1), w.astype(np.uint32))           # key list (weighted)
+    cbf.remove_many(_dev(k0[: B // 2]))                   # scattered decrement
+    cbf.remove_many(_dev(k1[: B // 2]), w[: B // 2].astype(np.uint32))  # key list
+    cbf.add_many(_dev(k2))
+    oc.update_keys(k0)
+    oc.update_keys(k1, w)
+    oc.update_keys(k0[: B // 2], -np.ones(B // 2, dtype=np.int64))
+    oc.update_keys(k1[: B // 2], -w[: B // 2])
+    oc.update_keys(k2)
+    assert np.array_equal(_table(cbf), oc.bloom)
+    assert cbf.elements_added == oc.els_added
+    assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
