@@ -149,14 +149,23 @@ int psk_bloom_check_finish(psk_sketch *s, uint8_t *out_dev, void *stream);
  * inserts); anything else is counted in PSK_CTR_VIOLATIONS / PSK_CTR_SATURATED.
  * add:    counters[h_i % m] = min(c + w, 2^32-1) for i<k        (countingbloom.py:125-155)
  * remove: conditional decrement                                 (countingbloom.py:176-208)
- * check:  out = min_i counters[h_i % m]                         (countingbloom.py:157-174) */
+ * check:  out = min_i counters[h_i % m]                         (countingbloom.py:157-174)
+ * Big tables (more than 2^26 counters; round 3):
+ *   - unit-weight add batches too small to pay for a pass over the table (n * k < m / 8) are write-combined automatically: the
+ *     batch is hashed and partitioned when it is handed over, its probes wait in persistent per-slice segments and reach the
+ *     table together with their successors (adds commute, the clamp at 2^32-1 is applied all the same: exact, no opt-in;
+ *     option "auto_combine" = 0 turns it off, "auto_combine_keys" sizes the segments).  Every entry point that reads the
+ *     table, removes or hands out its pointer applies what is waiting first (psk_flush before using psk_table_info's pointer).
+ *   - a unit-weight psk_cbf_remove of at least m / 8 probes decrements optimistically (one pass; exact whenever every counter
+ *     holds what the batch takes from it, i.e. every key is present) and otherwise undoes that and takes the lookup + masked
+ *     decrement path; it reads ONE 4-byte verdict back, i.e. synchronises `stream` once (option "remove_optimistic" = 0: never). */
 int psk_cbf_add(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
                 uint32_t key_len, const uint32_t *weights, int where, void *stream);
 int psk_cbf_remove(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
                    uint32_t key_len, const uint32_t *weights, int where, void *stream);
 int psk_cbf_check(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
                   uint32_t key_len, int where, uint32_t *out, void *stream);
-/* Write-combined updates (opt-in).  The fold of a big counter table read-modify-writes the whole table whatever the batch
+/* Write-combined updates incl. REMOVES (opt-in).  The fold of a big counter table read-modify-writes the whole table whatever the batch
  * brings (1 GiB at BASELINE config 4), so small batches -- the config's 1M-key add / remove batches -- are collected on the
  * device and applied as ONE partitioned update per list once "combine_keys" keys (psk_set_option, default 2^26) are waiting:
  * first the adds (countingbloom.py:135-155), then the removes as plain decrements of every index by the key's weight

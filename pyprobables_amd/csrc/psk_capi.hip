@@ -455,6 +455,8 @@ int64_t g_part_two_level_slices = 2048;     // tables cut into more slices than 
 int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGeom::dbg); 0 in production
 int64_t g_lookup_run_lanes = 0, g_bloom_lookup = 2, g_lookup_split = 1, g_part_tile_threads = 0, g_part_slice_bias = 0, g_part_wgs = 0, g_part_even_tiles = 1;
 int64_t g_lookup_half = 1;
+int64_t g_remove_dryrun = 1;   // validated unit-weight CBF removes into big tables: optimistic decrement first (psk_nibble.hpp), option "remove_optimistic"
+int64_t g_scratch_budget = 0;  // psk_set_option("scratch_budget_bytes"): cap on a handle's partition scratch (more, smaller rounds); 0 = none
 int64_t g_lookup_nibble = 1;   // CBF lookups into 2^25 .. 2^29 counters: 4-bit slice images (psk_nibble.hpp) from cells / 16 probes on; 2 = always; 0 = the 32-bit / 16-bit slices or direct
 int64_t g_nib_nt = 1;   // nontemporal table loads in k_nib_gather (1 GiB lookups 710 -> 656 us per 10 M keys); the fold of k_nib_apply re-writes what it
                         // reads and measured slower with them (795 -> 984 us): never there
@@ -486,6 +488,8 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "even_tiles")) g_part_even_tiles = value;
     else if (!strcmp(name, "dense_walk_groups")) g_part_dense_groups = value;
     else if (!strcmp(name, "lookup_half_slices")) g_lookup_half = value;
+    else if (!strcmp(name, "scratch_budget_bytes")) g_scratch_budget = value;
+    else if (!strcmp(name, "remove_optimistic")) g_remove_dryrun = value;
     else if (!strcmp(name, "lookup_nibble_slices")) g_lookup_nibble = value;
     else if (!strcmp(name, "update_nibble_slices")) g_update_nibble = value;
     else if (!strcmp(name, "nibble_update_layout")) g_nib_update_layout = value;
@@ -525,6 +529,8 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "even_tiles")) *value = g_part_even_tiles;
     else if (!strcmp(name, "dense_walk_groups")) *value = g_part_dense_groups;
     else if (!strcmp(name, "lookup_half_slices")) *value = g_lookup_half;
+    else if (!strcmp(name, "scratch_budget_bytes")) *value = g_scratch_budget;
+    else if (!strcmp(name, "remove_optimistic")) *value = g_remove_dryrun;
     else if (!strcmp(name, "lookup_nibble_slices")) *value = g_lookup_nibble;
     else if (!strcmp(name, "update_nibble_slices")) *value = g_update_nibble;
     else if (!strcmp(name, "nibble_update_layout")) *value = g_nib_update_layout;
@@ -808,7 +814,7 @@ static int scat_flush(psk_sketch *s, hipStream_t st)
     auto launch = [&](auto kern, const psk_sketch::ScatList *la, const psk_sketch::ScatList *lb, uint32_t direct) {
         PSK_TRY(set_dyn_lds(kern, lds));
         hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint32_t *)la->cnt.p, (const uint4 *)la->part.p,
-                           (const uint32_t *)(lb ? lb->cnt.p : nullptr), (const uint4 *)(lb ? lb->part.p : nullptr), sat, direct);
+                           (const uint32_t *)(lb ? lb->cnt.p : nullptr), (const uint4 *)(lb ? lb->part.p : nullptr), sat, direct, (uint32_t *)nullptr);
         HIP_TRY(hipGetLastError());
         return (int)PSK_OK;
     };
@@ -1015,6 +1021,25 @@ static int cbf_remove_composed(psk_sketch *s, const Batch &b, const uint32_t *w,
 {
     *done = false;
     if (!part_wanted(b.n, s->k, 4)) return PSK_OK;
+    if (!w) {
+        // Unit weights into a big table: decrement optimistically (psk_nibble.hpp) -- if every counter holds at least as much as the
+        // batch takes from it, every key is removed and one pass 1 + ONE pass over the table did it (the exact path: two pass 1s, a
+        // return trip and two passes).  The verdict is one 4-byte read-back: this call synchronises the stream once.  Otherwise the
+        // decrement is undone (exactly: wrapping arithmetic both ways) and the exact path below takes the batch.
+        bool launched = false;
+        PSK_TRY(cbf_remove_fast_begin(s, b, st, &launched));
+        if (launched) {
+            uint32_t flag = 1;
+            HIP_TRY(hipMemcpyAsync(&flag, s->s_flag.p, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (flag == 0) {
+                PSK_TRY(account_weights(s, (const uint32_t *)nullptr, b.n, PSK_CTR_REMOVED, (long long)s->k, st, false));
+                *done = true;
+                return PSK_OK;
+            }
+            PSK_TRY(cbf_remove_fast_undo(s, st));
+        }
+    }
     PSK_TRY(ensure(s->s_aux, b.n * 8 + 64));
     uint32_t *mins = (uint32_t *)s->s_aux.p, *amount = mins + ((b.n + 3) & ~3ULL);
     bool looked = false;

@@ -144,6 +144,7 @@ struct psk_sketch {
         hipStream_t last = nullptr;
         bool appended = false;
     } scat;
+    PartGeom rm_g{};     // geometry of the validated remove's fast path between its optimistic decrement and a possible undo
     // split lookup (psk_bloom_check_begin / _finish): pass 1 of the first round has run, the rest waits for the table
     struct {
         bool active = false, scattered = false;
@@ -392,6 +393,17 @@ static inline bool part_wanted(uint64_t n, uint32_t k, int64_t scale = 1)
     return g_part_mode != 0 && (int64_t)n >= g_part_min_keys * scale && k <= 32;
 }
 
+// Option "scratch_budget_bytes" (0 = none): caps the partition scratch of a handle by cutting a batch into more rounds.  per_key:
+// scratch bytes one key of a round occupies (bucket buffer incl. padding and slack, plus values / perm for lookups).
+extern PSK_HIDDEN int64_t g_scratch_budget;
+static inline uint64_t cap_round_by_budget(uint64_t rk, double per_key)
+{
+    if (g_scratch_budget <= 0 || per_key <= 0) return rk;
+    uint64_t cap = (uint64_t)((double)g_scratch_budget / per_key);
+    if (cap < (1u << 18)) cap = 1u << 18;  // (below ~256 K keys the per-round fixed costs dominate: the floor of the cap)
+    return rk < cap ? rk : cap;
+}
+
 // Keys per partition round.  Pass 2 reads back what pass 1 has just written: while a round's bucket buffer fits the
 // 256 MB Infinity Cache (MALL) most of that read never reaches HBM (measured, 10 M lookups: 475 MB in one round
 // 321 us, two rounds of 237 MB 271 us; inserts at 300 MB are still best in one round).  So a batch whose buffer
@@ -410,6 +422,7 @@ static inline uint64_t part_round_keys(uint64_t n, uint32_t k, int group)
             if (per < rk) rk = per;
         }
     }
+    rk = cap_round_by_budget(rk, (double)k * 16.0 / group * 1.5);
     return rk ? rk : 1;
 }
 
@@ -419,15 +432,17 @@ static inline uint64_t part_round_keys_big_table(uint64_t n, uint32_t k, int gro
 {
     const uint64_t rk = part_round_keys(n, k, group);
     if (table_bytes < (64ULL << 20)) return rk;
-    const uint64_t big = (uint64_t)g_part_max_keys < n ? (uint64_t)g_part_max_keys : n;
+    uint64_t big = (uint64_t)g_part_max_keys < n ? (uint64_t)g_part_max_keys : n;
+    big = cap_round_by_budget(big, (double)k * 16.0 / group * 1.5);
     return big > rk ? big : rk;
 }
 
 // Rounds of the two-level path: every round ends in a fold that read-modify-writes the WHOLE table (0.5 ms for 1 GiB),
 // which dwarfs what a cache-sized bucket buffer saves -- as few rounds as `partition_max_keys` allows
-static inline uint64_t part_round_keys_two_level(uint64_t n)
+static inline uint64_t part_round_keys_two_level(uint64_t n, uint32_t k = 7)
 {
-    const uint64_t rk = (uint64_t)g_part_max_keys < n ? (uint64_t)g_part_max_keys : n;
+    uint64_t rk = (uint64_t)g_part_max_keys < n ? (uint64_t)g_part_max_keys : n;
+    rk = cap_round_by_budget(rk, (double)k * (4.0 + 4.0) * 1.5);  // two bucket buffers (level 1: 4 B per probe, level 2: up to 4)
     return rk ? rk : 1;
 }
 
@@ -508,4 +523,8 @@ PSK_HIDDEN int flush_combined(psk_sketch *s, hipStream_t st);  // apply the writ
 // pass 1 of a unit-weight CBF batch, appended to the handle's persistent add (neg = 0) / decrement (neg = 1) list; *done = false:
 // the batch / table is not eligible (nothing was launched)
 PSK_DECLARE_VARIANTS(int, cbf_scat_append, (psk_sketch *s, const Batch &b, int neg, hipStream_t st, bool *done))
+// validated unit-weight remove, fast path: pass 1 + the optimistic decrement (flag in s_flag); flag up: _undo adds the probe groups back
+PSK_DECLARE_VARIANTS(int, cbf_remove_fast_begin, (psk_sketch *s, const Batch &b, hipStream_t st, bool *launched))
+PSK_DECLARE_VARIANTS(int, cbf_remove_fast_undo, (psk_sketch *s, hipStream_t st))
+extern PSK_HIDDEN int64_t g_remove_dryrun;
 extern PSK_HIDDEN int64_t g_auto_combine, g_auto_combine_keys, g_combine_keys, g_combine_scatter;

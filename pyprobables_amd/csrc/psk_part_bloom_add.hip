@@ -13,7 +13,7 @@ int PSK_VARIANT(bloom_add_partitioned)(psk_sketch *s, const Batch &b, hipStream_
     uint32_t sub_bits = 0;
     if (two_level_geometry(g, &g1, &sub_bits)) {
         // more slices than one pass can bin well: coarse buckets first (inline 32-bit probes), then k_part_split
-        const uint64_t round_keys = part_round_keys_two_level(b.n);
+        const uint64_t round_keys = part_round_keys_two_level(b.n, s->k);
         for (uint64_t start = 0; start < b.n; start += round_keys) {
             const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
             const Batch sub = sub_batch(b, start, cnt);

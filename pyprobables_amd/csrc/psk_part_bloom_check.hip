@@ -44,7 +44,7 @@ static bool check_geometry(psk_sketch *s, uint64_t n, PartGeom *g, uint64_t *rou
     // a keyed group spells the tile's ordinal inside its workgroup in 4 bits: at most 16 tiles per workgroup and round
     // (256 workgroups x 16 x 2048-key tiles for k <= 8; 512-key tiles beyond)
     const uint64_t cap = (uint64_t)PayKeyId::max_tiles_per_wg * (g_part_wgs > 0 ? (uint64_t)(g_part_wgs < 1024 ? g_part_wgs : 1024) : (keyed_wgs(*g) ? keyed_wgs(*g) : 256u)) *
-                         (s->k <= 8 ? 2048 : 512);
+                         (s->k <= 8 ? (g_part_tile_threads == 512 ? 1024 : 2048) : 512);  // (forced 512-thread tiles hold 1024 keys at k = 7, 8)
     if (rk > cap) rk = cap;
     *round_keys = rk;
     return true;
@@ -66,13 +66,18 @@ static int bloom_check_return_trip(psk_sketch *s, const Batch &b, uint8_t *out_d
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
         const Batch sub = sub_batch(b, start, cnt);
-        bool handled = false;
+        bool handled = false, fits = true;
         PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
             using Src = decltype(src);
             return with_kt<Src>(s->k, [&](auto kt) {
                 constexpr int KT = decltype(kt)::value;
                 constexpr int P4 = (KT + 7) / 8;
                 using TileSmall = PartTile<PayBloomLookup, KT, kPartThreads>;
+                {   // 16-bit stage positions: decided before anything is enqueued (else: not eligible, the keyed kernels take the batch)
+                    const size_t tile_max = PartTile<PayBloomLookup, KT, 1024>::TILE > TileSmall::TILE ? PartTile<PayBloomLookup, KT, 1024>::TILE : TileSmall::TILE;
+                    const uint32_t kq0 = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
+                    if (tile_max * kq0 + (size_t)5 * g.nbuckets + 3 > 0xFFFFu) { fits = false; return (int)PSK_OK; }
+                }
                 const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE + 1024;  // (+ workgroups: evened tiles, launch_scatter_nt)
                 PSK_TRY(ensure(s->s_perm, cnt * P4 * 16));
                 PSK_TRY(ensure(s->s_run, max_tiles * g.nbuckets * 8));
@@ -87,7 +92,6 @@ static int bloom_check_return_trip(psk_sketch *s, const Batch &b, uint8_t *out_d
                 HIP_TRY(hipGetLastError());
                 const uint32_t kq = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
                 const uint32_t stage_cap = (uint32_t)(((size_t)g.tile * kq + (size_t)5 * g.nbuckets + 3) & ~(size_t)3);
-                if (stage_cap > 0xFFFFu) return fail(PSK_EINVAL, "lookup tile of %u probes does not fit 16-bit stage positions", stage_cap);
                 const uint32_t stage_groups = stage_cap / 6 + 1;
                 const size_t lds3 = (size_t)8 * g.nbuckets + ((stage_groups + 15) & ~(size_t)15);
                 const uint64_t ntiles = (cnt + g.tile - 1) / g.tile;
@@ -101,7 +105,7 @@ static int bloom_check_return_trip(psk_sketch *s, const Batch &b, uint8_t *out_d
                 return (int)PSK_OK;
             });
         }));
-        if (!handled) return PSK_OK;
+        if (!handled || !fits) return PSK_OK;
     }
     // exact redo through the direct kernel, taken on the device only if a segment overflowed
     bool handled = false;
@@ -158,8 +162,8 @@ int PSK_VARIANT(bloom_check_partitioned)(psk_sketch *s, const Batch &b, uint8_t 
     if (scheme < 0) return scheme;
     if (scheme == 1) {
         PSK_TRY(bloom_check_return_trip(s, b, out_dev, st, done));
-        if (*done) PSK_TRY(publish_tally(s, b.n, 1, st));
-        return PSK_OK;
+        if (*done) return publish_tally(s, b.n, 1, st);
+        // (not eligible -- e.g. a tile too large for 16-bit stage positions: the keyed kernels below take the batch)
     }
     *done = false;
     PartGeom g;

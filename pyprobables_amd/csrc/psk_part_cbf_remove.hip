@@ -8,3 +8,41 @@ int PSK_VARIANT(cbf_remove_partitioned)(psk_sketch *s, const Batch &b, const uin
 {
     return counter_add_partitioned<IdxBloom, false, true>(s, b, w_dev, s->m, st, done);
 }
+
+// Validated remove of a unit-weight batch, fast path (psk_nibble.hpp, "OPTIMISTIC decrement"): pass 1 of all keys + the decrement that
+// checks T[c] >= R[c] while it subtracts; *launched = false: not eligible (nothing enqueued).  The caller reads the flag (s_flag): clear
+// = done; up = cbf_remove_fast_undo puts the counters back and the exact path takes the batch.
+int PSK_VARIANT(cbf_remove_fast_begin)(psk_sketch *s, const Batch &b, hipStream_t st, bool *launched)
+{
+    *launched = false;
+    const uint64_t cells = s->m;
+    if (g_update_nibble == 0 || g_remove_dryrun == 0 || cells <= (1ULL << 26) || !part_wanted(b.n, s->k, 4)) return PSK_OK;
+    if (b.n * (uint64_t)s->k < cells / 8 || b.n > part_round_keys_two_level(b.n, s->k)) return PSK_OK;  // (one round only)
+    PartGeom g;
+    if (!part_slices(cells, kNibShift, kNibShift, &g, kPartMaxBuckets, 7)) return PSK_OK;
+    g.k = s->k;
+    PSK_TRY(ensure(s->s_flag, 8));
+    uint32_t *flag = (uint32_t *)s->s_flag.p;
+    HIP_TRY(hipMemsetAsync(flag, 0, 4, st));
+    bool handled = false;
+    // (the spill of an overflowing segment would decrement with the reference's clamp, which the undo could not invert: such a
+    // batch -- hundreds of thousands of copies of one key -- raises the flag instead and the exact path handles it)
+    SpillRaiseFlagCounter spill{flag};
+    PSK_TRY(with_part_source(b, &handled, [&](auto src) {
+        using Src = decltype(src);
+        return with_kt<Src>(s->k, [&](auto kt) {
+            constexpr int KT = decltype(kt)::value;
+            return launch_scatter<Src, IdxBloom<kTuPow2>, PayNone, SpillRaiseFlagCounter, KT>(s, src, IdxBloom<kTuPow2>{s->md}, PayNone{}, spill, &g, b.n, st);
+        });
+    }));
+    if (!handled) return PSK_OK;
+    PSK_TRY(nib_apply_mode<3>(s, g, s->s_cnt.p, s->s_part.p, st, flag));
+    s->rm_g = g;
+    *launched = true;
+    return PSK_OK;
+}
+
+int PSK_VARIANT(cbf_remove_fast_undo)(psk_sketch *s, hipStream_t st)
+{
+    return nib_apply_mode<4>(s, s->rm_g, s->s_cnt.p, s->s_part.p, st);
+}

@@ -45,16 +45,22 @@ static inline int nib_scatter(psk_sketch *s, const Batch &sub, const uint32_t *m
     });
 }
 
+// MODE: k_nib_apply's (0 adds, 1 decrements, 3 optimistic decrement with `flag`, 4 its inverse)
+template <int MODE>
+static inline int nib_apply_mode(psk_sketch *s, const PartGeom &g, const void *cnt, const void *part, hipStream_t st, uint32_t *flag = nullptr)
+{
+    const size_t lds = (size_t)1 << (g.shift - 1);
+    auto kern = g_nib_update_layout ? k_nib_apply<MODE, true> : k_nib_apply<MODE, false>;
+    PSK_TRY(set_dyn_lds(kern, lds));
+    hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint32_t *)cnt, (const uint4 *)part,
+                       (const uint32_t *)nullptr, (const uint4 *)nullptr, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED), 0u, flag);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
 template <bool NEG>
 static inline int nib_apply(psk_sketch *s, const PartGeom &g, const void *cnt, const void *part, hipStream_t st)
 {
-    const size_t lds = (size_t)1 << (g.shift - 1);
-    auto kern = g_nib_update_layout ? k_nib_apply<NEG ? 1 : 0, true> : k_nib_apply<NEG ? 1 : 0, false>;
-    PSK_TRY(set_dyn_lds(kern, lds));
-    hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint32_t *)cnt, (const uint4 *)part,
-                       (const uint32_t *)nullptr, (const uint4 *)nullptr, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED), 0u);
-    HIP_TRY(hipGetLastError());
-    return PSK_OK;
+    return nib_apply_mode<NEG ? 1 : 0>(s, g, cnt, part, st);
 }
 
 // CountingBloomFilter unit-weight adds / decrements into 2^26 .. 2^29 counters: ONE level of 2^18-counter slices with 4-bit delta
@@ -70,7 +76,7 @@ static inline int cbf_unit_nibble(psk_sketch *s, const Batch &b, const uint32_t 
     PartGeom g;
     if (!part_slices(cells, kNibShift, kNibShift, &g, kPartMaxBuckets, 7)) return PSK_OK;
     g.k = s->k;
-    const uint64_t round_keys = part_round_keys_two_level(b.n);
+    const uint64_t round_keys = part_round_keys_two_level(b.n, s->k);
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
         bool handled = false;
@@ -106,7 +112,7 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
         // Pass 2 read-modify-writes every slice of the table: only worth it when the batch brings enough probes
         // (direct atomics into a 1 GiB table run at ~20 G/s; the table RMW at ~4 TB/s)
         if (b.n * (uint64_t)s->k < cells / 8) return PSK_OK;
-        const uint64_t round_keys = part_round_keys_two_level(b.n);
+        const uint64_t round_keys = part_round_keys_two_level(b.n, s->k);
         SpillCounter<SIGNED> spill{(uint32_t *)s->table, w_dev == nullptr, NEG, sat2};
         for (uint64_t start = 0; start < b.n; start += round_keys) {
             const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;

@@ -20,3 +20,5 @@ PSK_DISPATCH(cms_check_partitioned, (psk_sketch *s, const Batch &b, int query, i
              (s, b, query, els, out_dev, st, done))
 PSK_DISPATCH(cbf_check_partitioned, (psk_sketch *s, const Batch &b, uint32_t kk, uint32_t *out_dev, hipStream_t st, bool *done), (s, b, kk, out_dev, st, done))
 PSK_DISPATCH(cbf_scat_append, (psk_sketch *s, const Batch &b, int neg, hipStream_t st, bool *done), (s, b, neg, st, done))
+PSK_DISPATCH(cbf_remove_fast_begin, (psk_sketch *s, const Batch &b, hipStream_t st, bool *launched), (s, b, st, launched))
+PSK_DISPATCH(cbf_remove_fast_undo, (psk_sketch *s, hipStream_t st), (s, st))

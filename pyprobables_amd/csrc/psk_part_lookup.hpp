@@ -8,9 +8,10 @@
 // Keys per round.  Measured on MI355X (10 M CMS lookups): one round of 10 M keys 432 us, two 446, three cache-sized ones 464
 // -- the three kernels of a round stream ~50 B per key once and every round re-reads the table, so unlike the update
 // paths (part_round_keys) rounds are only cut at `partition_max_keys`.
-static inline uint64_t lookup_round_keys(uint64_t n, uint32_t)
+static inline uint64_t lookup_round_keys(uint64_t n, uint32_t k)
 {
-    const uint64_t rk = (uint64_t)g_part_max_keys < n ? (uint64_t)g_part_max_keys : n;
+    uint64_t rk = (uint64_t)g_part_max_keys < n ? (uint64_t)g_part_max_keys : n;
+    rk = cap_round_by_budget(rk, (double)k * (2.0 + 4.0) * 1.5 + 16.0 * ((k + 7) / 8) + 8.0);  // probes + values + perm + runinfo
     return rk ? rk : 1;
 }
 
@@ -39,13 +40,20 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
         const Batch sub = sub_batch(b, start, cnt);
-        bool handled = false;
+        bool handled = false, fits = true;
         PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
             using Src = decltype(src);
             return with_kt<Src>(kk, [&](auto kt) {
                 constexpr int KT = decltype(kt)::value;
                 constexpr int P4 = (KT + 7) / 8;
                 using TileSmall = PartTile<PayUnitLookup, KT, kPartThreads>;  // the smaller of the two tile sizes bounds the tile count
+                // 16-bit stage positions (perm[]): the largest tile pass 1 may choose must fit -- else not eligible (direct kernels),
+                // decided BEFORE anything is enqueued
+                {
+                    const size_t tile_max = PartTile<PayUnitLookup, KT, 1024>::TILE > TileSmall::TILE ? PartTile<PayUnitLookup, KT, 1024>::TILE : TileSmall::TILE;
+                    const uint32_t kq0 = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
+                    if (tile_max * kq0 + (size_t)7 * g.nbuckets + 3 > 0xFFFFu) { fits = false; return (int)PSK_OK; }
+                }
                 const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE + 1024;  // (+ workgroups: evened tiles, launch_scatter_nt)
                 PSK_TRY(ensure(s->s_perm, cnt * P4 * 16));
                 PSK_TRY(ensure(s->s_run, max_tiles * g.nbuckets * 8));
@@ -68,7 +76,6 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
                 // pass 3: back to key order, query epilogue
                 const uint32_t kq = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
                 const uint32_t stage_cap = (uint32_t)(((size_t)g.tile * kq + (size_t)7 * g.nbuckets + 3) & ~(size_t)3);
-                if (stage_cap > 0xFFFFu) return fail(PSK_EINVAL, "lookup tile of %u probes does not fit 16-bit stage positions", stage_cap);
                 const size_t lds3 = ((size_t)2 * g.nbuckets + stage_cap) * 4 + ((g.nbuckets + 15) & ~(size_t)15);
                 const uint64_t ntiles = (cnt + g.tile - 1) / g.tile;
                 auto kern = k_lookup_collect<Query, KT>;
@@ -85,7 +92,7 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
                 return (int)PSK_OK;
             });
         }));
-        if (!handled) return PSK_OK;  // layout without a partitioned instantiation: nothing was launched (first round)
+        if (!handled || !fits) return PSK_OK;  // layout without a partitioned instantiation / tile too large: nothing was launched (first round)
     }
     PSK_TRY(redo(flag, st));  // runs only if a segment overflowed (device-side flag): exact for any input
     *done = true;

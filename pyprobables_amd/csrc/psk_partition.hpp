@@ -193,6 +193,10 @@ struct SpillCounter {  // saturating CAS add (countminsketch.py:280-284,312-316 
         else cbf_sat_add(tab + idx, v, sat_ctr);
     }
 };
+struct SpillRaiseFlagCounter {  // optimistic CBF decrement (psk_nibble.hpp): a segment that overflows makes the whole batch take the exact path
+    uint32_t *flag;
+    __device__ __forceinline__ void operator()(uint32_t, uint32_t) const { *flag = 1u; }
+};
 struct SpillBloomTest {  // lookup probe: test it directly (bloom.py:269-271); `key` is the index inside this round
     const uint32_t *tab;
     uint8_t *out;

@@ -25,7 +25,7 @@ def pa():
 def force_partition():
     from pyprobables_amd import _native as N
 
-    names = ("partition", "partition_min_keys", "lookup_nibble_slices", "update_nibble_slices")
+    names = ("partition", "partition_min_keys", "lookup_nibble_slices", "update_nibble_slices", "remove_optimistic")
     old = [N.get_option(k) for k in names]
     N.set_option("partition", 1)
     N.set_option("partition_min_keys", 1)
@@ -103,16 +103,29 @@ def test_cbf_1GiB_unit_adds_and_validated_removes_through_nibble_deltas(pa, orac
     assert torch.equal(c2.table_tensor, cbf.table_tensor)
     del c2
     N.set_option("update_nibble_slices", 1)
-    # validated remove: distinct present keys + keys that were never added (no-ops: countingbloom.py:200-201)
-    present = oracle.gen_keys16(2_000_000, 3_000_000)            # keys [2M, 5M) of the stream: each present once
-    absent = oracle.gen_keys16(800_000_000, 2_200_000)
-    absent = absent[oc.check_keys(absent) == 0]                  # (a false positive would be "removed" by the reference too, and then the
-    rm = np.concatenate([present, absent])                       # result depends on the order inside the batch: not a well-formed stream)
-    cbf.remove_many(_dev(rm))
-    oc.update_keys(rm, -np.ones(rm.shape[0], dtype=np.int64))
-    assert np.array_equal(_table(cbf), oc.bloom), "validated remove (nibble lookup + masked decrement)"
+    # validated remove, every key present once: the optimistic decrement finds that every counter holds what the batch takes from it --
+    # no lookup, no amounts, one pass over the table (4.9 M keys: more than cells / 8 probes)
+    present = keys[1100:5_000_000]
+    cbf.remove_many(_dev(present))
+    oc.update_keys(present, -np.ones(present.shape[0], dtype=np.int64))
+    assert np.array_equal(_table(cbf), oc.bloom), "validated remove, optimistic fast path"
     assert cbf.elements_added == oc.els_added
     assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+    N.set_option("remove_optimistic", 0)                            # the same batch again through the exact path: put the keys back first
+    cbf.add_many(_dev(present))
+    cbf.remove_many(_dev(present))
+    N.set_option("remove_optimistic", 1)
+    assert np.array_equal(_table(cbf), oc.bloom), "validated remove, exact path (lookup + masked decrement)"
+    # present keys + keys that were never added (no-ops: countingbloom.py:200-201): the optimistic decrement underflows, is undone, and the exact path decides
+    absent = oracle.gen_keys16(800_000_000, 5_000_000)
+    absent = absent[oc.check_keys(absent) == 0]                  # (a false positive would be "removed" by the reference too, and then the
+    rm = np.concatenate([keys[5_000_000:], absent])              # result depends on the order inside the batch: not a well-formed stream)
+    cbf.remove_many(_dev(rm))
+    oc.update_keys(rm, -np.ones(rm.shape[0], dtype=np.int64))
+    assert np.array_equal(_table(cbf), oc.bloom), "validated remove with absent keys (undo + exact path)"
+    assert cbf.elements_added == oc.els_added
+    assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+    present = keys[5_000_000:]
     # lookups afterwards, present / removed / never seen
     probe = np.concatenate([keys[:300_000], present[:300_000], absent[:300_000]])
     assert np.array_equal(cbf.check_many(_dev(probe)).cpu().numpy().astype(np.uint32), oc.check_keys(probe))
