@@ -459,11 +459,12 @@ def side_measurements(ctx: Ctx, n, blm, keys):
     cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, device=dev)  # 2^28 x u32 = 1 GiB
     ms = timed_loop(torch, lambda: cbf.add_many(keys[:ncbf]), 3, warm=1)
     out["cbf_add_Mops_s"] = ncbf / ms / 1e3
-    rl["cbf_add"] = roofline("cbf_add", "CBF add into the 1 GiB table (two-level partition: k_part_scatter + k_part_split + k_counter_apply)",
+    rl["cbf_add"] = roofline("cbf_add", "CBF unit add into the 1 GiB table (one level of 2^18-counter nibble-delta slices: k_part_scatter + k_nib_apply<0>)",
                              ncbf, ms, "the fold read-modify-writes the whole 1 GiB table")
     ms = timed_loop(torch, lambda: cbf.check_many(keys[:ncbf]), 3, warm=1)
     out["cbf_check_Mkeys_s"] = ncbf / ms / 1e3
-    rl["cbf_check"] = roofline("cbf_check", "CBF lookup (min over 7 counters, 1 GiB table)", ncbf, ms, "see DESIGN.md 3.2")
+    rl["cbf_check"] = roofline("cbf_check", "CBF lookup (min over 7 counters, 1 GiB table): k_part_scatter<PayBloomLookup> + k_nib_gather + k_nib_collect",
+                               ncbf, ms, "pass 2 streams the whole 1 GiB table (107 B per key at 10 M keys) into 4-bit slice images")
     rm = EventTimer(torch)  # every remove needs its keys back in first: add (untimed), remove (timed), the first pair is warm-up
     for it in range(4):
         cbf.add_many(keys[:ncbf])
@@ -471,6 +472,8 @@ def side_measurements(ctx: Ctx, n, blm, keys):
     torch.cuda.synchronize()
     ms = rm.mean_ms("remove")
     out["cbf_remove_Mops_s"] = ncbf / ms / 1e3
+    rl["cbf_remove"] = roofline("cbf_remove", "validated CBF remove of present keys, 1 GiB table: k_part_scatter + k_nib_apply<3> (optimistic decrement, one pass over the table)",
+                                ncbf, ms, "the pass over the table (2 GiB read + written) whatever the batch brings")
     del cbf
     # random-access ceilings at the headline table size (2^23 words = 32 MiB) and at 1 GiB
     sink = torch.zeros(1, dtype=torch.int64, device=f"cuda:{dev}")
@@ -616,7 +619,8 @@ class Cfg4:
                                "partitioned update per 2^26 keys, all inside the timed step (the stream ends with a flush); removes are "
                                "decrements, exact for this well-formed stream"},
             "roofline": roofline("cbf_add", "CBF stream = per fold: k_part_scatter (coarse) + k_part_split + k_counter_apply over the 1 GiB table",
-                                 self.ops_per_step, ms, "the fold read-modify-writes the whole 1 GiB table; batches are combined before it", "cfg4_stream"),
+                                 self.ops_per_step, ms, "the fold read-modify-writes the whole 1 GiB table; batches are combined before it",
+                                 "cfg4_stream" if not self.args.no_combine else "cfg4_stream_nocombine"),
             "rooflines": {},
             "detail": {"elements_added": els, "expected_elements": expect, "sum_counters_equals_k_x_live": total == 7 * expect, "diagnostics": diag},
         }

@@ -455,6 +455,7 @@ int64_t g_part_two_level_slices = 2048;     // tables cut into more slices than 
 int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGeom::dbg); 0 in production
 int64_t g_lookup_run_lanes = 0, g_bloom_lookup = 2, g_lookup_split = 1, g_part_tile_threads = 0, g_part_slice_bias = 0, g_part_wgs = 0, g_part_even_tiles = 1;
 int64_t g_lookup_half = 1;
+int64_t g_lookup_collect_threads = 1024;
 int64_t g_remove_dryrun = 1;   // validated unit-weight CBF removes into big tables: optimistic decrement first (psk_nibble.hpp), option "remove_optimistic"
 int64_t g_scratch_budget = 0;  // psk_set_option("scratch_budget_bytes"): cap on a handle's partition scratch (more, smaller rounds); 0 = none
 int64_t g_lookup_nibble = 1;   // CBF lookups into 2^25 .. 2^29 counters: 4-bit slice images (psk_nibble.hpp) from cells / 16 probes on; 2 = always; 0 = the 32-bit / 16-bit slices or direct
@@ -488,6 +489,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "even_tiles")) g_part_even_tiles = value;
     else if (!strcmp(name, "dense_walk_groups")) g_part_dense_groups = value;
     else if (!strcmp(name, "lookup_half_slices")) g_lookup_half = value;
+    else if (!strcmp(name, "lookup_collect_threads")) g_lookup_collect_threads = value;
     else if (!strcmp(name, "scratch_budget_bytes")) g_scratch_budget = value;
     else if (!strcmp(name, "remove_optimistic")) g_remove_dryrun = value;
     else if (!strcmp(name, "lookup_nibble_slices")) g_lookup_nibble = value;
@@ -529,6 +531,7 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "even_tiles")) *value = g_part_even_tiles;
     else if (!strcmp(name, "dense_walk_groups")) *value = g_part_dense_groups;
     else if (!strcmp(name, "lookup_half_slices")) *value = g_lookup_half;
+    else if (!strcmp(name, "lookup_collect_threads")) *value = g_lookup_collect_threads;
     else if (!strcmp(name, "scratch_budget_bytes")) *value = g_scratch_budget;
     else if (!strcmp(name, "remove_optimistic")) *value = g_remove_dryrun;
     else if (!strcmp(name, "lookup_nibble_slices")) *value = g_lookup_nibble;

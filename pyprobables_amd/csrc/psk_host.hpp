@@ -180,6 +180,7 @@ extern PSK_HIDDEN int64_t g_lookup_nibble, g_update_nibble;  // CBF tables beyon
 extern PSK_HIDDEN int64_t g_part_dense_groups;   // pass 2 walks a wave's segments end to end when a segment holds fewer groups than this on average (0 = never)
 extern PSK_HIDDEN int64_t g_part_wgs;            // bench knob: pass 1 workgroups (0 = auto: one or two per CU)
 extern PSK_HIDDEN int64_t g_lookup_split;        // bench knob: 0 = never share a slice between two pass-2 workgroups
+extern PSK_HIDDEN int64_t g_lookup_collect_threads;  // pass 3 of the counter lookups: 1024 (two tiles in flight per CU) or 512 (four)
 extern PSK_HIDDEN int64_t g_lookup_run_lanes;  // bench knob of the counter lookups (lanes per run in pass 3; 0 = auto)
 
 // slices of a table of `cells` cells; max_shift = log2(cells one LDS slice may hold)

@@ -182,10 +182,9 @@ struct QueryCbfMin {   // countingbloom.py:166-174
     }
 };
 
-constexpr int kCollectThreads = 1024;
-
 // dynamic LDS: runinfo[B] (uint2) | stage[stage_cap] (values in the tile's sorted order) | fmt[B] bytes
-template <class Query, int KT>
+// kCollectThreads: 1024 = two workgroups (tiles in flight) per CU, 512 = four (round 3 A/B: option "lookup_collect_threads")
+template <class Query, int KT, int kCollectThreads>
 __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query, PartGeom g, uint64_t n, const uint4 *perm, const uint2 *runinfo,
                                                                     const uint32_t *vals, const uint8_t *fmt, uint32_t stage_cap, uint32_t run_lanes,
                                                                     typename Query::Out *out)
@@ -203,7 +202,7 @@ __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query,
     // runinfo -> runs of values -> perm): the NEXT tile's runinfo is fetched into registers while this tile's runs are
     // copied, and this tile's perm[] entries are requested before the copy starts.
     constexpr int kInfoRegs = kPartMaxBuckets / kCollectThreads;  // slices per thread (<= 2048 slices)
-    constexpr int kPre = 2;                                        // keys per thread whose perm[] is prefetched (tiles <= 2048 keys)
+    constexpr int kPre = 2048 / kCollectThreads;                   // keys per thread whose perm[] is prefetched (tiles <= 2048 keys)
     uint2 nxt[kInfoRegs];
 #pragma unroll
     for (int r = 0; r < kInfoRegs; ++r) {

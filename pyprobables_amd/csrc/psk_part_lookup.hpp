@@ -78,14 +78,16 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
                 const uint32_t stage_cap = (uint32_t)(((size_t)g.tile * kq + (size_t)7 * g.nbuckets + 3) & ~(size_t)3);
                 const size_t lds3 = ((size_t)2 * g.nbuckets + stage_cap) * 4 + ((g.nbuckets + 15) & ~(size_t)15);
                 const uint64_t ntiles = (cnt + g.tile - 1) / g.tile;
-                auto kern = k_lookup_collect<Query, KT>;
+                const bool narrow_wg = g_lookup_collect_threads == 512;
+                auto kern = narrow_wg ? k_lookup_collect<Query, KT, 512> : k_lookup_collect<Query, KT, 1024>;
                 PSK_TRY(set_dyn_lds(kern, lds3));
                 // lanes that copy one (tile, slice) run of values: the power of two at or above HALF the mean run -- a lane moves two
                 // 16-bit values at a time, the usual format; runs of 32-bit values take a second trip through the loop
                 uint32_t run_lanes = 4;
                 while (run_lanes < 64 && (uint64_t)run_lanes * 2 * g.nbuckets < (uint64_t)g.tile * kq) run_lanes *= 2;
                 if (g_lookup_run_lanes > 0) run_lanes = (uint32_t)g_lookup_run_lanes;
-                hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(kCollectThreads), lds3, st, query, g, cnt,
+                const uint64_t grid3 = narrow_wg ? 1024 : 512;
+                hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < grid3 ? ntiles : grid3)), dim3(narrow_wg ? 512 : 1024), lds3, st, query, g, cnt,
                                    (const uint4 *)s->s_perm.p, (const uint2 *)s->s_run.p, (const uint32_t *)s->s_vals.p, (const uint8_t *)fmt, stage_cap, run_lanes,
                                    out_dev + start);
                 HIP_TRY(hipGetLastError());

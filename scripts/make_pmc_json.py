@@ -41,6 +41,18 @@ for f in sorted(src.glob("pmc_*.json")):
     out[names.get(d["op"], d["op"])] = rec
     l2[names.get(d["op"], d["op"])] = {"l2_hit": d.get("l2_hit"), "keys": d["keys"],
                                         "kernels": {k: {"l2_hit": v.get("l2_hit"), "l2_requests_per_launch": v.get("l2_requests_per_launch")} for k, v in d["kernels"].items()}}
+# prof_ops.py's "cbf_remove" puts the keys back before every remove (else there is nothing to remove): the remove alone = that minus the add
+if "cbf_remove" in out and "cbf_add" in out and out["cbf_remove"]["keys"] == out["cbf_add"]["keys"]:
+    both = out.pop("cbf_remove")
+    both["note"] = "add_many + remove_many of the same keys per launch (scripts/prof_ops.py)"
+    out["cbf_add_plus_remove"] = both
+    hbm = both["hbm_bytes_per_launch"] - out["cbf_add"]["hbm_bytes_per_launch"]
+    out["cbf_remove"] = {"keys": both["keys"], "hbm_bytes_per_launch": hbm, "bytes_per_key": round(hbm / both["keys"], 1),
+                         "kernels": {k: v for k, v in both["kernels"].items() if "<3," in k or "SpillRaiseFlagCounter" in k or "PayUnitMasked" in k or "k_nib_gather" in k or "k_nib_collect" in k},
+                         "l2_hit": both.get("l2_hit"), "note": "cbf_add_plus_remove minus cbf_add (the validated remove's optimistic path: pass 1 + k_nib_apply<3>)"}
+    l2["cbf_add_plus_remove"] = l2.pop("cbf_remove")
+    l2["cbf_remove"] = {"l2_hit": next((v.get("l2_hit") for k, v in both["kernels"].items() if "<3," in k), None), "keys": both["keys"],
+                        "note": "L2 hit rate of k_nib_apply<3> (the optimistic decrement), the dominant kernel of the validated remove"}
 (ROOT / "profiles" / f"{TAG}_pmc_traffic.json").write_text(json.dumps(out, indent=1) + "\n")
 (ROOT / "profiles" / f"{TAG}_l2_hit.json").write_text(json.dumps(l2, indent=1) + "\n")
 print(f"wrote profiles/{TAG}_pmc_traffic.json:", {k: v["bytes_per_key"] for k, v in out.items() if isinstance(v, dict)})

@@ -7,8 +7,17 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/r03
 mkdir -p "$OUT"
 cd "$REPO"
-scripts/trace_bench.sh r03_cfg2 --steps 20 --warmup 5 --spinup 0.2 > /dev/null 2>&1
+# (the headline's own kernels: the extra configurations of the default line would mix their launches into the averages)
+scripts/trace_bench.sh r03_cfg2 --steps 20 --warmup 5 --spinup 0.2 --no-extra-configs > /dev/null 2>&1
 cp gpurun_out/trace_bench_r03_cfg2.txt "$OUT/rocprofv3_kernel_stats_cfg2.txt"
+for c in cfg3 cfg4 cfg5; do
+  scripts/trace_bench.sh r03_$c --config $c --steps 3 --warmup 1 --spinup 0.2 > /dev/null 2>&1
+  cp gpurun_out/trace_bench_r03_$c.txt "$OUT/rocprofv3_kernel_stats_$c.txt"
+done
+for op in cbf_check cbf_add cbf_remove cms_check bloom_check_fresh; do
+  scripts/trace_op.sh $op 10000000 5 > /dev/null 2>&1
+  cp gpurun_out/trace_$op.txt "$OUT/rocprofv3_kernel_stats_$op.txt"
+done
 for op in bloom_add bloom_check bloom_check_fresh cms_add cms_check cbf_add cbf_check cbf_remove; do
   scripts/pmc_op.sh $op 10000000 5 > /dev/null 2>&1
   cp gpurun_out/pmc_$op.json "$OUT/"
