@@ -233,3 +233,54 @@ def test_opt_in_combining_mixes_scattered_and_key_lists(pa, oracle, request):
     assert np.array_equal(_table(cbf), oc.bloom)
     assert cbf.elements_added == oc.els_added
     assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+
+
+@pytest.mark.parametrize("est,fpr,seed", [
+    (14_000_000, 0.2, 1),       # k = 2 (KT rounded up to 8), 4.7e7 counters
+    (9_000_000, 0.03, 2),       # k = 5 (exact KT), 6.6e7 counters
+    (5_000_000, 0.0002, 3),     # k = 12 (KT = 16: 512-thread tiles, one key per thread), 8.9e7 counters
+    (30_000_000, 0.05, 4),      # k = 4, 1.9e8 counters (> 2^27)
+])
+def test_cbf_nibble_paths_seeded_mix(pa, oracle, force_partition, est, fpr, seed):
+    """seeded differential runs over hash counts, table sizes and key layouts: unit and weighted adds, duplicate-heavy batches,
+    validated removes with and without absent keys, lookups incl. saturating counters -- every table and answer equals the oracle's"""
+    N = force_partition
+    rng = np.random.default_rng(seed)
+    cbf = pa.CountingBloomFilter(est_elements=est, false_positive_rate=fpr)
+    m, k = cbf.number_bits, cbf.number_hashes
+    assert m >= 2**25
+    oc = oracle.OracleCBF(m, k)
+    need = m // (8 * k) + 50_000                          # keys that make a unit batch eligible for the table pass
+    base = oracle.gen_keys16(seed * 100_000_000, need + 400_000)
+    a1 = base[:need].copy()
+    a1[rng.integers(0, need, 3000)] = base[5]             # one key 3000 times: its slices carry past 15 and fall back to atomics
+    cbf.add_many(_dev(a1))
+    oc.update_keys(a1)
+    assert np.array_equal(_table(cbf), oc.bloom), "unit add"
+    w = rng.integers(1, 5, 300_000).astype(np.int64)
+    a2 = base[need:need + 300_000]
+    cbf.add_many(_dev(a2), w.astype(np.uint32))           # weighted: the 32-bit paths
+    oc.update_keys(a2, w)
+    words = [("k%d-é€" % i) for i in range(40_000)]       # ragged str keys (code points > 255), host batch, below every threshold
+    cbf.add_many(words)
+    for x in words:
+        oc.add_alt(oracle.default_fnv_1a(x, k))
+    assert np.array_equal(_table(cbf), oc.bloom), "weighted + str adds"
+    probe = np.concatenate([a1[:200_000], a2[:100_000], oracle.gen_keys16(777_000_000 + seed, 200_000)])
+    assert np.array_equal(cbf.check_many(_dev(probe)).cpu().numpy().astype(np.uint32), oc.check_keys(probe)), "lookups"
+    # validated removes: all present (optimistic path), then a mix with absent keys (undo + exact path)
+    distinct = np.unique(a1, axis=0)
+    distinct = distinct[~(distinct == base[5]).all(axis=1)]
+    r1 = distinct[: need - 10_000] if distinct.shape[0] >= need - 10_000 else distinct
+    cbf.remove_many(_dev(r1))
+    oc.update_keys(r1, -np.ones(r1.shape[0], dtype=np.int64))
+    assert np.array_equal(_table(cbf), oc.bloom), "validated remove, all present"
+    absent = oracle.gen_keys16(888_000_000 + seed, need)
+    absent = absent[oc.check_keys(absent) == 0]
+    r2 = np.concatenate([a2[:100_000], absent])
+    cbf.remove_many(_dev(r2))                             # (weights default to 1: a2's keys keep w - 1)
+    oc.update_keys(r2, -np.ones(r2.shape[0], dtype=np.int64))
+    assert np.array_equal(_table(cbf), oc.bloom), "validated remove with absent keys"
+    assert cbf.elements_added == oc.els_added
+    assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+    assert np.array_equal(cbf.check_many(_dev(probe)).cpu().numpy().astype(np.uint32), oc.check_keys(probe)), "lookups after the removes"
