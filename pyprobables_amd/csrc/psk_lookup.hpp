@@ -73,19 +73,25 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const uint32_t
     const uint32_t mask = slice_cells - 1;
     const uint64_t c0 = (uint64_t)b * slice_cells;
     const uint16_t *smem16 = reinterpret_cast<const uint16_t *>(smem);
+    const uint32_t mycnt = lane_segment_count(segcnt, g, b);  // (requested before the slice: see lane_segment_count)
     uint32_t mx = 0;
-    for (uint32_t w = threadIdx.x * 4; w < slice_cells; w += kApplyThreads * 4) {
-        const uint64_t gc = c0 + w;
-        uint4 t = make_uint4(0, 0, 0, 0);
-        if (gc + 3 < tab_cells) t = *reinterpret_cast<const uint4 *>(tab + gc);
-        else {
-            if (gc + 0 < tab_cells) t.x = tab[gc + 0];
-            if (gc + 1 < tab_cells) t.y = tab[gc + 1];
-            if (gc + 2 < tab_cells) t.z = tab[gc + 2];
+    for (uint32_t wb = threadIdx.x * 4; wb < slice_cells; wb += kApplyThreads * 4 * kSliceLoads) {  // kSliceLoads pieces in flight per lane
+        uint4 tt[kSliceLoads];
+#pragma unroll
+        for (int u = 0; u < kSliceLoads; ++u) {
+            const uint32_t w = wb + (uint32_t)u * kApplyThreads * 4;
+            tt[u] = w < slice_cells ? slice_piece(tab, tab_cells, c0, w) : make_uint4(0, 0, 0, 0);
         }
-        if (HALF) *reinterpret_cast<uint2 *>(smem + w / 2) = make_uint2((t.x & 0xFFFFu) | (t.y << 16), (t.z & 0xFFFFu) | (t.w << 16));
-        else *reinterpret_cast<uint4 *>(smem + w) = t;
-        mx |= t.x | t.y | t.z | t.w;  // (an OR is enough to tell whether any counter has a bit at or above 2^16; negative CMS bins do)
+#pragma unroll
+        for (int u = 0; u < kSliceLoads; ++u) {
+            const uint32_t w = wb + (uint32_t)u * kApplyThreads * 4;
+            const uint4 t = tt[u];
+            if (w < slice_cells) {
+                if (HALF) *reinterpret_cast<uint2 *>(smem + w / 2) = make_uint2((t.x & 0xFFFFu) | (t.y << 16), (t.z & 0xFFFFu) | (t.w << 16));
+                else *reinterpret_cast<uint4 *>(smem + w) = t;
+            }
+            mx |= t.x | t.y | t.z | t.w;  // (an OR is enough to tell whether any counter has a bit at or above 2^16; negative CMS bins do)
+        }
     }
     for (int o = 32; o > 0; o >>= 1) mx |= __shfl_down(mx, o);
     if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = mx;
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_gather(const uint32_t
                 }
             }
         }
-    });
+    }, mycnt);
 }
 
 // ------------------------------------------------------------------------------------ pass 3
@@ -328,17 +334,8 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_gather(const uin
     const uint32_t b = blockIdx.x;
     const uint32_t slice_words = 1u << (g.shift - 5);
     const uint64_t w0 = (uint64_t)b * slice_words;
-    for (uint32_t w = threadIdx.x * 4; w < slice_words; w += kApplyThreads * 4) {
-        const uint64_t gw = w0 + w;
-        uint4 t = make_uint4(0, 0, 0, 0);
-        if (gw + 3 < tab_words) t = *reinterpret_cast<const uint4 *>(tab + gw);
-        else {
-            if (gw + 0 < tab_words) t.x = tab[gw + 0];
-            if (gw + 1 < tab_words) t.y = tab[gw + 1];
-            if (gw + 2 < tab_words) t.z = tab[gw + 2];
-        }
-        *reinterpret_cast<uint4 *>(smem + w) = t;
-    }
+    const uint32_t mycnt = lane_segment_count(segcnt, g, b);
+    load_slice(smem, tab, tab_words, w0, slice_words);
     __syncthreads();
     // (8 groups in flight per lane: 48 LDS words + the 8 groups stay inside the 128 VGPRs of a 1024-thread workgroup; with 12
     // the kernel spilled and ran 3x slower)
@@ -362,7 +359,7 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_gather(const uin
                 bits[at[d]] = (uint8_t)r;
             }
         }
-    });
+    }, mycnt);
 }
 
 // dynamic LDS: runinfo[B] (uint2) | stage bytes (one per group of the tile's sorted stage)

@@ -86,6 +86,7 @@ static __global__ __launch_bounds__(kApplyThreads) void k_nib_gather(const uint3
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = blockIdx.x;
+    const uint32_t mycnt = lane_segment_count(segcnt, g, b);
     nib_load_slice(smem, tab, tab_cells, g.shift, b, nt != 0);
     __syncthreads();
     constexpr int D = 8;  // (48 LDS words + 8 groups per lane stay inside the 128 VGPRs of a 1024-thread workgroup, see k_bloom_gather)
@@ -104,7 +105,7 @@ static __global__ __launch_bounds__(kApplyThreads) void k_nib_gather(const uint3
                 vals[at[d]] = r;
             }
         }
-    });
+    }, mycnt);
 }
 
 // dynamic LDS: runinfo[B] (uint2) | stage words (one per group of the tile's sorted stage)

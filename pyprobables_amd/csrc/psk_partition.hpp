@@ -866,16 +866,24 @@ constexpr int kApplyWaves = kApplyThreads / 64;
 //       the option `dense_walk_groups`, default 40).
 // body(q, at, wg): the D groups, their flat index in the bucket buffer (~0 = absent) and the pass-1 workgroup of their
 // segment (per lane in the dense walk); absent ones hold `pad`.
-template <int D, class Body>
-__device__ __forceinline__ void for_each_batch_at(const uint4 *buckets, const uint32_t *segcnt, const PartGeom &g, uint32_t b,
-                                                  const uint4 pad, Body body)
+// the group count of the segment lane `lane` of my wave walks (for_each_batch_at); a kernel may ask for it BEFORE it loads its
+// slice, so that the count -> addresses -> groups chain starts under the slice load instead of behind it
+__device__ __forceinline__ uint32_t lane_segment_count(const uint32_t *segcnt, const PartGeom &g, uint32_t b)
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t S = g.split > 1 ? g.split : 1, s0 = g.split > 1 ? g.split_idx : 0;
     const uint32_t mine_total = g.nwg > s0 ? (g.nwg - s0 + S - 1) / S : 0;                     // segments this workgroup walks
     const uint32_t nseg = mine_total > wave ? (mine_total - wave + kApplyWaves - 1) / kApplyWaves : 0;  // <= 64 per wave
-    uint32_t mycnt = 0;
-    if (lane < nseg) mycnt = segcnt[(uint64_t)b * g.nwg + s0 + S * (wave + kApplyWaves * lane)];
+    return lane < nseg ? segcnt[(uint64_t)b * g.nwg + s0 + S * (wave + kApplyWaves * lane)] : 0u;
+}
+
+template <int D, class Body>
+__device__ __forceinline__ void for_each_batch_at(const uint4 *buckets, const uint32_t *segcnt, const PartGeom &g, uint32_t b,
+                                                  const uint4 pad, Body body, uint32_t mycnt_pre = ~0u)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t S = g.split > 1 ? g.split : 1, s0 = g.split > 1 ? g.split_idx : 0;
+    const uint32_t mycnt = mycnt_pre != ~0u ? mycnt_pre : lane_segment_count(segcnt, g, b);
     if (g.dense) {
         const uint32_t incl = wave_inclusive_scan(mycnt), excl = incl - mycnt;
         const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -997,6 +1005,39 @@ __device__ __forceinline__ void for_each_batch(const uint4 *buckets, const uint3
 
 constexpr int kApplyDepth = 12;  // 16-byte loads in flight per lane
 
+// The 16-byte piece `w` (in words) of a table slice that starts at word w0; words at or beyond tab_words read as 0.
+__device__ __forceinline__ uint4 slice_piece(const uint32_t *tab, uint64_t tab_words, uint64_t w0, uint32_t w)
+{
+    const uint64_t gw = w0 + w;
+    if (gw + 3 < tab_words) return *reinterpret_cast<const uint4 *>(tab + gw);
+    uint4 t = make_uint4(0, 0, 0, 0);
+    if (gw + 0 < tab_words) t.x = tab[gw + 0];
+    if (gw + 1 < tab_words) t.y = tab[gw + 1];
+    if (gw + 2 < tab_words) t.z = tab[gw + 2];
+    return t;
+}
+
+// A table slice of `slice_words` words into LDS, kSliceLoads 16-byte loads in flight per lane (written as a plain loop the 8
+// pieces a lane moves for a 128 KiB slice were 8 DEPENDENT round trips -- load, wait, LDS store -- in front of every pass-2
+// workgroup's work: round 3)
+constexpr int kSliceLoads = 8;
+__device__ __forceinline__ void load_slice(uint32_t *smem, const uint32_t *tab, uint64_t tab_words, uint64_t w0, uint32_t slice_words)
+{
+    for (uint32_t wb = threadIdx.x * 4; wb < slice_words; wb += kApplyThreads * 4 * kSliceLoads) {
+        uint4 t[kSliceLoads];
+#pragma unroll
+        for (int u = 0; u < kSliceLoads; ++u) {
+            const uint32_t w = wb + (uint32_t)u * kApplyThreads * 4;
+            t[u] = w < slice_words ? slice_piece(tab, tab_words, w0, w) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < kSliceLoads; ++u) {
+            const uint32_t w = wb + (uint32_t)u * kApplyThreads * 4;
+            if (w < slice_words) *reinterpret_cast<uint4 *>(smem + w) = t[u];
+        }
+    }
+}
+
 // consumers that only issue LDS atomics: one callback per group
 template <class F4>
 __device__ __forceinline__ void for_each_group(const uint4 *buckets, const uint32_t *segcnt, const PartGeom &g, uint32_t b,
@@ -1091,17 +1132,8 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint3
     const uint32_t mask = (1u << g.shift) - 1;
     const uint64_t w0 = (uint64_t)b * slice_words;
     const uint32_t dbg = kBenchKnobs ? g.dbg : 0u;
-    for (uint32_t w = threadIdx.x * 4; w < slice_words && !(dbg & 128); w += kApplyThreads * 4) {
-        const uint64_t gw = w0 + w;
-        uint4 t = make_uint4(0, 0, 0, 0);
-        if (gw + 3 < tab_words) t = *reinterpret_cast<const uint4 *>(tab + gw);
-        else {
-            if (gw + 0 < tab_words) t.x = tab[gw + 0];
-            if (gw + 1 < tab_words) t.y = tab[gw + 1];
-            if (gw + 2 < tab_words) t.z = tab[gw + 2];
-        }
-        *reinterpret_cast<uint4 *>(smem + w) = t;
-    }
+    const uint32_t mycnt = lane_segment_count(segcnt, g, b);  // (requested before the slice: see lane_segment_count)
+    if (!(dbg & 128)) load_slice(smem, tab, tab_words, w0, slice_words);
     __syncthreads();
     const uint32_t kmask = (1u << (31 - g.shift)) - 1;
     for_each_batch_at<kApplyDepth>(buckets, segcnt, g, b, make_uint4(0, 0, 0, 0), [&](const uint4 (&q)[kApplyDepth], const uint64_t (&at)[kApplyDepth],
@@ -1130,7 +1162,7 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint3
                 if (mw) out[kbase + ((q[d].w >> g.shift) & kmask)] = 0;
             }
         }
-    });
+    }, mycnt);
     if (miss_ctr) {  // one atomic per workgroup (same-address device atomics serialise at ~11 ns each)
         for (int o = 32; o > 0; o >>= 1) nmiss += __shfl_down(nmiss, o);
         __syncthreads();  // every wave is done with the slice image: reuse its first words
