@@ -86,6 +86,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-detail", action="store_true", help="skip the CMS / CBF / GUPS side measurements")
     ap.add_argument("--no-combine", action="store_true", help="cfg4: apply every 1M-key batch at once (no write-combining of update batches)")
+    ap.add_argument("--borrow-keys", action="store_true", help="cfg4: the resident, never overwritten key batches are BORROWED (PSK_DEVICE_BORROWED): the "
+                    "engine keeps pointers and hashes them where they lie at the flush, instead of copying every batch into its key lists "
+                    "(same throughput, no 2 x 1.25 GiB of lists)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="psk_set_option before the run (A/B of engine tunables)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: merge, then look up (no lookup pass 1 under the merge)")
     ap.add_argument("--no-extra-configs", action="store_true", help="default run: skip the short cfg3 / cfg4 / cfg5 steps reported under `configs`")
@@ -576,7 +579,8 @@ class Cfg4:
         self.ctx, self.args, self.pa = ctx, args, pa
         self.B, self.nb = args.batch, args.batches
         self.keys = ctx.gen_keys(self.B * self.nb, 0)   # 50M keys = 800 MB resident
-        self.cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, device=ctx.dev, combine_updates=not args.no_combine)
+        self.mode = False if args.no_combine else ("borrow" if args.borrow_keys else True)
+        self.cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, device=ctx.dev, combine_updates=self.mode)
         assert self.cbf.number_bits == 2**28
         self.adds, self.removes = self.B * self.nb, (self.nb - 1) * (self.B // 2)
         self.ops_per_step = self.adds + self.removes
@@ -614,13 +618,16 @@ class Cfg4:
             "config": {"workload": f"cfg4: CountingBloomFilter(28005615, 0.01): 2^28 x uint32 = 1 GiB; per step clear + {self.nb} batches: "
                                    f"add {self.B} keys, remove the first {self.B // 2} keys of the previous batch",
                        "batch_keys": self.B, "batches": self.nb, "ops_per_step": self.ops_per_step, "parallelism": "single GPU",
-                       "combine_updates": not self.args.no_combine,
-                       "note": "combine_updates: the 1M-key batches are collected on the device (D2D copy of the keys) and applied as one "
-                               "partitioned update per 2^26 keys, all inside the timed step (the stream ends with a flush); removes are "
-                               "decrements, exact for this well-formed stream"},
+                       "combine_updates": self.mode,
+                       "note": "combine_updates: the 1M-key batches wait on the device and are applied as one partitioned update per list, all "
+                               "inside the timed step (the stream ends with a flush); removes are decrements, exact for this well-formed stream. "
+                               "True (default): every batch is copied into the engine's key lists (D2D) and read again at the flush; 'borrow' "
+                               "(--borrow-keys; legal here: the bench's key batches are resident and never overwritten): the engine keeps "
+                               "pointers to the batches and hashes them where they lie -- no key copy, one key read; False (--no-combine): "
+                               "every batch at once"},
             "roofline": roofline("cbf_add", "CBF stream = per fold: k_part_scatter (coarse) + k_part_split + k_counter_apply over the 1 GiB table",
                                  self.ops_per_step, ms, "the fold read-modify-writes the whole 1 GiB table; batches are combined before it",
-                                 "cfg4_stream" if not self.args.no_combine else "cfg4_stream_nocombine"),
+                                 {True: "cfg4_stream", "borrow": "cfg4_stream_borrow", False: "cfg4_stream_nocombine"}[self.mode]),
             "rooflines": {},
             "detail": {"elements_added": els, "expected_elements": expect, "sum_counters_equals_k_x_live": total == 7 * expect, "diagnostics": diag},
         }

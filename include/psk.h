@@ -53,7 +53,15 @@ enum psk_status {
     PSK_ECONTRACT = -5  /* batch-stream contract violated (see psk_get_counters) */
 };
 
-enum psk_where { PSK_HOST = 0, PSK_DEVICE = 1 };
+enum psk_where {
+    PSK_HOST = 0,
+    PSK_DEVICE = 1,
+    /* psk_cbf_update_combined only: a device buffer that stays valid AND UNCHANGED until the handle's next flush (any entry point
+     * that applies the waiting updates, psk_flush, psk_clear).  16-byte fixed-length keys are then not copied into the
+     * write-combining list: the flush hashes them where they lie, all borrowed batches in one pass (no key copy, one key read).
+     * Other layouts are copied as with PSK_DEVICE. */
+    PSK_DEVICE_BORROWED = 2
+};
 
 enum psk_layout { PSK_KEYS_FIXED = 0, PSK_KEYS_VARLEN8 = 1, PSK_KEYS_VARLEN32 = 2, PSK_KEYS_HASHES = 3 };
 

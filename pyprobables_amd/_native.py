@@ -17,7 +17,7 @@ from pathlib import Path
 from .exceptions import NativeLibraryError
 
 PSK_OK, PSK_EINVAL, PSK_ENODEV, PSK_ENOMEM, PSK_EHIP, PSK_ECONTRACT = 0, -1, -2, -3, -4, -5
-HOST, DEVICE = 0, 1
+HOST, DEVICE, DEVICE_BORROWED = 0, 1, 2
 KEYS_FIXED, KEYS_VARLEN8, KEYS_VARLEN32, KEYS_HASHES = 0, 1, 2, 3
 Q_MIN, Q_MEAN, Q_MEANMIN = 0, 1, 2
 OP_ADD, OP_REMOVE, OP_SIGNED = 0, 1, 2

@@ -25,6 +25,7 @@ VARIANT_SOURCES = [
     "psk_part_cbf_remove.hip",
     "psk_part_cms_check.hip",
     "psk_part_cbf_check.hip",
+    "psk_part_cbf_multi.hip",
 ]
 PLAIN_SOURCES = ["psk_capi.hip", "psk_index_ops.hip", "psk_merge.hip", "psk_part_dispatch.hip"]
 # (source, object stem, extra flags); the heaviest units first so that the pool stays busy to the end

@@ -48,14 +48,22 @@ class CountingBloomFilter(BloomFilter):
         1M-key batches into 1 GiB) only run fast when the removes wait as well.  They are then plain decrements applied
         after the window's adds -- exact for well-formed streams (every remove targets a key with enough live inserts), the
         contract of the unordered batch ops; a remove of an absent key is tallied in ``batch_diagnostics()['violations']``
-        instead of being a no-op (countingbloom.py:200-201)."""
+        instead of being a no-op (countingbloom.py:200-201).
+
+        ``combine_updates="borrow"``: as above, and device batches of 16-byte keys are not even copied -- the sketch keeps a
+        reference to the key tensor and hashes it where it lies at the flush (``PSK_DEVICE_BORROWED``).  The caller must not
+        OVERWRITE such a tensor before the next read of the sketch (``check*``, ``elements_added``, ``flush()`` ...)."""
         self._combine = bool(combine_updates)
+        self._borrow = combine_updates == "borrow"
+        self._borrowed: list = []
         super().__init__(est_elements, false_positive_rate, filepath, hex_string, hash_function, device)
 
     @classmethod
     def frombytes(cls, b, hash_function=None, device=None):
         inst = super().frombytes(b, hash_function, device)
         inst._combine = False
+        inst._borrow = False
+        inst._borrowed = []
         return inst
 
     @staticmethod
@@ -66,6 +74,8 @@ class CountingBloomFilter(BloomFilter):
         super()._flush()
         if self._tab is not None:  # write-combined updates (automatic for small add batches into big tables) reach the table
             self._tab.flush()
+            if getattr(self, "_borrowed", None):
+                self._borrowed.clear()  # (the flush has hashed the borrowed key tensors: they may go)
 
     def _table_len(self, n_bits: int) -> int:
         return int(n_bits)  # one uint32 per position (countingbloom.py:77)
@@ -75,7 +85,9 @@ class CountingBloomFilter(BloomFilter):
     def _fold_counters(self) -> None:
         if self._tab is None or not getattr(self, "_dirty", False):
             return
-        c = self._tab.counters()
+        c = self._tab.counters()  # (flushes the engine's write-combined updates)
+        if getattr(self, "_borrowed", None):
+            self._borrowed.clear()
         self._els_added = min(self._els_added + c[N.CTR_ADDED], _U64_MAX) - c[N.CTR_REMOVED]
         self._diag = [a + b for a, b in zip(getattr(self, "_diag", [0, 0]), (c[N.CTR_VIOLATIONS], c[N.CTR_SATURATED]))]
         self._tab.reset_counters()
@@ -102,6 +114,8 @@ class CountingBloomFilter(BloomFilter):
     def clear(self) -> None:
         super().clear()
         self._dirty, self._diag = False, [0, 0]
+        if getattr(self, "_borrowed", None):
+            self._borrowed.clear()
 
     # -------------------------------------------------------------- single-key ops (ordered kernel)
     def _ordered(self, b: KeyBatch, num_els, opmode: int) -> np.ndarray:
@@ -147,13 +161,21 @@ class CountingBloomFilter(BloomFilter):
     def _check_batch(self, b: KeyBatch):
         addr, fin = self._tab.out_buffer(b, b.n, np.uint32, _torch_dtype("int32"))
         N.check(N.lib().psk_cbf_check(self._tab.handle, *b.args(), b.where, addr, self._tab.stream))
+        if getattr(self, "_borrowed", None):
+            self._borrowed.clear()  # (the engine applied what was waiting before it looked anything up)
         return fin()
 
     def _update_batch(self, remove: bool, b: KeyBatch, num_els) -> None:
         keep: list = []
         w_addr, _ = weights_arg(num_els, b.n, np.uint32, b.where, keep, 0, _U32_MAX, self._tab.device)
         if getattr(self, "_combine", False):  # write-combined: collected on the device, applied per 2^26 keys
-            N.check(N.lib().psk_cbf_update_combined(self._tab.handle, *b.args(), w_addr, int(remove), b.where, self._tab.stream))
+            where = b.where
+            if getattr(self, "_borrow", False) and where == N.DEVICE and w_addr is None:
+                where = N.DEVICE_BORROWED        # the engine keeps the POINTER: hold the buffers until the next flush
+                self._borrowed.append(b.keep)
+                if len(self._borrowed) >= 4000:  # (the engine flushes at 4096 batches; drop our references in step)
+                    self._flush()
+            N.check(N.lib().psk_cbf_update_combined(self._tab.handle, *b.args(), w_addr, int(remove), where, self._tab.stream))
         else:
             fn = N.lib().psk_cbf_remove if remove else N.lib().psk_cbf_add
             N.check(fn(self._tab.handle, *b.args(), w_addr, b.where, self._tab.stream))

@@ -150,7 +150,7 @@ extern "C" int psk_destroy(psk_sketch *s)
     if (s->lk.dev) hipFree(s->lk.dev);
     if (s->lk.pin) hipHostFree((void *)s->lk.pin);
     for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
-                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt}) {
+                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->s_brw}) {
         if (b->p) hipFree(b->p);
         if (b->pin) hipHostFree(b->pin);
     }
@@ -191,6 +191,8 @@ extern "C" int psk_clear(psk_sketch *s, void *stream)
     hipStream_t st = (hipStream_t)stream;
     s->comb.add.n = s->comb.rem.n = 0;  // write-combined updates that have not reached the table are cleared with it
     s->comb.add.unit = s->comb.rem.unit = true;
+    s->comb.badd.clear();
+    s->comb.brem.clear();
     PSK_TRY(scat_drop(s, st));
     // one launch for the table AND the counter block (two fills are two ~5 us launches; clear sits in every bench step)
     const uint64_t nvec = s->padded_bytes / 16;
@@ -237,6 +239,8 @@ extern "C" int psk_write_table(psk_sketch *s, const void *src_host, uint64_t nby
     hipStream_t st = (hipStream_t)stream;
     s->comb.add.n = s->comb.rem.n = 0;  // the table is replaced: pending updates go with the old contents
     s->comb.add.unit = s->comb.rem.unit = true;
+    s->comb.badd.clear();
+    s->comb.brem.clear();
     PSK_TRY(scat_drop(s, st));
     HIP_TRY(hipMemsetAsync(s->table, 0, s->padded_bytes, st));
     HIP_TRY(hipMemcpyAsync(s->table, src_host, nbytes, hipMemcpyHostToDevice, st));
@@ -865,10 +869,46 @@ static int scat_append(psk_sketch *s, const Batch &b, bool neg, uint64_t cap, hi
     return PSK_OK;
 }
 
+// the borrowed batches of one list: their pointer / prefix tables go to the device, then ONE pass 1 over all of them + one fold
+static int borrowed_flush(psk_sketch *s, psk_sketch::BorrowList &bl, bool remove, hipStream_t st)
+{
+    const uint64_t n = bl.n();
+    if (n == 0) return PSK_OK;
+    const uint32_t nb = (uint32_t)bl.base.size();
+    PSK_TRY(ensure(s->s_brw, (uint64_t)(2 * nb + 2) * 8));
+    const void **base_dev = (const void **)s->s_brw.p;
+    uint64_t *start_dev = (uint64_t *)s->s_brw.p + nb;
+    HIP_TRY(hipMemcpyAsync(base_dev, bl.base.data(), (size_t)nb * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(start_dev, bl.start.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // (the host vectors are reused from here on; a flush is milliseconds of device work anyway)
+    std::vector<const void *> bases;
+    std::vector<uint64_t> starts;
+    bases.swap(bl.base);   // (cleared first: a failure must not re-apply the list on the next call)
+    starts.swap(bl.start);
+    bl.clear();
+    PSK_TRY(account_weights(s, (const uint32_t *)nullptr, n, remove ? PSK_CTR_REMOVED : PSK_CTR_ADDED, (long long)s->k, st, !remove));
+    bool done = false;
+    PSK_TRY(cbf_unit_multi_partitioned(s, (const void *const *)base_dev, start_dev, nb, n, remove ? 1 : 0, st, &done));
+    if (done) return PSK_OK;
+    for (uint32_t j = 0; j < nb; ++j) {  // table not eligible after all (option changed meanwhile): batch by batch through the general path
+        Batch b{PSK_KEYS_FIXED, bases[j], nullptr, starts[j + 1] - starts[j], 16};
+        unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
+        PSK_TRY(with_source(b, [&](auto src) {
+            if (remove) {
+                if (s->pow2) return launch_apply(src, CbfSub<true>{(uint32_t *)s->table, s->md, s->k, nullptr, sat - 1}, b.n, st);
+                return launch_apply(src, CbfSub<false>{(uint32_t *)s->table, s->md, s->k, nullptr, sat - 1}, b.n, st);
+            }
+            if (s->pow2) return launch_apply(src, CbfAdd<true>{(uint32_t *)s->table, s->md, s->k, nullptr, s->ctr, sat, false}, b.n, st);
+            return launch_apply(src, CbfAdd<false>{(uint32_t *)s->table, s->md, s->k, nullptr, s->ctr, sat, false}, b.n, st);
+        }));
+    }
+    return PSK_OK;
+}
+
 int flush_combined(psk_sketch *s, hipStream_t st)
 {
     if (s->kind != PSK_KIND_CBF) return PSK_OK;
-    const bool keys_pending = s->comb.add.n != 0 || s->comb.rem.n != 0;
+    const bool keys_pending = s->comb.add.n != 0 || s->comb.rem.n != 0 || s->comb.badd.n() != 0 || s->comb.brem.n() != 0;
     const bool scat_pending = s->scat.ready && (s->scat.add.n != 0 || s->scat.rem.n != 0);
     if (!keys_pending && !scat_pending) return PSK_OK;
     PSK_TRY(comb_order(s, st));
@@ -884,13 +924,15 @@ int flush_combined(psk_sketch *s, hipStream_t st)
         return cbf_apply_device(s, b, unit ? nullptr : (const uint32_t *)l.w.p, pass == 1, st);
     };
     PSK_TRY(key_list(0));
-    if (scat_pending && s->comb.rem.n != 0 && s->scat.add.n != 0) {  // key-list removes wait: the scattered adds must land before them
+    PSK_TRY(borrowed_flush(s, s->comb.badd, false, st));
+    if (scat_pending && (s->comb.rem.n != 0 || s->comb.brem.n() != 0) && s->scat.add.n != 0) {  // key-list removes wait: the scattered adds must land before them
         const uint64_t nr = s->scat.rem.n;
         s->scat.rem.n = 0;
         PSK_TRY(scat_flush(s, st));
         s->scat.rem.n = nr;
     }
     PSK_TRY(key_list(1));
+    PSK_TRY(borrowed_flush(s, s->comb.brem, true, st));
     return scat_flush(s, st);
 }
 
@@ -905,10 +947,25 @@ extern "C" int psk_cbf_update_combined(psk_sketch *s, int layout, const void *da
 {
     CHECK_HANDLE(s, PSK_KIND_CBF);
     PSK_TRY(check_hashes_width(s, layout, key_len));
-    if (where != PSK_HOST && where != PSK_DEVICE) return fail(PSK_EINVAL, "`where` must be PSK_HOST or PSK_DEVICE");
+    if (where != PSK_HOST && where != PSK_DEVICE && where != PSK_DEVICE_BORROWED) return fail(PSK_EINVAL, "`where` must be PSK_HOST, PSK_DEVICE or PSK_DEVICE_BORROWED");
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) return PSK_OK;
     const uint64_t cap = g_combine_keys > 0 ? (uint64_t)g_combine_keys : 0;
+    if (where == PSK_DEVICE_BORROWED) {
+        // 16-byte unit-weight keys into a table with the nibble geometry: remember WHERE they are, nothing else.  The flush hashes all
+        // borrowed batches of a list in one pass 1 where they lie (KeysFixed16Multi): no copy into a list, the keys are read once.
+        PartGeom probe;
+        const bool borrowable = layout == PSK_KEYS_FIXED && key_len == 16 && data && ((uintptr_t)data & 15) == 0 && !weights && cap && n <= cap &&
+                                g_update_nibble != 0 && s->k <= 32 && scat_geometry(s, cap, &probe);
+        if (borrowable) {
+            psk_sketch::BorrowList &bl = remove ? s->comb.brem : s->comb.badd;
+            if (bl.n() + n > cap || bl.base.size() >= 4096) PSK_TRY(flush_combined(s, st));
+            bl.base.push_back(data);
+            bl.start.push_back(bl.start.back() + n);
+            return comb_appended(s, st);  // (a flush on another stream waits for this one: the keys may still be in the making on it)
+        }
+        where = PSK_DEVICE;  // anything else is copied as usual
+    }
     // Scattered probes instead of key lists (option "combine_scatter", off): pass 1 per batch saves the key copy and the second read
     // of the keys, but measured on BASELINE cfg 4 (99 batches of 0.5-1 M keys) it costs more than it saves -- a 1 M-key pass 1 runs
     // two tiles per workgroup and pays its fixed costs (1024 cursors read and written per workgroup, pipeline fill) every time:
@@ -969,7 +1026,7 @@ extern "C" int psk_cbf_add(psk_sketch *s, int layout, const void *data, const ui
     // Automatic write-combining (no opt-in): a unit-weight batch too small to pay for a pass over a big table would take one
     // fabric atomic per probe.  Adds commute (countingbloom.py:135-155; the clamp at 2^32-1 is applied by the fold just the
     // same), so the batch is scattered now and folded with its successors; every entry point that reads or removes flushes first.
-    if (!weights && g_auto_combine != 0 && s->comb.rem.n == 0 && s->scat.rem.n == 0 && (int64_t)n >= g_part_min_keys &&
+    if (!weights && g_auto_combine != 0 && s->comb.rem.n == 0 && s->comb.brem.n() == 0 && s->scat.rem.n == 0 && (int64_t)n >= g_part_min_keys &&
         n * (uint64_t)s->k < s->m / 8 && g_auto_combine_keys > 0) {
         bool taken = false;
         PSK_TRY(scat_append(s, b, false, (uint64_t)g_auto_combine_keys, st, &taken));
@@ -1508,7 +1565,7 @@ extern "C" int psk_release_scratch(psk_sketch *s)
     PSK_TRY(flush_combined(s, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
-                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt}) {
+                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->s_brw}) {
         if (b->p) HIP_TRY(hipFree(b->p));
         b->p = nullptr;
         b->cap = 0;

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <type_traits>
+#include <vector>
 
 #include "../../include/psk.h"
 
@@ -97,6 +98,7 @@ struct psk_sketch {
     DevBuf s_part2, s_cnt2;                    // two-level path: bucket buffer + fill counts after the second split
     DevBuf s_merge;                            // multi-GPU merge (psk_merge_or / _sum): exchange buffers
     DevBuf s_tally;                            // weighted pass 1: (sum w, sum |w|) per workgroup, folded by k_tally_fold
+    DevBuf s_brw;                              // borrowed write-combined batches: pointer / prefix tables of a flush
     DevBuf s_vals, s_perm, s_run;              // partitioned counter lookups: values, per-key stage positions, per-(tile, slice) runs
     // Weighted counter updates: the caller (psk_capi.hip) posts what has to be accounted for the batch; a partitioned launcher
     // that scatters the weights takes the request over (PayWeight::tally sums them inside pass 1) and clears `pending`;
@@ -123,10 +125,17 @@ struct psk_sketch {
         uint64_t n = 0;
         bool unit = true;    // every batch so far had unit weights
     };
+    struct BorrowList {      // PSK_DEVICE_BORROWED batches (16-byte keys): pointers only, hashed where they lie at the flush
+        std::vector<const void *> base;
+        std::vector<uint64_t> start{0};   // prefix of the batch sizes
+        uint64_t n() const { return start.back(); }
+        void clear() { base.clear(); start.assign(1, 0); }
+    };
     struct {
         uint32_t key_len = 0;
         uint64_t cap = 0;    // keys per list
         PendList add, rem;
+        BorrowList badd, brem;
     } comb;
     // Write-combined unit-weight CBF updates kept as SCATTERED PROBES (round 3): pass 1 runs when a batch is handed over and
     // appends to persistent (slice, workgroup) segments; a flush is pass 2 alone (psk_nibble.hpp: one level of 2^18-counter
@@ -351,7 +360,7 @@ static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, con
 template <class Src, class F>
 static int with_kt(uint32_t k, F &&f)
 {
-    constexpr bool fast = std::is_same<Src, KeysFixed16>::value;
+    constexpr bool fast = std::is_same<Src, KeysFixed16>::value || std::is_same<Src, KeysFixed16Multi>::value;
     if (fast) {
         switch (k) {
             case 3: return f(std::integral_constant<int, 3>{});
@@ -524,6 +533,9 @@ PSK_HIDDEN int flush_combined(psk_sketch *s, hipStream_t st);  // apply the writ
 // pass 1 of a unit-weight CBF batch, appended to the handle's persistent add (neg = 0) / decrement (neg = 1) list; *done = false:
 // the batch / table is not eligible (nothing was launched)
 PSK_DECLARE_VARIANTS(int, cbf_scat_append, (psk_sketch *s, const Batch &b, int neg, hipStream_t st, bool *done))
+// unit-weight add (neg = 0) / unchecked decrement (neg = 1) of `n` borrowed 16-byte keys (device tables base[nb], start[nb + 1]) through the
+// nibble path; *done = false: table not eligible (nothing launched)
+PSK_DECLARE_VARIANTS(int, cbf_unit_multi_partitioned, (psk_sketch *s, const void *const *base_dev, const uint64_t *start_dev, uint32_t nb, uint64_t n, int neg, hipStream_t st, bool *done))
 // validated unit-weight remove, fast path: pass 1 + the optimistic decrement (flag in s_flag); flag up: _undo adds the probe groups back
 PSK_DECLARE_VARIANTS(int, cbf_remove_fast_begin, (psk_sketch *s, const Batch &b, hipStream_t st, bool *launched))
 PSK_DECLARE_VARIANTS(int, cbf_remove_fast_undo, (psk_sketch *s, hipStream_t st))

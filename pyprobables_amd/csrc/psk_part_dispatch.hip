@@ -22,3 +22,5 @@ PSK_DISPATCH(cbf_check_partitioned, (psk_sketch *s, const Batch &b, uint32_t kk,
 PSK_DISPATCH(cbf_scat_append, (psk_sketch *s, const Batch &b, int neg, hipStream_t st, bool *done), (s, b, neg, st, done))
 PSK_DISPATCH(cbf_remove_fast_begin, (psk_sketch *s, const Batch &b, hipStream_t st, bool *launched), (s, b, st, launched))
 PSK_DISPATCH(cbf_remove_fast_undo, (psk_sketch *s, hipStream_t st), (s, st))
+PSK_DISPATCH(cbf_unit_multi_partitioned, (psk_sketch *s, const void *const *base, const uint64_t *start, uint32_t nb, uint64_t n, int neg, hipStream_t st, bool *done),
+             (s, base, start, nb, n, neg, st, done))

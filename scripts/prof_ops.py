@@ -31,7 +31,8 @@ def gen(n, start):
 if op == "cfg4_stream":
     B, NB = n, 50
     allk = gen(B * NB, 0)
-    s = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, combine_updates=True)
+    mode = os.environ.get("PSK_CFG4_MODE", "copy")  # "copy" (bench.py's default) or "borrow"
+    s = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, combine_updates="borrow" if mode == "borrow" else True)
 
     def fn():
         s.clear()

@@ -284,3 +284,46 @@ def test_cbf_nibble_paths_seeded_mix(pa, oracle, force_partition, est, fpr, seed
     assert cbf.elements_added == oc.els_added
     assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
     assert np.array_equal(cbf.check_many(_dev(probe)).cpu().numpy().astype(np.uint32), oc.check_keys(probe)), "lookups after the removes"
+
+
+def test_borrowed_key_batches_are_hashed_where_they_lie(pa, oracle):
+    """combine_updates="borrow" (PSK_DEVICE_BORROWED): device batches of 16-byte keys are neither copied nor read until the flush, which
+    runs ONE pass 1 over all of them (KeysFixed16Multi); removes are plain decrements after the window's adds (well-formed stream);
+    weighted and non-16-byte batches in the same window are copied as usual"""
+    B, nb = 400_000, 14                                   # 5.6 M adds: the flush takes the pass over the table
+    cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, combine_updates="borrow")
+    oc = oracle.OracleCBF(2**28, 7)
+    held = []
+    for b in range(nb):
+        keys = oracle.gen_keys16(b * B, B)
+        dk = _dev(keys)
+        held.append(dk)                                   # (the sketch holds a reference too; the caller must not overwrite the tensor)
+        cbf.add_many(dk)
+        oc.update_keys(keys)
+        if b >= 1:
+            prev = oracle.gen_keys16((b - 1) * B, B // 2)
+            cbf.remove_many(held[b - 1][: B // 2])        # a view into a borrowed tensor
+            oc.update_keys(prev, -np.ones(B // 2, dtype=np.int64))
+        if b == 5:                                        # a weighted batch and 12-byte keys in the same window: copied
+            w = (np.arange(B, dtype=np.int64) % 3) + 1
+            extra = oracle.gen_keys16(900_000_000, B)
+            cbf.add_many(_dev(extra), w.astype(np.uint32))
+            oc.update_keys(extra, w)
+            k12 = np.ascontiguousarray(oracle.gen_keys16(950_000_000, 100_000)[:, :12])
+            cbf.add_many(_dev(k12))
+            oc.update_keys(k12)
+    assert np.array_equal(_table(cbf), oc.bloom)
+    assert cbf.elements_added == oc.els_added
+    assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+    # a short window (too few probes for a pass over the table: drained with atomics), ended by a lookup
+    keys = oracle.gen_keys16(nb * B, B)
+    dk = _dev(keys)
+    cbf.add_many(dk)
+    oc.update_keys(keys)
+    probe = np.concatenate([keys[:100_000], oracle.gen_keys16(990_000_000, 100_000)])
+    assert np.array_equal(cbf.check_many(_dev(probe)).cpu().numpy().astype(np.uint32), oc.check_keys(probe))
+    assert np.array_equal(_table(cbf), oc.bloom)
+    # clear drops what waits
+    cbf.add_many(dk)
+    cbf.clear()
+    assert int(cbf.table_tensor.abs().sum().item()) == 0 and cbf.elements_added == 0
