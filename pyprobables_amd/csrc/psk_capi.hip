@@ -483,6 +483,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "combine_keys")) g_combine_keys = value;
     else if (!strcmp(name, "auto_combine")) g_auto_combine = value;
     else if (!strcmp(name, "combine_scatter")) g_combine_scatter = value;
+    else if (!strcmp(name, "combine_fused_flush")) g_fused_flush = value;
     else if (!strcmp(name, "auto_combine_keys")) g_auto_combine_keys = value;
     else if (!strcmp(name, "lookup_run_lanes")) g_lookup_run_lanes = value;
     else if (!strcmp(name, "bloom_lookup")) g_bloom_lookup = value;
@@ -527,6 +528,7 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "combine_keys")) *value = g_combine_keys;
     else if (!strcmp(name, "auto_combine")) *value = g_auto_combine;
     else if (!strcmp(name, "combine_scatter")) *value = g_combine_scatter;
+    else if (!strcmp(name, "combine_fused_flush")) *value = g_fused_flush;
     else if (!strcmp(name, "auto_combine_keys")) *value = g_auto_combine_keys;
     else if (!strcmp(name, "bloom_lookup")) *value = g_bloom_lookup;
     else if (!strcmp(name, "lookup_split")) *value = g_lookup_split;
@@ -761,6 +763,9 @@ static int cbf_apply_device(psk_sketch *s, const Batch &b, const uint32_t *w, bo
 }
 
 // ---- write-combined updates as scattered probes (psk_sketch::scat, psk_nibble.hpp)
+int64_t g_fused_flush = 0;             // flush of both write-combined key lists as two pass 1s + ONE fold (adds, then decrements, per slice): measured
+                                       // SLOWER on BASELINE cfg 4 (4.50 vs 3.80 ms per step: one workgroup per slice streams both lists and folds twice
+                                       // back to back, nothing overlaps) -- off; option "combine_fused_flush"
 int64_t g_combine_scatter = 0;         // psk_cbf_update_combined: 1 = unit-weight batches wait as scattered probes instead of key lists (see there)
 int64_t g_auto_combine = 1;            // psk_cbf_add: small unit-weight batches into big tables wait as scattered probes (adds commute: exact)
 int64_t g_auto_combine_keys = 1 << 24; // keys per list in that mode (~0.8 GB of segments for k = 7, allocated on first use)
@@ -821,7 +826,7 @@ static int scat_flush(psk_sketch *s, hipStream_t st)
     auto launch = [&](auto kern, const psk_sketch::ScatList *la, const psk_sketch::ScatList *lb, uint32_t direct) {
         PSK_TRY(set_dyn_lds(kern, lds));
         hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint32_t *)la->cnt.p, (const uint4 *)la->part.p,
-                           (const uint32_t *)(lb ? lb->cnt.p : nullptr), (const uint4 *)(lb ? lb->part.p : nullptr), sat, direct, (uint32_t *)nullptr);
+                           (const uint32_t *)(lb ? lb->cnt.p : nullptr), (const uint4 *)(lb ? lb->part.p : nullptr), sat, direct, (uint32_t *)nullptr, g);
         HIP_TRY(hipGetLastError());
         return (int)PSK_OK;
     };
@@ -923,6 +928,34 @@ int flush_combined(psk_sketch *s, hipStream_t st)
         l.unit = true;
         return cbf_apply_device(s, b, unit ? nullptr : (const uint32_t *)l.w.p, pass == 1, st);
     };
+    // Both key lists due, unit weights, big table: scatter both (two bucket buffers), then ONE fold -- adds, then decrements -- per slice
+    // (k_nib_apply<2>): the slice a workgroup has just written is still on-die when it reads it back for the decrements.
+    // (only when no OTHER mechanism holds adds of this window: they would have to land before these removes)
+    if (s->comb.add.n && s->comb.rem.n && s->comb.add.unit && s->comb.rem.unit && g_fused_flush != 0 && s->comb.add.n * s->k >= s->m / 8 &&
+        s->comb.rem.n * s->k >= s->m / 8 && s->comb.badd.n() == 0 && !(s->scat.ready && s->scat.add.n != 0)) {
+        Batch ba{PSK_KEYS_FIXED, s->comb.add.keys.p, nullptr, s->comb.add.n, s->comb.key_len};
+        Batch br{PSK_KEYS_FIXED, s->comb.rem.keys.p, nullptr, s->comb.rem.n, s->comb.key_len};
+        PartGeom ga, gr;
+        bool oka = false, okr = false;
+        PSK_TRY(cbf_nib_scatter(s, ba, 0, 0, &ga, st, &oka));
+        if (oka) PSK_TRY(cbf_nib_scatter(s, br, 1, 1, &gr, st, &okr));
+        if (oka && okr) {
+            const uint64_t na = s->comb.add.n, nr = s->comb.rem.n;
+            s->comb.add.n = s->comb.rem.n = 0;
+            PSK_TRY(account_weights(s, (const uint32_t *)nullptr, na, PSK_CTR_ADDED, (long long)s->k, st, true));
+            PSK_TRY(account_weights(s, (const uint32_t *)nullptr, nr, PSK_CTR_REMOVED, (long long)s->k, st, false));
+            const size_t lds = (size_t)1 << (ga.shift - 1);
+            auto launch2 = [&](auto kern) {
+                PSK_TRY(set_dyn_lds(kern, lds));
+                hipLaunchKernelGGL(kern, dim3(ga.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, ga, (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p,
+                                   (const uint32_t *)s->s_cnt2.p, (const uint4 *)s->s_part2.p, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED), 0u, (uint32_t *)nullptr, gr);
+                HIP_TRY(hipGetLastError());
+                return (int)PSK_OK;
+            };
+            PSK_TRY(g_nib_update_layout ? launch2(k_nib_apply<2, true>) : launch2(k_nib_apply<2, false>));
+        }
+        // (oka && !okr: the adds sit scattered in s_part but nothing was applied -- the lists are untouched, the general path below redoes them)
+    }
     PSK_TRY(key_list(0));
     PSK_TRY(borrowed_flush(s, s->comb.badd, false, st));
     if (scat_pending && (s->comb.rem.n != 0 || s->comb.brem.n() != 0) && s->scat.add.n != 0) {  // key-list removes wait: the scattered adds must land before them

@@ -536,8 +536,10 @@ PSK_DECLARE_VARIANTS(int, cbf_scat_append, (psk_sketch *s, const Batch &b, int n
 // unit-weight add (neg = 0) / unchecked decrement (neg = 1) of `n` borrowed 16-byte keys (device tables base[nb], start[nb + 1]) through the
 // nibble path; *done = false: table not eligible (nothing launched)
 PSK_DECLARE_VARIANTS(int, cbf_unit_multi_partitioned, (psk_sketch *s, const void *const *base_dev, const uint64_t *start_dev, uint32_t nb, uint64_t n, int neg, hipStream_t st, bool *done))
+// pass 1 alone of a unit-weight batch into the handle's first / second bucket buffer (fused flush of the write-combined lists)
+PSK_DECLARE_VARIANTS(int, cbf_nib_scatter, (psk_sketch *s, const Batch &b, int neg, int second, PartGeom *g_out, hipStream_t st, bool *done))
 // validated unit-weight remove, fast path: pass 1 + the optimistic decrement (flag in s_flag); flag up: _undo adds the probe groups back
 PSK_DECLARE_VARIANTS(int, cbf_remove_fast_begin, (psk_sketch *s, const Batch &b, hipStream_t st, bool *launched))
 PSK_DECLARE_VARIANTS(int, cbf_remove_fast_undo, (psk_sketch *s, hipStream_t st))
 extern PSK_HIDDEN int64_t g_remove_dryrun;
-extern PSK_HIDDEN int64_t g_auto_combine, g_auto_combine_keys, g_combine_keys, g_combine_scatter;
+extern PSK_HIDDEN int64_t g_auto_combine, g_auto_combine_keys, g_combine_keys, g_combine_scatter, g_fused_flush;

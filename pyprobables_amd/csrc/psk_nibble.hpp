@@ -363,8 +363,9 @@ __device__ __forceinline__ void nib_apply_list(uint32_t *smem, uint32_t *carried
 template <int MODE, bool BLOCKS>
 __global__ __launch_bounds__(kApplyThreads) void k_nib_apply(uint32_t *tab, uint64_t tab_cells, PartGeom g, const uint32_t *segcnt_a, const uint4 *buckets_a,
                                                              const uint32_t *segcnt_b, const uint4 *buckets_b, unsigned long long *sat_ctr, uint32_t direct,
-                                                             uint32_t *flag)
+                                                             uint32_t *flag, PartGeom gb)
 {
+    // gb: geometry of list B (MODE 2; same slices as g, its own workgroup count / segment capacity)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t carried;
     const uint32_t b = blockIdx.x;
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_nib_apply(uint32_t *tab, uint
         __syncthreads();
     }
     if (MODE == 1) nib_apply_list<true, BLOCKS>(smem, &carried, tab, tab_cells, g, segcnt_a, buckets_a, sat_ctr, b, (direct & 1u) != 0, (direct & 2u) != 0);
-    if (MODE == 2) nib_apply_list<true, BLOCKS>(smem, &carried, tab, tab_cells, g, segcnt_b, buckets_b, sat_ctr, b, (direct & 1u) != 0, (direct & 2u) != 0);
+    if (MODE == 2) nib_apply_list<true, BLOCKS>(smem, &carried, tab, tab_cells, gb, segcnt_b, buckets_b, sat_ctr, b, (direct & 1u) != 0, (direct & 2u) != 0);
     if (MODE == 3) nib_apply_list<true, BLOCKS, 1>(smem, &carried, tab, tab_cells, g, segcnt_a, buckets_a, sat_ctr, b, (direct & 1u) != 0, (direct & 2u) != 0, flag);
     if (MODE == 4) nib_apply_list<false, BLOCKS, 2>(smem, &carried, tab, tab_cells, g, segcnt_a, buckets_a, sat_ctr, b, (direct & 1u) != 0, (direct & 2u) != 0, flag);
 }

@@ -19,3 +19,9 @@ int PSK_VARIANT(cbf_scat_append)(psk_sketch *s, const Batch &b, int neg, hipStre
     *done = handled;
     return PSK_OK;
 }
+
+// pass 1 alone (fused flush of the write-combined lists: psk_capi.hip flush_combined)
+int PSK_VARIANT(cbf_nib_scatter)(psk_sketch *s, const Batch &b, int neg, int second, PartGeom *g_out, hipStream_t st, bool *done)
+{
+    return cbf_nib_scatter_only(s, b, neg != 0, second != 0, g_out, st, done);
+}

@@ -24,7 +24,7 @@ int PSK_VARIANT(cbf_unit_multi_partitioned)(psk_sketch *s, const void *const *ba
     auto launch = [&](auto kern) {
         PSK_TRY(set_dyn_lds(kern, lds));
         hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p,
-                           (const uint32_t *)nullptr, (const uint4 *)nullptr, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED), direct, (uint32_t *)nullptr);
+                           (const uint32_t *)nullptr, (const uint4 *)nullptr, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED), direct, (uint32_t *)nullptr, g);
         HIP_TRY(hipGetLastError());
         return (int)PSK_OK;
     };

@@ -3,6 +3,8 @@
 #include "psk_host.hpp"
 #include "psk_nibble.hpp"
 
+#include <utility>
+
 // account_weights(), so ctr[6] holds this batch's sum|w| for the wrap check inside pass 2.
 // the weights of keys [start, ...) + the fused accounting request posted by the caller (psk_sketch::acct), if any
 static inline int pay_weights(psk_sketch *s, const uint32_t *w_dev, uint64_t start, PayWeight *pay)
@@ -53,7 +55,7 @@ static inline int nib_apply_mode(psk_sketch *s, const PartGeom &g, const void *c
     auto kern = g_nib_update_layout ? k_nib_apply<MODE, true> : k_nib_apply<MODE, false>;
     PSK_TRY(set_dyn_lds(kern, lds));
     hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint32_t *)cnt, (const uint4 *)part,
-                       (const uint32_t *)nullptr, (const uint4 *)nullptr, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED), 0u, flag);
+                       (const uint32_t *)nullptr, (const uint4 *)nullptr, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED), 0u, flag, g);
     HIP_TRY(hipGetLastError());
     return PSK_OK;
 }
@@ -61,6 +63,26 @@ template <bool NEG>
 static inline int nib_apply(psk_sketch *s, const PartGeom &g, const void *cnt, const void *part, hipStream_t st)
 {
     return nib_apply_mode<NEG ? 1 : 0>(s, g, cnt, part, st);
+}
+
+// Pass 1 alone of a unit-weight batch (one round) into the handle's first (second = false) or second bucket buffer: the fused flush of
+// the write-combined lists scatters both lists, then folds them in ONE launch (k_nib_apply<2>).  *done = false: not eligible.
+static inline int cbf_nib_scatter_only(psk_sketch *s, const Batch &b, bool neg, bool second, PartGeom *g_out, hipStream_t st, bool *done)
+{
+    *done = false;
+    const uint64_t cells = s->m;
+    if (g_update_nibble == 0 || cells <= (1ULL << 26) || !part_wanted(b.n, s->k, 4) || b.n > part_round_keys_two_level(b.n, s->k)) return PSK_OK;
+    PartGeom g;
+    if (!part_slices(cells, kNibShift, kNibShift, &g, kPartMaxBuckets, 7)) return PSK_OK;
+    g.k = s->k;
+    if (second) { std::swap(s->s_part, s->s_part2); std::swap(s->s_cnt, s->s_cnt2); }  // (launch_scatter fills s_part / s_cnt)
+    bool handled = false;
+    const int rc = nib_scatter<false>(s, b, nullptr, neg, &g, st, &handled);
+    if (second) { std::swap(s->s_part, s->s_part2); std::swap(s->s_cnt, s->s_cnt2); }
+    PSK_TRY(rc);
+    *g_out = g;
+    *done = handled;
+    return PSK_OK;
 }
 
 // CountingBloomFilter unit-weight adds / decrements into 2^26 .. 2^29 counters: ONE level of 2^18-counter slices with 4-bit delta
