@@ -1,3 +1,5 @@
+"""round-3 A/Bs on one MI355X: Bloom lookup schemes by the share of absent keys; CBF 1 GiB table: nibble-delta updates and image layouts,
+validated removes, nontemporal table loads of the lookups' pass 2"""
 import sys, torch
 sys.path.insert(0, "/root/repo")
 import pyprobables_amd as pa
@@ -20,7 +22,8 @@ mixed = torch.cat([keys[: n // 2], fresh[: n // 2]])
 q25 = torch.cat([keys[: 3 * n // 4], fresh[: n // 4]])
 blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01)
 blm.add_many(keys)
-for mode, name in ((0, "keyed"), (1, "return trip"), (3, "cascade"), (2, "auto")):
+# (round 3 also ran this loop with mode 3 = the two-stage cascade; the cascade was removed after it lost everywhere: DESIGN.md 3.3)
+for mode, name in ((0, "keyed"), (1, "return trip"), (2, "auto")):
     N.set_option("bloom_lookup", mode)
     print(f"bloom check {name:12s}: all-hit {tl(lambda: blm.check_many(keys)):7.1f} us  25%-fresh {tl(lambda: blm.check_many(q25)):7.1f}  half-fresh {tl(lambda: blm.check_many(mixed)):7.1f}  all-fresh {tl(lambda: blm.check_many(fresh)):7.1f}", flush=True)
 N.set_option("bloom_lookup", 2)
