@@ -327,3 +327,26 @@ def test_borrowed_key_batches_are_hashed_where_they_lie(pa, oracle):
     cbf.add_many(dk)
     cbf.clear()
     assert int(cbf.table_tensor.abs().sum().item()) == 0 and cbf.elements_added == 0
+
+
+def test_optimistic_remove_with_a_key_repeated_in_the_batch(pa, oracle, force_partition):
+    """a key held 40 times, removed 20 times in ONE batch next to 5 M other present keys: its counters take more hits than a 4-bit
+    delta holds, so their slices decrement with atomics inside the optimistic pass -- still every counter holds what the batch takes
+    (40 >= 20), no flag, no undo; the result equals the reference's 20 sequential removes (countingbloom.py:186-208)"""
+    n = 5_000_000
+    cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    oc = oracle.OracleCBF(2**28, 7)
+    keys = oracle.gen_keys16(0, n)
+    hot = oracle.gen_keys16(999_000_000, 1)
+    cbf.add_many(_dev(keys))
+    cbf.add_many(_dev(hot), 40)
+    oc.update_keys(keys)
+    oc.update_keys(hot, np.array([40], dtype=np.int64))
+    rm = keys.copy()
+    rm[np.arange(100, 100 + 20 * 1000, 1000)] = hot[0]   # 20 copies of the hot key replace 20 ordinary keys
+    cbf.remove_many(_dev(rm))
+    oc.update_keys(rm, -np.ones(n, dtype=np.int64))
+    assert np.array_equal(_table(cbf), oc.bloom)
+    assert cbf.elements_added == oc.els_added
+    assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+    assert int(cbf.check_many(_dev(np.repeat(hot, 300_000, axis=0))).cpu().numpy()[0]) == 20
