@@ -465,6 +465,7 @@ int64_t g_scratch_budget = 0;  // psk_set_option("scratch_budget_bytes"): cap on
 int64_t g_lookup_nibble = 1;   // CBF lookups into 2^25 .. 2^29 counters: 4-bit slice images (psk_nibble.hpp) from cells / 16 probes on; 2 = always; 0 = the 32-bit / 16-bit slices or direct
 int64_t g_nib_nt = 1;   // nontemporal table loads in k_nib_gather (1 GiB lookups 710 -> 656 us per 10 M keys); the fold of k_nib_apply re-writes what it
                         // reads and measured slower with them (795 -> 984 us): never there
+int64_t g_nib_min_lg_lookup = 23, g_nib_min_lg_update = 24;  // see nib_geometry (psk_host.hpp); measured crossovers: scripts/ab_nib_threshold.py
 int64_t g_nib_update_layout = 1;   // see psk_nibble.hpp (bench A/B)
 int64_t g_update_nibble = 1;   // CBF unit-weight adds / decrements into 2^26 .. 2^29 counters: 4-bit delta images, one level; 0 = two-level 32-bit path
 int64_t g_part_dense_groups = 40;   // pass 2: segments of fewer groups (mean) are walked end to end (for_each_batch_at); 0 = never
@@ -500,6 +501,8 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "lookup_nibble_slices")) g_lookup_nibble = value;
     else if (!strcmp(name, "update_nibble_slices")) g_update_nibble = value;
     else if (!strcmp(name, "nibble_update_layout")) g_nib_update_layout = value;
+    else if (!strcmp(name, "nibble_min_lg_lookup")) g_nib_min_lg_lookup = value < 20 ? 20 : value;
+    else if (!strcmp(name, "nibble_min_lg_update")) g_nib_min_lg_update = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_nt_loads")) g_nib_nt = value;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
@@ -543,6 +546,8 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "lookup_nibble_slices")) *value = g_lookup_nibble;
     else if (!strcmp(name, "update_nibble_slices")) *value = g_update_nibble;
     else if (!strcmp(name, "nibble_update_layout")) *value = g_nib_update_layout;
+    else if (!strcmp(name, "nibble_min_lg_lookup")) *value = g_nib_min_lg_lookup;
+    else if (!strcmp(name, "nibble_min_lg_update")) *value = g_nib_min_lg_update;
     else if (!strcmp(name, "nibble_nt_loads")) *value = g_nib_nt;
     else if (!strcmp(name, "scatter_workgroups")) *value = g_part_wgs;
     else if (!strcmp(name, "slice_bias")) *value = g_part_slice_bias;
@@ -844,6 +849,10 @@ static int scat_flush(psk_sketch *s, hipStream_t st)
 static int scat_append(psk_sketch *s, const Batch &b, bool neg, uint64_t cap, hipStream_t st, bool *done)
 {
     *done = false;
+    {   // a list must stay within what one fold's 4-bit deltas hold (nib_load_ok): ~2.5 probes per counter
+        const uint64_t by_table = s->m * 5 / (2 * (uint64_t)(s->k ? s->k : 1));
+        if (cap > by_table) cap = by_table;
+    }
     if (s->kind != PSK_KIND_CBF || g_update_nibble == 0 || b.n == 0 || b.n > cap || s->k > 32) return PSK_OK;
     if (b.layout == PSK_KEYS_HASHES && b.key_len < s->k) return PSK_OK;
     if (!s->scat.ready || s->scat.cap != cap) {
@@ -992,7 +1001,9 @@ extern "C" int psk_cbf_update_combined(psk_sketch *s, int layout, const void *da
                                 g_update_nibble != 0 && s->k <= 32 && scat_geometry(s, cap, &probe);
         if (borrowable) {
             psk_sketch::BorrowList &bl = remove ? s->comb.brem : s->comb.badd;
-            if (bl.n() + n > cap || bl.base.size() >= 4096) PSK_TRY(flush_combined(s, st));
+            const uint64_t by_table = s->m * 5 / (2 * (uint64_t)s->k);  // (what one fold's 4-bit deltas hold: nib_load_ok)
+            const uint64_t capb = cap < by_table ? cap : by_table;
+            if (bl.n() + n > capb || bl.base.size() >= 4096) PSK_TRY(flush_combined(s, st));
             bl.base.push_back(data);
             bl.start.push_back(bl.start.back() + n);
             return comb_appended(s, st);  // (a flush on another stream waits for this one: the keys may still be in the making on it)

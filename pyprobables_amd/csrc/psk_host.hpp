@@ -216,10 +216,25 @@ static inline bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_
     return true;
 }
 
+// Geometry of the 4-bit slice images (psk_nibble.hpp): slices of 2^15 .. 2^18 counters, at least 256 of them when the table allows
+// (2^18 from 2^26 counters on: 1024 slices for BASELINE cfg 4's 2^28).  update = false: lookups (tables of 2^nibble_min_lg_lookup
+// counters and more), true: unit adds / decrements / write-combining segments (more than 2^nibble_min_lg_update counters).
+extern PSK_HIDDEN int64_t g_nib_min_lg_lookup, g_nib_min_lg_update;
+static inline bool nib_geometry(uint64_t cells, bool update, PartGeom *g)
+{
+    if (update ? cells <= (1ULL << g_nib_min_lg_update) : cells < (1ULL << g_nib_min_lg_lookup)) return false;
+    return part_slices(cells, kNibShift, 15, g, kPartMaxBuckets, 8);
+}
+
+// A 4-bit DELTA image holds at most 15 hits per counter and round; a round that brings more than ~2.5 probes per counter on average
+// overflows some counter of nearly every slice and would run at the atomics' rate (measured: 10 M keys into 1.7e7 counters, 4.2 probes
+// per counter: 1.8 ms against 0.31 ms through the 32-bit slices).  At 2.5 the tail P(Poisson >= 16) is ~3e-9 per counter.
+static inline bool nib_load_ok(uint64_t n, uint32_t k, uint64_t cells) { return n * (uint64_t)k * 2 <= cells * 5; }
+
 // The fixed geometry of a handle's persistent lists for `cap` keys per list (psk_sketch::scat); false: the table is not eligible.
 static inline bool scat_geometry(const psk_sketch *s, uint64_t cap, PartGeom *g)
 {
-    if (s->m <= (1ULL << 26) || !part_slices(s->m, kNibShift, kNibShift, g, kPartMaxBuckets, 7)) return false;
+    if (!nib_geometry(s->m, true, g)) return false;
     g->k = s->k;
     g->nwg = 256;
     g->append = 1;

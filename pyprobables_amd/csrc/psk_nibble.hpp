@@ -11,7 +11,7 @@ namespace psk {
 // MIN (countingbloom.py:166-174): min_j min(c_j, 15) == min(min_j c_j, 15), so a 4-bit saturating image answers exactly
 // whenever the answer is below 15.  A slice is 2^18 counters held as nibbles (128 KiB): 1024 slices for 2^28 counters, one
 // level, the 6 x 20-bit probe groups of the Bloom lookups.  A key whose min comes out as 15 raises the redo flag and the
-// flag-guarded direct kernel answers the batch (exact for any table; rare).
+// k_cbf_recheck15 answers exactly those keys from the table itself (exact for any table).
 //   pass 2  k_nib_gather   loads the slice (coalesced, 1 MiB), packs it to nibbles, streams the slice's probe groups and
 //                          writes ONE dword per group: nibble e = min(counter of probe e, 15)
 //   pass 3  k_nib_collect  as k_bloom_collect with dword runs: every key takes the min of its k nibbles
@@ -203,6 +203,27 @@ __global__ __launch_bounds__(kBloomCollectThreads) void k_nib_collect(PartGeom g
     if (ambiguous) *flag = 1u;
 }
 
+// The keys k_nib_collect could not answer (result 15: every counter of the key is 15 or more), one by one from the table itself; runs
+// only when the ambiguity flag is up.  A batch with one heavy hitter then costs one sweep over out[] and k gathers for that key -- not
+// a second, direct lookup of the whole batch (round 3, first version: a 10 M-key lookup into 9.6e7 counters whose keys had been added
+// six times each fell from 13.4 to 5.4 G keys/s because 35 of the keys had a min of 18).
+template <class Src, bool POW2>
+__global__ __launch_bounds__(kBlock) void k_cbf_recheck15(const uint32_t *amb, Src src, const uint32_t *tab, Mod md, uint32_t kk, uint64_t n, uint32_t *out)
+{
+    if (*amb == 0) return;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        if (out[i] != 15u) continue;
+        const typename Src::Key key = src.load(i);
+        uint32_t mn = 0xFFFFFFFFu;
+        for_each_hash(src, key, i, kk, [&](uint32_t, uint64_t h) {
+            const uint32_t v = tab[reduce<POW2>(md, h)];
+            mn = v < mn ? v : mn;
+        });
+        out[i] = mn;
+    }
+}
+
 // ------------------------------------------------------------------------------------ validated remove, OPTIMISTIC decrement
 // countingbloom.py:186-208 removes a key only if the min of its k counters is non-zero (and not frozen).  As a batch that is a
 // lookup of every key (a return trip: three passes) followed by the decrement of the keys that passed.  For the batches one
@@ -318,7 +339,7 @@ __device__ __forceinline__ void nib_apply_list(uint32_t *smem, uint32_t *carried
             uint32_t d[U];
             uint4 t[U][2];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < U; ++u) {  // (slices of 2^15 counters and more: blocks is a multiple of U = 4)
                 const uint64_t gc = c0 + (uint64_t)(k0 + u) * 8192u + 4u * threadIdx.x;
                 d[u] = smem[(k0 + u) * 1024u + threadIdx.x];
                 t[u][0] = t[u][1] = zero4;

@@ -15,7 +15,16 @@ int PSK_VARIANT(cbf_check_partitioned)(psk_sketch *s, const Batch &b, uint32_t k
             return (int)PSK_OK;
         });
     };
-    PSK_TRY(cbf_check_nibble(s, b, kk, out_dev, st, done, redo));  // big tables: 4-bit slice images (psk_nibble.hpp)
+    auto recheck = [&](const uint32_t *amb, hipStream_t st2) {
+        bool handled = false;
+        return with_part_source(b, &handled, [&](auto src) {
+            using Src = decltype(src);
+            hipLaunchKernelGGL((k_cbf_recheck15<Src, kTuPow2>), dim3(grid_for_keys(b.n)), dim3(kBlock), 0, st2, amb, src, (const uint32_t *)s->table, s->md, kk, b.n, out_dev);
+            HIP_TRY(hipGetLastError());
+            return (int)PSK_OK;
+        });
+    };
+    PSK_TRY(cbf_check_nibble(s, b, kk, out_dev, st, done, redo, recheck));  // big tables: 4-bit slice images (psk_nibble.hpp)
     if (*done) return PSK_OK;
     return counter_check_partitioned<IdxBloom>(s, b, kk, s->m, QueryCbfMin{}, out_dev, st, done, redo);
 }

@@ -8,9 +8,9 @@ int PSK_VARIANT(cbf_unit_multi_partitioned)(psk_sketch *s, const void *const *ba
 {
     *done = false;
     const uint64_t cells = s->m;
-    if (g_update_nibble == 0 || cells <= (1ULL << 26) || n == 0 || n > part_round_keys_two_level(n, s->k)) return PSK_OK;
+    if (g_update_nibble == 0 || n == 0 || n > part_round_keys_two_level(n, s->k) || !nib_load_ok(n, s->k, cells)) return PSK_OK;
     PartGeom g;
-    if (!part_slices(cells, kNibShift, kNibShift, &g, kPartMaxBuckets, 7)) return PSK_OK;
+    if (!nib_geometry(cells, true, &g)) return PSK_OK;
     g.k = s->k;
     SpillCounter<false> spill{(uint32_t *)s->table, true, neg != 0, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED)};
     const KeysFixed16Multi src{(const uint4 *const *)base_dev, start_dev, nb, (uint64_t)((((unsigned __int128)nb) << 64) / n)};

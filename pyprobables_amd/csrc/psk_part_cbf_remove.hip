@@ -16,10 +16,10 @@ int PSK_VARIANT(cbf_remove_fast_begin)(psk_sketch *s, const Batch &b, hipStream_
 {
     *launched = false;
     const uint64_t cells = s->m;
-    if (g_update_nibble == 0 || g_remove_dryrun == 0 || cells <= (1ULL << 26) || !part_wanted(b.n, s->k, 4)) return PSK_OK;
-    if (b.n * (uint64_t)s->k < cells / 8 || b.n > part_round_keys_two_level(b.n, s->k)) return PSK_OK;  // (one round only)
+    if (g_update_nibble == 0 || g_remove_dryrun == 0 || !part_wanted(b.n, s->k, 4)) return PSK_OK;
+    if (b.n * (uint64_t)s->k < cells / 8 || b.n > part_round_keys_two_level(b.n, s->k) || !nib_load_ok(b.n, s->k, cells)) return PSK_OK;  // (one round only)
     PartGeom g;
-    if (!part_slices(cells, kNibShift, kNibShift, &g, kPartMaxBuckets, 7)) return PSK_OK;
+    if (!nib_geometry(cells, true, &g)) return PSK_OK;
     g.k = s->k;
     PSK_TRY(ensure(s->s_flag, 8));
     uint32_t *flag = (uint32_t *)s->s_flag.p;

@@ -71,9 +71,9 @@ static inline int cbf_nib_scatter_only(psk_sketch *s, const Batch &b, bool neg, 
 {
     *done = false;
     const uint64_t cells = s->m;
-    if (g_update_nibble == 0 || cells <= (1ULL << 26) || !part_wanted(b.n, s->k, 4) || b.n > part_round_keys_two_level(b.n, s->k)) return PSK_OK;
+    if (g_update_nibble == 0 || !part_wanted(b.n, s->k, 4) || b.n > part_round_keys_two_level(b.n, s->k) || !nib_load_ok(b.n, s->k, cells)) return PSK_OK;
     PartGeom g;
-    if (!part_slices(cells, kNibShift, kNibShift, &g, kPartMaxBuckets, 7)) return PSK_OK;
+    if (!nib_geometry(cells, true, &g)) return PSK_OK;
     g.k = s->k;
     if (second) { std::swap(s->s_part, s->s_part2); std::swap(s->s_cnt, s->s_cnt2); }  // (launch_scatter fills s_part / s_cnt)
     bool handled = false;
@@ -93,11 +93,12 @@ static inline int cbf_unit_nibble(psk_sketch *s, const Batch &b, const uint32_t 
 {
     *done = false;
     const uint64_t cells = s->m;
-    if (g_update_nibble == 0 || cells <= (1ULL << 26) || !part_wanted(b.n, s->k, 4)) return PSK_OK;
+    if (g_update_nibble == 0 || !part_wanted(b.n, s->k, 4)) return PSK_OK;
     if (b.n * (uint64_t)s->k < cells / 8) return PSK_OK;
     PartGeom g;
-    if (!part_slices(cells, kNibShift, kNibShift, &g, kPartMaxBuckets, 7)) return PSK_OK;
+    if (!nib_geometry(cells, true, &g)) return PSK_OK;
     g.k = s->k;
+    if (!nib_load_ok(b.n, s->k, cells)) return PSK_OK;  // (more than ~2.5 probes per counter: the 32-bit slices take the batch)
     const uint64_t round_keys = part_round_keys_two_level(b.n, s->k);
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;

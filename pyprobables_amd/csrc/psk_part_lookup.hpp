@@ -104,23 +104,25 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
 // CountingBloomFilter lookups through NIBBLE slices (psk_nibble.hpp): tables of 2^25 .. 2^29 counters -- beyond 1024 of the 32-bit
 // slices above the three passes below win (fewer, longer runs in pass 1 and pass 3), and beyond 2^27 counters they are the only
 // partitioned form (BASELINE cfg 4's 1 GiB table: 1024 slices of 2^18 counters).  countingbloom.py:166-174.
-template <class Redo>
-static inline int cbf_check_nibble(psk_sketch *s, const Batch &b, uint32_t kk, uint32_t *out_dev, hipStream_t st, bool *done, Redo &&redo)
+// redo(flag, st): the whole batch through the direct kernel if a pass-1 segment overflowed; recheck(amb, st): the keys whose nibble answer is
+// 15 from the table itself (k_cbf_recheck15)
+template <class Redo, class Recheck>
+static inline int cbf_check_nibble(psk_sketch *s, const Batch &b, uint32_t kk, uint32_t *out_dev, hipStream_t st, bool *done, Redo &&redo, Recheck &&recheck)
 {
     *done = false;
     const uint64_t cells = s->m;
-    if (g_lookup_nibble == 0 || cells < (1ULL << 25) || !part_wanted(b.n, kk, 4)) return PSK_OK;
+    if (g_lookup_nibble == 0 || !part_wanted(b.n, kk, 4)) return PSK_OK;
     // pass 2 reads the WHOLE table (4 B per counter at ~4.4 TB/s: 0.25 ms for 2^28 counters) where the direct kernel fetches one
     // 64-byte line per probe (52 G probes/s): worth it from about cells / 16 probes on (measured on the 1 GiB table: a 0.5 M-key
     // lookup 67 us direct, 0.4 ms through the slices)
     if (g_lookup_nibble != 2 && b.n * (uint64_t)kk < cells / 16) return PSK_OK;  // (2: always -- tests)
     PartGeom g;
-    if (!part_slices(cells, kNibShift, kNibShift, &g, kPartMaxBuckets, 7)) return PSK_OK;
+    if (!nib_geometry(cells, false, &g)) return PSK_OK;
     g.k = kk;
     const uint64_t round_keys = lookup_round_keys(b.n, kk);
     PSK_TRY(ensure(s->s_flag, 8));
-    uint32_t *flag = (uint32_t *)s->s_flag.p;
-    HIP_TRY(hipMemsetAsync(flag, 0, 4, st));
+    uint32_t *flag = (uint32_t *)s->s_flag.p, *amb = flag + 1;  // [0] a segment overflowed, [1] a key's answer is ambiguous (15)
+    HIP_TRY(hipMemsetAsync(flag, 0, 8, st));
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
         const Batch sub = sub_batch(b, start, cnt);
@@ -158,14 +160,15 @@ static inline int cbf_check_nibble(psk_sketch *s, const Batch &b, uint32_t kk, u
                 while (run_lanes < 64 && (uint64_t)run_lanes * 6 * g.nbuckets < (uint64_t)g.tile * kq + 6ULL * g.nbuckets) run_lanes *= 2;
                 if (g_lookup_run_lanes > 0) run_lanes = (uint32_t)g_lookup_run_lanes;
                 hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(kBloomCollectThreads), lds3, st, g, cnt, (const uint4 *)s->s_perm.p,
-                                   (const uint2 *)s->s_run.p, (const uint32_t *)s->s_vals.p, stage_groups, run_lanes, out_dev + start, flag);
+                                   (const uint2 *)s->s_run.p, (const uint32_t *)s->s_vals.p, stage_groups, run_lanes, out_dev + start, amb);
                 HIP_TRY(hipGetLastError());
                 return (int)PSK_OK;
             });
         }));
         if (!handled || !fits) return PSK_OK;  // (only ever on the first round: nothing was launched)
     }
-    PSK_TRY(redo(flag, st));  // a segment overflowed, or a key's counters are all 15 or more: exact redo by the direct kernel
+    PSK_TRY(recheck(amb, st));  // keys whose counters are all 15 or more: answered from the table itself (flag-guarded)
+    PSK_TRY(redo(flag, st));     // a segment overflowed: exact redo of the batch by the direct kernel (flag-guarded)
     *done = true;
     return PSK_OK;
 }
