@@ -281,6 +281,25 @@ def roofline(op: str, kernel: str, units: int, ms: float, limiter: str, traffic_
 
 
 # ----------------------------------------------------------------------------------------------- CPU baseline
+
+
+def host_cores():
+    """threads the all-cores CPU legs use: the CPUs this process may run on, capped by the container's CPU-time quota (cgroup
+    cpu.max).  On the GPU boxes the affinity mask shows 256 CPUs but the quota is 16 CPUs' worth of time: 256 threads then
+    time-share 16 cores (measured: 44 Mkeys/s with 256 threads, 60-75 with 16-64; scripts/cpu_scaling.py)."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"{aff} CPUs in the affinity mask"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period)))
+            note += f", cgroup cpu.max = {q} CPUs"
+            aff = min(aff, q)
+    except (OSError, ValueError):
+        pass
+    return aff, note
+
+
 def cpu_baseline(n_sample: int, reps: int = 3):
     """(i) a pure-Python mirror of the reference's per-key loop on a 100k-key sample, (ii) the plain-C
     oracle (kind 'port') on one core and on all host cores (per-thread replica + OR merge).  ~20 s of host work."""
@@ -303,20 +322,20 @@ def cpu_baseline(n_sample: int, reps: int = 3):
     one = {"value": ops / t_total / 1e6, "unit": "Mkeys/s", "cores": 1, "kind": "port", "seconds": t_total,
            "sample": f"{reps} x (insert {n_sample} + check {n_sample}) 16-byte keys into m=2^28 k=7, oracle/psk_oracle.c (gcc -O2), 1 thread"}
     # -- C port, all cores
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    n_mt = max(n_sample * 4, cores * 1_000_000)  # enough keys per thread for the merge of T replicas to amortise
+    cores, quota_note = host_cores()
+    n_mt = max(n_sample * 4, cores * 6_000_000)  # enough keys per thread for the merge of T replicas to amortise (a few seconds per leg)
     obm = oracle.OracleBloom(m, k)
     found = obm.insert_check_mt(0, n_mt, cores)
     t_mt = obm.mt_seconds                          # the three phases; replica allocation / first touch is outside the clock
     allc = {"value": 2 * n_mt / t_mt / 1e6, "unit": "Mkeys/s", "cores": cores, "kind": "port", "seconds": t_mt, "all_found": found == n_mt,
-            "sample": f"insert {n_mt} + check {n_mt} keys, {cores} threads: per-thread 32 MiB replica, OR merge, lookups (oracle/psk_oracle.c, key generation included)"}
+            "sample": f"insert {n_mt} + check {n_mt} keys, {cores} threads ({quota_note}): per-thread 32 MiB replica, OR merge, lookups (oracle/psk_oracle.c, key generation included)"}
     # -- C port, all cores, ONE shared table with relaxed atomic ORs (no replicas, no merge): the honest "all cores" figure
     obs = oracle.OracleBloom(m, k)
     found_s = obs.insert_check_mt_shared(0, n_mt, cores)
     t_sh = obs.mt_seconds
     shared = {"value": 2 * n_mt / t_sh / 1e6, "unit": "Mkeys/s", "cores": cores, "kind": "port", "seconds": t_sh, "all_found": found_s == n_mt,
               "table_equals_replica_variant": bool((obs.bloom == obm.bloom).all()),
-              "sample": f"insert {n_mt} + check {n_mt} keys, {cores} threads on ONE shared 32 MiB table (__atomic_fetch_or, relaxed), lookups (oracle/psk_oracle.c, key generation included)"}
+              "sample": f"insert {n_mt} + check {n_mt} keys, {cores} threads ({quota_note}) on ONE shared 32 MiB table (__atomic_fetch_or, relaxed), lookups (oracle/psk_oracle.c, key generation included)"}
     # -- pure-Python mirror (what the reference's interpreted loop costs here; never the reference itself)
     n_py = 100_000
     mb = pymirror.MirrorBloom(m, k)

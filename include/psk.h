@@ -115,7 +115,7 @@ uint64_t psk_cms_table_bytes(uint64_t width, uint32_t depth); /* 4*width*depth r
 int psk_bloom_create(uint64_t m_bits, uint32_t k, int device, void *ext_table, psk_sketch **out);
 int psk_cbf_create(uint64_t m, uint32_t k, int device, void *ext_table, psk_sketch **out);
 int psk_cms_create(uint64_t width, uint32_t depth, int device, void *ext_table, psk_sketch **out);
-int psk_destroy(psk_sketch *s);
+int psk_destroy(psk_sketch *s);                             /* ext_table: write-combined updates still waiting are applied first (NULL stream + sync) */
 int psk_clear(psk_sketch *s, void *stream);                 /* bloom.py:217-221, countminsketch.py:240-244 */
 int psk_synchronize(psk_sketch *s, void *stream);
 int psk_release_scratch(psk_sketch *s);                     /* free staging + partition buffers (regrow on demand) */

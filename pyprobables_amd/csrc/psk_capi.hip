@@ -145,6 +145,9 @@ extern "C" int psk_destroy(psk_sketch *s)
     if (!s) return PSK_OK;
     DeviceScope scope;
     (void)scope.enter(s->device);
+    if (!s->owns_table && s->table) {  // the caller's table outlives the handle: write-combined updates still waiting must reach it
+        if (flush_combined(s, nullptr) == PSK_OK) (void)hipStreamSynchronize(nullptr);
+    }
     if (s->owns_table && s->table) hipFree(s->table);
     if (s->ctr) hipFree(s->ctr);
     if (s->lk.dev) hipFree(s->lk.dev);

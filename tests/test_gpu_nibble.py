@@ -350,3 +350,27 @@ def test_optimistic_remove_with_a_key_repeated_in_the_batch(pa, oracle, force_pa
     assert cbf.elements_added == oc.els_added
     assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
     assert int(cbf.check_many(_dev(np.repeat(hot, 300_000, axis=0))).cpu().numpy()[0]) == 20
+
+
+def test_destroy_applies_waiting_updates_to_a_caller_owned_table(pa, oracle):
+    """C ABI, ext_table: a handle over the caller's table is destroyed while automatically write-combined adds still wait in its
+    segments -- psk_destroy applies them first (the table outlives the handle; include/psk.h)"""
+    import ctypes as C
+    from pyprobables_amd import _native as N
+
+    L = N.lib()
+    m, k, n = 2**25 + 12_345, 5, 150_000                 # more than 2^24 counters: the batch waits as scattered probes
+    table = torch.zeros(int(L.psk_cbf_table_bytes(m)) // 4, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    h = C.c_void_p()
+    N.check(L.psk_cbf_create(m, k, 0, table.data_ptr(), C.byref(h)))
+    keys = oracle.gen_keys16(31, n)
+    dk = _dev(keys)
+    torch.cuda.synchronize()
+    N.check(L.psk_cbf_add(h, N.KEYS_FIXED, dk.data_ptr(), None, n, 16, None, N.DEVICE, None))
+    torch.cuda.synchronize()
+    assert int(table.count_nonzero().item()) == 0        # nothing has reached the table yet
+    N.check(L.psk_destroy(h))
+    oc = oracle.OracleCBF(m, k)
+    oc.update_keys(keys)
+    assert np.array_equal(table.cpu().numpy().view(np.uint32)[:m], oc.bloom)
