@@ -158,7 +158,7 @@ int psk_bloom_check_finish(psk_sketch *s, uint8_t *out_dev, void *stream);
  * add:    counters[h_i % m] = min(c + w, 2^32-1) for i<k        (countingbloom.py:125-155)
  * remove: conditional decrement                                 (countingbloom.py:176-208)
  * check:  out = min_i counters[h_i % m]                         (countingbloom.py:157-174)
- * Big tables (more than 2^26 counters; round 3):
+ * Big tables (more than 2^24 counters -- option "nibble_min_lg_update"; round 3):
  *   - unit-weight add batches too small to pay for a pass over the table (n * k < m / 8) are write-combined automatically: the
  *     batch is hashed and partitioned when it is handed over, its probes wait in persistent per-slice segments and reach the
  *     table together with their successors (adds commute, the clamp at 2^32-1 is applied all the same: exact, no opt-in;
