@@ -134,7 +134,8 @@ def test_cfg4_cbf_1GiB_mixed_stream(pa, oracle):
 
 def test_cfg4_cbf_1GiB_mixed_stream_write_combined(pa, oracle):
     """the same 50-batch stream with combine_updates=True (what bench.py --config cfg4 runs): 1M-key batches wait on the
-    device and reach the 1 GiB table as a few large partitioned updates; compared with the oracle at three points"""
+    device and reach the 1 GiB table as a few large partitioned updates; table and elements_added compared with the oracle after
+    every fifth batch, lookups in between"""
     B, nb = 1_000_000, 50
     cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, combine_updates=True)
     oc = oracle.OracleCBF(2**28, 7)
@@ -144,11 +145,16 @@ def test_cfg4_cbf_1GiB_mixed_stream_write_combined(pa, oracle):
         if b >= 1:
             cbf.remove_many(dev_keys((b - 1) * B, B // 2))
             oc.update_keys(oracle.gen_keys16((b - 1) * B, B // 2), -np.ones(B // 2, dtype=np.int64))
-        if b in (17, 33, nb - 1):
+        quiet = 20 <= b < 40           # one long window: 20 batches wait together (30 M keys in the two lists)
+        if (b % 5 == 2 and not quiet) or b in (40, nb - 1):  # (every read flushes what waits)
             want = torch.from_numpy(oc.bloom.view(np.int32)).cuda()
             assert torch.equal(cbf.table_tensor[: want.numel()], want), f"table differs after batch {b}"
             del want
             assert cbf.elements_added == oc.els_added
+        elif b % 5 == 0 and not quiet:  # a lookup in the middle of a window (it flushes too): present / just removed / absent keys
+            starts = [max(b - 1, 0) * B, b * B, (b + 1) * B]
+            got = cbf.check_many(torch.cat([dev_keys(s0, 100_000) for s0 in starts])).cpu().numpy().view(np.uint32)
+            assert np.array_equal(got, oc.check_keys(np.concatenate([oracle.gen_keys16(s0, 100_000) for s0 in starts]))), f"lookups differ after batch {b}"
     assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
 
 
