@@ -483,10 +483,20 @@ def side_measurements(ctx: Ctx, n, blm, keys):
     out["cbf_add_Mops_s"] = ncbf / ms / 1e3
     rl["cbf_add"] = roofline("cbf_add", "CBF unit add into the 1 GiB table (one level of 2^18-counter nibble-delta slices: k_part_scatter + k_nib_apply<0>)",
                              ncbf, ms, "the fold read-modify-writes the whole 1 GiB table")
-    ms = timed_loop(torch, lambda: cbf.check_many(keys[:ncbf]), 3, warm=1)
+    from pyprobables_amd import _native as _N
+    _N.set_option("cbf_lookup_shadow", 0)  # `cbf_check` = a lookup of a table that has just changed: the whole 32-bit table is read
+    try:
+        ms = timed_loop(torch, lambda: cbf.check_many(keys[:ncbf]), 3, warm=1)
+    finally:
+        _N.set_option("cbf_lookup_shadow", 1)
     out["cbf_check_Mkeys_s"] = ncbf / ms / 1e3
     rl["cbf_check"] = roofline("cbf_check", "CBF lookup (min over 7 counters, 1 GiB table): k_part_scatter<PayBloomLookup> + k_nib_gather + k_nib_collect",
                                ncbf, ms, "pass 2 streams the whole 1 GiB table (107 B per key at 10 M keys) into 4-bit slice images")
+    # read-mostly: from the third lookup in a row of an unchanged table on, pass 2 loads the 4-bit images the second one left behind (128 MiB)
+    ms = timed_loop(torch, lambda: cbf.check_many(keys[:ncbf]), 5, warm=3)
+    out["cbf_check_unchanged_table_Mkeys_s"] = ncbf / ms / 1e3
+    rl["cbf_check_unchanged_table"] = roofline("cbf_check", "CBF lookup of an unchanged 1 GiB table: k_part_scatter<PayBloomLookup> + k_nib_gather (kept 4-bit images) + k_nib_collect",
+                                               ncbf, ms, "pass 2 loads the kept images (cells / 2 bytes) instead of the table", "cbf_check_unchanged_table")
     rm = EventTimer(torch)  # every remove needs its keys back in first: add (untimed), remove (timed), the first pair is warm-up
     for it in range(4):
         cbf.add_many(keys[:ncbf])

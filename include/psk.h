@@ -166,7 +166,12 @@ int psk_bloom_check_finish(psk_sketch *s, uint8_t *out_dev, void *stream);
  *     table, removes or hands out its pointer applies what is waiting first (psk_flush before using psk_table_info's pointer).
  *   - a unit-weight psk_cbf_remove of at least m / 8 probes decrements optimistically (one pass; exact whenever every counter
  *     holds what the batch takes from it, i.e. every key is present) and otherwise undoes that and takes the lookup + masked
- *     decrement path; it reads ONE 4-byte verdict back, i.e. synchronises `stream` once (option "remove_optimistic" = 0: never). */
+ *     decrement path; it reads ONE 4-byte verdict back, i.e. synchronises `stream` once (option "remove_optimistic" = 0: never).
+ *   - lookups of a table that is not changing (from 2^23 counters on): the partitioned psk_cbf_check squeezes the 32-bit table
+ *     into 4-bit slice images on every call; from the second such call in a row on it keeps them (cells / 2 bytes, freed by
+ *     psk_release_scratch) and later calls on the same stream load them instead, until any entry point that may write the
+ *     table -- or psk_table_info, which hands its pointer out -- is called on the handle (option "cbf_lookup_shadow" = 0: never).
+ *     Whoever writes to the table behind the engine's back must say so afterwards: psk_rescan_bound (as for the wrap-free bound). */
 int psk_cbf_add(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
                 uint32_t key_len, const uint32_t *weights, int where, void *stream);
 int psk_cbf_remove(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,

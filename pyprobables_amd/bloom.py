@@ -157,8 +157,11 @@ class BloomFilter:
 
     @property
     def table_tensor(self):
-        """the torch int32 tensor backing the table (padded to 16 B); what the multi-GPU merge reduces"""
+        """the torch int32 tensor backing the table (padded to 16 B); what the multi-GPU merge reduces.  Handing it out tells the
+        engine that the table may be written from outside (``psk_table_info``): anything it derived from the table is dropped.
+        A caller that keeps the tensor and writes to it LATER must say so (``psk_rescan_bound`` / taking the property again)."""
         self._flush()
+        _ = self._tab.ptr
         return self._tab.tensor
 
     @property

@@ -153,7 +153,7 @@ extern "C" int psk_destroy(psk_sketch *s)
     if (s->lk.dev) hipFree(s->lk.dev);
     if (s->lk.pin) hipHostFree((void *)s->lk.pin);
     for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
-                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->s_brw}) {
+                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->s_brw, &s->shadow.img}) {
         if (b->p) hipFree(b->p);
         if (b->pin) hipHostFree(b->pin);
     }
@@ -162,13 +162,18 @@ extern "C" int psk_destroy(psk_sketch *s)
     return PSK_OK;
 }
 
-#define CHECK_HANDLE(s, want_kind)                                                       \
+#define CHECK_HANDLE_RO(s, want_kind)                                                    \
     do {                                                                                 \
         if (!(s)) return fail(PSK_EINVAL, "sketch handle is NULL");                      \
         if ((want_kind) >= 0 && (s)->kind != (want_kind))                                \
             return fail(PSK_EINVAL, "wrong sketch kind %d for this call", (s)->kind);    \
     } while (0);                                                                         \
     PSK_USE_DEVICE((s)->device)
+// every entry point that may change the table (or hands its pointer out) moves the table's version on: what was derived from the
+// table -- psk_sketch::shadow, the 4-bit images of the nibble-slice lookup -- is stale from here on.  Read-only entries: _RO.
+#define CHECK_HANDLE(s, want_kind)                                                       \
+    CHECK_HANDLE_RO(s, want_kind);                                                       \
+    ++(s)->table_version
 
 // table (padded to 16 bytes) and the handle's counter block, zeroed by one kernel
 static __global__ __launch_bounds__(kBlock) void k_clear(uint4 *tab, uint64_t nvec, long long *ctr)
@@ -209,7 +214,7 @@ extern "C" int psk_clear(psk_sketch *s, void *stream)
 
 extern "C" int psk_synchronize(psk_sketch *s, void *stream)
 {
-    CHECK_HANDLE(s, -1);
+    CHECK_HANDLE_RO(s, -1);
     PSK_TRY(flush_combined(s, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return PSK_OK;
@@ -218,6 +223,7 @@ extern "C" int psk_synchronize(psk_sketch *s, void *stream)
 extern "C" int psk_table_info(psk_sketch *s, void **dev_ptr, uint64_t *padded_bytes, uint64_t *logical_bytes)
 {
     if (!s) return fail(PSK_EINVAL, "sketch handle is NULL");
+    ++s->table_version;  // the pointer leaves the engine: whoever holds it may write
     if (dev_ptr) *dev_ptr = s->table;
     if (padded_bytes) *padded_bytes = s->padded_bytes;
     if (logical_bytes) *logical_bytes = s->logical_bytes;
@@ -226,7 +232,7 @@ extern "C" int psk_table_info(psk_sketch *s, void **dev_ptr, uint64_t *padded_by
 
 extern "C" int psk_read_table(psk_sketch *s, void *dst_host, uint64_t nbytes, void *stream)
 {
-    CHECK_HANDLE(s, -1);
+    CHECK_HANDLE_RO(s, -1);
     if (!dst_host || nbytes > s->padded_bytes) return fail(PSK_EINVAL, "bad read_table arguments");
     hipStream_t st = (hipStream_t)stream;
     PSK_TRY(flush_combined(s, st));
@@ -275,7 +281,7 @@ extern "C" int psk_rescan_bound(psk_sketch *s, void *stream)
 
 extern "C" int psk_get_counters(psk_sketch *s, int64_t out[PSK_CTR_COUNT], void *stream)
 {
-    CHECK_HANDLE(s, -1);
+    CHECK_HANDLE_RO(s, -1);
     if (!out) return fail(PSK_EINVAL, "out is NULL");
     hipStream_t st = (hipStream_t)stream;
     PSK_TRY(flush_combined(s, st));  // the tallies describe every update handed over so far
@@ -466,6 +472,8 @@ int64_t g_lookup_collect_threads = 1024;
 int64_t g_remove_dryrun = 1;   // validated unit-weight CBF removes into big tables: optimistic decrement first (psk_nibble.hpp), option "remove_optimistic"
 int64_t g_scratch_budget = 0;  // psk_set_option("scratch_budget_bytes"): cap on a handle's partition scratch (more, smaller rounds); 0 = none
 int64_t g_lookup_nibble = 1;   // CBF lookups into 2^25 .. 2^29 counters: 4-bit slice images (psk_nibble.hpp) from cells / 16 probes on; 2 = always; 0 = the 32-bit / 16-bit slices or direct
+int64_t g_cbf_shadow_hits = 0;
+int64_t g_cbf_shadow = 1;  // nibble-slice lookups keep their 4-bit images while the table is unchanged (psk_sketch::shadow; cells / 2 bytes)
 int64_t g_nib_nt = 1;   // nontemporal table loads in k_nib_gather (1 GiB lookups 710 -> 656 us per 10 M keys); the fold of k_nib_apply re-writes what it
                         // reads and measured slower with them (795 -> 984 us): never there
 int64_t g_nib_min_lg_lookup = 23, g_nib_min_lg_update = 24;  // see nib_geometry (psk_host.hpp); measured crossovers: scripts/ab_nib_threshold.py
@@ -507,6 +515,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "nibble_min_lg_lookup")) g_nib_min_lg_lookup = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_min_lg_update")) g_nib_min_lg_update = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_nt_loads")) g_nib_nt = value;
+    else if (!strcmp(name, "cbf_lookup_shadow")) g_cbf_shadow = value;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
 }
@@ -552,6 +561,8 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "nibble_min_lg_lookup")) *value = g_nib_min_lg_lookup;
     else if (!strcmp(name, "nibble_min_lg_update")) *value = g_nib_min_lg_update;
     else if (!strcmp(name, "nibble_nt_loads")) *value = g_nib_nt;
+    else if (!strcmp(name, "cbf_lookup_shadow")) *value = g_cbf_shadow;
+    else if (!strcmp(name, "cbf_lookup_shadow_hits")) *value = g_cbf_shadow_hits;
     else if (!strcmp(name, "scatter_workgroups")) *value = g_part_wgs;
     else if (!strcmp(name, "slice_bias")) *value = g_part_slice_bias;
     else return fail(PSK_EINVAL, "unknown option %s", name);
@@ -928,6 +939,7 @@ int flush_combined(psk_sketch *s, hipStream_t st)
     const bool keys_pending = s->comb.add.n != 0 || s->comb.rem.n != 0 || s->comb.badd.n() != 0 || s->comb.brem.n() != 0;
     const bool scat_pending = s->scat.ready && (s->scat.add.n != 0 || s->scat.rem.n != 0);
     if (!keys_pending && !scat_pending) return PSK_OK;
+    ++s->table_version;  // (also from the read-only entry points: what waited reaches the table now)
     PSK_TRY(comb_order(s, st));
     // adds first: a remove whose add waits in the same window must find it applied.  Two mechanisms may hold updates -- key lists
     // (weighted batches, tables below the nibble geometry) and scattered probes: all adds of both, then all removes of both.
@@ -983,7 +995,7 @@ int flush_combined(psk_sketch *s, hipStream_t st)
 
 extern "C" int psk_flush(psk_sketch *s, void *stream)
 {
-    CHECK_HANDLE(s, -1);
+    CHECK_HANDLE_RO(s, -1);
     return flush_combined(s, (hipStream_t)stream);
 }
 
@@ -1215,7 +1227,7 @@ extern "C" int psk_cbf_remove(psk_sketch *s, int layout, const void *data, const
 extern "C" int psk_cbf_check(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
                              uint32_t key_len, int where, uint32_t *out, void *stream)
 {
-    CHECK_HANDLE(s, PSK_KIND_CBF);
+    CHECK_HANDLE_RO(s, PSK_KIND_CBF);
     if (n && !out) return fail(PSK_EINVAL, "out is NULL");
     if (layout == PSK_KEYS_HASHES && key_len == 0) return fail(PSK_EINVAL, "check needs at least one hash per key");
     hipStream_t st = (hipStream_t)stream;
@@ -1228,7 +1240,10 @@ extern "C" int psk_cbf_check(psk_sketch *s, int layout, const void *data, const 
     const uint32_t kk = layout == PSK_KEYS_HASHES ? key_len : s->k;
     {
         bool done = false;
-        PSK_TRY(cbf_check_partitioned(s, b, kk, (uint32_t *)o.dev, st, &done));
+        s->shadow.allow = true;  // (only here: a lookup INSIDE an updating entry point is followed by writes at the same table version)
+        const int rc = cbf_check_partitioned(s, b, kk, (uint32_t *)o.dev, st, &done);
+        s->shadow.allow = false;
+        PSK_TRY(rc);
         if (done) return finish(where, &o, st);
     }
     PSK_TRY(with_source(b, [&](auto src) {
@@ -1612,12 +1627,14 @@ extern "C" int psk_release_scratch(psk_sketch *s)
     PSK_TRY(flush_combined(s, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
-                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->s_brw}) {
+                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->s_brw, &s->shadow.img}) {
         if (b->p) HIP_TRY(hipFree(b->p));
         b->p = nullptr;
         b->cap = 0;
     }
     s->scat.ready = false;
+    s->shadow.built = s->shadow.seen = ~0ULL;
+    s->shadow.seen_count = 0;
     return PSK_OK;
 }
 

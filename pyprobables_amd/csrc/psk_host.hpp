@@ -154,6 +154,19 @@ struct psk_sketch {
         bool appended = false;
     } scat;
     PartGeom rm_g{};     // geometry of the validated remove's fast path between its optimistic decrement and a possible undo
+    // Read-mostly CountingBloomFilter tables (round 3): the nibble-slice lookup reads the whole 32-bit table to build its 4-bit
+    // images (1 GiB for BASELINE cfg 4).  When the table has not changed since the previous lookup the images are kept -- a linear
+    // 4-bit saturating copy of the table, cells / 2 bytes -- and later lookups load them instead (k_nib_gather).  `table_version`
+    // counts the entry points that may change the table (CHECK_HANDLE; the read-only ones use CHECK_HANDLE_RO), `built` is the
+    // version the copy mirrors, `seen` the version of the previous nibble lookup; the copy is used on the stream that built it.
+    uint64_t table_version = 0;
+    struct {
+        DevBuf img;
+        uint64_t built = ~0ULL, seen = ~0ULL, words = 0;
+        uint32_t seen_count = 0;  // nibble-eligible lookups in a row that found version `seen`
+        hipStream_t stream = nullptr;
+        bool allow = false;  // set by psk_cbf_check around its lookup
+    } shadow;
     // split lookup (psk_bloom_check_begin / _finish): pass 1 of the first round has run, the rest waits for the table
     struct {
         bool active = false, scattered = false;
@@ -183,6 +196,7 @@ extern PSK_HIDDEN int64_t g_part_slice_bias;     // bench knob: added to log2(ce
 extern PSK_HIDDEN int64_t g_part_tile_threads;   // pass 1 workgroup shape for k <= 8: 0 = auto (launch_scatter), 512 / 1024 = forced
 extern PSK_HIDDEN int64_t g_part_even_tiles;     // 1 (default): pass 1 evens the tile size out over the workgroups
 extern PSK_HIDDEN int64_t g_lookup_half;           // 1 (default): counter lookups into 2^26 .. 2^27 counters use 2^16-counter slices of 16-bit values
+extern PSK_HIDDEN int64_t g_cbf_shadow;         // keep the nibble-slice lookup's images of an unchanged table
 extern PSK_HIDDEN int64_t g_nib_nt;             // nontemporal table loads in the nibble-slice kernels (bench A/B)
 extern PSK_HIDDEN int64_t g_nib_update_layout;  // delta-image layout of k_nib_apply: 0 pieces, 1 blocks (psk_nibble.hpp)
 extern PSK_HIDDEN int64_t g_lookup_nibble, g_update_nibble;  // CBF tables beyond one level of 32-bit slices: 4-bit slice images (psk_nibble.hpp)

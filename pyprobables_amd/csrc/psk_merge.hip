@@ -130,6 +130,7 @@ extern "C" int psk_merge_or(psk_sketch *s, void *nccl_comm, void *stream)
     if (s->kind != PSK_KIND_BLOOM) return fail(PSK_EINVAL, "psk_merge_or merges Bloom filters (counters: psk_merge_sum)");
     if (!nccl_comm) return fail(PSK_EINVAL, "communicator is NULL");
     PSK_USE_DEVICE(s->device);
+    ++s->table_version;  // the merge rewrites the table (psk_sketch::shadow is stale from here on)
     Rccl *R;
     PSK_TRY(rccl(&R));
     ncclComm_t comm = (ncclComm_t)nccl_comm;
@@ -168,6 +169,7 @@ extern "C" int psk_merge_sum(psk_sketch *s, void *nccl_comm, void *stream)
     if (s->kind == PSK_KIND_BLOOM) return fail(PSK_EINVAL, "psk_merge_sum merges counter tables (Bloom: psk_merge_or)");
     if (!nccl_comm) return fail(PSK_EINVAL, "communicator is NULL");
     PSK_USE_DEVICE(s->device);
+    ++s->table_version;  // the merge rewrites the table (psk_sketch::shadow is stale from here on)
     Rccl *R;
     PSK_TRY(rccl(&R));
     ncclComm_t comm = (ncclComm_t)nccl_comm;

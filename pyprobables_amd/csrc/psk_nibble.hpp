@@ -81,14 +81,42 @@ __device__ __forceinline__ void nib_load_slice(uint32_t *smem, const uint32_t *t
     }
 }
 
+// shadow_in: the slice images as an earlier launch left them (psk_sketch::shadow: a linear 4-bit copy of the table, valid while the
+// table is unchanged) -- 1/8 of the bytes; shadow_out: leave them behind for the next lookup.  Both null: build and forget.
 static __global__ __launch_bounds__(kApplyThreads) void k_nib_gather(const uint32_t *tab, uint64_t tab_cells, PartGeom g, const uint32_t *segcnt,
-                                                                     const uint4 *buckets, uint32_t *vals, uint32_t nt)
+                                                                     const uint4 *buckets, uint32_t *vals, uint32_t nt, const uint32_t *shadow_in,
+                                                                     uint32_t *shadow_out)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = blockIdx.x;
     const uint32_t mycnt = lane_segment_count(segcnt, g, b);
-    nib_load_slice(smem, tab, tab_cells, g.shift, b, nt != 0);
+    const uint32_t vecs = 1u << (g.shift - 5);  // 16-byte pieces of one image (2^(shift-3) words)
+    if (shadow_in) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(shadow_in) + (uint64_t)b * vecs;
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        constexpr int U = 8;
+        for (uint32_t p0 = threadIdx.x; p0 < vecs; p0 += kApplyThreads * U) {
+            uint4 t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t pc = p0 + (uint32_t)u * kApplyThreads;
+                t[u] = pc < vecs ? src[pc] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t pc = p0 + (uint32_t)u * kApplyThreads;
+                if (pc < vecs) dst[pc] = t[u];
+            }
+        }
+    } else {
+        nib_load_slice(smem, tab, tab_cells, g.shift, b, nt != 0);
+    }
     __syncthreads();
+    if (shadow_out) {  // (the stores drain under the probe stream below)
+        uint4 *dst = reinterpret_cast<uint4 *>(shadow_out) + (uint64_t)b * vecs;
+        const uint4 *src = reinterpret_cast<const uint4 *>(smem);
+        for (uint32_t pc = threadIdx.x; pc < vecs; pc += kApplyThreads) dst[pc] = src[pc];
+    }
     constexpr int D = 8;  // (48 LDS words + 8 groups per lane stay inside the 128 VGPRs of a 1024-thread workgroup, see k_bloom_gather)
     for_each_batch_at<D>(buckets, segcnt, g, b, make_uint4(0, 0, 0, 0), [&](const uint4 (&q)[D], const uint64_t (&at)[D], const uint32_t (&)[D]) {
         uint32_t w[D][6];

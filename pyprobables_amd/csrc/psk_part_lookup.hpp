@@ -5,6 +5,8 @@
 #include "psk_lookup.hpp"
 #include "psk_nibble.hpp"
 
+extern PSK_HIDDEN int64_t g_cbf_shadow_hits;  // nibble-slice lookups that loaded kept images (psk_sketch::shadow)
+
 // Keys per round.  Measured on MI355X (10 M CMS lookups): one round of 10 M keys 432 us, two 446, three cache-sized ones 464
 // -- the three kernels of a round stream ~50 B per key once and every round re-reads the table, so unlike the update
 // paths (part_round_keys) rounds are only cut at `partition_max_keys`.
@@ -115,14 +117,44 @@ static inline int cbf_check_nibble(psk_sketch *s, const Batch &b, uint32_t kk, u
     // pass 2 reads the WHOLE table (4 B per counter at ~4.4 TB/s: 0.25 ms for 2^28 counters) where the direct kernel fetches one
     // 64-byte line per probe (52 G probes/s): worth it from about cells / 16 probes on (measured on the 1 GiB table: a 0.5 M-key
     // lookup 67 us direct, 0.4 ms through the slices)
-    if (g_lookup_nibble != 2 && b.n * (uint64_t)kk < cells / 16) return PSK_OK;  // (2: always -- tests)
     PartGeom g;
     if (!nib_geometry(cells, false, &g)) return PSK_OK;
     g.k = kk;
+    const uint64_t shadow_words = (uint64_t)g.nbuckets << (g.shift - 3);
+    // (with the table's 4-bit images at hand -- psk_sketch::shadow, below -- the pass reads 1/8 of that: from cells / 64 probes on;
+    // measured on the 1 GiB table: 1 M keys 134 us direct, ~75 us through kept images)
+    const bool shadow_ready = g_cbf_shadow != 0 && s->shadow.allow && s->shadow.built == s->table_version && s->shadow.words == shadow_words &&
+                              s->shadow.stream == st && s->shadow.img.p != nullptr;
+    const bool may_shadow = g_cbf_shadow != 0 && s->shadow.allow;
+    if (may_shadow) {  // lookups in a row that found this version of the table (this one included)
+        if (s->shadow.seen == s->table_version) ++s->shadow.seen_count;
+        else s->shadow.seen = s->table_version, s->shadow.seen_count = 1;
+    }
+    const uint64_t probes = b.n * (uint64_t)kk;
+    if (g_lookup_nibble != 2) {  // (2: always -- tests)
+        // below the crossover of the plain pass a batch takes the slices only through kept images -- or, the third such lookup in a
+        // row of an unchanged table, to leave them behind (one pass over the table, repaid by the lookups that follow)
+        if (probes < cells / 64) return PSK_OK;
+        if (probes < cells / 16 && !shadow_ready && !(may_shadow && s->shadow.seen_count >= 3)) return PSK_OK;
+    }
     const uint64_t round_keys = lookup_round_keys(b.n, kk);
     PSK_TRY(ensure(s->s_flag, 8));
     uint32_t *flag = (uint32_t *)s->s_flag.p, *amb = flag + 1;  // [0] a segment overflowed, [1] a key's answer is ambiguous (15)
     HIP_TRY(hipMemsetAsync(flag, 0, 8, st));
+    // The 4-bit images of an unchanged table (psk_sketch::shadow): loaded when they mirror this version of the table; left behind
+    // when they will be read again -- a second round of this call, or the second lookup in a row that finds the table unchanged.
+    bool shadow_used = false;
+    const uint32_t *shadow_in = nullptr;
+    uint32_t *shadow_out = nullptr;
+    if (g_cbf_shadow != 0 && s->shadow.allow) {
+        if (shadow_ready) {
+            shadow_in = (const uint32_t *)s->shadow.img.p;
+        } else if (b.n > round_keys || s->shadow.seen_count >= 2) {
+            // (an allocation failure only costs the shortcut)
+            if (s->shadow.img.cap >= shadow_words * 4 || ensure(s->shadow.img, shadow_words * 4) == PSK_OK) shadow_out = (uint32_t *)s->shadow.img.p;
+            s->shadow.built = ~0ULL;  // until the first round below has been enqueued
+        }
+    }
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
         const Batch sub = sub_batch(b, start, cnt);
@@ -148,8 +180,17 @@ static inline int cbf_check_nibble(psk_sketch *s, const Batch &b, uint32_t kk, u
                 const size_t lds2 = (size_t)1 << (g.shift - 1);
                 PSK_TRY(set_dyn_lds(k_nib_gather, lds2));
                 hipLaunchKernelGGL(k_nib_gather, dim3(g.nbuckets), dim3(kApplyThreads), lds2, st, (const uint32_t *)s->table, cells, g,
-                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint32_t *)s->s_vals.p, (uint32_t)(g_nib_nt != 0));
+                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint32_t *)s->s_vals.p, (uint32_t)(g_nib_nt != 0), shadow_in,
+                                   shadow_out);
                 HIP_TRY(hipGetLastError());
+                shadow_used = shadow_used || shadow_in != nullptr;
+                if (shadow_out) {  // the images are complete behind this launch: the next round / lookup on this stream loads them
+                    s->shadow.built = s->table_version;
+                    s->shadow.words = shadow_words;
+                    s->shadow.stream = st;
+                    shadow_in = shadow_out;
+                    shadow_out = nullptr;
+                }
                 const uint32_t stage_cap = (uint32_t)(((size_t)g.tile * kq + (size_t)5 * g.nbuckets + 3) & ~(size_t)3);
                 const uint32_t stage_groups = stage_cap / 6 + 1;
                 const size_t lds3 = (size_t)8 * g.nbuckets + (size_t)4 * ((stage_groups + 3) & ~3u);
@@ -167,6 +208,7 @@ static inline int cbf_check_nibble(psk_sketch *s, const Batch &b, uint32_t kk, u
         }));
         if (!handled || !fits) return PSK_OK;  // (only ever on the first round: nothing was launched)
     }
+    if (shadow_used) ++g_cbf_shadow_hits;  // (calls that loaded the images; option "cbf_lookup_shadow_hits": tests)
     PSK_TRY(recheck(amb, st));  // keys whose counters are all 15 or more: answered from the table itself (flag-guarded)
     PSK_TRY(redo(flag, st));     // a segment overflowed: exact redo of the batch by the direct kernel (flag-guarded)
     *done = true;

@@ -9,7 +9,7 @@ ROOT = Path(__file__).resolve().parent.parent
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r03"
 src = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / TAG
 names = {"bloom_add": "bloom_insert", "bloom_check": "bloom_check", "bloom_check_fresh": "bloom_check_all_fresh", "cms_add": "cms_add_weighted",
-         "cms_check": "cms_check", "cbf_add": "cbf_add", "cbf_check": "cbf_check", "cbf_remove": "cbf_remove", "cfg4_stream": "cfg4_stream",
+         "cms_check": "cms_check", "cbf_add": "cbf_add", "cbf_check": "cbf_check", "cbf_check_kept": "cbf_check_unchanged_table", "cbf_remove": "cbf_remove", "cfg4_stream": "cfg4_stream",
          "bloom31_add": "bloom31_insert", "bloom31_check": "bloom31_check"}
 SCALABLE = {"bloom31_add", "bloom31_check"}  # measured on one 2^25-key call; cfg 5 makes ceil(n / 2^25) such calls per step
 out = {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run one engine operation repeatedly (for rocprofv3 --kernel-trace --stats / --pmc):  prof_ops.py <op> [n] [iters]
-ops: bloom_add bloom_check bloom_check_fresh bloom31_add bloom31_check cms_add cms_add_unit cms_check cbf_add cbf_check cbf_remove cbf25_check cbf25_add
+ops: bloom_add bloom_check bloom_check_fresh bloom31_add bloom31_check cms_add cms_add_unit cms_check cbf_add cbf_check cbf_check_kept cbf_remove cbf25_check cbf25_add
      cfg4_stream (n = keys per batch, 50 batches: BASELINE cfg 4's add / remove stream, write-combined, flush included)"""
 import sys
 from pathlib import Path
@@ -71,7 +71,12 @@ else:
     s = pa.CountingBloomFilter(est_elements=3_500_000, false_positive_rate=0.01) if op.startswith("cbf25") else \
         pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01)
     s.add_many(keys)
-    fn = {"add": lambda: s.add_many(keys), "check": lambda: s.check_many(keys), "remove": lambda: (s.add_many(keys), s.remove_many(keys))}[op.split("_", 1)[1]]  # (remove: the keys go back in first, so that every remove finds its key)
+    # check: a lookup of a table that has just changed (the whole 32-bit table is read: the kept 4-bit images are switched off);
+    # check_kept: the third and later lookups in a row of an unchanged table (psk_sketch::shadow; the two set-up calls below build the images)
+    if op.endswith("_check"):
+        N.set_option("cbf_lookup_shadow", 0)
+    fn = {"add": lambda: s.add_many(keys), "check": lambda: s.check_many(keys), "check_kept": lambda: s.check_many(keys),
+          "remove": lambda: (s.add_many(keys), s.remove_many(keys))}[op.split("_", 1)[1]]  # (remove: the keys go back in first, so that every remove finds its key)
 launches = 2 + iters + (1 if op in ("bloom_add", "bloom31_add", "cms_add", "cbf_add", "cbf25_add") else 0)  # the set-up insert runs the same kernels
 for _ in range(2):
     fn()

@@ -14,14 +14,17 @@ for c in cfg3 cfg4 cfg5; do
   scripts/trace_bench.sh r03_$c --config $c --steps 3 --warmup 1 --spinup 0.2 > /dev/null 2>&1
   cp gpurun_out/trace_bench_r03_$c.txt "$OUT/rocprofv3_kernel_stats_$c.txt"
 done
-for op in cbf_check cbf_add cbf_remove cms_check bloom_check_fresh; do
-  scripts/trace_op.sh $op 10000000 5 > /dev/null 2>&1
+for op in cbf_check cbf_check_kept cbf_add cbf_remove cms_check bloom_check_fresh; do
+  scripts/trace_op.sh $op 10000000 $([ $op = cbf_check_kept ] && echo 40 || echo 5) > /dev/null 2>&1
   cp gpurun_out/trace_$op.txt "$OUT/rocprofv3_kernel_stats_$op.txt"
 done
 for op in bloom_add bloom_check bloom_check_fresh cms_add cms_check cbf_add cbf_check cbf_remove; do
   scripts/pmc_op.sh $op 10000000 5 > /dev/null 2>&1
   cp gpurun_out/pmc_$op.json "$OUT/"
 done
+# (40 launches: the two set-up lookups that build the kept images read the whole table and are averaged in -- ~ +8 %)
+scripts/pmc_op.sh cbf_check_kept 10000000 40 > /dev/null 2>&1
+cp gpurun_out/pmc_cbf_check_kept.json "$OUT/"
 for op in bloom31_add bloom31_check; do
   scripts/pmc_op.sh $op 33554432 3 > /dev/null 2>&1
   cp gpurun_out/pmc_$op.json "$OUT/"

@@ -374,3 +374,93 @@ def test_destroy_applies_waiting_updates_to_a_caller_owned_table(pa, oracle):
     oc = oracle.OracleCBF(m, k)
     oc.update_keys(keys)
     assert np.array_equal(table.cpu().numpy().view(np.uint32)[:m], oc.bloom)
+
+
+def test_repeated_lookups_keep_the_4bit_images_until_the_table_changes(pa, oracle, force_partition):
+    """read-mostly tables: the second lookup in a row that finds the table unchanged leaves its 4-bit slice images behind and the following
+    ones load them instead of the 32-bit table (psk_sketch::shadow); EVERY way of changing the table must drop them -- adds (direct,
+    write-combined, weighted), removes, clear, writes through the table tensor, import -- and so must a lookup on another stream"""
+    N = force_partition
+    hits = lambda: N.get_option("cbf_lookup_shadow_hits")
+    cbf = pa.CountingBloomFilter(est_elements=10_000_000, false_positive_rate=0.01)   # 9.6e7 counters, non power of two
+    m, k = cbf.number_bits, cbf.number_hashes
+    oc = oracle.OracleCBF(m, k)
+    base = oracle.gen_keys16(77, 700_000)
+    cbf.add_many(_dev(base[:400_000]))
+    oc.update_keys(base[:400_000])
+    probe = np.concatenate([base[:300_000], base[400_000:]])       # the second half is absent for now
+    dp = _dev(probe)
+
+    def looks(times, expect_hits):
+        h0 = hits()
+        for _ in range(times):
+            assert np.array_equal(cbf.check_many(dp).cpu().numpy().astype(np.uint32), oc.check_keys(probe))
+        assert hits() - h0 == expect_hits, (hits() - h0, expect_hits)
+
+    looks(4, 2)                                  # plain, build, load, load
+    cbf.add_many(_dev(base[400_000:450_000]))    # a small unit batch (waits as scattered probes; the lookup's flush applies it)
+    oc.update_keys(base[400_000:450_000])
+    looks(3, 1)
+    w = np.full(20_000, 3, dtype=np.uint32)
+    cbf.add_many(_dev(base[450_000:470_000]), w)  # weighted: the 32-bit paths
+    oc.update_keys(base[450_000:470_000], w.astype(np.int64))
+    looks(3, 1)
+    cbf.remove_many(_dev(base[:100_000]))        # validated remove (its own internal lookup must neither build nor load the images)
+    oc.update_keys(base[:100_000], -np.ones(100_000, dtype=np.int64))
+    looks(3, 1)
+    big = oracle.gen_keys16(5_000_000, 2_000_000)  # a batch large enough for the table pass
+    cbf.add_many(_dev(big))
+    oc.update_keys(big)
+    looks(3, 1)
+    cbf.remove_many(_dev(big))                   # optimistic decrement of the whole batch
+    oc.update_keys(big, -np.ones(big.shape[0], dtype=np.int64))
+    looks(3, 1)
+    # a write from outside through the table tensor: taking the property tells the engine
+    t = cbf.table_tensor
+    idx = [int(h % m) for h in oracle.default_fnv_1a(bytes(probe[-1]), k)]
+    for c in set(idx):
+        t[c] += 2
+        oc.bloom[c] += 2
+    looks(3, 1)
+    # another stream: the images were built on the first one
+    s2 = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    h0 = hits()
+    with torch.cuda.stream(s2):
+        got = cbf.check_many(dp)
+    s2.synchronize()
+    assert np.array_equal(got.cpu().numpy().astype(np.uint32), oc.check_keys(probe)) and hits() == h0
+    # several rounds in ONE call: the first round leaves the images behind for the others
+    N.set_option("partition_max_keys", 200_000)
+    try:
+        cbf.add_many(_dev(base[470_000:471_000]))
+        oc.update_keys(base[470_000:471_000])
+        h0 = hits()
+        assert np.array_equal(cbf.check_many(dp).cpu().numpy().astype(np.uint32), oc.check_keys(probe))
+        assert hits() - h0 == 1                  # (counted per call)
+    finally:
+        N.set_option("partition_max_keys", 1 << 26)
+    cbf.clear()
+    oc = oracle.OracleCBF(m, k)
+    looks(3, 1)
+    # below the crossover of the plain pass (here 1.5e6 <= probes < 6e6) a batch goes direct -- until the third lookup in a row finds the
+    # table unchanged: that one takes the slices and leaves the images behind, the following ones load them
+    N.set_option("lookup_nibble_slices", 1)
+    cbf.add_many(_dev(base[:300_000]))
+    oc.update_keys(base[:300_000])
+    small, want_small = dp[:400_000], oc.check_keys(probe[:400_000])
+    h0 = hits()
+    for _ in range(5):
+        assert np.array_equal(cbf.check_many(small).cpu().numpy().astype(np.uint32), want_small)
+    assert hits() - h0 == 2
+    tiny = dp[:100_000]                           # fewer than cells / 64 probes: always direct
+    assert np.array_equal(cbf.check_many(tiny).cpu().numpy().astype(np.uint32), want_small[:100_000]) and hits() - h0 == 2
+    N.set_option("lookup_nibble_slices", 2)
+    # the option off: same answers, nothing kept
+    N.set_option("cbf_lookup_shadow", 0)
+    try:
+        cbf.add_many(_dev(base[:50_000]))
+        oc.update_keys(base[:50_000])
+        looks(3, 0)
+    finally:
+        N.set_option("cbf_lookup_shadow", 1)
