@@ -203,3 +203,102 @@ def test_fuzz_big_tables(pa, oracle, engine_options, seed):
         assert np.array_equal(np.frombuffer(bytes(cbf.bloom), dtype=np.uint32), oc.bloom)
         assert cbf.elements_added == oc.els_added
         assert np.array_equal(cbf.check_many(dk[:50_000]).cpu().numpy().view(np.uint32), oc.check_keys(keys[:50_000]))
+
+
+# CountingBloomFilter state machine on tables large enough for the 4-bit slice images (psk_nibble.hpp): random sequences of unit / weighted
+# adds of every size class (direct, automatically write-combined, table pass), validated removes with present and absent keys, lookups above
+# and below the crossovers (repeated: the kept images of an unchanged table), clear, writes through the table tensor -- the whole table,
+# elements_added and every answer equal the oracle's after every operation
+@pytest.mark.parametrize("seed", range(8 + EXTRA // 20))
+def test_fuzz_cbf_big_table_state_machine(pa, oracle, engine_options, seed):
+    N = engine_options
+    rng = np.random.default_rng(9000 + seed)
+    names = ("lookup_nibble_slices", "nibble_min_lg_lookup", "nibble_min_lg_update", "auto_combine_keys", "remove_optimistic", "cbf_lookup_shadow")
+    old = {k: N.get_option(k) for k in names}
+    try:
+        N.set_option("partition", 1)
+        N.set_option("partition_min_keys", int(rng.choice([1, 4096])))
+        N.set_option("nibble_min_lg_lookup", int(rng.choice([20, 23])))
+        N.set_option("nibble_min_lg_update", int(rng.choice([20, 24])))
+        N.set_option("lookup_nibble_slices", int(rng.choice([1, 1, 2])))
+        N.set_option("auto_combine_keys", int(rng.choice([1 << 24, 1 << 19])))
+        N.set_option("remove_optimistic", int(rng.integers(0, 2)))
+        k_fpr = {4: 0.06, 5: 0.03, 7: 0.008, 10: 0.001}
+        k = int(rng.choice(list(k_fpr)))
+        cells_target = int(rng.choice([2**23 + 12345, 2**24, 3 * 2**23, 2**25 + 999, 2**26]))
+        est = int(cells_target * 0.4804530139182 / -np.log(k_fpr[k]))
+        cbf = pa.CountingBloomFilter(est_elements=est, false_positive_rate=k_fpr[k])
+        m = cbf.number_bits
+        assert cbf.number_hashes == k and m >= 2**22
+        oc = oracle.OracleCBF(m, k)
+        pool = oracle.gen_keys16(seed * 50_000_000, 6_000_000)
+        live = []          # (start, count) ranges of the pool that are in the filter exactly once more than removed
+        cursor = 0
+
+        def table_ok(what):
+            assert np.array_equal(cbf.table_tensor.cpu().numpy().view(np.uint32)[:m], oc.bloom), what
+            assert cbf.elements_added == oc.els_added, what
+
+        for step in range(int(rng.integers(6, 11))):
+            op = int(rng.choice([0, 0, 1, 2, 2, 3, 3, 3, 4, 5]))
+            if op == 0 or not live:      # unit add of a fresh range
+                n = int(rng.choice([3_000, 60_000, 400_000, 1_500_000]))
+                n = min(n, pool.shape[0] - cursor)
+                if n <= 0:
+                    continue
+                ks = pool[cursor:cursor + n]
+                cbf.add_many(_dev(ks) if rng.integers(0, 4) else ks)
+                oc.update_keys(ks)
+                live.append((cursor, n))
+                cursor += n
+                what = f"step {step}: unit add of {n}"
+            elif op == 1:                # weighted add on top of a live range
+                s0, n0 = live[int(rng.integers(0, len(live)))]
+                n = min(n0, int(rng.choice([2_000, 200_000])))
+                w = rng.integers(1, 5, size=n).astype(np.uint32)
+                cbf.add_many(_dev(pool[s0:s0 + n]), _dev(w.view(np.int32)))
+                oc.update_keys(pool[s0:s0 + n], w.astype(np.int64))
+                what = f"step {step}: weighted add of {n}"   # (the extra weight stays in: only one unit per key is ever taken back below)
+            elif op == 2:                # validated remove: (part of) a live range, sometimes with absent keys mixed in
+                s0, n0 = live.pop(int(rng.integers(0, len(live))))
+                n = n0 if rng.integers(0, 2) else max(n0 // 2, 1)
+                ks = pool[s0:s0 + n]
+                if n0 - n:
+                    live.append((s0 + n, n0 - n))
+                if rng.integers(0, 2):
+                    absent = oracle.gen_keys16(3_000_000_000 + step * 1_000_000 + seed, int(rng.choice([100, 50_000])))
+                    absent = absent[oc.check_keys(absent) == 0]
+                    ks = np.concatenate([ks, absent])
+                cbf.remove_many(_dev(ks))
+                oc.update_keys(ks, -np.ones(ks.shape[0], dtype=np.int64))   # (the oracle's remove of an absent key is the reference's no-op)
+                what = f"step {step}: remove of {ks.shape[0]}"
+            elif op == 3:                # lookups, repeated: present, removed and never-seen keys
+                n = int(rng.choice([5_000, 300_000, 1_200_000]))
+                hi = max(cursor, 1)
+                s0 = int(rng.integers(0, hi))
+                probe = np.concatenate([pool[s0:s0 + n // 2], oracle.gen_keys16(4_000_000_000 + step, n - n // 2)])
+                dp = _dev(probe)
+                want = oc.check_keys(probe)
+                for rep in range(int(rng.integers(1, 5))):
+                    assert np.array_equal(cbf.check_many(dp).cpu().numpy().view(np.uint32), want), f"step {step}: lookup {rep} of {n}"
+                continue
+            elif op == 4:                # a write from outside through the table tensor
+                t = cbf.table_tensor
+                cells = rng.integers(0, m, size=50)
+                for c in np.unique(cells):
+                    t[int(c)] += 1
+                    oc.bloom[int(c)] += 1
+                what = f"step {step}: outside write"
+            else:
+                if rng.integers(0, 3):
+                    continue
+                cbf.clear()
+                oc = oracle.OracleCBF(m, k)
+                live, what = [], f"step {step}: clear"
+            if rng.integers(0, 2):
+                table_ok(what)
+        table_ok("end")
+        assert cbf.batch_diagnostics()["saturated"] == 0
+    finally:
+        for kx, v in old.items():
+            N.set_option(kx, v)
