@@ -627,3 +627,55 @@ def test_work_follows_torchs_current_stream(pa, oracle):
         ob.add_keys(keys[lo:hi])
         assert np.array_equal(np.frombuffer(bytes(blm.bloom), dtype=np.uint8), ob.bloom)
         assert np.array_equal(res.cpu().numpy().astype(np.uint8), ob.check_keys(keys))
+
+
+def test_exports_match_the_reference_text_for_text(pa, tmp_path):
+    """export_c_header / export / export_hex / bytes / export_size / the statistics string of small filters against what the REAL
+    reference wrote for the same keys (tests/golden/golden_export.json, generated by tests/golden/gen_golden_export.py:
+    bloom.py:274-338, countingbloom.py:80-123, countminsketch.py:147-166), and the files load back (frombytes / filepath)"""
+    import hashlib
+    import json
+    from pathlib import Path
+
+    cases = json.loads((Path(__file__).resolve().parent / "golden" / "golden_export.json").read_text())["cases"]
+
+    def same(got: str, want):
+        if isinstance(want, dict):
+            return len(got) == want["len"] and hashlib.sha256(got.encode("utf-8")).hexdigest() == want["sha256"]
+        return got == want
+
+    for c in cases:
+        if c["kind"] == "cms":
+            s = pa.CountMinSketch(width=c["width"], depth=c["depth"])
+            for kx, w in zip(c["keys"], c["weights"]):
+                s.add(kx, w)
+            assert bytes(s).hex() == c["bytes_hex"] and str(s) == c["str"] and s.elements_added == c["elements_added"]
+            assert [s.check(kx) for kx in c["keys"]] == c["checks"]
+            f = tmp_path / "s.cms"
+            s.export(str(f))
+            assert f.read_bytes().hex() == c["file_hex"]
+            back = pa.CountMinSketch(filepath=str(f))
+            assert bytes(back).hex() == c["bytes_hex"] and [back.check(kx) for kx in c["keys"]] == c["checks"]
+            continue
+        cls = pa.BloomFilter if c["kind"] == "bloom" else pa.CountingBloomFilter
+        flt = cls(est_elements=c["est_elements"], false_positive_rate=c["false_positive_rate"])
+        for kx in c["keys"]:
+            flt.add(kx)
+        if c["kind"] == "cbf":
+            flt.add(c["keys"][0], 5)
+            flt.remove(c["keys"][1])
+        h = tmp_path / "f.h"
+        flt.export_c_header(str(h))
+        assert same(h.read_text(encoding="utf-8"), c["c_header"]), c["kind"]
+        assert flt.export_size() == c["export_size"]
+        assert same(flt.export_hex(), c["export_hex"]) and same(bytes(flt).hex(), c["bytes_hex"])
+        f = tmp_path / "f.blm"
+        flt.export(str(f))
+        assert same(f.read_bytes().hex(), c["file_hex"])
+        assert str(flt) == c["str"]
+        assert flt.estimate_elements() == c["estimate_elements"] and flt.elements_added == c["elements_added"]
+        assert flt.current_false_positive_rate() == c["current_false_positive_rate"]
+        back = cls(filepath=str(f))
+        assert same(bytes(back).hex(), c["bytes_hex"]) and all(back.check(kx) for kx in c["keys"] if kx != c["keys"][1] or c["kind"] == "bloom")
+        again = cls.frombytes(f.read_bytes())
+        assert same(again.export_hex(), c["export_hex"])
