@@ -1072,7 +1072,6 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = blockIdx.x;
     const uint32_t slice_words = 1u << (g.shift - 5);
-    const uint32_t mask = (1u << g.shift) - 1;
     for (uint32_t w = threadIdx.x; w < slice_words; w += kApplyThreads) smem[w] = 0;
     __syncthreads();
     // group = two 64-bit halves of 3 x 20-bit slice-local bit indices, valid count in bits 60..63
