@@ -117,11 +117,6 @@ struct psk_sketch {
         unsigned long long *dev = nullptr;           // [0] misses of the call in flight
         volatile unsigned long long *pin = nullptr;  // [0] misses, [1] units (probes or keys), [2] scheme that produced them
         int mode = 0;                                // 0 keyed probes + miss stores, 1 return trip
-        // the tally is published every kPublishEvery-th call of a run of same-scheme calls (a one-thread kernel writing pinned host
-        // memory is ~5 us of stream time: 1 % of the headline step); `units` / `calls` accumulate what the device tally has seen since
-        unsigned long long units = 0;
-        uint32_t calls = 0;
-        int scheme = -1;
     } lk;
     // write-combined CBF updates (psk_cbf_update_combined): key batches wait here until a list is full, then each list is
     // applied as ONE partitioned update (the fold of a big table read-modify-writes the whole table whatever the batch size)
