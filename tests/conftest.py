@@ -41,4 +41,11 @@ def _engine_options_from_env():
         from pyprobables_amd import _native as N
 
         N.set_option("partition_min_keys", int(val))
+    # PSK_TEST_OPTS="cbf_lookup_shadow=0,auto_combine=0" pytest -m gpu ...: the suite under other engine defaults (robustness sweeps; the
+    # tests that pin a default's own mechanics -- image loads counted, batches left waiting -- are expected to object, parity must not)
+    for kv in os.environ.get("PSK_TEST_OPTS", "").split(","):
+        if "=" in kv:
+            from pyprobables_amd import _native as N
+
+            N.set_option(kv.split("=")[0].strip(), int(kv.split("=")[1], 0))
     yield
