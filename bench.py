@@ -471,7 +471,7 @@ def side_measurements(ctx: Ctx, n, blm, keys):
     cms = pa.CountMinSketch(width=2**20, depth=5, device=dev)
     ms = timed_loop(torch, lambda: cms.add_many(keys, w), 5)
     out["cms_add_Mupd_s"] = n / ms / 1e3
-    rl["cms_add"] = roofline("cms_add", "CMS weighted add = k_part_scatter<...,IdxCms<pow2>,PayWeight,...,5> (sums the weights) + k_tally_fold + k_counter_apply",
+    rl["cms_add"] = roofline("cms_add", "CMS weighted add = k_part_scatter<...,IdxCms<pow2>,PayWeightSmall (weights 0..15 as 20-bit fields; PayWeight otherwise),...,5> (sums the weights) + k_tally_fold + k_counter_apply",
                              n, ms, "pass 1 (5 FNV-1a chains + LDS counting sort), pass 2 folds 2^15-cell slices", "cms_add_weighted")
     ms = timed_loop(torch, lambda: cms.check_many(keys), 5)
     out["cms_check_Mkeys_s"] = n / ms / 1e3
@@ -585,7 +585,7 @@ class Cfg3:
                                    "(10 passes over 10M 16-byte keys, weights 1..7) + (SUM merge)",
                        "keys_per_rank": n, "passes": self.PASSES, "width": 2**20, "depth": 5,
                        "parallelism": f"key-range x{ctx.world}, replica per GPU, allreduce(SUM)" if ctx.world > 1 else "single GPU"},
-            "roofline": roofline("cms_add", "CMS weighted add = k_part_scatter<...,IdxCms<pow2>,PayWeight,...,5> (sums the weights) + k_tally_fold + k_counter_apply "
+            "roofline": roofline("cms_add", "CMS weighted add = k_part_scatter<...,IdxCms<pow2>,PayWeightSmall (weights 0..15 as 20-bit fields; PayWeight otherwise),...,5> (sums the weights) + k_tally_fold + k_counter_apply "
                                  "(one pass of 10M updates between two HIP events)", n, add_ms,
                                  "pass 1 (5 FNV-1a chains + LDS counting sort), pass 2 folds 2^15-cell slices", "cms_add_weighted"),
             "rooflines": {"cms_check": roofline("cms_check", "CMS lookup (min over 5 rows)", n, chk_ms, "see DESIGN.md 3.2")},

@@ -152,6 +152,7 @@ extern "C" int psk_destroy(psk_sketch *s)
     if (s->ctr) hipFree(s->ctr);
     if (s->lk.dev) hipFree(s->lk.dev);
     if (s->lk.pin) hipHostFree((void *)s->lk.pin);
+    if (s->wt.pin) hipHostFree((void *)s->wt.pin);
     for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
                       &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->s_brw, &s->shadow.img}) {
         if (b->p) hipFree(b->p);
@@ -472,6 +473,7 @@ int64_t g_lookup_collect_threads = 1024;
 int64_t g_remove_dryrun = 1;   // validated unit-weight CBF removes into big tables: optimistic decrement first (psk_nibble.hpp), option "remove_optimistic"
 int64_t g_scratch_budget = 0;  // psk_set_option("scratch_budget_bytes"): cap on a handle's partition scratch (more, smaller rounds); 0 = none
 int64_t g_lookup_nibble = 1;   // CBF lookups into 2^25 .. 2^29 counters: 4-bit slice images (psk_nibble.hpp) from cells / 16 probes on; 2 = always; 0 = the 32-bit / 16-bit slices or direct
+int64_t g_small_weights = 1;   // PayWeightSmall for weighted CountMinSketch adds (psk_sketch::wt)
 int64_t g_cbf_shadow_hits = 0;
 int64_t g_cbf_shadow = 1;  // nibble-slice lookups keep their 4-bit images while the table is unchanged (psk_sketch::shadow; cells / 2 bytes)
 int64_t g_nib_nt = 1;   // nontemporal table loads in k_nib_gather (1 GiB lookups 710 -> 656 us per 10 M keys); the fold of k_nib_apply re-writes what it
@@ -516,6 +518,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "nibble_min_lg_update")) g_nib_min_lg_update = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_nt_loads")) g_nib_nt = value;
     else if (!strcmp(name, "cbf_lookup_shadow")) g_cbf_shadow = value;
+    else if (!strcmp(name, "cms_small_weights")) g_small_weights = value;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
 }
@@ -562,6 +565,7 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "nibble_min_lg_update")) *value = g_nib_min_lg_update;
     else if (!strcmp(name, "nibble_nt_loads")) *value = g_nib_nt;
     else if (!strcmp(name, "cbf_lookup_shadow")) *value = g_cbf_shadow;
+    else if (!strcmp(name, "cms_small_weights")) *value = g_small_weights;
     else if (!strcmp(name, "cbf_lookup_shadow_hits")) *value = g_cbf_shadow_hits;
     else if (!strcmp(name, "scatter_workgroups")) *value = g_part_wgs;
     else if (!strcmp(name, "slice_bias")) *value = g_part_slice_bias;

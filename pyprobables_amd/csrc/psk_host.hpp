@@ -153,6 +153,15 @@ struct psk_sketch {
         hipStream_t last = nullptr;
         bool appended = false;
     } scat;
+    // Probe format of the next weighted counter add (PayWeight: 4 bytes per probe, any weight; PayWeightSmall: 2.7, weights 0 .. 15 in the
+    // group, others straight to the table): follows what pass 1 of the previous weighted batches counted -- k_tally_fold leaves
+    // (weights outside 0 .. 15, batch number) on a pinned page, read without synchronisation.  One such weight keeps the wide format
+    // for the next 64 batches.
+    struct {
+        volatile unsigned long long *pin = nullptr;
+        unsigned long long issued = 0, seen = 0;
+        uint32_t backoff = 0;
+    } wt;
     PartGeom rm_g{};     // geometry of the validated remove's fast path between its optimistic decrement and a possible undo
     // Read-mostly CountingBloomFilter tables (round 3): the nibble-slice lookup reads the whole 32-bit table to build its 4-bit
     // images (1 GiB for BASELINE cfg 4).  When the table has not changed since the previous lookup the images are kept -- a linear
@@ -196,6 +205,7 @@ extern PSK_HIDDEN int64_t g_part_slice_bias;     // bench knob: added to log2(ce
 extern PSK_HIDDEN int64_t g_part_tile_threads;   // pass 1 workgroup shape for k <= 8: 0 = auto (launch_scatter), 512 / 1024 = forced
 extern PSK_HIDDEN int64_t g_part_even_tiles;     // 1 (default): pass 1 evens the tile size out over the workgroups
 extern PSK_HIDDEN int64_t g_lookup_half;           // 1 (default): counter lookups into 2^26 .. 2^27 counters use 2^16-counter slices of 16-bit values
+extern PSK_HIDDEN int64_t g_small_weights;     // weighted CMS adds: 0 never the compact probe format, 1 by the hint, 2 always (tests)
 extern PSK_HIDDEN int64_t g_cbf_shadow;         // keep the nibble-slice lookup's images of an unchanged table
 extern PSK_HIDDEN int64_t g_nib_nt;             // nontemporal table loads in the nibble-slice kernels (bench A/B)
 extern PSK_HIDDEN int64_t g_nib_update_layout;  // delta-image layout of k_nib_apply: 0 pieces, 1 blocks (psk_nibble.hpp)

@@ -11,8 +11,8 @@ static inline int pay_weights(psk_sketch *s, const uint32_t *w_dev, uint64_t sta
 {
     *pay = PayWeight{w_dev ? w_dev + start : nullptr};
     if (w_dev && s->acct.pending) {
-        PSK_TRY(ensure(s->s_tally, 1024 * sizeof(ulonglong2)));  // one slot per pass-1 workgroup (<= 512)
-        pay->tally = (ulonglong2 *)s->s_tally.p;
+        PSK_TRY(ensure(s->s_tally, 1024 * sizeof(ulonglong4)));  // one slot per pass-1 workgroup (<= 512)
+        pay->tally = (ulonglong4 *)s->s_tally.p;
         pay->weights_signed = s->acct.weights_signed ? 1 : 0;
     }
     return PSK_OK;
@@ -22,10 +22,32 @@ static inline int pay_weights(psk_sketch *s, const uint32_t *w_dev, uint64_t sta
 static inline int fold_tally(psk_sketch *s, const PayWeight &pay, uint32_t nwg, hipStream_t st)
 {
     if (!pay.tally) return PSK_OK;
-    hipLaunchKernelGGL(k_tally_fold, dim3(1), dim3(256), 0, st, (const ulonglong2 *)pay.tally, nwg, s->ctr, s->acct.which, s->acct.bound_mult,
-                       s->acct.grow_bound ? 1 : 0);
+    if (!s->wt.pin) {  // the page the next batch's choice of probe format reads (psk_sketch::wt)
+        void *pin = nullptr;
+        HIP_TRY(hipHostMalloc(&pin, 32, hipHostMallocDefault));
+        s->wt.pin = (volatile unsigned long long *)pin;
+        s->wt.pin[0] = s->wt.pin[1] = 0;
+    }
+    hipLaunchKernelGGL(k_tally_fold, dim3(1), dim3(256), 0, st, (const ulonglong4 *)pay.tally, nwg, s->ctr, s->acct.which, s->acct.bound_mult,
+                       s->acct.grow_bound ? 1 : 0, s->wt.pin, ++s->wt.issued);
     HIP_TRY(hipGetLastError());
     return PSK_OK;
+}
+
+// the compact probe format for this weighted batch?  (exact either way: a weight outside 0 .. 15 goes to the table directly -- at the atomics'
+// rate, hence the hint: the count of such weights pass 1 of the previous batches saw)
+static inline bool small_weights_wanted(psk_sketch *s)
+{
+    if (g_small_weights != 1) return g_small_weights == 2;
+    if (!s->wt.pin) return false;
+    const unsigned long long big = s->wt.pin[0], seq = s->wt.pin[1];
+    if (seq == 0) return false;  // nothing published yet
+    if (seq != s->wt.seen) {
+        s->wt.seen = seq;
+        if (big) s->wt.backoff = 64;
+        else if (s->wt.backoff) --s->wt.backoff;
+    }
+    return s->wt.backoff == 0;
 }
 
 // One round of pass 1 for the NIBBLE update path (psk_nibble.hpp): 6 x 20-bit probe groups of the keys of `sub` (all of them, or -- mask
@@ -174,7 +196,11 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
         return PSK_OK;
     }
     if (g.nbuckets > (uint32_t)kPartMaxBuckets) return PSK_OK;
-    const uint64_t round_keys = part_round_keys_big_table(b.n, s->k, w_dev ? PayWeight::group : PayUnit::group, s->padded_bytes);
+    // weighted CountMinSketch adds: the compact probe format (PayWeightSmall) when the table allows it (the stage holds weight << 27 | cell)
+    // and the previous weighted batches brought no weight outside 0 .. 15
+    bool small_fmt = false;
+    if constexpr (SIGNED && !NEG) small_fmt = w_dev != nullptr && cells < (1ULL << kSmallWeightShift) && g.shift <= 15 && small_weights_wanted(s);
+    const uint64_t round_keys = part_round_keys_big_table(b.n, s->k, w_dev ? (small_fmt ? PayWeightSmall::group : PayWeight::group) : PayUnit::group, s->padded_bytes);
     unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
@@ -188,6 +214,14 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
                 constexpr int KT = decltype(kt)::value;
                 SpillCounter<SIGNED> spill{(uint32_t *)s->table, w_dev == nullptr, NEG, sat};
                 if (w_dev) {
+                    if constexpr (SIGNED && !NEG && std::is_same<Src, KeysFixed16>::value) {  // (the fast key layout only: instantiations)
+                        if (small_fmt) {
+                            const PayWeightSmall pay{payw.w, payw.tally, payw.weights_signed};
+                            return launch_scatter<Src, IDX<kTuPow2>, PayWeightSmall, SpillCounter<SIGNED>, KT>(s, src, IDX<kTuPow2>{s->md}, pay, spill, &g, cnt, st);
+                        }
+                    } else {
+                        small_fmt = false;
+                    }
                     const PayWeight pay = payw;
                     return launch_scatter<Src, IDX<kTuPow2>, PayWeight, SpillCounter<SIGNED>, KT>(s, src, IDX<kTuPow2>{s->md}, pay, spill, &g, cnt, st);
                 }
@@ -197,7 +231,14 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
         if (!handled) return PSK_OK;
         PSK_TRY(fold_tally(s, payw, g.nwg, st));
         const size_t lds = (size_t)4 << g.shift;
-        if (w_dev) {
+        if (w_dev && small_fmt) {
+            if constexpr (SIGNED && !NEG) {
+                auto kern = k_counter_apply<SIGNED, 2, NEG>;
+                PSK_TRY(set_dyn_lds(kern, lds));
+                hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g,
+                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (const long long *)s->ctr, sat);
+            }
+        } else if (w_dev) {
             auto kern = k_counter_apply<SIGNED, true, NEG>;
             PSK_TRY(set_dyn_lds(kern, lds));
             hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g,

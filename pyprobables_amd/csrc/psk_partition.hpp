@@ -121,6 +121,10 @@ struct pay_has_keep { static constexpr bool value = false; };
 template <class Pay>
 struct pay_has_keep<Pay, decltype((void)&Pay::keep)> { static constexpr bool value = true; };
 template <class Pay, class = void>
+struct pay_weighted_plain { static constexpr bool value = false; };
+template <class Pay>
+struct pay_weighted_plain<Pay, decltype((void)Pay::weighted_plain)> { static constexpr bool value = Pay::weighted_plain; };
+template <class Pay, class = void>
 struct pay_is_lookup { static constexpr bool value = false; };
 template <class Pay>
 struct pay_is_lookup<Pay, decltype((void)Pay::lookup)> { static constexpr bool value = Pay::lookup; };
@@ -152,9 +156,25 @@ struct PayWeight {
     // every weight anyway, so every workgroup also leaves (sum w, sum |w|) of its keys in tally[blockIdx.x] -- plain stores,
     // no atomics: 768 same-address atomics at the kernel's end cost as much as the pass they replaced -- and the one-block
     // k_tally_fold between pass 1 and pass 2 adds the slots into the handle's device counters.  null: nothing to account.
-    ulonglong2 *tally = nullptr;
+    ulonglong4 *tally = nullptr;   // (sum w, sum |w|, weights outside 0 .. 15, -)
     int weights_signed = 0;
     __device__ __forceinline__ uint32_t operator()(uint64_t i, uint64_t) const { return w ? w[i] : 1u; }
+};
+// Weighted counter adds whose weights fit four bits (1 .. 15: what a count-min sketch is fed in practice; round 3): PayNone's 6 x 20-bit
+// groups with field = weight << 15 | 15-bit slice-local cell -- 2.7 bytes per probe instead of PayWeight's 4, and the plain stage (no
+// per-group slice ids).  The LDS stage holds weight << 27 | cell (tables below 2^27 cells; bit 31 stays the pad marker).  A weight of 0
+// travels as a field that adds nothing; one of 16 or more (any negative one) goes to the table directly -- exact saturating add -- and
+// leaves such a field behind.  The host picks this format when the previous weighted batches had no such weight (PayWeight::tally's
+// third count, published to a pinned page by k_tally_fold).
+constexpr uint32_t kSmallWeightBits = 4, kSmallWeightShift = 27, kSmallCellMask = (1u << kSmallWeightShift) - 1;
+struct PayWeightSmall {
+    static constexpr int mode = kModePlain;
+    static constexpr int group = 6;
+    static constexpr bool weighted_plain = true;
+    const uint32_t *w;
+    ulonglong4 *tally = nullptr;
+    int weights_signed = 0;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i, uint64_t) const { return w[i]; }
 };
 struct PayZero {   // level 1 of the two-level Bloom insert: 4 x 32-bit (0 << shift | bit index inside the coarse bucket)
     static constexpr int group = 4;
@@ -298,7 +318,8 @@ __device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t
             const uint4 a1 = reinterpret_cast<const uint4 *>(stage)[2 * gi + 1];
             c[0] = a0.x; c[1] = a0.y; c[2] = a0.z; c[3] = a0.w; c[4] = a1.x; c[5] = a1.y; c[6] = a1.z; c[7] = a1.w;
         }
-        const uint32_t b = c[0] >> g.shift;
+        constexpr bool WP = pay_weighted_plain<Pay>::value;  // stage word = weight << 27 | cell
+        const uint32_t b = (WP ? c[0] & kSmallCellMask : c[0]) >> g.shift;
         const uint32_t slot = delta[b] + gi;
         if (slot < g.segcap) {
             uint4 o;
@@ -307,10 +328,13 @@ __device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t
                 // (cells are < 2^31 and the pad is all ones: the sign bits of c[1..5] count the pads -- no compare / carry chains)
                 const uint32_t nv = 6u - ((c[1] >> 31) + (c[2] >> 31) + (c[3] >> 31) + (c[4] >> 31) + (c[5] >> 31));
                 const uint32_t n0 = nv < 3 ? nv : 3, n1 = nv - n0;
-                const unsigned long long h0 = (unsigned long long)(c[0] & mask) | ((unsigned long long)(c[1] & mask) << 20) |
-                                              ((unsigned long long)(c[2] & mask) << 40) | ((unsigned long long)n0 << 60);
-                const unsigned long long h1 = (unsigned long long)(c[3] & mask) | ((unsigned long long)(c[4] & mask) << 20) |
-                                              ((unsigned long long)(c[5] & mask) << 40) | ((unsigned long long)n1 << 60);
+                // (weighted: field = weight << 15 | cell in the slice; a pad's field is never read -- n0 / n1 say how many are valid)
+                // (a pad -- all ones -- becomes the all-zero field: weight 0, so pass 2 needs no count test per field)
+                auto fld = [&](uint32_t x) -> unsigned long long {
+                    return WP ? (unsigned long long)(((x & mask) | ((x >> kSmallWeightShift) << 15)) & ~(uint32_t)((int32_t)x >> 31)) : (unsigned long long)(x & mask);
+                };
+                const unsigned long long h0 = fld(c[0]) | (fld(c[1]) << 20) | ((fld(c[2]) & 0xFFFFFull) << 40) | ((unsigned long long)n0 << 60);
+                const unsigned long long h1 = fld(c[3]) | (fld(c[4]) << 20) | ((fld(c[5]) & 0xFFFFFull) << 40) | ((unsigned long long)n1 << 60);
                 o = make_uint4((uint32_t)h0, (uint32_t)(h0 >> 32), (uint32_t)h1, (uint32_t)(h1 >> 32));
             } else {
                 auto h16 = [&](uint32_t x) -> uint32_t { return (x & mask) | ((uint32_t)((int32_t)x >> 31) & 0xFFFFu); };  // pad (all ones) -> 0xFFFF
@@ -321,7 +345,10 @@ __device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t
         } else {  // segment full: exact fallback, probe by probe
 #pragma unroll
             for (int e = 0; e < GS; ++e)
-                if (c[e] != kPadProbe) spill(c[e], 0u);
+                if (c[e] != kPadProbe) {
+                    if constexpr (WP) spill(c[e] & kSmallCellMask, c[e] >> kSmallWeightShift);
+                    else spill(c[e], 0u);
+                }
         }
     } else if constexpr (Pay::mode == kModeInline) {
         const uint4 e = reinterpret_cast<const uint4 *>(stage)[gi];  // four final words (weight << shift | cell in slice)
@@ -417,6 +444,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
 
     long long tally_s = 0;            // fused weight accounting (PayWeight::tally)
     unsigned long long tally_a = 0;
+    uint32_t tally_b = 0;             // weights outside 0 .. 15 (the next batch's choice of probe format, PayWeightSmall)
     uint32_t ordinal = ~0u;  // of the tile inside this workgroup's sequence (keyed probes carry it)
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         ++ordinal;
@@ -447,7 +475,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
             const uint64_t i = base + (uint64_t)q * NT + threadIdx.x;
             if (i < tile_end) {
                 const typename Src::Key key = kPartPipeline ? kcur[q] : src.load(i);
-                if (PAIR) payload[q] = pay(i, base);
+                if (PAIR || pay_weighted_plain<Pay>::value) payload[q] = pay(i, base);
                 if constexpr (IdxFn::lo32) {  // 32-bit chains (power-of-two table: the upper hash halves are dead)
                     uint32_t h[KT];
                     if (dbg & 4) {
@@ -581,6 +609,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
                         const long long v = pay.weights_signed ? (long long)(int32_t)payload[q] : (long long)payload[q];
                         tally_s += v;
                         tally_a += (unsigned long long)(v < 0 ? -v : v);
+                        tally_b += (uint32_t)(payload[q] >= (1u << kSmallWeightBits));
                     }
                 }
                 // the k offsets first, then the k stores: written as one loop hipcc waits for every off[] read before the stage[]
@@ -604,6 +633,13 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
                             }
                             stage[p] = enc;
                             if (p % GS == 0) gb[p / GS] = cell >> g.shift;
+                        } else if constexpr (pay_weighted_plain<Pay>::value) {
+                            uint32_t wq = payload[q];
+                            if (wq >= (1u << kSmallWeightBits)) {  // big / negative weight: exact saturating add on the table, a no-op field stays
+                                spill(idx[q][j], wq);
+                                wq = 0;
+                            }
+                            stage[p] = (wq << kSmallWeightShift) | idx[q][j];
                         } else {
                             stage[p] = idx[q][j];
                         }
@@ -657,17 +693,19 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
             for (int o = 32; o > 0; o >>= 1) {
                 tally_s += __shfl_down(tally_s, o);
                 tally_a += __shfl_down(tally_a, o);
+                tally_b += __shfl_down(tally_b, o);
             }
             unsigned long long *red = reinterpret_cast<unsigned long long *>(stage);
             if ((threadIdx.x & 63) == 0) {
-                red[2 * (threadIdx.x >> 6)] = (unsigned long long)tally_s;
-                red[2 * (threadIdx.x >> 6) + 1] = tally_a;
+                red[3 * (threadIdx.x >> 6)] = (unsigned long long)tally_s;
+                red[3 * (threadIdx.x >> 6) + 1] = tally_a;
+                red[3 * (threadIdx.x >> 6) + 2] = tally_b;
             }
             lds_barrier();
             if (threadIdx.x == 0) {
-                unsigned long long ss = 0, aa = 0;
-                for (int w = 0; w < NT / 64; ++w) { ss += red[2 * w]; aa += red[2 * w + 1]; }
-                pay.tally[blockIdx.x] = make_ulonglong2(ss, aa);
+                unsigned long long ss = 0, aa = 0, bb = 0;
+                for (int w = 0; w < NT / 64; ++w) { ss += red[3 * w]; aa += red[3 * w + 1]; bb += red[3 * w + 2]; }
+                pay.tally[blockIdx.x] = make_ulonglong4(ss, aa, bb, 0ULL);
             }
         }
     }
@@ -681,25 +719,34 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
 // The per-workgroup (sum w, sum |w|) slots of a weighted pass 1 -> the handle's device counters: ctr[which] += sum w
 // (elements_added terms), ctr[6] = sum |w| * bound_mult of THIS round (pass 2's wrap check), and, when grow_bound, the
 // saturating bound on |counter| ctr[4].  One block; the stream orders it between pass 1 and pass 2.
-static __global__ __launch_bounds__(256) void k_tally_fold(const ulonglong2 *slots, uint32_t nslots, long long *ctr, int which, long long bound_mult,
-                                                           int grow_bound)
+// big_pin (pinned host page, may be null): [0] = how many weights of this batch lay outside 0 .. 15, [1] = the batch's number -- read
+// by the host WITHOUT synchronisation when it picks the next weighted batch's probe format (a stale answer only costs speed: PayWeightSmall
+// is exact for any weight)
+static __global__ __launch_bounds__(256) void k_tally_fold(const ulonglong4 *slots, uint32_t nslots, long long *ctr, int which, long long bound_mult,
+                                                           int grow_bound, volatile unsigned long long *big_pin, unsigned long long seq)
 {
-    __shared__ unsigned long long ps[4], pa[4];
-    unsigned long long ss = 0, aa = 0;
+    __shared__ unsigned long long ps[4], pa[4], pb[4];
+    unsigned long long ss = 0, aa = 0, bb = 0;
     for (uint32_t i = threadIdx.x; i < nslots; i += 256) {
-        const ulonglong2 v = slots[i];
+        const ulonglong4 v = slots[i];
         ss += v.x;
         aa += v.y;
+        bb += v.z;
     }
     for (int o = 32; o > 0; o >>= 1) {
         ss += __shfl_down(ss, o);
         aa += __shfl_down(aa, o);
+        bb += __shfl_down(bb, o);
     }
-    if ((threadIdx.x & 63) == 0) { ps[threadIdx.x >> 6] = ss; pa[threadIdx.x >> 6] = aa; }
+    if ((threadIdx.x & 63) == 0) { ps[threadIdx.x >> 6] = ss; pa[threadIdx.x >> 6] = aa; pb[threadIdx.x >> 6] = bb; }
     __syncthreads();
     if (threadIdx.x == 0) {
         ss = ps[0] + ps[1] + ps[2] + ps[3];
         aa = pa[0] + pa[1] + pa[2] + pa[3];
+        if (big_pin) {
+            big_pin[0] = pb[0] + pb[1] + pb[2] + pb[3];
+            big_pin[1] = seq;  // (which batch the count belongs to: the host numbers them)
+        }
         if (which >= 0) ctr[which] += (long long)ss;
         const unsigned long long add = aa * (unsigned long long)bound_mult;
         ctr[6] = (long long)(add >> 63 ? (1ULL << 62) : add);
@@ -1181,7 +1228,9 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint3
 // else uint32 counters clamped at 2^32-1 (countingbloom.py:149-153).
 // Exact for any order as long as the per-cell partial sums do not wrap 32 bits: unit weights -- the host
 // checks n*k < 2^31; weighted -- ctr[6] = sum|w| of the batch, else every probe takes the saturating CAS.
-template <bool SIGNED, bool WEIGHTED, bool NEG>
+// FMT: the probe format -- 0 unit adds (8 x 16-bit cells), 1 weighted (4 x 32-bit: weight << shift | cell), 2 small weights (PayWeightSmall: 6 x
+// 20-bit fields weight << 15 | cell in two counted halves)
+template <bool SIGNED, int FMT, bool NEG>
 __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, uint64_t tab_cells, PartGeom g,
                                                                  const uint32_t *segcnt, const uint4 *buckets,
                                                                  const long long *ctr, unsigned long long *sat_ctr)
@@ -1192,21 +1241,40 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, 
     const uint32_t mask = slice_cells - 1;
     const uint64_t c0 = (uint64_t)b * slice_cells;
     const uint4 pad4 = make_uint4(kPadProbe, kPadProbe, kPadProbe, kPadProbe);  // (unit adds: 0xFFFF halves)
+    constexpr bool WEIGHTED = FMT != 0;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    // a half of a PayWeightSmall group: 3 fields (weight << 15 | cell), valid count in bits 60..63
+    // (32-bit field extraction; slots past a run's end and the slots of weights that went to the table directly carry weight 0. zero4 -- what
+    // for_each_group hands the lanes past a segment's end -- is three such fields per half)
+    auto small_half = [&](uint32_t lo, uint32_t hi, auto &&one) {
+        const uint32_t f[3] = {lo & 0xFFFFFu, __builtin_amdgcn_alignbit(hi, lo, 20) & 0xFFFFFu, (hi >> 8) & 0xFFFFFu};
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            if (f[e] >> 15) one(f[e] & 0x7FFFu, f[e] >> 15);
+    };
     if (WEIGHTED && ctr[6] >= (1LL << 31)) {
-        auto slow = [&](uint32_t x) {
-            if (x == kPadProbe) return;
-            const uint64_t cell = c0 + (x & mask);
-            const uint32_t w = x >> g.shift;
+        auto slow1 = [&](uint32_t cell_in_slice, uint32_t w) {
+            const uint64_t cell = c0 + cell_in_slice;
             if (SIGNED) cms_sat_add((int32_t *)tab + cell, NEG ? -(int64_t)w : (int64_t)w, sat_ctr);
             else if (NEG) cbf_sat_sub(tab + cell, w, sat_ctr - 1);
             else cbf_sat_add(tab + cell, w, sat_ctr);
         };
-        for_each_group(buckets, segcnt, g, b, pad4, [&](const uint4 q) { slow(q.x); slow(q.y); slow(q.z); slow(q.w); });
+        if constexpr (FMT == 2) {
+            for_each_group(buckets, segcnt, g, b, zero4, [&](const uint4 q) { small_half(q.x, q.y, slow1); small_half(q.z, q.w, slow1); });
+        } else {
+            auto slow = [&](uint32_t x) {
+                if (x != kPadProbe) slow1(x & mask, x >> g.shift);
+            };
+            for_each_group(buckets, segcnt, g, b, pad4, [&](const uint4 q) { slow(q.x); slow(q.y); slow(q.z); slow(q.w); });
+        }
         return;
     }
     for (uint32_t w = threadIdx.x; w < slice_cells; w += kApplyThreads) smem[w] = 0;
     __syncthreads();
-    if (WEIGHTED) {
+    if constexpr (FMT == 2) {
+        auto add1 = [&](uint32_t cell_in_slice, uint32_t w) { atomicAdd(&smem[cell_in_slice], NEG ? 0u - w : w); };  // ds_add_u32
+        for_each_group(buckets, segcnt, g, b, zero4, [&](const uint4 q) { small_half(q.x, q.y, add1); small_half(q.z, q.w, add1); });
+    } else if (WEIGHTED) {
         auto add = [&](uint32_t x) {
             if (x != kPadProbe) atomicAdd(&smem[x & mask], NEG ? 0u - (x >> g.shift) : (x >> g.shift));  // ds_add_u32
         };

@@ -672,3 +672,40 @@ def test_bloom_lookup_auto_mode_follows_the_miss_rate_and_stays_exact(pa, oracle
     outs = [blm.check_many(b) for b in (df, dk, df, dk, dm)]
     for got, want in zip(outs, (want_miss, want_hit, want_miss, want_hit, want_mixed)):
         assert np.array_equal(got.cpu().numpy().astype(np.uint8), want)
+
+
+def test_cms_weighted_adds_compact_probe_format(pa, oracle, force_partition):
+    """weighted CountMinSketch adds whose weights fit four bits travel as 20-bit fields (PayWeightSmall, countminsketch.py:267-288): forced on,
+    forced off and chosen by the hint of the previous batches -- every bin, elements_added and every answer equal the oracle's, whatever the
+    weights turn out to be (0, 15, 16, large, negative: the ones outside 0 .. 15 reach the table directly)"""
+    N = force_partition
+    old = N.get_option("cms_small_weights")
+    rng = np.random.default_rng(31)
+    n = 400_000
+    keys = oracle.gen_keys16(77_000, n)
+    dk = _dev(keys)
+    try:
+        for width, depth in ((2**20, 5), (1_000_003, 4), (2**16, 3)):
+            for mode in (2, 0, 1):
+                N.set_option("cms_small_weights", mode)
+                cms = pa.CountMinSketch(width=width, depth=depth)
+                oc = oracle.OracleCMS(width, depth)
+                batches = [
+                    rng.integers(1, 8, size=n),                                   # cfg 3's weights
+                    rng.integers(0, 16, size=n),                                  # the whole small range, zeros included
+                    np.where(rng.random(n) < 0.001, 16 + rng.integers(0, 5000, size=n), rng.integers(1, 16, size=n)),   # a few big ones
+                    rng.integers(1, 8, size=n),
+                    np.where(rng.random(n) < 0.5, -rng.integers(1, 4, size=n), rng.integers(1, 16, size=n)),            # negative weights
+                    rng.integers(100, 100_000, size=n),                           # nothing small at all
+                    rng.integers(1, 8, size=n),
+                ]
+                for i, w in enumerate(batches):
+                    w32 = w.astype(np.int32)
+                    cms.add_many(dk, _dev(w32))
+                    oc.add_keys(keys, w32)
+                    if i in (1, 4, 6):
+                        assert np.array_equal(cms.table_tensor.cpu().numpy()[: oc.bins.size], oc.bins), (width, depth, mode, i)
+                        assert cms.elements_added == oc.els_added
+                assert np.array_equal(cms.check_many(dk[:50_000]).cpu().numpy().astype(np.int64), oc.check_keys(keys[:50_000]))
+    finally:
+        N.set_option("cms_small_weights", old)
