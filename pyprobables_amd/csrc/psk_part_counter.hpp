@@ -34,6 +34,21 @@ static inline int fold_tally(psk_sketch *s, const PayWeight &pay, uint32_t nwg, 
     return PSK_OK;
 }
 
+// the same accounting folded into pass 2 (k_counter_apply's TallyArgs) instead of the k_tally_fold launch between the passes
+static inline int tally_args(psk_sketch *s, const PayWeight &pay, uint32_t nwg, TallyArgs *ta)
+{
+    *ta = TallyArgs{};
+    if (!pay.tally) return PSK_OK;
+    if (!s->wt.pin) {
+        void *pin = nullptr;
+        HIP_TRY(hipHostMalloc(&pin, 32, hipHostMallocDefault));
+        s->wt.pin = (volatile unsigned long long *)pin;
+        s->wt.pin[0] = s->wt.pin[1] = 0;
+    }
+    *ta = TallyArgs{(const ulonglong4 *)pay.tally, nwg, s->acct.which, s->acct.bound_mult, s->acct.grow_bound ? 1 : 0, s->wt.pin, ++s->wt.issued};
+    return PSK_OK;
+}
+
 // the compact probe format for this weighted batch?  (exact either way: a weight outside 0 .. 15 goes to the table directly -- at the atomics'
 // rate, hence the hint: the count of such weights pass 1 of the previous batches saw)
 static inline bool small_weights_wanted(psk_sketch *s)
@@ -181,13 +196,13 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
                 auto kern = k_counter_apply<SIGNED, true, NEG>;
                 PSK_TRY(set_dyn_lds(kern, lds));
                 hipLaunchKernelGGL(kern, dim3(g2.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g2,
-                                   (const uint32_t *)s->s_cnt2.p, (const uint4 *)s->s_part2.p, (const long long *)s->ctr, sat2);
+                                   (const uint32_t *)s->s_cnt2.p, (const uint4 *)s->s_part2.p, (long long *)s->ctr, sat2, TallyArgs{});
             } else {
                 PSK_TRY((split_level2<1, SpillCounter<SIGNED>>(s, g1, &g2, sub_bits, cnt * (uint64_t)s->k, spill, st)));
                 auto kern = k_counter_apply<SIGNED, false, NEG>;
                 PSK_TRY(set_dyn_lds(kern, lds));
                 hipLaunchKernelGGL(kern, dim3(g2.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g2,
-                                   (const uint32_t *)s->s_cnt2.p, (const uint4 *)s->s_part2.p, (const long long *)s->ctr, sat2);
+                                   (const uint32_t *)s->s_cnt2.p, (const uint4 *)s->s_part2.p, (long long *)s->ctr, sat2, TallyArgs{});
             }
             HIP_TRY(hipGetLastError());
         }
@@ -229,25 +244,26 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
             });
         }));
         if (!handled) return PSK_OK;
-        PSK_TRY(fold_tally(s, payw, g.nwg, st));
+        TallyArgs ta;  // pass 1's weight sums are booked by pass 2 (no launch between the passes)
+        PSK_TRY(tally_args(s, payw, g.nwg, &ta));
         const size_t lds = (size_t)4 << g.shift;
         if (w_dev && small_fmt) {
             if constexpr (SIGNED && !NEG) {
                 auto kern = k_counter_apply<SIGNED, 2, NEG>;
                 PSK_TRY(set_dyn_lds(kern, lds));
                 hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g,
-                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (const long long *)s->ctr, sat);
+                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (long long *)s->ctr, sat, ta);
             }
         } else if (w_dev) {
             auto kern = k_counter_apply<SIGNED, true, NEG>;
             PSK_TRY(set_dyn_lds(kern, lds));
             hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g,
-                               (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (const long long *)s->ctr, sat);
+                               (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (long long *)s->ctr, sat, ta);
         } else {
             auto kern = k_counter_apply<SIGNED, false, NEG>;
             PSK_TRY(set_dyn_lds(kern, lds));
             hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g,
-                               (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (const long long *)s->ctr, sat);
+                               (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (long long *)s->ctr, sat, ta);
         }
         HIP_TRY(hipGetLastError());
     }

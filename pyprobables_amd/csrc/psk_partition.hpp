@@ -1228,15 +1228,69 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint3
 // else uint32 counters clamped at 2^32-1 (countingbloom.py:149-153).
 // Exact for any order as long as the per-cell partial sums do not wrap 32 bits: unit weights -- the host
 // checks n*k < 2^31; weighted -- ctr[6] = sum|w| of the batch, else every probe takes the saturating CAS.
+// The accounting of a weighted pass 1 (PayWeight::tally), folded into pass 2 (round 3; it used to be the one-block k_tally_fold between the
+// passes, ~5 us of stream time per round): every workgroup sums the slots for its own wrap check, workgroup 0 also books the sums.
+struct TallyArgs {
+    const ulonglong4 *slots = nullptr;  // null: nothing to fold (ctr[6] holds the round's sum |w| already)
+    uint32_t nslots = 0;
+    int which = -1;                     // PSK_CTR_ADDED / PSK_CTR_REMOVED (or -1)
+    long long bound_mult = 1;
+    int grow_bound = 0;
+    volatile unsigned long long *big_pin = nullptr;  // see k_tally_fold
+    unsigned long long seq = 0;
+};
+
 // FMT: the probe format -- 0 unit adds (8 x 16-bit cells), 1 weighted (4 x 32-bit: weight << shift | cell), 2 small weights (PayWeightSmall: 6 x
 // 20-bit fields weight << 15 | cell in two counted halves)
 template <bool SIGNED, int FMT, bool NEG>
 __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, uint64_t tab_cells, PartGeom g,
                                                                  const uint32_t *segcnt, const uint4 *buckets,
-                                                                 const long long *ctr, unsigned long long *sat_ctr)
+                                                                 long long *ctr, unsigned long long *sat_ctr, TallyArgs ta)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = blockIdx.x;
+    long long round_abs = 0;  // sum |w| * bound_mult of this round (the wrap check below)
+    if (FMT != 0) {
+        if (ta.slots) {
+            __shared__ unsigned long long red[3 * (kApplyThreads / 64)];
+            unsigned long long ss = 0, aa = 0, bb = 0;
+            for (uint32_t i = threadIdx.x; i < ta.nslots; i += kApplyThreads) {
+                const ulonglong4 v = ta.slots[i];
+                ss += v.x;
+                aa += v.y;
+                bb += v.z;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                ss += __shfl_down(ss, o);
+                aa += __shfl_down(aa, o);
+                bb += __shfl_down(bb, o);
+            }
+            if ((threadIdx.x & 63) == 0) {
+                red[3 * (threadIdx.x >> 6)] = ss;
+                red[3 * (threadIdx.x >> 6) + 1] = aa;
+                red[3 * (threadIdx.x >> 6) + 2] = bb;
+            }
+            __syncthreads();
+            ss = aa = bb = 0;
+            for (int w = 0; w < kApplyThreads / 64; ++w) { ss += red[3 * w]; aa += red[3 * w + 1]; bb += red[3 * w + 2]; }
+            const unsigned long long add = aa * (unsigned long long)ta.bound_mult;
+            round_abs = (long long)(add >> 63 ? (1ULL << 62) : add);
+            if (b == 0 && threadIdx.x == 0) {  // the books (what k_tally_fold does)
+                if (ta.which >= 0) ctr[ta.which] += (long long)ss;
+                ctr[6] = round_abs;
+                if (ta.grow_bound) {
+                    const unsigned long long nb = (unsigned long long)ctr[4] + add;
+                    ctr[4] = (nb < add || nb > (1ULL << 62)) ? (1LL << 62) : (long long)nb;
+                }
+                if (ta.big_pin) {
+                    ta.big_pin[0] = bb;
+                    ta.big_pin[1] = ta.seq;
+                }
+            }
+        } else {
+            round_abs = ctr[6];
+        }
+    }
     const uint32_t slice_cells = 1u << g.shift;
     const uint32_t mask = slice_cells - 1;
     const uint64_t c0 = (uint64_t)b * slice_cells;
@@ -1252,7 +1306,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, 
         for (int e = 0; e < 3; ++e)
             if (f[e] >> 15) one(f[e] & 0x7FFFu, f[e] >> 15);
     };
-    if (WEIGHTED && ctr[6] >= (1LL << 31)) {
+    if (WEIGHTED && round_abs >= (1LL << 31)) {
         auto slow1 = [&](uint32_t cell_in_slice, uint32_t w) {
             const uint64_t cell = c0 + cell_in_slice;
             if (SIGNED) cms_sat_add((int32_t *)tab + cell, NEG ? -(int64_t)w : (int64_t)w, sat_ctr);
