@@ -55,9 +55,9 @@ static inline bool small_weights_wanted(psk_sketch *s)
 {
     if (g_small_weights != 1) return g_small_weights == 2;
     if (!s->wt.pin) return false;
-    const unsigned long long big = s->wt.pin[0], seq = s->wt.pin[1];
+    const unsigned long long seq = s->wt.pin[1], big = s->wt.pin[0], seq2 = s->wt.pin[1];  // (the device writes the count, then the number)
     if (seq == 0) return false;  // nothing published yet
-    if (seq != s->wt.seen) {
+    if (seq == seq2 && seq != s->wt.seen) {
         s->wt.seen = seq;
         if (big) s->wt.backoff = 64;
         else if (s->wt.backoff) --s->wt.backoff;
