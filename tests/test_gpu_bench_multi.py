@@ -44,6 +44,23 @@ def test_two_ranks_merge_to_the_single_stream_filter(extra):
     assert line["roofline"]["bound"] == "hbm" and line["roofline"]["achieved"] > 0
 
 
+def test_eight_ranks_on_one_device():
+    """the driver's largest run, 8 ranks, with every rank on cuda:0 (gloo): eight shards, eight bit-range slices per exchange, one merged
+    filter equal to the single-stream one -- the rank arithmetic of the N = 8 run is the same code"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, PSK_BENCH_SINGLE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--spinup", "0", "--keys-per-rank", "500000"]
+    line = _run(cmd, env)
+    assert line["n_gpus"] == 8 and line["rc"] == 0 and line["detail"]["all_inserted_found"] is True
+    assert line["detail"]["merged_table_equals_single_stream"] is True
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--config", "cfg5", "--n-total", "8000003", "--steps", "1", "--warmup", "1", "--spinup", "0"]
+    line = _run(cmd, env)
+    assert line["n_gpus"] == 8 and line["detail"]["all_inserted_found"] is True and line["detail"]["merged_prefix_equals_single_stream"] is True
+
+
 def test_launched_under_torch_distributed_run():
     """the other launch form: python -m torch.distributed.run ... bench.py --gpus 2"""
     torch = pytest.importorskip("torch")
