@@ -219,10 +219,24 @@ __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query,
         const uint32_t wg = (uint32_t)(tile % g.nwg);  // the pass-1 workgroup that owned this tile names the segments
         const uint64_t base = tile * g.tile;
         const uint64_t end = base + g.tile < n ? base + g.tile : n;
+        // Run descriptors (round 3: the kernel was instruction bound -- 27 M VALU + 29 M SALU wave-instructions per 10 M keys, most of them
+        // the per-lane address arithmetic of the run copies: every one of a run's 16-32 lanes redid the 64-bit segment base, the room
+        // clamp and the format test).  The thread that holds a slice's runinfo turns it, once, into what the copy loop needs:
+        //   .x = first 16-byte unit of the run's values (16-bit format: 2 * segment base + group; 32-bit: segment base + group, in 32-byte
+        //        groups) -- below 2^32, the host checks;  .y = stage offset (a multiple of 8; bit 0 = 16-bit format) << 16 | dwords to copy
 #pragma unroll
         for (int r = 0; r < kInfoRegs; ++r) {
             const uint32_t b = threadIdx.x + (uint32_t)r * kCollectThreads;
-            if (b < B) info[b] = nxt[r];
+            if (b < B) {
+                const uint2 ri = nxt[r];
+                const uint32_t cnt = ri.y & 0xFFFFu, off = ri.y >> 16;
+                const uint64_t seg = seg_index(g, b, wg) * g.segcap;
+                const uint32_t room = ri.x < g.segcap ? (g.segcap - ri.x) * GS : 0;  // (an overflowed run: the flag is up, the redo overwrites out[])
+                const uint32_t lim = cnt < room ? cnt : room;
+                const bool two = fmt_lds[b] != 0;
+                info[b] = two ? make_uint2((uint32_t)(2 * seg + ri.x), ((off | 1u) << 16) | ((lim + 1) / 2))
+                              : make_uint2((uint32_t)(seg + ri.x), (off << 16) | lim);
+            }
         }
         uint4 pw[kPre][P4];
 #pragma unroll
@@ -255,29 +269,24 @@ __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query,
                 const uint32_t b = b0 + (uint32_t)u * stride;
                 live[u] = two[u] = false;
                 if (b < B) {
-                    const uint2 ri = info[b];
-                    const uint32_t cnt = ri.y & 0xFFFFu, off = ri.y >> 16;
-                    const uint64_t seg = seg_index(g, b, wg) * g.segcap;
-                    const uint32_t room = ri.x < g.segcap ? (g.segcap - ri.x) * GS : 0;  // (an overflowed run: the flag is up, the redo overwrites out[])
-                    const uint32_t lim = cnt < room ? cnt : room;
-                    two[u] = fmt_lds[b] != 0;
+                    const uint2 rd = info[b];
+                    const uint32_t cnt = rd.y & 0xFFFFu, off = (rd.y >> 16) & ~1u;
+                    two[u] = (rd.y >> 16) & 1u;
+                    live[u] = e0 < cnt;
                     if (two[u]) {  // 16-bit values, the segment's groups packed at 16 bytes each: a lane moves TWO values (one dword);
                         // the odd tail lands on the run's pad slots
-                        const uint32_t *src = vals + seg * GS + (uint64_t)ri.x * (GS / 2);
-                        const uint32_t lim2 = (lim + 1) / 2;
+                        const uint32_t *src = vals + (uint64_t)rd.x * 4;
                         at[u] = off + 2 * e0;
-                        live[u] = e0 < lim2;
                         if (live[u]) v[u] = src[e0];
-                        for (uint32_t e = e0 + rl; e < lim2; e += rl) {  // longer runs
+                        for (uint32_t e = e0 + rl; e < cnt; e += rl) {  // longer runs
                             const uint32_t x = src[e];
                             *reinterpret_cast<uint2 *>(stage + off + 2 * e) = make_uint2(x & 0xFFFFu, x >> 16);
                         }
                     } else {
-                        const uint32_t *src = vals + (seg + ri.x) * GS;
+                        const uint32_t *src = vals + (uint64_t)rd.x * 8;
                         at[u] = off + e0;
-                        live[u] = e0 < lim;
                         if (live[u]) v[u] = src[e0];
-                        for (uint32_t e = e0 + rl; e < lim; e += rl) stage[off + e] = src[e];
+                        for (uint32_t e = e0 + rl; e < cnt; e += rl) stage[off + e] = src[e];
                     }
                 }
             }

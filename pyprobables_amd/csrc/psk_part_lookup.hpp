@@ -14,6 +14,10 @@ static inline uint64_t lookup_round_keys(uint64_t n, uint32_t k)
 {
     uint64_t rk = (uint64_t)g_part_max_keys < n ? (uint64_t)g_part_max_keys : n;
     rk = cap_round_by_budget(rk, (double)k * (2.0 + 4.0) * 1.5 + 16.0 * ((k + 7) / 8) + 8.0);  // probes + values + perm + runinfo
+    // pass 3 addresses a run's values by a 32-bit unit index (k_lookup_collect's run descriptors): at most 2^31 probes per round keeps the
+    // round's groups, pads included, far below 2^31
+    const uint64_t by_probes = (1ULL << 31) / (k ? k : 1);
+    if (rk > by_probes) rk = by_probes;
     return rk ? rk : 1;
 }
 
