@@ -473,6 +473,7 @@ int64_t g_lookup_collect_threads = 1024;
 int64_t g_remove_dryrun = 1;   // validated unit-weight CBF removes into big tables: optimistic decrement first (psk_nibble.hpp), option "remove_optimistic"
 int64_t g_scratch_budget = 0;  // psk_set_option("scratch_budget_bytes"): cap on a handle's partition scratch (more, smaller rounds); 0 = none
 int64_t g_lookup_nibble = 1;   // CBF lookups into 2^25 .. 2^29 counters: 4-bit slice images (psk_nibble.hpp) from cells / 16 probes on; 2 = always; 0 = the 32-bit / 16-bit slices or direct
+int64_t g_small_weights_used = 0;
 int64_t g_small_weights = 1;   // PayWeightSmall for weighted CountMinSketch adds (psk_sketch::wt)
 int64_t g_cbf_shadow_hits = 0;
 int64_t g_cbf_shadow = 1;  // nibble-slice lookups keep their 4-bit images while the table is unchanged (psk_sketch::shadow; cells / 2 bytes)
@@ -566,6 +567,7 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "nibble_nt_loads")) *value = g_nib_nt;
     else if (!strcmp(name, "cbf_lookup_shadow")) *value = g_cbf_shadow;
     else if (!strcmp(name, "cms_small_weights")) *value = g_small_weights;
+    else if (!strcmp(name, "cms_small_weights_used")) *value = g_small_weights_used;
     else if (!strcmp(name, "cbf_lookup_shadow_hits")) *value = g_cbf_shadow_hits;
     else if (!strcmp(name, "scatter_workgroups")) *value = g_part_wgs;
     else if (!strcmp(name, "slice_bias")) *value = g_part_slice_bias;

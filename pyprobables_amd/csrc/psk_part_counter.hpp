@@ -49,6 +49,8 @@ static inline int tally_args(psk_sketch *s, const PayWeight &pay, uint32_t nwg, 
     return PSK_OK;
 }
 
+extern PSK_HIDDEN int64_t g_small_weights_used;
+
 // the compact probe format for this weighted batch?  (exact either way: a weight outside 0 .. 15 goes to the table directly -- at the atomics'
 // rate, hence the hint: the count of such weights pass 1 of the previous batches saw)
 static inline bool small_weights_wanted(psk_sketch *s)
@@ -215,6 +217,7 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
     // and the previous weighted batches brought no weight outside 0 .. 15
     bool small_fmt = false;
     if constexpr (SIGNED && !NEG) small_fmt = w_dev != nullptr && cells < (1ULL << kSmallWeightShift) && g.shift <= 15 && small_weights_wanted(s);
+    const bool small_asked = small_fmt;
     const uint64_t round_keys = part_round_keys_big_table(b.n, s->k, w_dev ? (small_fmt ? PayWeightSmall::group : PayWeight::group) : PayUnit::group, s->padded_bytes);
     unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
     for (uint64_t start = 0; start < b.n; start += round_keys) {
@@ -268,6 +271,7 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
         HIP_TRY(hipGetLastError());
     }
     if (w_dev) s->acct.pending = false;  // pass 1 summed the weights
+    if (small_asked && small_fmt) ++g_small_weights_used;  // (calls that travelled in the compact format; option "cms_small_weights_used": tests)
     *done = true;
     return PSK_OK;
 }

@@ -709,3 +709,41 @@ def test_cms_weighted_adds_compact_probe_format(pa, oracle, force_partition):
                 assert np.array_equal(cms.check_many(dk[:50_000]).cpu().numpy().astype(np.int64), oc.check_keys(keys[:50_000]))
     finally:
         N.set_option("cms_small_weights", old)
+
+
+def test_cms_compact_format_follows_the_hint_and_backs_off(pa, oracle, force_partition):
+    """option cms_small_weights = 1 (default): the first weighted batch of a sketch travels in the wide format; once pass 1 has reported a
+    batch without any weight outside 0 .. 15 the compact one is taken; ONE such weight keeps the wide format for the next 64 weighted
+    batches (psk_sketch::wt) -- and every bin equals the oracle's throughout"""
+    N = force_partition
+    assert N.get_option("cms_small_weights") == 1
+    used = lambda: N.get_option("cms_small_weights_used")
+    n = 200_000
+    keys = oracle.gen_keys16(4242, n)
+    dk = _dev(keys)
+    small = _dev(np.full(n, 3, dtype=np.int32))
+    big = np.full(n, 3, dtype=np.int32)
+    big[7] = 1000
+    dbig = _dev(big)
+    cms = pa.CountMinSketch(width=2**18, depth=5)
+    oc = oracle.OracleCMS(2**18, 5)
+
+    def add(w_dev, w_host, expect_compact):
+        u0 = used()
+        cms.add_many(dk, w_dev)
+        torch.cuda.synchronize()               # the hint of this batch is on the pinned page before the next call reads it
+        oc.add_keys(keys, w_host)
+        assert (used() - u0 == 1) == expect_compact, (used() - u0, expect_compact)
+
+    w3 = np.full(n, 3, dtype=np.int32)
+    add(small, w3, False)                      # nothing known yet: wide
+    add(small, w3, True)
+    add(small, w3, True)
+    add(dbig, big, True)                       # (the big weight itself goes to the table directly: exact, and it is reported)
+    for _ in range(3):
+        add(small, w3, False)                  # backing off
+    assert np.array_equal(cms.table_tensor.cpu().numpy()[: oc.bins.size], oc.bins) and cms.elements_added == oc.els_added
+    for _ in range(61):
+        add(small, w3, False)
+    add(small, w3, True)                       # 64 weighted batches after the report: compact again
+    assert np.array_equal(cms.table_tensor.cpu().numpy()[: oc.bins.size], oc.bins) and cms.elements_added == oc.els_added
