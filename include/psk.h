@@ -97,7 +97,13 @@ int psk_device_count(int *count);
  * collective path on a one-rank communicator), "even_tiles" (default 1: pass 1 gives every workgroup the same number of equally
  * sized tiles), "dense_walk_groups" (default 40: pass 2 walks a wave's segments end to end -- every lane of a load busy -- when a
  * (slice, workgroup) segment holds fewer 16-byte groups than this on average, e.g. small batches into 2048-slice tables), "lookup_half_slices" (default 1: CMS / CBF lookups into tables of 2^26 .. 2^27
- * counters run partitioned over slices of 2^16 counters held as 16-bit values; 0 = such tables use the direct kernels); bench knobs: "lookup_split", "lookup_run_lanes", "tile_threads", "scatter_workgroups", "slice_bias" */
+ * counters run partitioned over slices of 2^16 counters held as 16-bit values; 0 = such tables use the direct kernels);
+ * round 3: "auto_combine" / "auto_combine_keys", "remove_optimistic", "lookup_nibble_slices", "update_nibble_slices", "nibble_min_lg_lookup",
+ * "nibble_min_lg_update", "cbf_lookup_shadow" (all described with psk_cbf_add below), "scratch_budget_bytes" (cap on the partition scratch of a
+ * round; 0 = none), "cms_small_weights" (weighted psk_cms_add: 1 (default) = weights 0 .. 15 travel as 20-bit fields once the previous batches
+ * brought no other weight, 0 = never, 2 = always -- exact either way, a weight outside the range goes to the table directly); read-only
+ * counters for tests: "cbf_lookup_shadow_hits", "cms_small_weights_used";
+ * bench knobs: "lookup_split", "lookup_run_lanes", "tile_threads", "scatter_workgroups", "slice_bias" */
 int psk_set_option(const char *name, int64_t value);
 int psk_get_option(const char *name, int64_t *value);
 /* bench-only: s_memtime totals per phase of the last partition pass 1 (option part_debug & 32) */
