@@ -8,6 +8,7 @@ undefined so the library binds to the HIP runtime already loaded in the process 
 from __future__ import annotations
 
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -26,12 +27,13 @@ VARIANT_SOURCES = [
     "psk_part_cms_check.hip",
     "psk_part_cbf_check.hip",
     "psk_part_cbf_multi.hip",
+    "psk_part_cbf_window.hip",
 ]
 PLAIN_SOURCES = ["psk_capi.hip", "psk_index_ops.hip", "psk_merge.hip", "psk_part_dispatch.hip"]
 # (source, object stem, extra flags); the heaviest units first so that the pool stays busy to the end
 SOURCES = [(f, Path(f).stem + f"_v{v}", [f"-DPSK_TU_POW2={v}"]) for f in VARIANT_SOURCES for v in (1, 0)] + \
           [(f, Path(f).stem, []) for f in PLAIN_SOURCES]
-HEADERS = ["psk_device.hpp", "psk_partition.hpp", "psk_host.hpp", "psk_part_counter.hpp", "psk_lookup.hpp", "psk_part_lookup.hpp", "psk_nibble.hpp", "psk_digest.hpp",
+HEADERS = ["psk_device.hpp", "psk_partition.hpp", "psk_host.hpp", "psk_part_counter.hpp", "psk_lookup.hpp", "psk_part_lookup.hpp", "psk_nibble.hpp", "psk_window.hpp", "psk_digest.hpp",
            "../../include/psk.h"]
 OUT = CSRC / "libpsk_hip.so"
 OBJ = CSRC / "build"
@@ -51,6 +53,20 @@ def _newest_header() -> float:
     return max((CSRC / h).resolve().stat().st_mtime for h in HEADERS)
 
 
+_INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _deps(path: Path, seen=None) -> set:
+    """the files `path` includes with quotes, transitively (every translation unit is rebuilt only when one of ITS headers changed)"""
+    seen = set() if seen is None else seen
+    for inc in _INC.findall(path.read_text()):
+        f = (path.parent / inc).resolve()
+        if f.exists() and f not in seen:
+            seen.add(f)
+            _deps(f, seen)
+    return seen
+
+
 def needs_build() -> bool:
     if not OUT.exists():
         return True
@@ -62,7 +78,7 @@ def _compile(item, force: bool, verbose: bool, objdir: Path, extra: list) -> Pat
     src, stem, flags = item
     extra = [*extra, *flags]
     obj = objdir / (stem + ".o")
-    dep = max((CSRC / src).stat().st_mtime, _newest_header())
+    dep = max([(CSRC / src).stat().st_mtime] + [f.stat().st_mtime for f in _deps(CSRC / src)])
     if force or not obj.exists() or obj.stat().st_mtime < dep:
         cmd = [hipcc(), *FLAGS, *extra, "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:

@@ -3,6 +3,7 @@
 #include "psk_host.hpp"
 #include "psk_digest.hpp"
 #include "psk_nibble.hpp"
+#include "psk_window.hpp"
 
 #include <map>
 #include <mutex>
@@ -154,10 +155,12 @@ extern "C" int psk_destroy(psk_sketch *s)
     if (s->lk.pin) hipHostFree((void *)s->lk.pin);
     if (s->wt.pin) hipHostFree((void *)s->wt.pin);
     for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
-                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->s_brw, &s->shadow.img}) {
+                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->s_brw, &s->shadow.img,
+                      &s->win.keys, &s->s_snap, &s->s_wstat, &s->s_phase}) {
         if (b->p) hipFree(b->p);
         if (b->pin) hipHostFree(b->pin);
     }
+    if (s->win.pin) hipHostFree(s->win.pin);
     if (s->scat.ev) hipEventDestroy(s->scat.ev);
     delete s;
     return PSK_OK;
@@ -202,6 +205,8 @@ extern "C" int psk_clear(psk_sketch *s, void *stream)
     s->comb.add.unit = s->comb.rem.unit = true;
     s->comb.badd.clear();
     s->comb.brem.clear();
+    s->win.n = 0;  // (the update window too; a window's back-off is a property of the stream and stays)
+    s->win.batches.clear();
     PSK_TRY(scat_drop(s, st));
     // one launch for the table AND the counter block (two fills are two ~5 us launches; clear sits in every bench step)
     const uint64_t nvec = s->padded_bytes / 16;
@@ -251,6 +256,8 @@ extern "C" int psk_write_table(psk_sketch *s, const void *src_host, uint64_t nby
     s->comb.add.unit = s->comb.rem.unit = true;
     s->comb.badd.clear();
     s->comb.brem.clear();
+    s->win.n = 0;
+    s->win.batches.clear();
     PSK_TRY(scat_drop(s, st));
     HIP_TRY(hipMemsetAsync(s->table, 0, s->padded_bytes, st));
     HIP_TRY(hipMemcpyAsync(s->table, src_host, nbytes, hipMemcpyHostToDevice, st));
@@ -520,6 +527,9 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "nibble_nt_loads")) g_nib_nt = value;
     else if (!strcmp(name, "cbf_lookup_shadow")) g_cbf_shadow = value;
     else if (!strcmp(name, "cms_small_weights")) g_small_weights = value;
+    else if (!strcmp(name, "update_window")) g_window = value;
+    else if (!strcmp(name, "update_window_keys")) g_window_keys = value;
+    else if (!strcmp(name, "update_window_force_fail")) g_window_force_fail = value;
     else return fail(PSK_EINVAL, "unknown option %s", name);
     return PSK_OK;
 }
@@ -567,6 +577,11 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "nibble_nt_loads")) *value = g_nib_nt;
     else if (!strcmp(name, "cbf_lookup_shadow")) *value = g_cbf_shadow;
     else if (!strcmp(name, "cms_small_weights")) *value = g_small_weights;
+    else if (!strcmp(name, "update_window")) *value = g_window;
+    else if (!strcmp(name, "update_window_keys")) *value = g_window_keys;
+    else if (!strcmp(name, "update_window_force_fail")) *value = g_window_force_fail;
+    else if (!strcmp(name, "update_window_folds")) *value = g_window_folds;
+    else if (!strcmp(name, "update_window_replays")) *value = g_window_replays;
     else if (!strcmp(name, "cms_small_weights_used")) *value = g_small_weights_used;
     else if (!strcmp(name, "cbf_lookup_shadow_hits")) *value = g_cbf_shadow_hits;
     else if (!strcmp(name, "scatter_workgroups")) *value = g_part_wgs;
@@ -939,9 +954,124 @@ static int borrowed_flush(psk_sketch *s, psk_sketch::BorrowList &bl, bool remove
     return PSK_OK;
 }
 
+// ---- update windows (psk_window.hpp): small unit-weight add / remove batches of 16-byte keys into big tables wait, in arrival order,
+// as key copies; win_flush applies them in one pass over the table, proving the removes while it folds -- or replays them one by one
+int64_t g_window = 1;                // option "update_window"
+int64_t g_window_keys = 1 << 26;     // option "update_window_keys": most keys a window holds (16 bytes each); also cells / 4 and the scratch budget
+int64_t g_window_folds = 0, g_window_replays = 0;  // windows applied by the fold / replayed batch by batch (tests, bench)
+int64_t g_window_force_fail = 0;     // tests: pretend the proof failed (exercises undo + replay on a well-formed stream)
+constexpr size_t kWinMaxBatches = 4096;
+
+static uint64_t win_capacity(const psk_sketch *s)
+{
+    uint64_t cap = s->m / 4;
+    if (cap < (1u << 20)) cap = 1u << 20;
+    if (g_window_keys > 0 && cap > (uint64_t)g_window_keys) cap = (uint64_t)g_window_keys;
+    cap = cap_round_by_budget(cap, 16.0 + (double)s->k * (16.0 / 6.0) * 1.5);  // key copy + probe groups with their padding
+    return cap;
+}
+
+static bool win_eligible(const psk_sketch *s, int layout, const void *data, uint32_t key_len, const uint32_t *weights, uint64_t n)
+{
+    PartGeom g;
+    return s->kind == PSK_KIND_CBF && g_window != 0 && g_update_nibble != 0 && !weights && layout == PSK_KEYS_FIXED && key_len == 16 && data && n != 0 &&
+           (int64_t)n >= g_part_min_keys && n * (uint64_t)s->k < s->m / 8 && s->k <= 32 && n <= win_capacity(s) && nib_geometry(s->m, true, &g);
+}
+
+static int cbf_remove_device(psk_sketch *s, const Batch &b, const uint32_t *w, hipStream_t st);
+
+// every waiting batch through the per-batch paths, in arrival order (windows too small for a pass over the table, tables / options that
+// rule the fold out, and the windows whose proof failed)
+static int win_replay(psk_sketch *s, const void *keys, const std::vector<psk_sketch::WinBatch> &batches, hipStream_t st)
+{
+    ++s->win.replays;
+    ++g_window_replays;
+    for (const auto &wb : batches) {
+        const Batch b{PSK_KEYS_FIXED, (const uint8_t *)keys + wb.start * 16, nullptr, wb.n, 16};
+        if (wb.remove) PSK_TRY(cbf_remove_device(s, b, nullptr, st));
+        else PSK_TRY(cbf_apply_device(s, b, nullptr, false, st));
+    }
+    return PSK_OK;
+}
+
+static int win_flush(psk_sketch *s, hipStream_t st)
+{
+    if (s->win.n == 0) return PSK_OK;
+    PSK_TRY(comb_order(s, st));
+    std::vector<psk_sketch::WinBatch> batches;
+    batches.swap(s->win.batches);  // (cleared first: a failure must not re-apply the window on the next call)
+    const uint64_t n = s->win.n;
+    s->win.n = 0;
+    const void *keys = s->win.keys.p;
+    // runs of same-type batches are the fold's phases
+    std::vector<WinPhaseHost> ph;
+    uint64_t n_add = 0, n_rem = 0;
+    for (const auto &wb : batches) {
+        if (!ph.empty() && ph.back().remove == wb.remove) ph.back().n += wb.n;
+        else ph.push_back(WinPhaseHost{wb.start, wb.n, wb.remove});
+        (wb.remove ? n_rem : n_add) += wb.n;
+    }
+    // One phase: a plain batch (the partitioned add / the validated remove take it as a whole).  Too few probes for a pass over the
+    // table, or a recent window whose proof failed: batch by batch.
+    if (ph.size() == 1) {
+        const Batch b{PSK_KEYS_FIXED, keys, nullptr, n, 16};
+        return ph[0].remove ? cbf_remove_device(s, b, nullptr, st) : cbf_apply_device(s, b, nullptr, false, st);
+    }
+    const bool worth = n * (uint64_t)s->k >= s->m / 8 && ph.size() <= (size_t)kWinMaxPhases;
+    if (worth && s->win.backoff == 0) {
+        bool launched = false, ok = false;
+        PSK_TRY(cbf_window_fold(s, ph.data(), (uint32_t)ph.size(), keys, n, st, &launched, &ok));
+        if (launched && ok) {
+            ++s->win.folds;
+            ++g_window_folds;
+            PSK_TRY(account_weights(s, (const uint32_t *)nullptr, n_add, PSK_CTR_ADDED, (long long)s->k, st, true));
+            return account_weights(s, (const uint32_t *)nullptr, n_rem, PSK_CTR_REMOVED, (long long)s->k, st, false);
+        }
+        if (launched) s->win.backoff = 8;  // this stream removes keys that are not there: stop paying for fold + undo for a while
+    } else if (s->win.backoff) {
+        --s->win.backoff;
+    }
+    return win_replay(s, keys, batches, st);
+}
+
+// hand a batch over to the window (eligible: win_eligible); host batches are copied straight from the caller's buffer
+static int win_append(psk_sketch *s, const void *data, uint64_t n, bool remove, int where, hipStream_t st)
+{
+    const uint64_t cap = win_capacity(s);
+    if (s->win.cap != cap && s->win.n) PSK_TRY(win_flush(s, st));
+    if (s->win.n + n > cap || s->win.batches.size() >= kWinMaxBatches) PSK_TRY(win_flush(s, st));
+    if (s->win.n && !s->win.batches.empty() && s->win.batches.back().remove != (remove ? 1u : 0u)) {
+        size_t phases = 1;  // (a new phase: the fold holds at most kWinMaxPhases of them)
+        for (size_t i = 1; i < s->win.batches.size(); ++i) phases += s->win.batches[i].remove != s->win.batches[i - 1].remove;
+        if (phases >= (size_t)kWinMaxPhases) PSK_TRY(win_flush(s, st));
+    }
+    s->win.cap = cap;
+    PSK_TRY(ensure(s->win.keys, cap * 16));  // full capacity at once: growing would drop the waiting keys
+    PSK_TRY(comb_order(s, st));
+    HIP_TRY(hipMemcpyAsync((uint8_t *)s->win.keys.p + s->win.n * 16, data, n * 16, where == PSK_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+    s->win.batches.push_back(psk_sketch::WinBatch{s->win.n, n, remove ? 1u : 0u});
+    s->win.n += n;
+    PSK_TRY(comb_appended(s, st));
+    if (where == PSK_HOST) HIP_TRY(hipStreamSynchronize(st));  // the caller may reuse its buffer on return
+    return PSK_OK;
+}
+
 int flush_combined(psk_sketch *s, hipStream_t st)
 {
     if (s->kind != PSK_KIND_CBF) return PSK_OK;
+    if (s->win.n) {  // (the window holds what arrived AFTER anything the older mechanisms below hold: see win_append's callers)
+        ++s->table_version;
+        if (s->comb.add.n || s->comb.rem.n || s->comb.badd.n() || s->comb.brem.n() || (s->scat.ready && (s->scat.add.n || s->scat.rem.n))) {
+            std::vector<psk_sketch::WinBatch> keep;
+            keep.swap(s->win.batches);
+            const uint64_t wn = s->win.n;
+            s->win.n = 0;
+            PSK_TRY(flush_combined(s, st));
+            s->win.batches.swap(keep);
+            s->win.n = wn;
+        }
+        PSK_TRY(win_flush(s, st));
+    }
     const bool keys_pending = s->comb.add.n != 0 || s->comb.rem.n != 0 || s->comb.badd.n() != 0 || s->comb.brem.n() != 0;
     const bool scat_pending = s->scat.ready && (s->scat.add.n != 0 || s->scat.rem.n != 0);
     if (!keys_pending && !scat_pending) return PSK_OK;
@@ -1086,12 +1216,18 @@ extern "C" int psk_cbf_add(psk_sketch *s, int layout, const void *data, const ui
     CHECK_HANDLE(s, PSK_KIND_CBF);
     PSK_TRY(check_hashes_width(s, layout, key_len));
     hipStream_t st = (hipStream_t)stream;
+    if (where != PSK_HOST && where != PSK_DEVICE) return fail(PSK_EINVAL, "`where` must be PSK_HOST or PSK_DEVICE");
+    if (win_eligible(s, layout, data, key_len, weights, n)) {
+        // (what the older write-combining mechanisms hold arrived earlier: it goes first)
+        if (s->comb.add.n || s->comb.rem.n || s->comb.badd.n() || s->comb.brem.n() || (s->scat.ready && (s->scat.add.n || s->scat.rem.n))) PSK_TRY(flush_combined(s, st));
+        return win_append(s, data, n, false, where, st);
+    }
     Batch b;
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
     // Automatic write-combining (no opt-in): a unit-weight batch too small to pay for a pass over a big table would take one
     // fabric atomic per probe.  Adds commute (countingbloom.py:135-155; the clamp at 2^32-1 is applied by the fold just the
     // same), so the batch is scattered now and folded with its successors; every entry point that reads or removes flushes first.
-    if (!weights && g_auto_combine != 0 && s->comb.rem.n == 0 && s->comb.brem.n() == 0 && s->scat.rem.n == 0 && (int64_t)n >= g_part_min_keys &&
+    if (!weights && g_auto_combine != 0 && s->win.n == 0 && s->comb.rem.n == 0 && s->comb.brem.n() == 0 && s->scat.rem.n == 0 && (int64_t)n >= g_part_min_keys &&
         n * (uint64_t)s->k < s->m / 8 && g_auto_combine_keys > 0) {
         bool taken = false;
         PSK_TRY(scat_append(s, b, false, (uint64_t)g_auto_combine_keys, st, &taken));
@@ -1198,35 +1334,46 @@ static int cbf_remove_composed(psk_sketch *s, const Batch &b, const uint32_t *w,
     return PSK_OK;
 }
 
+// the validated remove (countingbloom.py:186-208) of a device-resident batch: composed from the partitioned pipelines when the batch is
+// large enough, else the direct kernel
+static int cbf_remove_device(psk_sketch *s, const Batch &b, const uint32_t *w, hipStream_t st)
+{
+    if (b.n == 0) return PSK_OK;
+    bool done = false;
+    PSK_TRY(cbf_remove_composed(s, b, w, st, &done));
+    if (done) return PSK_OK;
+    return with_source(b, [&](auto src) {
+        using Src = decltype(src);
+        if (s->pow2)
+            hipLaunchKernelGGL((k_cbf_remove<Src, true>), dim3(grid_for(b.n)), dim3(kBlock), 0, st, src, (uint32_t *)s->table, s->md, s->k, w, b.n,
+                               (unsigned long long *)s->ctr);
+        else
+            hipLaunchKernelGGL((k_cbf_remove<Src, false>), dim3(grid_for(b.n)), dim3(kBlock), 0, st, src, (uint32_t *)s->table, s->md, s->k, w, b.n,
+                               (unsigned long long *)s->ctr);
+        HIP_TRY(hipGetLastError());
+        return (int)PSK_OK;
+    });
+}
+
 extern "C" int psk_cbf_remove(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
                               uint32_t key_len, const uint32_t *weights, int where, void *stream)
 {
     CHECK_HANDLE(s, PSK_KIND_CBF);
     PSK_TRY(check_hashes_width(s, layout, key_len));
     hipStream_t st = (hipStream_t)stream;
+    if (where != PSK_HOST && where != PSK_DEVICE) return fail(PSK_EINVAL, "`where` must be PSK_HOST or PSK_DEVICE");
+    if (win_eligible(s, layout, data, key_len, weights, n)) {
+        // A small batch into a big table: it waits in the update window (with the adds around it, in order) for a shared pass over
+        // the table; the flush proves that it would have removed every key at this point of the stream, or replays it right here.
+        if (s->comb.add.n || s->comb.rem.n || s->comb.badd.n() || s->comb.brem.n() || (s->scat.ready && (s->scat.add.n || s->scat.rem.n))) PSK_TRY(flush_combined(s, st));
+        return win_append(s, data, n, true, where, st);
+    }
     PSK_TRY(flush_combined(s, st));  // write-combined updates reach the table before anything else touches it
     Batch b;
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
     const uint32_t *w;
     PSK_TRY(stage_vec(s->s_w, weights, n, where, st, &w));
-    {
-        bool done = false;
-        PSK_TRY(cbf_remove_composed(s, b, w, st, &done));
-        if (done) return finish(where, nullptr, st);
-    }
-    if (n) {
-        PSK_TRY(with_source(b, [&](auto src) {
-            using Src = decltype(src);
-            if (s->pow2)
-                hipLaunchKernelGGL((k_cbf_remove<Src, true>), dim3(grid_for(n)), dim3(kBlock), 0, st, src,
-                                   (uint32_t *)s->table, s->md, s->k, w, n, (unsigned long long *)s->ctr);
-            else
-                hipLaunchKernelGGL((k_cbf_remove<Src, false>), dim3(grid_for(n)), dim3(kBlock), 0, st, src,
-                                   (uint32_t *)s->table, s->md, s->k, w, n, (unsigned long long *)s->ctr);
-            HIP_TRY(hipGetLastError());
-            return (int)PSK_OK;
-        }));
-    }
+    PSK_TRY(cbf_remove_device(s, b, w, st));
     return finish(where, nullptr, st);
 }
 
@@ -1633,7 +1780,8 @@ extern "C" int psk_release_scratch(psk_sketch *s)
     PSK_TRY(flush_combined(s, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
-                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->s_brw, &s->shadow.img}) {
+                      &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->s_brw, &s->shadow.img,
+                      &s->win.keys, &s->s_snap, &s->s_wstat, &s->s_phase}) {
         if (b->p) HIP_TRY(hipFree(b->p));
         b->p = nullptr;
         b->cap = 0;

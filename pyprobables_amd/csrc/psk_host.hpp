@@ -162,6 +162,22 @@ struct psk_sketch {
         unsigned long long issued = 0, seen = 0;
         uint32_t backoff = 0;
     } wt;
+    // Update WINDOW (psk_window.hpp, round 4): small unit-weight add / remove batches of 16-byte keys into a big table wait here, in
+    // arrival order, as key copies; the flush proves while it folds that every remove would have succeeded at its own position of the
+    // stream (else: undo + batch-by-batch replay), so the result is the reference's for ANY stream -- no opt-in, no contract.
+    struct WinBatch {
+        uint64_t start, n;   // keys [start, start + n) of the list
+        uint32_t remove;
+    };
+    struct {
+        DevBuf keys;         // uint8[cap][16]
+        uint64_t n = 0, cap = 0;
+        std::vector<WinBatch> batches;
+        uint32_t backoff = 0;      // windows left that are replayed batch by batch without trying the fold (after a failed proof)
+        void *pin = nullptr;       // pinned staging of the phase table
+        uint64_t folds = 0, replays = 0;   // statistics (psk_get_option "update_window_folds" / "_replays" report the globals)
+    } win;
+    DevBuf s_snap, s_wstat, s_phase;           // window fold: per-phase segment fill counts, per-part status, phase table
     PartGeom rm_g{};     // geometry of the validated remove's fast path between its optimistic decrement and a possible undo
     // Read-mostly CountingBloomFilter tables (round 3): the nibble-slice lookup reads the whole 32-bit table to build its 4-bit
     // images (1 GiB for BASELINE cfg 4).  When the table has not changed since the previous lookup the images are kept -- a linear
@@ -580,5 +596,13 @@ PSK_DECLARE_VARIANTS(int, cbf_nib_scatter, (psk_sketch *s, const Batch &b, int n
 // validated unit-weight remove, fast path: pass 1 + the optimistic decrement (flag in s_flag); flag up: _undo adds the probe groups back
 PSK_DECLARE_VARIANTS(int, cbf_remove_fast_begin, (psk_sketch *s, const Batch &b, hipStream_t st, bool *launched))
 PSK_DECLARE_VARIANTS(int, cbf_remove_fast_undo, (psk_sketch *s, hipStream_t st))
+// The fold of an update window (psk_window.hpp): phase-aware pass 1 over the window's key list + k_win_fold; *launched = false: table /
+// window not eligible (nothing changed); *ok = false: the proof failed -- the fold has been undone, the caller replays batch by batch.
+struct WinPhaseHost {
+    uint64_t start, n;
+    uint32_t remove;
+};
+PSK_DECLARE_VARIANTS(int, cbf_window_fold, (psk_sketch *s, const WinPhaseHost *ph, uint32_t nph, const void *keys_dev, uint64_t nlist, hipStream_t st, bool *launched, bool *ok))
+extern PSK_HIDDEN int64_t g_window, g_window_keys, g_window_folds, g_window_replays, g_window_force_fail;
 extern PSK_HIDDEN int64_t g_remove_dryrun;
 extern PSK_HIDDEN int64_t g_auto_combine, g_auto_combine_keys, g_combine_keys, g_combine_scatter, g_fused_flush;

@@ -1,0 +1,98 @@
+// update windows of the CountingBloomFilter (psk_window.hpp): phase-aware pass 1 + the phase-by-phase fold (own translation unit)
+#include "psk_part_counter.hpp"
+#include "psk_window.hpp"
+
+template <int KT, int NT>
+static int window_scatter(psk_sketch *s, const WinPhaseHost *ph, uint32_t nph, const void *keys_dev, uint64_t nlist, PartGeom *g, uint32_t *flag,
+                          hipStream_t st)
+{
+    using Tile = PartTile<PayNonePhased, KT, NT>;
+    const uint64_t tk = Tile::TILE;
+    // phases start on tile boundaries: phase p owns ceil(n_p / tile) tiles, the last one short
+    if (!s->win.pin) HIP_TRY(hipHostMalloc(&s->win.pin, (kWinMaxPhases + 1) * sizeof(PhaseDesc), hipHostMallocDefault));
+    PhaseDesc *hd = (PhaseDesc *)s->win.pin;
+    uint64_t tiles = 0;
+    for (uint32_t p = 0; p < nph; ++p) {
+        hd[p] = PhaseDesc{(uint32_t)tiles, ph[p].remove, (long long)ph[p].start - (long long)(tiles * tk), ph[p].n};
+        tiles += (ph[p].n + tk - 1) / tk;
+    }
+    if (tiles >= (1ULL << 31)) return fail(PSK_EINVAL, "update window of %llu tiles", (unsigned long long)tiles);
+    hd[nph] = PhaseDesc{(uint32_t)tiles, 0u, 0LL, 0ULL};
+    PSK_TRY(ensure(s->s_phase, (kWinMaxPhases + 1) * sizeof(PhaseDesc)));
+    HIP_TRY(hipMemcpyAsync(s->s_phase.p, hd, (nph + 1) * sizeof(PhaseDesc), hipMemcpyHostToDevice, st));  // (pinned: consumed before the flush's sync)
+    const uint32_t nwg = 256;  // one 1024-thread workgroup per CU (k <= 8), every one of them writes its snapshots
+    const uint64_t tiles_per_wg = (tiles + nwg - 1) / nwg;
+    const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
+    const double mean = (double)tiles_per_wg * (double)tk * kk / (double)g->nbuckets;
+    const uint64_t segcap = (uint64_t)(mean / Tile::GS + 0.5 * (double)tiles_per_wg + 8.0 * __builtin_sqrt(mean) / Tile::GS + 16.0);
+    if (segcap >= (1u << 24) || (uint64_t)g->nbuckets * segcap >= (1ULL << 32)) return fail(PSK_EINVAL, "update window too large (segments of %llu groups)", (unsigned long long)segcap);
+    g->nwg = nwg;
+    g->segcap = (uint32_t)segcap;
+    g->tile = (uint32_t)tk;
+    g->dense = 0;
+    g->append = 0;
+    PSK_TRY(ensure(s->s_part, (uint64_t)g->nbuckets * nwg * segcap * 16 + 256));
+    PSK_TRY(ensure(s->s_cnt, (uint64_t)g->nbuckets * nwg * 4 + 128));
+    PSK_TRY(ensure(s->s_snap, (uint64_t)nph * g->nbuckets * nwg * 4));
+    const PayNonePhased pay{(const PhaseDesc *)s->s_phase.p, nph, (uint32_t *)s->s_snap.p, nlist};
+    // (an overflowing segment would need the reference's clamp, which the undo could not invert: it raises the flag instead)
+    const SpillRaiseFlagCounter spill{flag};
+    const size_t lds = scatter_lds_bytes<PayNonePhased, KT, NT>(g);
+    auto kern = k_part_scatter<KeysFixed16, IdxBloom<kTuPow2>, PayNonePhased, SpillRaiseFlagCounter, KT, NT>;
+    PSK_TRY(set_dyn_lds(kern, lds));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, st, KeysFixed16{(const uint4 *)keys_dev}, IdxBloom<kTuPow2>{s->md}, pay, spill, *g, tiles * tk,
+                       (uint32_t *)s->s_cnt.p, (uint4 *)s->s_part.p);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
+
+int PSK_VARIANT(cbf_window_fold)(psk_sketch *s, const WinPhaseHost *ph, uint32_t nph, const void *keys_dev, uint64_t nlist, hipStream_t st, bool *launched,
+                                 bool *ok)
+{
+    *launched = false;
+    *ok = false;
+    PartGeom g;
+    if (g_update_nibble == 0 || nph == 0 || nph > (uint32_t)kWinMaxPhases || nlist == 0 || s->k > 32 || !nib_geometry(s->m, true, &g)) return PSK_OK;
+    g.k = s->k;
+    PSK_TRY(ensure(s->s_flag, 8));
+    uint32_t *flag = (uint32_t *)s->s_flag.p;
+    HIP_TRY(hipMemsetAsync(flag, 0, 4, st));
+    bool fits = true;
+    PSK_TRY(with_kt<KeysFixed16>(s->k, [&](auto kt) {
+        constexpr int KT = decltype(kt)::value;
+        if constexpr (KT <= 8) {
+            if (scatter_lds_bytes<PayNonePhased, KT, 1024>(&g) <= kScatterLdsBudget) return window_scatter<KT, 1024>(s, ph, nph, keys_dev, nlist, &g, flag, st);
+        }
+        if (scatter_lds_bytes<PayNonePhased, KT, kPartThreads>(&g) <= kScatterLdsBudget) return window_scatter<KT, kPartThreads>(s, ph, nph, keys_dev, nlist, &g, flag, st);
+        fits = false;
+        return (int)PSK_OK;
+    }));
+    if (!fits) return PSK_OK;
+    *launched = true;
+    const WinPhases wp{nph, (const PhaseDesc *)s->s_phase.p};
+    const uint32_t pshift = g.shift < kWinPartShift ? g.shift : kWinPartShift;
+    const uint32_t parts = g.nbuckets << (g.shift - pshift);
+    const size_t lds = (size_t)1 << pshift;
+    PSK_TRY(ensure(s->s_wstat, (uint64_t)parts * 4));
+    {
+        auto kern = k_win_fold<false>;
+        PSK_TRY(set_dyn_lds(kern, lds));
+        hipLaunchKernelGGL(kern, dim3(parts), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint4 *)s->s_part.p, (const uint32_t *)s->s_snap.p,
+                           wp, (uint32_t *)s->s_wstat.p, flag);
+        HIP_TRY(hipGetLastError());
+    }
+    if (g_window_force_fail) HIP_TRY(hipMemsetAsync(flag, 1, 4, st));  // (tests: the undo + replay path on a well-formed stream)
+    uint32_t verdict = 1;
+    HIP_TRY(hipMemcpyAsync(&verdict, flag, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (verdict == 0) {
+        *ok = true;
+        return PSK_OK;
+    }
+    auto kern = k_win_fold<true>;  // the proof failed: put every part back where it was
+    PSK_TRY(set_dyn_lds(kern, lds));
+    hipLaunchKernelGGL(kern, dim3(parts), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint4 *)s->s_part.p, (const uint32_t *)s->s_snap.p, wp,
+                       (uint32_t *)s->s_wstat.p, flag);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}

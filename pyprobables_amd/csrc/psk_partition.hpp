@@ -129,6 +129,11 @@ struct pay_is_lookup { static constexpr bool value = false; };
 template <class Pay>
 struct pay_is_lookup<Pay, decltype((void)Pay::lookup)> { static constexpr bool value = Pay::lookup; };
 
+template <class Pay, class = void>
+struct pay_is_phased { static constexpr bool value = false; };
+template <class Pay>
+struct pay_is_phased<Pay, decltype((void)Pay::phased)> { static constexpr bool value = Pay::phased; };
+
 // payload functors: the second word a probe carries through the LDS sort (key i of a tile starting at base)
 struct PayNone {   // Bloom insert: 6 probes per group, 20-bit slice-local bit indices
     static constexpr int mode = kModePlain;
@@ -142,6 +147,28 @@ struct PayUnitMasked {  // PayNone's probes, for the keys with amount[i] != 0 on
     const uint32_t *amount;
     __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
     __device__ __forceinline__ uint32_t keep(uint64_t i) const { return amount[i]; }
+};
+// One PHASE of a CountingBloomFilter update window (psk_window.hpp): a run of same-type batches (all adds, or all removes) of the
+// window's key list.  Pass 1 runs ONCE over the whole list, but a tile never straddles two phases: phase p owns the tiles
+// [tile0, next phase's tile0), key j of tile t is list entry key_off + t * tile + j, and the phase's last tile is short.
+struct PhaseDesc {
+    uint32_t tile0;            // first pass-1 tile of the phase (entry [nph] closes the table: tile0 = number of tiles)
+    uint32_t remove;           // 0 adds, 1 removes (countingbloom.py:135-155 / :186-208)
+    long long key_off;
+    unsigned long long nkeys;
+};
+// PayNone's probes for such a list.  A (slice, workgroup) segment receives its tiles in tile order, i.e. in phase order, so the
+// segment's fill count at the END of every phase cuts it into per-phase pieces: the workgroup leaves these counts in
+// snap[phase][slice][workgroup] (the fold walks a slice phase by phase: adds, barrier, removes that must not meet a zero, ...).
+struct PayNonePhased {
+    static constexpr int mode = kModePlain;
+    static constexpr int group = 6;
+    static constexpr bool phased = true;
+    const PhaseDesc *ph;       // device array [nph + 1]
+    uint32_t nph;
+    uint32_t *snap;            // [nph][nbuckets][nwg]
+    uint64_t nlist;            // keys in the list (prefetches are clamped to it)
+    __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
 };
 struct PayUnit {   // unit-weight counter adds: 8 probes per group, 16-bit slice-local cell indices (slices <= 2^15 cells)
     static constexpr int mode = kModePlain;
@@ -393,7 +420,10 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t dbg = kBenchKnobs ? g.dbg : 0u;  // folds to 0 in the shipped build
     const uint32_t B = g.nbuckets;
-    const uint64_t last = n ? n - 1 : 0;       // index the clamped prefetches fall back to (the key buffer holds at least one key)
+    constexpr bool PHASED = pay_is_phased<Pay>::value;  // n = tiles x tile size (virtual: every phase is padded to whole tiles)
+    uint64_t nlim = n;                         // keys the source holds
+    if constexpr (PHASED) nlim = pay.nlist;
+    const uint64_t last = nlim ? nlim - 1 : 0; // index the clamped prefetches fall back to (the key buffer holds at least one key)
     uint32_t *hist0 = smem;  // two copies: tile t counts in one while the scan phase of tile t zeroes the other
     uint32_t *off = hist0 + 2 * B;
     uint32_t *delta = off + B;
@@ -422,13 +452,31 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     // Software pipeline over tiles: the NEXT tile's keys are loaded right after this tile's hash phase and
     // pinned before this tile's write-out stores are issued (vmcnt counts loads and stores in order on CDNA4:
     // a key load waited for AFTER the stores would also wait for ~300 KB of stores to drain).
+    // list index of tile t's first key; phased lists: p (a phase at or before t's) moves on to t's phase -- uniform, scalar loads
+    auto tile_base = [&](uint64_t t, uint32_t &p) -> uint64_t {
+        if constexpr (PHASED) {
+            if (t >= ntiles) return nlim;  // (past the end: every lane clamps)
+            while (p + 1 < pay.nph && t >= (uint64_t)pay.ph[p + 1].tile0) ++p;
+            return (uint64_t)(pay.ph[p].key_off + (long long)(t * tk));
+        } else {
+            return t * tk;
+        }
+    };
+    uint32_t ph_cur = 0;  // phased lists: first phase whose end-of-phase counts I have not written yet
+    auto write_snapshot = [&](uint32_t p) {
+        if constexpr (PHASED) {
+            for (uint32_t b = threadIdx.x; b < B; b += NT) pay.snap[((uint64_t)p * B + b) * g.nwg + blockIdx.x] = cur[b];
+        }
+    };
     typename Src::Key kcur[KPT];
     if (kPartPipeline) {
+        uint32_t p0 = 0;
+        const uint64_t b0 = tile_base(blockIdx.x, p0);
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
-            const uint64_t i = (uint64_t)blockIdx.x * tk + (uint64_t)q * NT + threadIdx.x;
-            kcur[q] = src.load(i < n ? i : last);  // coalesced; clamped, never branched around (a conditional load
-        }                                           // makes hipcc wait vmcnt(0) per element: serial round trips)
+            const uint64_t i = b0 + (uint64_t)q * NT + threadIdx.x;
+            kcur[q] = src.load(i < nlim ? i : last);  // coalesced; clamped, never branched around (a conditional load
+        }                                              // makes hipcc wait vmcnt(0) per element: serial round trips)
     }
 
     // phase profile (dbg & 32): lane 0 of wave 0 accumulates s_memtime deltas per phase; bench-only
@@ -456,8 +504,15 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         // ---- hash + histogram: rank = my position among this tile's probes of the same slice
         uint32_t idx[KPT][KT], rank[KPT][KT], payload[KPT];
         uint32_t fold = 0;
-        const uint64_t base = tile * tk;
-        const uint64_t tile_end = base + tk < n ? base + tk : n;
+        uint32_t ph_tile = ph_cur;
+        const uint64_t base = tile_base(tile, ph_tile);
+        uint64_t tile_end = base + tk < nlim ? base + tk : nlim;
+        if constexpr (PHASED) {
+            // cur[] is what my segments held after my last tile, i.e. at the end of every phase before this tile's
+            for (; ph_cur < ph_tile; ++ph_cur) write_snapshot(ph_cur);
+            const uint64_t left = pay.ph[ph_tile].nkeys - (tile - pay.ph[ph_tile].tile0) * tk;  // keys of the phase from this tile on
+            tile_end = base + (left < tk ? left : tk);
+        }
         // Pay::keep (masked batches): a key whose flag is 0 sends no probes.  The flags are requested up front and first consumed
         // behind the key's hash chains, which hides the load.
         constexpr bool KEEP = pay_has_keep<Pay>::value;
@@ -466,7 +521,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
 #pragma unroll
             for (int q = 0; q < KPT; ++q) {
                 const uint64_t i = base + (uint64_t)q * NT + threadIdx.x;
-                kw[q] = pay.keep(i < n ? i : last);
+                kw[q] = pay.keep(i < nlim ? i : last);
             }
         }
         auto kept = [&](int q) -> bool { if constexpr (KEEP) return kw[q] != 0; else return true; };
@@ -527,11 +582,12 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         if (dbg & 2) {  // bench-only: keep the hashes alive, skip the rest of the tile (uniform)
             if (fold == 0x12345u) segcnt[0] = fold;
             if (kPartPipeline) {
-                const uint64_t nbase = (tile + gridDim.x) * tk;
+                uint32_t pn = ph_tile;
+                const uint64_t nbase = tile_base(tile + gridDim.x, pn);
 #pragma unroll
                 for (int q = 0; q < KPT; ++q) {
                     const uint64_t i = nbase + (uint64_t)q * NT + threadIdx.x;
-                    kcur[q] = src.load(i < n ? i : last);
+                    kcur[q] = src.load(i < nlim ? i : last);
                 }
             }
             continue;
@@ -542,11 +598,12 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
 
         // ---- prefetch the next tile's keys (consumed -- pinned -- before the write-out below)
         if (kPartPipeline) {
-            const uint64_t nbase = (tile + gridDim.x) * tk;
+            uint32_t pn = ph_tile;
+            const uint64_t nbase = tile_base(tile + gridDim.x, pn);
 #pragma unroll
             for (int q = 0; q < KPT; ++q) {
                 const uint64_t i = nbase + (uint64_t)q * NT + threadIdx.x;
-                kcur[q] = src.load(i < n ? i : last);  // unconditional (clamped) on purpose, see above
+                kcur[q] = src.load(i < nlim ? i : last);  // unconditional (clamped) on purpose, see above
             }
         }
 
@@ -682,6 +739,9 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         PSK_TICK(5);
     }
     lds_barrier();
+    if constexpr (PHASED) {  // the phases behind my last tile (all of them for a workgroup without tiles)
+        for (; ph_cur < pay.nph; ++ph_cur) write_snapshot(ph_cur);
+    }
     if ((dbg & 32) && threadIdx.x == 0) {  // counts land behind the segment counts (host reserves the room)
         unsigned long long *prof = reinterpret_cast<unsigned long long *>(segcnt + (size_t)g.nbuckets * g.nwg);
         for (int ph = 1; ph < 12; ++ph) atomicAdd(prof + ph, t_acc[ph]);

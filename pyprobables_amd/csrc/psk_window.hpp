@@ -1,0 +1,273 @@
+// psk_window.hpp -- CountingBloomFilter update WINDOWS: small add / remove batches wait together and reach a big table in one pass
+// over it, with the reference's per-batch semantics (round 4).
+//
+// Why: folding a big table (BASELINE cfg 4: 2^28 counters, 1 GiB) costs a pass over the WHOLE table whatever the batch brings, so
+// a stream of 1 M-key batches only runs fast when many batches share one pass.  Adds commute; removes do not: countingbloom.py:186-208
+// removes a key only if the min of its counters is non-zero (and not frozen at 2^32-1) AT THAT POINT of the stream.  Deferring a
+// remove past later adds is therefore exact only if it would have succeeded at its own position.  Here that is PROVEN while folding:
+//   * the window keeps its batches in arrival order; runs of same-type batches are PHASES (adds, removes, adds, ...);
+//   * pass 1 (k_part_scatter<..., PayNonePhased>) runs once over the window's key list; a tile never straddles two phases, and a
+//     (slice, workgroup) segment receives its tiles in order, so the end-of-phase fill counts (snap[phase][slice][workgroup]) cut
+//     every segment into per-phase pieces;
+//   * the fold (k_win_fold) keeps a BYTE image of the real counters of its table part in LDS (min(counter, 255); 2^17 counters =
+//     128 KiB, two workgroups per 2^18-counter slice, each applying the probes of its half) and walks the slice's probes phase by
+//     phase: adds with a returning ds_add, barrier, removes with a returning ds_sub whose old byte must be 1 .. 254.
+//     With T[c] the counter before a remove phase and R[c] the phase's probes on it:  T[c] >= R[c] for every c, none frozen  ==>
+//     every key of the phase is removed whatever the order inside it (each of its counters holds >= 1 just before its own
+//     decrement), and the result is T - R.  By induction over the phases the window's result is the sequential one.
+//   * a remove that meets a zero (or a frozen / saturating counter) raises the window's flag: the host then UNDOES the fold
+//     (k_win_fold<true>: the inverse net delta, wrapping arithmetic, exact) and replays the window batch by batch through the
+//     validated per-batch path -- the reference's semantics for any stream, automatically.
+// Counters of 254 and more do not fit the image's arithmetic: a part that touches one drops its image and applies its probes, phase
+// by phase, with wrapping atomics on the table itself (the part is its alone) -- same checks, exact.
+#pragma once
+#include "psk_nibble.hpp"
+
+namespace psk {
+
+constexpr uint32_t kWinPartShift = 17;  // log2(counters of one workgroup's byte image): 128 KiB
+constexpr int kWinMaxPhases = 256;
+struct WinPhases {
+    uint32_t nph;
+    const PhaseDesc *ph;                // device table of pass 1 (ph[p].remove; uniform reads)
+};
+// what a fold workgroup did to its table part (status[blockIdx.x]); the undo inverts exactly that
+constexpr uint32_t kWinWritten = 0;   // image written back
+constexpr uint32_t kWinAborted = 1;   // a remove met a zero: nothing written
+constexpr uint32_t kWinAtomics = 2;   // applied with wrapping atomics on the table (a counter >= 254 in play)
+
+// the six slice-local indices of a probe group that are valid (PayNone: two halves of 3 x 20 bits, valid count in bits 60..63)
+template <class F>
+__device__ __forceinline__ void win_each_probe(const uint4 &q, F &&f)
+{
+    const uint32_t n0 = q.y >> 28, n1 = q.w >> 28;
+    const unsigned long long h0 = ((unsigned long long)q.y << 32) | q.x, h1 = ((unsigned long long)q.w << 32) | q.z;
+    if (n0 > 0) f((uint32_t)h0 & 0xFFFFFu);
+    if (n0 > 1) f((uint32_t)(h0 >> 20) & 0xFFFFFu);
+    if (n0 > 2) f((uint32_t)(h0 >> 40) & 0xFFFFFu);
+    if (n1 > 0) f((uint32_t)h1 & 0xFFFFFu);
+    if (n1 > 1) f((uint32_t)(h1 >> 20) & 0xFFFFFu);
+    if (n1 > 2) f((uint32_t)(h1 >> 40) & 0xFFFFFu);
+}
+
+// Which segment (pass-1 workgroup) of the slice a lane walks: wave w owns segments [w * spw, (w + 1) * spw), L lanes each.
+struct WinLane {
+    uint32_t seg, sub, L;
+    bool active;
+};
+__device__ __forceinline__ WinLane win_lane(const PartGeom &g)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t spw = (g.nwg + kApplyWaves - 1) / kApplyWaves;  // <= 64 (pass 1 runs at most 64 * kApplyWaves workgroups)
+    uint32_t L = 1;
+    while (L * 2 * spw <= 64) L *= 2;
+    WinLane w;
+    w.L = L;
+    w.sub = lane % L;
+    w.seg = wave * spw + lane / L;
+    w.active = lane / L < spw && w.seg < g.nwg;
+    return w;
+}
+
+// plain walk, phase by phase (the rare paths: atomics on the table, undo).  op(index in slice, phase removes?)
+template <class Op>
+__device__ __forceinline__ void win_walk_simple(const PartGeom &g, const uint4 *buckets, const uint32_t *snap, const WinPhases &wp, uint32_t b,
+                                                bool barriers, Op &&op)
+{
+    const WinLane wl = win_lane(g);
+    const uint4 *src = buckets + seg_index(g, b, wl.active ? wl.seg : 0) * g.segcap;
+    uint32_t lo = 0;
+    for (uint32_t p = 0; p < wp.nph; ++p) {
+        uint32_t hi = 0;
+        if (wl.active) {
+            hi = snap[((uint64_t)p * g.nbuckets + b) * g.nwg + wl.seg];
+            hi = hi < g.segcap ? hi : g.segcap;
+        }
+        const bool rem = wp.ph[p].remove != 0;
+        for (uint32_t gi = lo + wl.sub; gi < hi; gi += wl.L) {
+            const uint4 q = src[gi];
+            win_each_probe(q, [&](uint32_t x) { op(x, rem); });
+        }
+        lo = hi;
+        if (barriers) {
+            __threadfence();
+            __syncthreads();
+        }
+    }
+}
+
+// UNDO = false: apply the window to my table part (blockIdx.x = slice * parts + part); flag: a remove met a zero / a counter
+// would freeze -- the window has to be undone and replayed.  UNDO = true: the exact inverse of what the forward launch did.
+// dynamic LDS: the byte image, 2^min(shift, 17) bytes
+template <bool UNDO>
+__global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint64_t tab_cells, PartGeom g, const uint4 *buckets, const uint32_t *snap,
+                                                            WinPhases wp, uint32_t *status, uint32_t *flag)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ uint32_t s_viol, s_taint;
+    const uint32_t pshift = g.shift < kWinPartShift ? g.shift : kWinPartShift;
+    const uint32_t nparts = 1u << (g.shift - pshift);
+    const uint32_t b = blockIdx.x / nparts, h = blockIdx.x % nparts;
+    const uint32_t pieces = 1u << (pshift - 2);  // 16-byte pieces of my table part = words of the image
+    const uint32_t pmask = (1u << pshift) - 1;
+    const uint64_t c0 = ((uint64_t)b << g.shift) + ((uint64_t)h << pshift);
+    if (c0 >= tab_cells) {
+        if (!UNDO && threadIdx.x == 0) status[blockIdx.x] = kWinAborted;  // (a part past the table's end: nothing to do, nothing to undo)
+        return;
+    }
+    uint32_t st_fwd = kWinWritten;
+    if (UNDO) {
+        st_fwd = status[blockIdx.x];
+        if (st_fwd == kWinAborted) return;
+    }
+    // ---- applied with atomics on the table itself (forward: after the image gave up, below; undo: the inverse, any order)
+    auto atomics_pass = [&](bool inverse) {
+        uint32_t bad = 0;
+        win_walk_simple(g, buckets, snap, wp, b, !inverse, [&](uint32_t x, bool rem) {
+            if ((x >> pshift) != h) return;
+            uint32_t *cell = tab + c0 + (x & pmask);
+            if (inverse) {
+                if (rem) atomicAdd(cell, 1u);
+                else atomicSub(cell, 1u);
+            } else if (rem) {
+                const uint32_t old = atomicSub(cell, 1u);  // countingbloom.py:198-206: zero -> not removed, 2^32-1 -> frozen
+                bad |= (uint32_t)(old == 0u) | (uint32_t)(old == 0xFFFFFFFFu);
+            } else {
+                const uint32_t old = atomicAdd(cell, 1u);  // countingbloom.py:149-153 clamps at 2^32-1: the replay does that
+                bad |= (uint32_t)(old >= 0xFFFFFFFEu);
+            }
+        });
+        if (bad) *flag = 1u;
+    };
+    if (UNDO && st_fwd == kWinAtomics) {
+        atomics_pass(true);
+        return;
+    }
+    // ---- my part of the table -> byte image (min(counter, 255); 255 marks a counter the image cannot follow)
+    if (threadIdx.x == 0) s_viol = s_taint = 0;
+    {
+        constexpr int U = 8;
+        for (uint32_t p0 = threadIdx.x; p0 < pieces; p0 += kApplyThreads * U) {
+            uint4 t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t pc = p0 + (uint32_t)u * kApplyThreads;
+                t[u] = pc < pieces ? nib_load_piece(tab, tab_cells, c0 + 4ULL * pc) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t pc = p0 + (uint32_t)u * kApplyThreads;
+                auto by = [](uint32_t c) -> uint32_t { return c < 255u ? c : 255u; };
+                if (pc < pieces) smem[pc] = by(t[u].x) | (by(t[u].y) << 8) | (by(t[u].z) << 16) | (by(t[u].w) << 24);
+            }
+        }
+    }
+    __syncthreads();
+    if (UNDO) {
+        // the inverse net delta, in any order: word arithmetic modulo 2^32 -- carries between the bytes cancel, every byte ends
+        // where it started (all of them were below 255 when the forward launch wrote them)
+        win_walk_simple(g, buckets, snap, wp, b, false, [&](uint32_t x, bool rem) {
+            if ((x >> pshift) != h) return;
+            const uint32_t c = x & pmask, one = 1u << ((c & 3u) * 8u);
+            if (rem) atomicAdd(&smem[c >> 2], one);
+            else atomicSub(&smem[c >> 2], one);
+        });
+        __syncthreads();
+    } else {
+        // ---- the phases, in order.  Probe groups are requested K phases ahead (their addresses depend on the snapshots only, not on
+        // the image): a phase of a 1 M-key batch is ~1.4 groups per lane, far too little to hide an HBM round trip behind.
+        constexpr int K = 4, R = 2;  // phases in flight, groups per lane and phase held in registers (more: loaded on demand)
+        const WinLane wl = win_lane(g);
+        const uint4 *src = buckets + seg_index(g, b, wl.active ? wl.seg : 0) * g.segcap;
+        const uint32_t nph = wp.nph;
+        auto cum = [&](uint32_t p) -> uint32_t {  // groups of my segment up to the end of phase p
+            if (!wl.active) return 0u;
+            const uint32_t pp = p < nph ? p : nph - 1;
+            const uint32_t v = snap[((uint64_t)pp * g.nbuckets + b) * g.nwg + wl.seg];
+            return v < g.segcap ? v : g.segcap;
+        };
+        uint32_t viol = 0, taint = 0;
+        auto apply = [&](const uint4 &q, bool rem) {
+            win_each_probe(q, [&](uint32_t x) {
+                if ((x >> pshift) != h) return;
+                const uint32_t c = x & pmask, sh = (c & 3u) * 8u;
+                if (rem) {
+                    const uint32_t ob = (atomicSub(&smem[c >> 2], 1u << sh) >> sh) & 255u;  // ds_sub_rtn_u32
+                    viol |= (uint32_t)(ob == 0u);
+                    taint |= (uint32_t)(ob == 255u);
+                } else {
+                    const uint32_t ob = (atomicAdd(&smem[c >> 2], 1u << sh) >> sh) & 255u;  // ds_add_rtn_u32
+                    taint |= (uint32_t)(ob >= 254u);
+                }
+            });
+        };
+        uint32_t C[2 * K + 1], N[K];  // C[i] = cum(p0 - 1 + i)
+        uint4 Q[K][R];
+        C[0] = 0;
+#pragma unroll
+        for (int i = 1; i <= 2 * K; ++i) C[i] = cum((uint32_t)(i - 1));
+        const uint4 zero4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t gi = C[j] + wl.sub + (uint32_t)r * wl.L;
+                Q[j][r] = gi < C[j + 1] ? src[gi] : zero4;
+            }
+        for (uint32_t p0 = 0; p0 < nph; p0 += K) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint32_t p = p0 + (uint32_t)j;
+                if (p < nph) {  // (uniform)
+                    const bool rem = wp.ph[p].remove != 0;
+                    N[j] = cum(p0 + 2 * K + (uint32_t)j);  // lands K phases before it is used
+#pragma unroll
+                    for (int r = 0; r < R; ++r) apply(Q[j][r], rem);  // (absent groups are all-zero: no valid probe)
+                    for (uint32_t gi = C[j] + wl.sub + (uint32_t)R * wl.L; gi < C[j + 1]; gi += wl.L) apply(src[gi], rem);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {  // phase p + K takes the registers over
+                        const uint32_t gi = C[j + K] + wl.sub + (uint32_t)r * wl.L;
+                        Q[j][r] = gi < C[j + K + 1] ? src[gi] : zero4;
+                    }
+                    lds_barrier();  // the next phase reads what this one left in the image (LDS only: the loads stay in flight)
+                }
+            }
+#pragma unroll
+            for (int i = 0; i <= K; ++i) C[i] = C[i + K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) C[K + 1 + i] = N[i];
+        }
+        if (viol) s_viol = 1u;
+        if (taint) s_taint = 1u;
+        __syncthreads();
+        if (s_taint) {  // a counter of 254 or more in play: the image is void (bytes may have carried); the table part is still untouched
+            if (threadIdx.x == 0) status[blockIdx.x] = kWinAtomics;
+            atomics_pass(false);
+            return;
+        }
+        if (s_viol) {  // a remove met a zero: nothing of this part reaches the table; the host undoes the others and replays the window
+            if (threadIdx.x == 0) {
+                status[blockIdx.x] = kWinAborted;
+                *flag = 1u;
+            }
+            return;
+        }
+        if (threadIdx.x == 0) status[blockIdx.x] = kWinWritten;
+    }
+    // ---- image -> table (a byte of 255 is a counter nobody touched: it keeps its value)
+    for (uint32_t pc = threadIdx.x; pc < pieces; pc += kApplyThreads) {
+        const uint32_t w = smem[pc];
+        const uint64_t gc = c0 + 4ULL * pc;
+        const uint32_t v[4] = {w & 255u, (w >> 8) & 255u, (w >> 16) & 255u, w >> 24};
+        const bool marked = v[0] == 255u || v[1] == 255u || v[2] == 255u || v[3] == 255u;
+        if (!marked && gc + 3 < tab_cells) {
+            *reinterpret_cast<uint4 *>(tab + gc) = make_uint4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (v[e] != 255u && gc + e < tab_cells) tab[gc + e] = v[e];
+        }
+    }
+}
+
+}  // namespace psk

@@ -1,0 +1,204 @@
+"""CountingBloomFilter UPDATE WINDOWS (psk_window.hpp, round 4): small add_many / remove_many batches into a big table wait
+together, in arrival order, and reach the table in ONE pass -- through the plain default API, with the reference's semantics
+(countingbloom.py:135-155, :186-208) for ANY stream: the fold proves, phase by phase, that every remove would have succeeded at its
+own position of the stream; a window for which it cannot (removes of absent keys ...) is undone and replayed batch by batch.
+Every case compares the whole table and ``elements_added`` with the sequential oracle."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def pa():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import pyprobables_amd
+
+    return pyprobables_amd
+
+
+@pytest.fixture()
+def N():
+    from pyprobables_amd import _native as N
+
+    names = ("update_window", "update_window_keys", "update_window_force_fail")
+    old = [N.get_option(k) for k in names]
+    yield N
+    for k, v in zip(names, old):
+        N.set_option(k, v)
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _table(cbf):
+    return cbf.table_tensor.cpu().numpy().view(np.uint32)[: cbf.number_bits]
+
+
+def _stream(oracle, nb, B, seed=11):
+    """BASELINE cfg 4's shape: batch b adds B keys and (b >= 1) removes the first half of batch b - 1"""
+    keys = oracle.gen_keys16(seed, nb * B)
+    ops = []
+    for b in range(nb):
+        ops.append((False, keys[b * B:(b + 1) * B]))
+        if b >= 1:
+            ops.append((True, keys[(b - 1) * B:(b - 1) * B + B // 2]))
+    return ops
+
+
+def _run(cbf, oc, ops):
+    for rem, kk in ops:
+        if rem:
+            cbf.remove_many(_dev(kk))
+            oc.update_keys(kk, -np.ones(len(kk), dtype=np.int64))
+        else:
+            cbf.add_many(_dev(kk))
+            oc.update_keys(kk)
+
+
+def _same(cbf, oc):
+    assert np.array_equal(_table(cbf), oc.bloom)
+    assert cbf.elements_added == oc.els_added
+
+
+@pytest.mark.parametrize("est", [3_600_000, 10_000_000])
+def test_mixed_stream_is_folded_in_one_pass_and_matches_the_oracle(pa, oracle, N, est):
+    """3.45e7 counters (132 slices of 2^18: two fold workgroups per slice) and 9.6e7 (Barrett indices)"""
+    cbf = pa.CountingBloomFilter(est_elements=est, false_positive_rate=0.01)
+    m, k = cbf.number_bits, cbf.number_hashes
+    assert m > 2**24
+    B = 200_000 if est < 5_000_000 else 400_000
+    assert B * k < m // 8  # every batch is "small": it waits
+    ops = _stream(oracle, 12, B)
+    oc = oracle.OracleCBF(m, k)
+    folds, replays = N.get_option("update_window_folds"), N.get_option("update_window_replays")
+    _run(cbf, oc, ops)
+    _same(cbf, oc)  # (reading the table flushes the window)
+    assert N.get_option("update_window_folds") == folds + 1 and N.get_option("update_window_replays") == replays
+    assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+    # lookups see the folded table
+    probe = np.concatenate([ops[0][1][:5000], ops[-2][1][:5000], oracle.gen_keys16(777, 5000)])
+    assert np.array_equal(cbf.check_many(_dev(probe)).cpu().numpy().view(np.uint32), oc.check_keys(probe))
+
+
+def test_window_over_a_loaded_table_and_across_flushes(pa, oracle, N):
+    """removes of keys that an EARLIER window added (the proof reads the table's own counters), lookups between the batches"""
+    cbf = pa.CountingBloomFilter(est_elements=3_600_000, false_positive_rate=0.01)
+    m, k = cbf.number_bits, cbf.number_hashes
+    oc = oracle.OracleCBF(m, k)
+    base = oracle.gen_keys16(3, 2_000_000)
+    cbf.add_many(_dev(base))  # a big batch: straight to the table
+    oc.update_keys(base)
+    B = 250_000
+    fresh = oracle.gen_keys16(4, 8 * B)
+    folds = N.get_option("update_window_folds")
+    for r in range(2):
+        for b in range(4):
+            a = fresh[(4 * r + b) * B:(4 * r + b + 1) * B]
+            d = base[(4 * r + b) * B // 2:(4 * r + b + 1) * B // 2]  # present since the first batch
+            cbf.add_many(_dev(a))
+            oc.update_keys(a)
+            cbf.remove_many(_dev(d))
+            oc.update_keys(d, -np.ones(len(d), dtype=np.int64))
+        got = cbf.check_many(_dev(fresh[: 4 * (r + 1) * B: 997])).cpu().numpy().view(np.uint32)  # flushes
+        assert np.array_equal(got, oc.check_keys(fresh[: 4 * (r + 1) * B: 997]))
+    _same(cbf, oc)
+    assert N.get_option("update_window_folds") == folds + 2
+
+
+def test_removes_of_absent_keys_undo_the_fold_and_replay(pa, oracle, N):
+    """countingbloom.py:200-201: a remove of an absent key is a no-op -- the window cannot prove such a stream, undoes its fold
+    and replays the batches one by one; the result is the oracle's table, not a violation tally"""
+    cbf = pa.CountingBloomFilter(est_elements=3_600_000, false_positive_rate=0.01)
+    m, k = cbf.number_bits, cbf.number_hashes
+    B = 200_000
+    ops = _stream(oracle, 12, B)
+    absent = oracle.gen_keys16(999, B // 2)
+    ops.insert(7, (True, np.concatenate([absent, ops[4][1][B // 2:B // 2 + 1000]])))  # never added + present ones, mixed
+    oc = oracle.OracleCBF(m, k)
+    folds, replays = N.get_option("update_window_folds"), N.get_option("update_window_replays")
+    _run(cbf, oc, ops)
+    _same(cbf, oc)
+    assert N.get_option("update_window_replays") == replays + 1 and N.get_option("update_window_folds") == folds
+    assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+    # the stream keeps coming, well-formed again: after the back-off the fold is back
+    more = _stream(oracle, 12, B, seed=12)
+    for _ in range(10):
+        _run(cbf, oc, more[:3])
+        _same(cbf, oc)
+        more_rm = [(True, more[0][1][B // 2:]), (True, more[2][1])]  # put the counters back for the next turn
+        _run(cbf, oc, more_rm)
+    _run(cbf, oc, more)
+    _same(cbf, oc)
+    assert N.get_option("update_window_folds") >= folds + 1
+
+
+def test_forced_failure_undoes_exactly(pa, oracle, N):
+    """the undo kernel alone: a well-formed window whose verdict is forced to 'failed' must come out the same through the replay"""
+    cbf = pa.CountingBloomFilter(est_elements=3_600_000, false_positive_rate=0.01)
+    m, k = cbf.number_bits, cbf.number_hashes
+    oc = oracle.OracleCBF(m, k)
+    pre = oracle.gen_keys16(21, 1_500_000)
+    cbf.add_many(_dev(pre), np.full(len(pre), 3, dtype=np.uint32))
+    oc.update_keys(pre, np.full(len(pre), 3, dtype=np.int64))
+    N.set_option("update_window_force_fail", 1)
+    replays = N.get_option("update_window_replays")
+    _run(cbf, oc, _stream(oracle, 10, 250_000, seed=5))
+    _same(cbf, oc)
+    assert N.get_option("update_window_replays") == replays + 1
+
+
+def test_counters_beyond_the_byte_image_take_the_atomics(pa, oracle, N):
+    """a part that meets a counter of 254 or more drops its image and applies its probes to the table itself -- exact"""
+    cbf = pa.CountingBloomFilter(est_elements=3_600_000, false_positive_rate=0.01)
+    m, k = cbf.number_bits, cbf.number_hashes
+    oc = oracle.OracleCBF(m, k)
+    B = 200_000
+    ops = _stream(oracle, 12, B, seed=31)
+    hot = ops[2][1][:50]
+    cbf.add_many(_dev(hot), np.full(50, 1000, dtype=np.uint32))  # 350 counters at 1000 and more
+    oc.update_keys(hot, np.full(50, 1000, dtype=np.int64))
+    frozen = ops[4][1][:3]
+    cbf.add_many(_dev(frozen), np.full(3, 2**32 - 1, dtype=np.uint32))  # and 21 frozen ones (2^32 - 1)
+    oc.update_keys(frozen, np.full(3, 2**32 - 1, dtype=np.int64))
+    _run(cbf, oc, ops)  # batch 2 / 4 add to and batch 3 / 5's removes take from those counters
+    _same(cbf, oc)
+
+
+def test_duplicates_inside_the_window(pa, oracle, N):
+    """the same keys added several times and removed as often, and 300 copies of one key (a counter that crosses 254 mid-window)"""
+    cbf = pa.CountingBloomFilter(est_elements=3_600_000, false_positive_rate=0.01)
+    m, k = cbf.number_bits, cbf.number_hashes
+    oc = oracle.OracleCBF(m, k)
+    kk = oracle.gen_keys16(41, 150_000)
+    rep = np.concatenate([kk[:1]] * 300 + [kk[1:100_000]])
+    ops = [(False, kk), (False, kk), (True, kk), (False, rep), (True, kk), (False, kk), (True, rep), (False, kk), (True, kk), (True, kk)]
+    ops = ops * 2
+    _run(cbf, oc, ops)
+    _same(cbf, oc)
+
+
+def test_option_off_and_host_batches(pa, oracle, N):
+    cbf = pa.CountingBloomFilter(est_elements=3_600_000, false_positive_rate=0.01)
+    m, k = cbf.number_bits, cbf.number_hashes
+    oc = oracle.OracleCBF(m, k)
+    ops = _stream(oracle, 12, 200_000, seed=51)
+    folds = N.get_option("update_window_folds")
+    for rem, kk in ops:  # numpy batches: copied straight from the caller's buffer, which may be reused at once
+        buf = kk.copy()
+        (cbf.remove_many if rem else cbf.add_many)(buf)
+        buf[:] = 0
+        oc.update_keys(kk, -np.ones(len(kk), dtype=np.int64) if rem else None)
+    _same(cbf, oc)
+    assert N.get_option("update_window_folds") == folds + 1
+    N.set_option("update_window", 0)
+    cbf.clear()
+    oc = oracle.OracleCBF(m, k)
+    _run(cbf, oc, ops[:8])
+    _same(cbf, oc)
+    assert N.get_option("update_window_folds") == folds + 1
