@@ -131,7 +131,7 @@ def test_removes_of_absent_keys_undo_the_fold_and_replay(pa, oracle, N):
     for _ in range(10):
         _run(cbf, oc, more[:3])
         _same(cbf, oc)
-        more_rm = [(True, more[0][1][B // 2:]), (True, more[2][1])]  # put the counters back for the next turn
+        more_rm = [(True, more[0][1][B // 2:]), (True, more[1][1])]  # put the counters back for the next turn
         _run(cbf, oc, more_rm)
     _run(cbf, oc, more)
     _same(cbf, oc)
