@@ -85,7 +85,9 @@ def parse():
     ap.add_argument("--spinup", type=float, default=1.0, help="seconds of untimed steps before warm-up (clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-detail", action="store_true", help="skip the CMS / CBF / GUPS side measurements")
-    ap.add_argument("--no-combine", action="store_true", help="cfg4: apply every 1M-key batch at once (no write-combining of update batches)")
+    ap.add_argument("--no-combine", action="store_true", help="cfg4: apply every 1M-key batch at once (update windows off: psk_set_option update_window=0)")
+    ap.add_argument("--legacy-combine", action="store_true", help="cfg4: the round-2/3 opt-in (combine_updates=True: removes are plain decrements applied after "
+                    "the window's adds -- exact for well-formed streams only); default is the plain API, whose update windows are exact for any stream")
     ap.add_argument("--borrow-keys", action="store_true", help="cfg4: the resident, never overwritten key batches are BORROWED (PSK_DEVICE_BORROWED): the "
                     "engine keeps pointers and hashes them where they lie at the flush, instead of copying every batch into its key lists "
                     "(same throughput, no 2 x 1.25 GiB of lists)")
@@ -608,8 +610,15 @@ class Cfg4:
         self.ctx, self.args, self.pa = ctx, args, pa
         self.B, self.nb = args.batch, args.batches
         self.keys = ctx.gen_keys(self.B * self.nb, 0)   # 50M keys = 800 MB resident
-        self.mode = False if args.no_combine else ("borrow" if args.borrow_keys else True)
-        self.cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, device=ctx.dev, combine_updates=self.mode)
+        # default: the plain API (add_many / remove_many, no opt-in) -- the engine's update windows (psk_window.hpp) make the small
+        # batches share passes over the table and keep the reference's semantics for any stream
+        self.mode = "off" if args.no_combine else ("borrow" if args.borrow_keys else (True if args.legacy_combine else "window"))
+        if self.mode == "off":
+            from pyprobables_amd import _native as N
+
+            N.set_option("update_window", 0)
+        self.cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, device=ctx.dev,
+                                          combine_updates=self.mode if self.mode in (True, "borrow") else False)
         assert self.cbf.number_bits == 2**28
         self.adds, self.removes = self.B * self.nb, (self.nb - 1) * (self.B // 2)
         self.ops_per_step = self.adds + self.removes
@@ -634,6 +643,12 @@ class Cfg4:
     def instrumented(self):
         pass
 
+    @staticmethod
+    def _opt(name):
+        from pyprobables_amd import _native as N
+
+        return N.get_option(name)
+
     def finish(self, ms_step):
         ctx, torch, cbf = self.ctx, self.ctx.torch, self.cbf
         expect = self.adds - self.removes
@@ -647,18 +662,20 @@ class Cfg4:
             "config": {"workload": f"cfg4: CountingBloomFilter(28005615, 0.01): 2^28 x uint32 = 1 GiB; per step clear + {self.nb} batches: "
                                    f"add {self.B} keys, remove the first {self.B // 2} keys of the previous batch",
                        "batch_keys": self.B, "batches": self.nb, "ops_per_step": self.ops_per_step, "parallelism": "single GPU",
-                       "combine_updates": self.mode,
-                       "note": "combine_updates: the 1M-key batches wait on the device and are applied as one partitioned update per list, all "
-                               "inside the timed step (the stream ends with a flush); removes are decrements, exact for this well-formed stream. "
-                               "True (default): every batch is copied into the engine's key lists (D2D) and read again at the flush; 'borrow' "
-                               "(--borrow-keys; legal here: the bench's key batches are resident and never overwritten): the engine keeps "
-                               "pointers to the batches and hashes them where they lie -- no key copy, one key read; False (--no-combine): "
-                               "every batch at once"},
-            "roofline": roofline("cbf_add", "CBF stream = per fold: k_part_scatter (coarse) + k_part_split + k_counter_apply over the 1 GiB table",
+                       "api": {"window": "default (add_many / remove_many, no opt-in)", "off": "default API, update windows off",
+                               True: "opt-in combine_updates=True", "borrow": "opt-in combine_updates='borrow'"}[self.mode],
+                       "combine_updates": self.mode if self.mode in (True, "borrow") else False,
+                       "note": "default API: the engine lets the 1M-key batches wait, in arrival order, in an update window and applies them in one "
+                               "pass over the table that PROVES every remove (psk_window.hpp; exact for any stream: a window it cannot prove is "
+                               "undone and replayed batch by batch), all inside the timed step (the stream ends with a flush).  --legacy-combine / "
+                               "--borrow-keys: the round-3 opt-ins (removes as plain decrements after the window's adds: well-formed streams only); "
+                               "--no-combine: update windows off, every batch at once"},
+            "roofline": roofline("cbf_add", "CBF stream = per window: key copies + k_part_scatter<PayNonePhased> + k_win_fold over the 1 GiB table",
                                  self.ops_per_step, ms, "the fold read-modify-writes the whole 1 GiB table; batches are combined before it",
-                                 {True: "cfg4_stream", "borrow": "cfg4_stream_borrow", False: "cfg4_stream_nocombine"}[self.mode]),
+                                 {True: "cfg4_stream", "borrow": "cfg4_stream_borrow", "off": "cfg4_stream_nocombine", "window": "cfg4_stream_window"}[self.mode]),
             "rooflines": {},
-            "detail": {"elements_added": els, "expected_elements": expect, "sum_counters_equals_k_x_live": total == 7 * expect, "diagnostics": diag},
+            "detail": {"elements_added": els, "expected_elements": expect, "sum_counters_equals_k_x_live": total == 7 * expect, "diagnostics": diag,
+                       "update_window_folds": self._opt("update_window_folds"), "update_window_replays": self._opt("update_window_replays")},
         }
         return line, ([] if ok else ["parity property violated (cfg4)"])
 

@@ -957,14 +957,14 @@ static int borrowed_flush(psk_sketch *s, psk_sketch::BorrowList &bl, bool remove
 // ---- update windows (psk_window.hpp): small unit-weight add / remove batches of 16-byte keys into big tables wait, in arrival order,
 // as key copies; win_flush applies them in one pass over the table, proving the removes while it folds -- or replays them one by one
 int64_t g_window = 1;                // option "update_window"
-int64_t g_window_keys = 1 << 26;     // option "update_window_keys": most keys a window holds (16 bytes each); also cells / 4 and the scratch budget
+int64_t g_window_keys = 1 << 27;     // option "update_window_keys": most keys a window holds (16 bytes each); also cells / 2 and the scratch budget
 int64_t g_window_folds = 0, g_window_replays = 0;  // windows applied by the fold / replayed batch by batch (tests, bench)
 int64_t g_window_force_fail = 0;     // tests: pretend the proof failed (exercises undo + replay on a well-formed stream)
 constexpr size_t kWinMaxBatches = 4096;
 
 static uint64_t win_capacity(const psk_sketch *s)
 {
-    uint64_t cap = s->m / 4;
+    uint64_t cap = s->m / 2;  // (BASELINE cfg 4's whole 74.5 M-operation step is one window of the 2^28-counter table)
     if (cap < (1u << 20)) cap = 1u << 20;
     if (g_window_keys > 0 && cap > (uint64_t)g_window_keys) cap = (uint64_t)g_window_keys;
     cap = cap_round_by_budget(cap, 16.0 + (double)s->k * (16.0 / 6.0) * 1.5);  // key copy + probe groups with their padding

@@ -3,24 +3,36 @@
 #include "psk_window.hpp"
 
 template <int KT, int NT>
-static int window_scatter(psk_sketch *s, const WinPhaseHost *ph, uint32_t nph, const void *keys_dev, uint64_t nlist, PartGeom *g, uint32_t *flag,
-                          hipStream_t st)
+static int window_scatter(psk_sketch *s, const WinPhaseHost *ph, uint32_t nph_host, const void *keys_dev, uint64_t nlist, PartGeom *g, uint32_t *flag,
+                          hipStream_t st, uint32_t *nph_out)
 {
     using Tile = PartTile<PayNonePhased, KT, NT>;
     const uint64_t tk = Tile::TILE;
     // phases start on tile boundaries: phase p owns ceil(n_p / tile) tiles, the last one short
     if (!s->win.pin) HIP_TRY(hipHostMalloc(&s->win.pin, (kWinMaxPhases + 1) * sizeof(PhaseDesc), hipHostMallocDefault));
     PhaseDesc *hd = (PhaseDesc *)s->win.pin;
+    const uint32_t nwg = 256;  // one 1024-thread workgroup per CU (k <= 8), every one of them writes its snapshots
+    // A phase of the fold is at most two tiles per pass-1 workgroup (longer runs of same-type batches are cut: k_win_fold holds a
+    // phase's probe groups of a segment in a fixed number of registers).
+    const uint64_t cut = 2ULL * nwg * tk;
     uint64_t tiles = 0;
-    for (uint32_t p = 0; p < nph; ++p) {
-        hd[p] = PhaseDesc{(uint32_t)tiles, ph[p].remove, (long long)ph[p].start - (long long)(tiles * tk), ph[p].n};
-        tiles += (ph[p].n + tk - 1) / tk;
+    uint32_t nph = 0;
+    for (uint32_t p = 0; p < nph_host; ++p) {
+        for (uint64_t off = 0; off < ph[p].n; off += cut) {
+            const uint64_t cnt = ph[p].n - off < cut ? ph[p].n - off : cut;
+            if (nph >= (uint32_t)kWinMaxPhases) {  // (the caller replays such a window batch by batch)
+                *nph_out = 0;
+                return PSK_OK;
+            }
+            hd[nph++] = PhaseDesc{(uint32_t)tiles, ph[p].remove, (long long)(ph[p].start + off) - (long long)(tiles * tk), cnt};
+            tiles += (cnt + tk - 1) / tk;
+        }
     }
+    *nph_out = nph;
     if (tiles >= (1ULL << 31)) return fail(PSK_EINVAL, "update window of %llu tiles", (unsigned long long)tiles);
     hd[nph] = PhaseDesc{(uint32_t)tiles, 0u, 0LL, 0ULL};
     PSK_TRY(ensure(s->s_phase, (kWinMaxPhases + 1) * sizeof(PhaseDesc)));
     HIP_TRY(hipMemcpyAsync(s->s_phase.p, hd, (nph + 1) * sizeof(PhaseDesc), hipMemcpyHostToDevice, st));  // (pinned: consumed before the flush's sync)
-    const uint32_t nwg = 256;  // one 1024-thread workgroup per CU (k <= 8), every one of them writes its snapshots
     const uint64_t tiles_per_wg = (tiles + nwg - 1) / nwg;
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
     const double mean = (double)tiles_per_wg * (double)tk * kk / (double)g->nbuckets;
@@ -52,27 +64,27 @@ int PSK_VARIANT(cbf_window_fold)(psk_sketch *s, const WinPhaseHost *ph, uint32_t
     *launched = false;
     *ok = false;
     PartGeom g;
-    if (g_update_nibble == 0 || nph == 0 || nph > (uint32_t)kWinMaxPhases || nlist == 0 || s->k > 32 || !nib_geometry(s->m, true, &g)) return PSK_OK;
+    if (g_update_nibble == 0 || nph == 0 || nlist == 0 || s->k > 32 || !nib_geometry(s->m, true, &g)) return PSK_OK;
     g.k = s->k;
     PSK_TRY(ensure(s->s_flag, 8));
     uint32_t *flag = (uint32_t *)s->s_flag.p;
     HIP_TRY(hipMemsetAsync(flag, 0, 4, st));
-    bool fits = true;
+    uint32_t nph_dev = 0;  // phases of the fold (0: the window does not fit -- nothing was launched)
     PSK_TRY(with_kt<KeysFixed16>(s->k, [&](auto kt) {
         constexpr int KT = decltype(kt)::value;
         if constexpr (KT <= 8) {
-            if (scatter_lds_bytes<PayNonePhased, KT, 1024>(&g) <= kScatterLdsBudget) return window_scatter<KT, 1024>(s, ph, nph, keys_dev, nlist, &g, flag, st);
+            if (scatter_lds_bytes<PayNonePhased, KT, 1024>(&g) <= kScatterLdsBudget) return window_scatter<KT, 1024>(s, ph, nph, keys_dev, nlist, &g, flag, st, &nph_dev);
         }
-        if (scatter_lds_bytes<PayNonePhased, KT, kPartThreads>(&g) <= kScatterLdsBudget) return window_scatter<KT, kPartThreads>(s, ph, nph, keys_dev, nlist, &g, flag, st);
-        fits = false;
+        if (scatter_lds_bytes<PayNonePhased, KT, kPartThreads>(&g) <= kScatterLdsBudget) return window_scatter<KT, kPartThreads>(s, ph, nph, keys_dev, nlist, &g, flag, st, &nph_dev);
         return (int)PSK_OK;
     }));
-    if (!fits) return PSK_OK;
+    if (nph_dev == 0) return PSK_OK;
     *launched = true;
-    const WinPhases wp{nph, (const PhaseDesc *)s->s_phase.p};
+    const WinPhases wp{nph_dev, (const PhaseDesc *)s->s_phase.p};
     const uint32_t pshift = g.shift < kWinPartShift ? g.shift : kWinPartShift;
     const uint32_t parts = g.nbuckets << (g.shift - pshift);
-    const size_t lds = (size_t)1 << pshift;
+    const size_t lds = win_fold_lds(g, nph_dev);
+    if (lds > 160 * 1024) return fail(PSK_EINVAL, "update window: %u phases of %u segments do not fit the fold's LDS", nph_dev, g.nwg);
     PSK_TRY(ensure(s->s_wstat, (uint64_t)parts * 4));
     {
         auto kern = k_win_fold<false>;

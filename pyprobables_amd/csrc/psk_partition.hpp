@@ -465,7 +465,9 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     uint32_t ph_cur = 0;  // phased lists: first phase whose end-of-phase counts I have not written yet
     auto write_snapshot = [&](uint32_t p) {
         if constexpr (PHASED) {
-            for (uint32_t b = threadIdx.x; b < B; b += NT) pay.snap[((uint64_t)p * B + b) * g.nwg + blockIdx.x] = cur[b];
+            // (bit 31: the phase removes -- the fold reads the phase's type off the counts it loads anyway, phases ahead of their use)
+            const uint32_t type_bit = pay.ph[p].remove ? 0x80000000u : 0u;
+            for (uint32_t b = threadIdx.x; b < B; b += NT) pay.snap[((uint64_t)p * B + b) * g.nwg + blockIdx.x] = cur[b] | type_bit;
         }
     };
     typename Src::Key kcur[KPT];

@@ -23,10 +23,12 @@
 #pragma once
 #include "psk_nibble.hpp"
 
+#include <type_traits>
+
 namespace psk {
 
 constexpr uint32_t kWinPartShift = 17;  // log2(counters of one workgroup's byte image): 128 KiB
-constexpr int kWinMaxPhases = 256;
+constexpr int kWinMaxPhases = 192;   // (their 4-bit group counts sit next to the image: 192 x 128 bytes for 256 pass-1 workgroups)
 struct WinPhases {
     uint32_t nph;
     const PhaseDesc *ph;                // device table of pass 1 (ph[p].remove; uniform reads)
@@ -48,6 +50,24 @@ __device__ __forceinline__ void win_each_probe(const uint4 &q, F &&f)
     if (n1 > 0) f((uint32_t)h1 & 0xFFFFFu);
     if (n1 > 1) f((uint32_t)(h1 >> 20) & 0xFFFFFu);
     if (n1 > 2) f((uint32_t)(h1 >> 40) & 0xFFFFFu);
+}
+
+// The fold's probe-group prefetch is issued behind hipcc's back (inline asm) and waited for with explicit counts.  hipcc inserts its
+// own s_waitcnt in front of every use of a loaded register, and across a loop's back edge its count is conservative: it drained ALL loads
+// in flight at every phase, or every K-th phase, whatever the source looked like (five formulations measured: 3.1-3.4 ms per fold of
+// BASELINE cfg 4's step).  vmcnt counts in order, so "the oldest R loads have landed" is s_waitcnt vmcnt(loads issued since).
+// Rules that keep this safe: the registers are touched by nothing between win_gld4 and win_wait (checked in the ISA: no v_mov of them),
+// win_wait names them as read-write operands so that no use can be scheduled in front of it, and every path out of the loop waits
+// for vmcnt(0) before the registers can be given to anything else.
+typedef uint32_t win_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void win_gld4(win_u32x4 &dst, const uint4 *p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void win_wait(win_u32x4 &a, win_u32x4 &b, win_u32x4 &c)
+{
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
 }
 
 // Which segment (pass-1 workgroup) of the slice a lane walks: wave w owns segments [w * spw, (w + 1) * spw), L lanes each.
@@ -80,7 +100,7 @@ __device__ __forceinline__ void win_walk_simple(const PartGeom &g, const uint4 *
     for (uint32_t p = 0; p < wp.nph; ++p) {
         uint32_t hi = 0;
         if (wl.active) {
-            hi = snap[((uint64_t)p * g.nbuckets + b) * g.nwg + wl.seg];
+            hi = snap[((uint64_t)p * g.nbuckets + b) * g.nwg + wl.seg] & 0x7FFFFFFFu;  // (bit 31: the phase's type)
             hi = hi < g.segcap ? hi : g.segcap;
         }
         const bool rem = wp.ph[p].remove != 0;
@@ -96,9 +116,15 @@ __device__ __forceinline__ void win_walk_simple(const PartGeom &g, const uint4 *
     }
 }
 
+static inline size_t win_fold_lds(const PartGeom &g, uint32_t nph)
+{
+    const uint32_t pshift = g.shift < kWinPartShift ? g.shift : kWinPartShift;
+    return ((size_t)1 << pshift) + (((size_t)nph * ((g.nwg + 1) / 2) + 3) & ~(size_t)3) + (((size_t)nph + 31) / 32) * 4 + 16;
+}
+
 // UNDO = false: apply the window to my table part (blockIdx.x = slice * parts + part); flag: a remove met a zero / a counter
 // would freeze -- the window has to be undone and replayed.  UNDO = true: the exact inverse of what the forward launch did.
-// dynamic LDS: the byte image, 2^min(shift, 17) bytes
+// dynamic LDS: the byte image, 2^min(shift, 17) bytes | 4-bit group counts [phases][ceil(nwg / 2)] | phase types (win_fold_lds)
 template <bool UNDO>
 __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint64_t tab_cells, PartGeom g, const uint4 *buckets, const uint32_t *snap,
                                                             WinPhases wp, uint32_t *status, uint32_t *flag)
@@ -174,69 +200,114 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
         });
         __syncthreads();
     } else {
-        // ---- the phases, in order.  Probe groups are requested K phases ahead (their addresses depend on the snapshots only, not on
-        // the image): a phase of a 1 M-key batch is ~1.4 groups per lane, far too little to hide an HBM round trip behind.
-        constexpr int K = 4, R = 2;  // phases in flight, groups per lane and phase held in registers (more: loaded on demand)
+        // ---- the phases, in order.  A phase is at most ~2 pass-1 tiles per workgroup (the host cuts longer ones): ~1.4 probe groups per
+        // lane, far too little to hide an HBM round trip behind, so the groups are requested K phases ahead.  Their addresses follow from
+        // the snapshots alone: those are turned into per-(phase, segment) group COUNTS first (4 bits each, next to the image in LDS --
+        // a segment-phase of more than R * L groups does not fit the registers anyway and sends the part to the atomics), so that the
+        // walk's only global loads are the groups themselves, R per lane and phase, unconditional (clamped address; whether the lane
+        // has a group is applied where the group is used): hipcc can then count the loads in flight and wait for the oldest only
+        // (s_waitcnt vmcnt(n) counts in order; with loads under branches, or loaded registers copied / selected before their phase,
+        // it drains every load at every phase -- the first version: 3.3 us per phase).
+        constexpr int K = 3, R = 3;  // phases in flight; groups per lane and phase
         const WinLane wl = win_lane(g);
         const uint4 *src = buckets + seg_index(g, b, wl.active ? wl.seg : 0) * g.segcap;
         const uint32_t nph = wp.nph;
-        auto cum = [&](uint32_t p) -> uint32_t {  // groups of my segment up to the end of phase p
-            if (!wl.active) return 0u;
-            const uint32_t pp = p < nph ? p : nph - 1;
-            const uint32_t v = snap[((uint64_t)pp * g.nbuckets + b) * g.nwg + wl.seg];
-            return v < g.segcap ? v : g.segcap;
-        };
-        uint32_t viol = 0, taint = 0;
-        auto apply = [&](const uint4 &q, bool rem) {
-            win_each_probe(q, [&](uint32_t x) {
-                if ((x >> pshift) != h) return;
-                const uint32_t c = x & pmask, sh = (c & 3u) * 8u;
-                if (rem) {
-                    const uint32_t ob = (atomicSub(&smem[c >> 2], 1u << sh) >> sh) & 255u;  // ds_sub_rtn_u32
-                    viol |= (uint32_t)(ob == 0u);
-                    taint |= (uint32_t)(ob == 255u);
-                } else {
-                    const uint32_t ob = (atomicAdd(&smem[c >> 2], 1u << sh) >> sh) & 255u;  // ds_add_rtn_u32
-                    taint |= (uint32_t)(ob >= 254u);
+        uint8_t *cnt4 = reinterpret_cast<uint8_t *>(smem + pieces);     // [nph][ceil(nwg / 2)]: two segments per byte
+        uint32_t *types = smem + pieces + ((nph * ((g.nwg + 1) / 2) + 3) / 4);  // bit p: phase p removes
+        const uint32_t row = (g.nwg + 1) / 2;
+        for (uint32_t i = threadIdx.x; i < (nph + 31) / 32; i += kApplyThreads) types[i] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nph * row; i += kApplyThreads) {
+            const uint32_t p = i / row, s2 = (i - p * row) * 2;
+            uint32_t byte = 0, ty = 0;
+#pragma unroll
+            for (uint32_t e = 0; e < 2; ++e) {
+                if (s2 + e < g.nwg) {
+                    const uint32_t cur = snap[((uint64_t)p * g.nbuckets + b) * g.nwg + s2 + e];
+                    const uint32_t prev = p ? snap[((uint64_t)(p - 1) * g.nbuckets + b) * g.nwg + s2 + e] & 0x7FFFFFFFu : 0u;
+                    ty = cur >> 31;
+                    const uint32_t c1 = cur & 0x7FFFFFFFu, hi = c1 < g.segcap ? c1 : g.segcap, lo = prev < g.segcap ? prev : g.segcap;
+                    const uint32_t d = hi - lo;
+                    byte |= (d < 15u ? d : 15u) << (4 * e);
                 }
-            });
+            }
+            cnt4[i] = (uint8_t)byte;
+            if (s2 == 0 && ty) atomicOr(&types[p >> 5], 1u << (p & 31));
+        }
+        __syncthreads();
+        uint32_t viol = 0, taint = 0;
+        auto count = [&](uint32_t p) -> uint32_t {  // groups of my segment in phase p (0 past the end / for an idle lane)
+            if (p >= nph || !wl.active) return 0u;
+            const uint32_t d = (cnt4[p * row + (wl.seg >> 1)] >> (4 * (wl.seg & 1))) & 15u;
+            return d;
         };
-        uint32_t C[2 * K + 1], N[K];  // C[i] = cum(p0 - 1 + i)
-        uint4 Q[K][R];
-        C[0] = 0;
+        // one probe group: the returning LDS atomics of its probes (mine: valid slot, my half of the slice) issue back to back, then the
+        // old bytes are judged.  rm: all ones in a remove phase, else 0.  The atomics run under the lane's own predicate: the LDS pipe
+        // is what bounds a phase (~3 lanes per clock and CU for random returning atomics), so a probe of the other half must not cost
+        // a slot -- a fully branch-free version that added 0 for those took 3.3 us per phase, as long as the waits it replaced.
+        // (per group: ~12 VALU per probe -- the fold is bound by VALU issue, 4 cycles per wave64 instruction with four waves per SIMD,
+        // not by its waits: three applies per lane and phase at ~130 instructions each were 2.7 us per phase)
+        const uint32_t amask = pmask & ~3u;          // byte address of the counter's word in the image
+        auto apply = [&](const win_u32x4 &q, uint32_t rm) {
+            const uint32_t n0 = q.y >> 28, n1 = q.w >> 28;
+            const uint32_t x[6] = {q.x, __builtin_amdgcn_alignbit(q.y, q.x, 20), q.y >> 8, q.z, __builtin_amdgcn_alignbit(q.w, q.z, 20), q.w >> 8};
+            const uint32_t pm = rm | 1u;             // +1 (adds) or -1 (removes): shifted into the counter's byte lane
+            uint32_t ob[6];
 #pragma unroll
-        for (int i = 1; i <= 2 * K; ++i) C[i] = cum((uint32_t)(i - 1));
-        const uint4 zero4 = make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < K; ++j)
+            for (int e = 0; e < 6; ++e) {
+                const bool mine = (uint32_t)(e % 3) < (e < 3 ? n0 : n1) && ((x[e] >> pshift) & ((1u << (20 - kWinPartShift)) - 1u)) == h;
+                const uint32_t sh = (x[e] & 3u) * 8u;
+                uint32_t old = 0x01010101u;          // (a probe that is not mine: an old byte nobody objects to)
+                if (mine) old = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(smem) + (x[e] & amask)), pm << sh);  // ds_add_rtn_u32
+                ob[e] = (old >> sh) & 255u;
+            }
+            // removes: every old byte must be 1 .. 254 (0: the key is not there -- countingbloom.py:200-201; 255: beyond the image);
+            // adds: 0 .. 253 (254 would become the marker)
+            const uint32_t mn = min(min(min(ob[0], ob[1]), min(ob[2], ob[3])), min(ob[4], ob[5]));
+            const uint32_t mx = max(max(max(ob[0], ob[1]), max(ob[2], ob[3])), max(ob[4], ob[5]));
+            viol |= rm & (uint32_t)(mn == 0u);
+            taint |= (uint32_t)(mx >= 254u + (rm & 1u));
+        };
+        // the R groups of a phase that brings `d` groups from `lo` on in my segment; a lane without a group re-reads the phase's
+        // first one and remembers that it has none (qv: applied where the group is used)
+        static_assert(R == 3, "win_wait names three registers");
+        auto fetch = [&](win_u32x4 (&q)[R], uint32_t (&qv)[R], uint32_t lo, uint32_t d) {
+            const uint32_t safe = lo < g.segcap ? lo : g.segcap - 1;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const uint32_t gi = C[j] + wl.sub + (uint32_t)r * wl.L;
-                Q[j][r] = gi < C[j + 1] ? src[gi] : zero4;
+                const uint32_t o = wl.sub + (uint32_t)r * wl.L;
+                win_gld4(q[r], src + (o < d ? lo + o : safe));
+                qv[r] = o < d ? 0xFFFFFFFFu : 0u;
             }
+            taint |= (uint32_t)(d > (uint32_t)R * wl.L);  // more groups than the registers take (or the 4-bit count's marker): atomics
+        };
+        win_u32x4 Q[K][R];
+        uint32_t QV[K][R];
+        uint32_t lo_ahead = 0;  // first group of the next phase to be fetched
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t d = count((uint32_t)j);
+            fetch(Q[j], QV[j], lo_ahead, d);
+            lo_ahead += d;
+        }
         for (uint32_t p0 = 0; p0 < nph; p0 += K) {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const uint32_t p = p0 + (uint32_t)j;
                 if (p < nph) {  // (uniform)
-                    const bool rem = wp.ph[p].remove != 0;
-                    N[j] = cum(p0 + 2 * K + (uint32_t)j);  // lands K phases before it is used
+                    const uint32_t rm = 0u - ((types[p >> 5] >> (p & 31)) & 1u);
+                    const uint32_t d = count(p + K);
+                    win_wait<(K - 1) * R>(Q[j][0], Q[j][1], Q[j][2]);  // K * R loads in flight: this phase's are the oldest R
 #pragma unroll
-                    for (int r = 0; r < R; ++r) apply(Q[j][r], rem);  // (absent groups are all-zero: no valid probe)
-                    for (uint32_t gi = C[j] + wl.sub + (uint32_t)R * wl.L; gi < C[j + 1]; gi += wl.L) apply(src[gi], rem);
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {  // phase p + K takes the registers over
-                        const uint32_t gi = C[j + K] + wl.sub + (uint32_t)r * wl.L;
-                        Q[j][r] = gi < C[j + K + 1] ? src[gi] : zero4;
-                    }
+                    for (int r = 0; r < R; ++r)
+                        if (QV[j][r]) apply(Q[j][r], rm);  // (a lane without an r-th group sits it out; a wave without one skips it)
+                    fetch(Q[j], QV[j], lo_ahead, d);  // phase p + K takes the registers over
+                    lo_ahead += d;
                     lds_barrier();  // the next phase reads what this one left in the image (LDS only: the loads stay in flight)
                 }
             }
-#pragma unroll
-            for (int i = 0; i <= K; ++i) C[i] = C[i + K];
-#pragma unroll
-            for (int i = 0; i < K; ++i) C[K + 1 + i] = N[i];
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the prefetches past the last phase: their registers are still theirs
         if (viol) s_viol = 1u;
         if (taint) s_taint = 1u;
         __syncthreads();
