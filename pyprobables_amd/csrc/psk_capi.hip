@@ -527,6 +527,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "nibble_nt_loads")) g_nib_nt = value;
     else if (!strcmp(name, "cbf_lookup_shadow")) g_cbf_shadow = value;
     else if (!strcmp(name, "cms_small_weights")) g_small_weights = value;
+    else if (!strcmp(name, "remove_exact")) g_remove_exact = value;
     else if (!strcmp(name, "update_window")) g_window = value;
     else if (!strcmp(name, "update_window_keys")) g_window_keys = value;
     else if (!strcmp(name, "update_window_force_fail")) g_window_force_fail = value;
@@ -577,6 +578,8 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "nibble_nt_loads")) *value = g_nib_nt;
     else if (!strcmp(name, "cbf_lookup_shadow")) *value = g_cbf_shadow;
     else if (!strcmp(name, "cms_small_weights")) *value = g_small_weights;
+    else if (!strcmp(name, "remove_exact")) *value = g_remove_exact;
+    else if (!strcmp(name, "cbf_ordered_replays")) *value = g_cbf_ordered_replays;
     else if (!strcmp(name, "update_window")) *value = g_window;
     else if (!strcmp(name, "update_window_keys")) *value = g_window_keys;
     else if (!strcmp(name, "update_window_force_fail")) *value = g_window_force_fail;
@@ -789,7 +792,7 @@ static int cbf_apply_device(psk_sketch *s, const Batch &b, const uint32_t *w, bo
     PSK_TRY(post_acct(s, w, b.n, remove ? PSK_CTR_REMOVED : PSK_CTR_ADDED, (long long)s->k, st, !remove, false));
     unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
     bool done = false;
-    PSK_TRY(remove ? cbf_remove_partitioned(s, b, w, st, &done) : cbf_add_partitioned(s, b, w, st, &done));
+    PSK_TRY(remove ? cbf_remove_partitioned(s, b, w, st, &done, 0, nullptr) : cbf_add_partitioned(s, b, w, st, &done));
     PSK_TRY(settle_acct(s, w, b.n, st));
     if (done) return PSK_OK;
     return with_source(b, [&](auto src) {
@@ -1256,82 +1259,142 @@ extern "C" int psk_cbf_add(psk_sketch *s, int layout, const void *data, const ui
 
 // countingbloom.py:198-203 for a whole batch: from the min over the key's counters (a lookup) to the amount actually removed
 //   mn == 0 (absent) or mn == 2^32-1 (frozen): nothing;  else to_remove = min(mn, num_els)
-// a partial removal (mn < num_els) makes the result depend on the order inside the batch: tallied as a violation
-static __global__ __launch_bounds__(kBlock) void k_cbf_to_remove(const uint32_t *mins, const uint32_t *weights, uint64_t n, uint32_t *to_remove,
-                                                                 unsigned long long *viol_ctr)
+// a partial removal (mn < num_els) makes the result depend on the order inside the batch: `dep` is raised
+static __global__ __launch_bounds__(kBlock) void k_cbf_to_remove(const uint32_t *mins, const uint32_t *weights, uint64_t n, uint32_t *to_remove, uint32_t *dep)
 {
-    unsigned long long viol = 0;
+    uint32_t partial = 0;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const uint32_t mn = mins[i], w = weights ? weights[i] : 1u;
         uint32_t tr = 0;
         if (mn != 0 && mn != 0xFFFFFFFFu) {
             tr = mn > w ? w : mn;
-            viol += tr != w;
+            partial |= (uint32_t)(tr != w);
         }
         to_remove[i] = tr;
     }
-    for (int o = 32; o > 0; o >>= 1) viol += __shfl_down(viol, o);
-    if ((threadIdx.x & 63) == 0 && viol) atomicAdd(viol_ctr, viol);
+    if (partial) *dep = 1u;
 }
 
-// Large remove batches: the remove is a lookup (the min of the key's k counters) followed by a conditional decrement, so it
-// is composed from the two partitioned pipelines instead of 2k random fabric transactions per key: mins <- lookup,
-// to_remove <- k_cbf_to_remove, then the partitioned decrement with to_remove as per-key weights (weight 0 = no-op).
-static int cbf_remove_composed(psk_sketch *s, const Batch &b, const uint32_t *w, hipStream_t st, bool *done)
+static __global__ void k_widen_u32(const uint32_t *w, uint64_t n, int64_t *out)
 {
-    *done = false;
-    if (!part_wanted(b.n, s->k, 4)) return PSK_OK;
-    if (!w) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (int64_t)w[i];
+}
+
+// tmp[1] (sum of the amounts, k_weight_sum's booking slot) -> ctr[PSK_CTR_REMOVED]
+static __global__ void k_book_removed(long long *ctr, const long long *tmp)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr[PSK_CTR_REMOVED] += tmp[PSK_CTR_REMOVED];
+}
+
+int64_t g_cbf_ordered_replays = 0;  // remove batches whose result depended on the order inside them: undone, replayed in order (tests)
+int64_t g_remove_exact = 1;         // option "remove_exact": 0 = round 3's composition (clamps and tallies instead of replaying)
+
+// The validated remove (countingbloom.py:186-208) of a device-resident batch, as a TRANSACTION.  Unordered execution gives the
+// reference's table whenever the result does not depend on the order inside the batch; here that is CHECKED and, where it fails, the
+// batch is put back and executed in order:
+//   0. unit weights into a big table: the optimistic decrement (psk_nibble.hpp) -- every key present: done in one pass over the table;
+//   1. mins <- lookup of every key's k counters (the state BEFORE the batch);
+//   2. amounts <- min(mn, num_els), 0 for absent / frozen keys; a partial removal (mn < num_els) raises the flag;
+//   3. decrement by the amounts, wrapping, flag raised wherever a counter would go below zero or is frozen.  With T[c] >= the batch's
+//      total on c for every counter, every key that step 2 found present is still present when its turn comes, whatever the order --
+//      and a key found absent stays absent (removes only lower counters): the unordered result IS the sequential one;
+//   4. flag up: the same amounts are added back (wrapping: the exact inverse) and the batch runs through k_cbf_ordered, one key after
+//      the other -- the reference literally, for any batch (duplicates beyond their count, keys running a shared counter dry ...).
+static int cbf_remove_exact(psk_sketch *s, const Batch &b, const uint32_t *w, hipStream_t st)
+{
+    if (b.n == 0) return PSK_OK;
+    const bool big = part_wanted(b.n, s->k, 4);
+    if (!w && big) {
         // Unit weights into a big table: decrement optimistically (psk_nibble.hpp) -- if every counter holds at least as much as the
-        // batch takes from it, every key is removed and one pass 1 + ONE pass over the table did it (the exact path: two pass 1s, a
-        // return trip and two passes).  The verdict is one 4-byte read-back: this call synchronises the stream once.  Otherwise the
-        // decrement is undone (exactly: wrapping arithmetic both ways) and the exact path below takes the batch.
+        // batch takes from it, every key is removed and one pass 1 + ONE pass over the table did it.  The verdict is one 4-byte
+        // read-back.  Otherwise the decrement is undone (exactly: wrapping arithmetic both ways) and the steps below take the batch.
         bool launched = false;
         PSK_TRY(cbf_remove_fast_begin(s, b, st, &launched));
         if (launched) {
             uint32_t flag = 1;
             HIP_TRY(hipMemcpyAsync(&flag, s->s_flag.p, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            if (flag == 0) {
-                PSK_TRY(account_weights(s, (const uint32_t *)nullptr, b.n, PSK_CTR_REMOVED, (long long)s->k, st, false));
-                *done = true;
-                return PSK_OK;
-            }
+            if (flag == 0) return account_weights(s, (const uint32_t *)nullptr, b.n, PSK_CTR_REMOVED, (long long)s->k, st, false);
             PSK_TRY(cbf_remove_fast_undo(s, st));
         }
     }
-    PSK_TRY(ensure(s->s_aux, b.n * 8 + 64));
-    uint32_t *mins = (uint32_t *)s->s_aux.p, *amount = mins + ((b.n + 3) & ~3ULL);
+    // s_aux: mins[n] | amounts[n] | scratch counter block | (ordered replay of a weighted batch: int64 weights[n])
+    const uint64_t n4 = (b.n + 3) & ~3ULL;
+    PSK_TRY(ensure(s->s_aux, n4 * 8 + 128 + (w ? b.n * 8 : 0)));
+    uint32_t *mins = (uint32_t *)s->s_aux.p, *amount = mins + n4;
+    long long *tmp = (long long *)(amount + n4);
     bool looked = false;
-    PSK_TRY(cbf_check_partitioned(s, b, s->k, mins, st, &looked));
+    if (big) PSK_TRY(cbf_check_partitioned(s, b, s->k, mins, st, &looked));
     if (!looked) {
-        // tables beyond the one-level lookup (more than 2048 LDS slices): direct gathers for the mins -- worth it only when
-        // the decrement can take the two-level fold (the batch brings at least cells / 8 probes)
-        if (b.n * (uint64_t)s->k < s->m / 8) return PSK_OK;
         PSK_TRY(with_source(b, [&](auto src) {
             if (s->pow2) return launch_apply(src, CbfCheck<true>{(const uint32_t *)s->table, s->md, s->k, mins}, b.n, st);
             return launch_apply(src, CbfCheck<false>{(const uint32_t *)s->table, s->md, s->k, mins}, b.n, st);
         }));
     }
-    hipLaunchKernelGGL(k_cbf_to_remove, dim3(grid_for(b.n) > 1024 ? 1024 : grid_for(b.n)), dim3(kBlock), 0, st, (const uint32_t *)mins, w, b.n, amount,
-                       (unsigned long long *)(s->ctr + PSK_CTR_VIOLATIONS));
+    PSK_TRY(ensure(s->s_flag, 8));
+    uint32_t *flag = (uint32_t *)s->s_flag.p;
+    HIP_TRY(hipMemsetAsync(flag, 0, 4, st));
+    hipLaunchKernelGGL(k_cbf_to_remove, dim3(grid_for(b.n) > 1024 ? 1024 : grid_for(b.n)), dim3(kBlock), 0, st, (const uint32_t *)mins, w, b.n, amount, flag);
     HIP_TRY(hipGetLastError());
-    PSK_TRY(post_acct(s, (const uint32_t *)amount, b.n, PSK_CTR_REMOVED, (long long)s->k, st, false, false));
-    s->acct.weights01 = w == nullptr;  // unit removes: every amount is 0 or 1
-    bool dec = false;
-    PSK_TRY(cbf_remove_partitioned(s, b, amount, st, &dec));
-    s->acct.weights01 = false;
-    PSK_TRY(settle_acct(s, (const uint32_t *)amount, b.n, st));
-    if (!dec) {  // not eligible after all: the same decrement through the direct kernel
-        unsigned long long *viol = (unsigned long long *)(s->ctr + PSK_CTR_VIOLATIONS);
-        PSK_TRY(with_source(b, [&](auto src) {
-            if (s->pow2) return launch_apply(src, CbfSub<true>{(uint32_t *)s->table, s->md, s->k, amount, viol}, b.n, st);
-            return launch_apply(src, CbfSub<false>{(uint32_t *)s->table, s->md, s->k, amount, viol}, b.n, st);
-        }));
+    // the amounts' sum: into a scratch block (booked once the verdict is in), and as this round's sum |w| for pass 2's wrap check
+    HIP_TRY(hipMemsetAsync(tmp, 0, sizeof(long long) * PSK_CTR_COUNT, st));
+    hipLaunchKernelGGL((k_weight_sum<uint32_t>), dim3(grid_for(b.n) > 256 ? 256 : grid_for(b.n)), dim3(kBlock), 0, st, (const uint32_t *)amount, b.n, tmp,
+                       (int)PSK_CTR_REMOVED, (long long)s->k, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(s->ctr + 6, tmp + 6, sizeof(long long), hipMemcpyDeviceToDevice, st));
+    s->acct.pending = false;
+    auto decrement = [&](int opt, bool *partitioned) {  // opt 1: checked, 2: inverse.  The same path both times (same batch, same options)
+        *partitioned = false;
+        if (big) {
+            s->acct.weights01 = w == nullptr;  // unit removes: every amount is 0 or 1 (masked unit probes may serve)
+            const int rc = cbf_remove_partitioned(s, b, amount, st, partitioned, opt, flag);
+            s->acct.weights01 = false;
+            PSK_TRY(rc);
+        }
+        if (*partitioned) return (int)PSK_OK;
+        return with_source(b, [&](auto src) {
+            if (s->pow2) return launch_apply(src, CbfSubChecked<true>{(uint32_t *)s->table, s->md, s->k, amount, flag, opt == 2}, b.n, st);
+            return launch_apply(src, CbfSubChecked<false>{(uint32_t *)s->table, s->md, s->k, amount, flag, opt == 2}, b.n, st);
+        });
+    };
+    bool part1 = false, part2 = false;
+    PSK_TRY(decrement(1, &part1));
+    uint32_t verdict = 1;
+    HIP_TRY(hipMemcpyAsync(&verdict, flag, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (verdict == 0) {
+        hipLaunchKernelGGL(k_book_removed, dim3(1), dim3(1), 0, st, s->ctr, (const long long *)tmp);
+        HIP_TRY(hipGetLastError());
+        return PSK_OK;
     }
-    *done = true;
-    return PSK_OK;
+    PSK_TRY(decrement(2, &part2));
+    if (part1 != part2) return fail(PSK_EHIP, "transactional remove: the undo took another path than the decrement");
+    ++g_cbf_ordered_replays;
+    const int64_t *w64 = nullptr;
+    if (w) {
+        int64_t *dst = (int64_t *)(tmp + PSK_CTR_COUNT + 2);
+        hipLaunchKernelGGL(k_widen_u32, dim3(grid_for(b.n) > 1024 ? 1024 : grid_for(b.n)), dim3(kBlock), 0, st, w, b.n, dst);
+        HIP_TRY(hipGetLastError());
+        w64 = dst;
+    }
+    uint64_t *wide = nullptr;  // (k beyond the ordered kernel's register arrays: index / value lists in device scratch)
+    if (s->k > (uint32_t)kMaxKOrdered) {
+        PSK_TRY(ensure(s->s_out, 16ULL * s->k));
+        wide = (uint64_t *)s->s_out.p;
+    }
+    return with_source(b, [&](auto src) {
+        using Src = decltype(src);
+        if (s->pow2)
+            hipLaunchKernelGGL((k_cbf_ordered<Src, true>), dim3(1), dim3(64), 0, st, src, (uint32_t *)s->table, s->md, s->k, w64, (int)PSK_OP_REMOVE, b.n,
+                               (uint32_t *)nullptr, (unsigned long long *)s->ctr, wide);
+        else
+            hipLaunchKernelGGL((k_cbf_ordered<Src, false>), dim3(1), dim3(64), 0, st, src, (uint32_t *)s->table, s->md, s->k, w64, (int)PSK_OP_REMOVE, b.n,
+                               (uint32_t *)nullptr, (unsigned long long *)s->ctr, wide);
+        HIP_TRY(hipGetLastError());
+        return (int)PSK_OK;
+    });
 }
 
 // the validated remove (countingbloom.py:186-208) of a device-resident batch: composed from the partitioned pipelines when the batch is
@@ -1339,9 +1402,9 @@ static int cbf_remove_composed(psk_sketch *s, const Batch &b, const uint32_t *w,
 static int cbf_remove_device(psk_sketch *s, const Batch &b, const uint32_t *w, hipStream_t st)
 {
     if (b.n == 0) return PSK_OK;
-    bool done = false;
-    PSK_TRY(cbf_remove_composed(s, b, w, st, &done));
-    if (done) return PSK_OK;
+    if (g_remove_exact != 0) return cbf_remove_exact(s, b, w, st);
+    // (option "remove_exact" = 0, bench A/B: the one-kernel form -- per key: read the k counters, decide, subtract; exact for
+    // well-formed batches, deviations tallied in PSK_CTR_VIOLATIONS)
     return with_source(b, [&](auto src) {
         using Src = decltype(src);
         if (s->pow2)

@@ -562,6 +562,34 @@ struct CbfSub {  // unordered decrement of every index (no min pre-check): the w
     __device__ __forceinline__ void end(State &, uint64_t) const {}
 };
 
+// The transactional decrement by per-key amounts (psk_capi.hip cbf_remove_exact): wrapping subtraction that raises `flag` when a counter
+// would go below zero or is frozen at 2^32-1 -- the reference's result (countingbloom.py:198-206) then depends on the order inside the
+// batch; `inverse`: adds the same amounts back (exact: wrapping both ways)
+template <bool POW2>
+struct CbfSubChecked {
+    uint32_t *tab;
+    Mod md;
+    uint32_t k;
+    const uint32_t *amounts;
+    uint32_t *flag;
+    bool inverse;
+    struct State { uint32_t w; };
+    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ State begin(uint64_t i) const { return State{amounts ? amounts[i] : 1u}; }
+    __device__ __forceinline__ void apply(State &st, uint32_t, uint64_t h) const
+    {
+        if (st.w == 0) return;
+        uint32_t *p = tab + reduce<POW2>(md, h);
+        if (inverse) {
+            atomicAdd(p, st.w);
+        } else {
+            const uint32_t old = atomicSub(p, st.w);
+            if (old < st.w || old == 0xFFFFFFFFu) *flag = 1u;
+        }
+    }
+    __device__ __forceinline__ void end(State &, uint64_t) const {}
+};
+
 template <bool POW2>
 struct CbfAdd {  // countingbloom.py:135-155 add_alt (k independent increments; duplicates add twice)
     uint32_t *tab;

@@ -580,7 +580,7 @@ PSK_DECLARE_VARIANTS(int, bloom_check_finish_partitioned, (psk_sketch *s, uint8_
 PSK_DECLARE_VARIANTS(int, cms_add_partitioned, (psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done))
 PSK_DECLARE_VARIANTS(int, cms_remove_partitioned, (psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done))
 PSK_DECLARE_VARIANTS(int, cbf_add_partitioned, (psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done))
-PSK_DECLARE_VARIANTS(int, cbf_remove_partitioned, (psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done))  // unchecked decrement
+PSK_DECLARE_VARIANTS(int, cbf_remove_partitioned, (psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done, int opt, uint32_t *flag))  // decrement by w (opt: SpillCounter)
 // lookups (psk_lookup.hpp): query = psk_query; out_dev int32 (min / mean) or int64 (mean-min); kk = hashes per key
 PSK_DECLARE_VARIANTS(int, cms_check_partitioned, (psk_sketch *s, const Batch &b, int query, int64_t els_added, void *out_dev, hipStream_t st, bool *done))
 PSK_DECLARE_VARIANTS(int, cbf_check_partitioned, (psk_sketch *s, const Batch &b, uint32_t kk, uint32_t *out_dev, hipStream_t st, bool *done))
@@ -603,6 +603,7 @@ struct WinPhaseHost {
     uint32_t remove;
 };
 PSK_DECLARE_VARIANTS(int, cbf_window_fold, (psk_sketch *s, const WinPhaseHost *ph, uint32_t nph, const void *keys_dev, uint64_t nlist, hipStream_t st, bool *launched, bool *ok))
+extern PSK_HIDDEN int64_t g_remove_exact, g_cbf_ordered_replays;
 extern PSK_HIDDEN int64_t g_window, g_window_keys, g_window_folds, g_window_replays, g_window_force_fail;
 extern PSK_HIDDEN int64_t g_remove_dryrun;
 extern PSK_HIDDEN int64_t g_auto_combine, g_auto_combine_keys, g_combine_keys, g_combine_scatter, g_fused_flush;

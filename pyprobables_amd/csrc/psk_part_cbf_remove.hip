@@ -4,9 +4,11 @@
 // The unchecked decrement of every index by the key's weight: what countingbloom.py:186-208 does for a well-formed stream
 // (min_val >= num_els, so to_remove == num_els); frozen counters stay, a counter that would go below zero is tallied as a
 // contract violation (k_counter_apply's fold).  Used by the write-combined update path.
-int PSK_VARIANT(cbf_remove_partitioned)(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done)
+// opt 1: the transactional form (wrapping subtraction, `flag` raised where the reference's result would depend on the order inside the
+// batch); opt 2: its inverse.  The same batch and amounts must be passed to both.
+int PSK_VARIANT(cbf_remove_partitioned)(psk_sketch *s, const Batch &b, const uint32_t *w_dev, hipStream_t st, bool *done, int opt, uint32_t *flag)
 {
-    return counter_add_partitioned<IdxBloom, false, true>(s, b, w_dev, s->m, st, done);
+    return counter_add_partitioned<IdxBloom, false, true>(s, b, w_dev, s->m, st, done, opt, flag);
 }
 
 // Validated remove of a unit-weight batch, fast path (psk_nibble.hpp, "OPTIMISTIC decrement"): pass 1 of all keys + the decrement that

@@ -71,9 +71,9 @@ static inline bool small_weights_wanted(psk_sketch *s)
 // != nullptr, decrements only -- those with mask[i] != 0) into the handle's bucket buffer, or (fixed) appended to persistent segments.
 template <bool MASKABLE>
 static inline int nib_scatter(psk_sketch *s, const Batch &sub, const uint32_t *mask, bool neg, PartGeom *g, hipStream_t st, bool *handled,
-                              const ScatterTarget *fixed = nullptr)
+                              const ScatterTarget *fixed = nullptr, int opt = 0, uint32_t *flag = nullptr)
 {
-    SpillCounter<false> spill{(uint32_t *)s->table, true, neg, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED)};
+    SpillCounter<false> spill{(uint32_t *)s->table, true, neg, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED), flag, opt};
     return with_part_source(sub, handled, [&](auto src) {
         using Src = decltype(src);
         return with_kt<Src>(s->k, [&](auto kt) {
@@ -127,8 +127,9 @@ static inline int cbf_nib_scatter_only(psk_sketch *s, const Batch &b, bool neg, 
 // CountingBloomFilter unit-weight adds / decrements into 2^26 .. 2^29 counters: ONE level of 2^18-counter slices with 4-bit delta
 // images (the 32-bit images need the two-level path there).  w01: the per-key weights are known to be 0 or 1 (the amounts of the
 // validated remove): keys with 0 send no probes.  Eligible when the batch brings enough probes to pay for the pass over the table.
+// opt / flag (decrements): the transactional remove, see SpillCounter
 template <bool NEG>
-static inline int cbf_unit_nibble(psk_sketch *s, const Batch &b, const uint32_t *w01, hipStream_t st, bool *done)
+static inline int cbf_unit_nibble(psk_sketch *s, const Batch &b, const uint32_t *w01, hipStream_t st, bool *done, int opt = 0, uint32_t *flag = nullptr)
 {
     *done = false;
     const uint64_t cells = s->m;
@@ -142,9 +143,11 @@ static inline int cbf_unit_nibble(psk_sketch *s, const Batch &b, const uint32_t 
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
         bool handled = false;
-        PSK_TRY(nib_scatter<NEG>(s, sub_batch(b, start, cnt), w01 ? w01 + start : nullptr, NEG, &g, st, &handled));
+        PSK_TRY(nib_scatter<NEG>(s, sub_batch(b, start, cnt), w01 ? w01 + start : nullptr, NEG, &g, st, &handled, nullptr, opt, flag));
         if (!handled) return PSK_OK;  // (first round: nothing was launched)
-        PSK_TRY(nib_apply<NEG>(s, g, s->s_cnt.p, s->s_part.p, st));
+        if (NEG && opt == 1) PSK_TRY(nib_apply_mode<3>(s, g, s->s_cnt.p, s->s_part.p, st, flag));
+        else if (NEG && opt == 2) PSK_TRY(nib_apply_mode<4>(s, g, s->s_cnt.p, s->s_part.p, st));
+        else PSK_TRY(nib_apply<NEG>(s, g, s->s_cnt.p, s->s_part.p, st));
     }
     *done = true;
     return PSK_OK;
@@ -152,13 +155,13 @@ static inline int cbf_unit_nibble(psk_sketch *s, const Batch &b, const uint32_t 
 
 template <template <bool> class IDX, bool SIGNED, bool NEG>
 static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const uint32_t *w_dev, uint64_t cells, hipStream_t st,
-                                   bool *done)
+                                   bool *done, int opt = 0, uint32_t *flag = nullptr)
 {
     *done = false;
     if (!part_wanted(b.n, s->k, 4)) return PSK_OK;
     if constexpr (!SIGNED) {  // CountingBloomFilter: unit weights (or 0 / 1 amounts) into a big table -> nibble deltas, one level
         if (!w_dev || s->acct.weights01) {
-            PSK_TRY(cbf_unit_nibble<NEG>(s, b, w_dev, st, done));
+            PSK_TRY(cbf_unit_nibble<NEG>(s, b, w_dev, st, done, opt, flag));
             if (*done) return PSK_OK;  // (weights, if any, stay to be accounted by the caller's stand-alone pass: acct.pending is untouched)
         }
     }
@@ -175,7 +178,10 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
         // (direct atomics into a 1 GiB table run at ~20 G/s; the table RMW at ~4 TB/s)
         if (b.n * (uint64_t)s->k < cells / 8) return PSK_OK;
         const uint64_t round_keys = part_round_keys_two_level(b.n, s->k);
-        SpillCounter<SIGNED> spill{(uint32_t *)s->table, w_dev == nullptr, NEG, sat2};
+        SpillCounter<SIGNED> spill{(uint32_t *)s->table, w_dev == nullptr, NEG, sat2, flag, opt};
+        TallyArgs ta2{};
+        ta2.opt = (uint32_t)opt;
+        ta2.flag = flag;
         for (uint64_t start = 0; start < b.n; start += round_keys) {
             const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
             const Batch sub = sub_batch(b, start, cnt);
@@ -198,13 +204,13 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
                 auto kern = k_counter_apply<SIGNED, true, NEG>;
                 PSK_TRY(set_dyn_lds(kern, lds));
                 hipLaunchKernelGGL(kern, dim3(g2.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g2,
-                                   (const uint32_t *)s->s_cnt2.p, (const uint4 *)s->s_part2.p, (long long *)s->ctr, sat2, TallyArgs{});
+                                   (const uint32_t *)s->s_cnt2.p, (const uint4 *)s->s_part2.p, (long long *)s->ctr, sat2, ta2);
             } else {
                 PSK_TRY((split_level2<1, SpillCounter<SIGNED>>(s, g1, &g2, sub_bits, cnt * (uint64_t)s->k, spill, st)));
                 auto kern = k_counter_apply<SIGNED, false, NEG>;
                 PSK_TRY(set_dyn_lds(kern, lds));
                 hipLaunchKernelGGL(kern, dim3(g2.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, cells, g2,
-                                   (const uint32_t *)s->s_cnt2.p, (const uint4 *)s->s_part2.p, (long long *)s->ctr, sat2, TallyArgs{});
+                                   (const uint32_t *)s->s_cnt2.p, (const uint4 *)s->s_part2.p, (long long *)s->ctr, sat2, ta2);
             }
             HIP_TRY(hipGetLastError());
         }
@@ -230,7 +236,7 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
             using Src = decltype(src);
             return with_kt<Src>(s->k, [&](auto kt) {
                 constexpr int KT = decltype(kt)::value;
-                SpillCounter<SIGNED> spill{(uint32_t *)s->table, w_dev == nullptr, NEG, sat};
+                SpillCounter<SIGNED> spill{(uint32_t *)s->table, w_dev == nullptr, NEG, sat, flag, opt};
                 if (w_dev) {
                     if constexpr (SIGNED && !NEG && std::is_same<Src, KeysFixed16>::value) {  // (the fast key layout only: instantiations)
                         if (small_fmt) {
@@ -249,6 +255,8 @@ static inline int counter_add_partitioned(psk_sketch *s, const Batch &b, const u
         if (!handled) return PSK_OK;
         TallyArgs ta;  // pass 1's weight sums are booked by pass 2 (no launch between the passes)
         PSK_TRY(tally_args(s, payw, g.nwg, &ta));
+        ta.opt = (uint32_t)opt;
+        ta.flag = flag;
         const size_t lds = (size_t)4 << g.shift;
         if (w_dev && small_fmt) {
             if constexpr (SIGNED && !NEG) {

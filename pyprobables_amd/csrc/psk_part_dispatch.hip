@@ -15,7 +15,7 @@ PSK_DISPATCH(bloom_check_finish_partitioned, (psk_sketch *s, uint8_t *out_dev, h
 PSK_DISPATCH(cms_add_partitioned, (psk_sketch *s, const Batch &b, const uint32_t *w, hipStream_t st, bool *done), (s, b, w, st, done))
 PSK_DISPATCH(cms_remove_partitioned, (psk_sketch *s, const Batch &b, const uint32_t *w, hipStream_t st, bool *done), (s, b, w, st, done))
 PSK_DISPATCH(cbf_add_partitioned, (psk_sketch *s, const Batch &b, const uint32_t *w, hipStream_t st, bool *done), (s, b, w, st, done))
-PSK_DISPATCH(cbf_remove_partitioned, (psk_sketch *s, const Batch &b, const uint32_t *w, hipStream_t st, bool *done), (s, b, w, st, done))
+PSK_DISPATCH(cbf_remove_partitioned, (psk_sketch *s, const Batch &b, const uint32_t *w, hipStream_t st, bool *done, int opt, uint32_t *flag), (s, b, w, st, done, opt, flag))
 PSK_DISPATCH(cms_check_partitioned, (psk_sketch *s, const Batch &b, int query, int64_t els, void *out_dev, hipStream_t st, bool *done),
              (s, b, query, els, out_dev, st, done))
 PSK_DISPATCH(cbf_check_partitioned, (psk_sketch *s, const Batch &b, uint32_t kk, uint32_t *out_dev, hipStream_t st, bool *done), (s, b, kk, out_dev, st, done))

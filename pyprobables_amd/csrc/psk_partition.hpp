@@ -232,9 +232,22 @@ struct SpillCounter {  // saturating CAS add (countminsketch.py:280-284,312-316 
     uint32_t *tab;
     bool unit, neg;
     unsigned long long *sat_ctr;
+    // The transactional CBF decrement (psk_capi.hip cbf_remove_exact): opt 1 = wrapping subtraction that raises `flag` when a counter
+    // would go below zero or is frozen (the batch is then order-dependent: undone and replayed in order), opt 2 = its inverse.
+    uint32_t *flag = nullptr;
+    int opt = 0;
     __device__ __forceinline__ void operator()(uint32_t idx, uint32_t w) const
     {
         const uint32_t v = unit ? 1u : w;
+        if (!SIGNED && opt == 1) {
+            const uint32_t old = atomicSub(tab + idx, v);
+            if (old < v || old == 0xFFFFFFFFu) *flag = 1u;
+            return;
+        }
+        if (!SIGNED && opt == 2) {
+            atomicAdd(tab + idx, v);
+            return;
+        }
         if (SIGNED) cms_sat_add((int32_t *)tab + idx, neg ? -(int64_t)(int32_t)v : (int64_t)(int32_t)v, sat_ctr);
         else if (neg) cbf_sat_sub(tab + idx, v, sat_ctr - 1);  // (the violations tally sits right before the saturation tally)
         else cbf_sat_add(tab + idx, v, sat_ctr);
@@ -1300,6 +1313,10 @@ struct TallyArgs {
     int grow_bound = 0;
     volatile unsigned long long *big_pin = nullptr;  // see k_tally_fold
     unsigned long long seq = 0;
+    // CBF decrements (NEG, !SIGNED) only -- the transactional remove: opt 1 = wrapping subtraction, `flag` raised when a counter would
+    // go below zero or is frozen (countingbloom.py:198-206 then depends on the order inside the batch); opt 2 = the inverse (adds back)
+    uint32_t opt = 0;
+    uint32_t *flag = nullptr;
 };
 
 // FMT: the probe format -- 0 unit adds (8 x 16-bit cells), 1 weighted (4 x 32-bit: weight << shift | cell), 2 small weights (PayWeightSmall: 6 x
@@ -1371,6 +1388,15 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, 
     if (WEIGHTED && round_abs >= (1LL << 31)) {
         auto slow1 = [&](uint32_t cell_in_slice, uint32_t w) {
             const uint64_t cell = c0 + cell_in_slice;
+            if (!SIGNED && NEG && ta.opt == 1) {
+                const uint32_t old = atomicSub(tab + cell, w);
+                if (old < w || old == 0xFFFFFFFFu) *ta.flag = 1u;
+                return;
+            }
+            if (!SIGNED && NEG && ta.opt == 2) {
+                atomicAdd(tab + cell, w);
+                return;
+            }
             if (SIGNED) cms_sat_add((int32_t *)tab + cell, NEG ? -(int64_t)w : (int64_t)w, sat_ctr);
             else if (NEG) cbf_sat_sub(tab + cell, w, sat_ctr - 1);
             else cbf_sat_add(tab + cell, w, sat_ctr);
@@ -1405,11 +1431,17 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, 
     }
     __syncthreads();
     unsigned long long sat = 0, viol = 0;
+    uint32_t bad = 0;
     auto fold = [&](uint32_t t, uint32_t d) -> uint32_t {  // the reference's saturating add
         if (!SIGNED && NEG) {
             // CBF decrement (countingbloom.py:203-206 with to_remove == num_els, i.e. a well-formed stream): a counter frozen
             // at 2^32-1 stays; one that would go below zero means the stream was not well-formed -- tallied, clamped at 0
             const uint32_t amount = 0u - d;
+            if (ta.opt == 1) {
+                if (t < amount || t == 0xFFFFFFFFu) bad = 1u;
+                return t - amount;
+            }
+            if (ta.opt == 2) return t + amount;
             if (t == 0xFFFFFFFFu) return t;
             if (t < amount) { ++viol; return 0u; }
             return t - amount;
@@ -1460,6 +1492,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_counter_apply(uint32_t *tab, 
     }
     if (sat) atomicAdd(sat_ctr, sat);
     if (viol) atomicAdd(sat_ctr - 1, viol);
+    if (bad) *ta.flag = 1u;
 }
 
 }  // namespace psk
