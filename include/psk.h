@@ -106,6 +106,15 @@ int psk_device_count(int *count);
  * bench knobs: "lookup_split", "lookup_run_lanes", "tile_threads", "scatter_workgroups", "slice_bias" */
 int psk_set_option(const char *name, int64_t value);
 int psk_get_option(const char *name, int64_t *value);
+/* Per-sketch options (round 4): "partition_min_keys", "cbf_lookup_shadow", "auto_combine", "update_window", "update_window_keys",
+ * "scratch_budget_bytes", "remove_exact", "bloom_lookup" can differ between the sketches of one process -- psk_set_option keeps the
+ * DEFAULT of each, psk_sketch_set_option overrides it for one handle (value INT64_MIN: follow the default again).  One more name exists
+ * per sketch only: "table_private" = 1 declares that whoever holds the pointer of a caller-owned table (ext_table) announces EVERY write it
+ * makes behind the engine's back (psk_table_info before, psk_rescan_bound after); without that promise -- and between psk_table_info(&ptr)
+ * and the next psk_rescan_bound -- the engine keeps nothing derived from the table (the 4-bit images of repeated psk_cbf_check calls).
+ * No reference counterpart (tunables of this engine). */
+int psk_sketch_set_option(psk_sketch *s, const char *name, int64_t value);
+int psk_sketch_get_option(psk_sketch *s, const char *name, int64_t *value);
 /* bench-only: s_memtime totals per phase of the last partition pass 1 (option part_debug & 32) */
 int psk_debug_phase_profile(psk_sketch *s, uint32_t nbuckets, uint32_t nwg, uint64_t out[12]);
 

@@ -63,6 +63,9 @@ class DeviceTable:
         h = C.c_void_p()
         N.check(create(self.m, self.k, self.device, ext, C.byref(h)))
         self.handle = h
+        if ext is not None:
+            # the tensor is this object's own: nothing writes it behind the engine's back without saying so (`ptr` / `exposed_ptr`)
+            N.check(L.psk_sketch_set_option(h, b"table_private", 1))
 
     # -- lifetime
     def close(self):
@@ -89,11 +92,36 @@ class DeviceTable:
 
     @property
     def ptr(self) -> int:
-        """raw device pointer of the table (pending write-combined updates are applied first)"""
+        """raw device pointer of the table for THIS package's own table kernels (pending write-combined updates are applied
+        first; the engine is told that the table may change NOW -- not that somebody keeps the pointer)"""
+        self.flush()
+        if self.tensor is None:
+            return self.exposed_ptr
+        N.check(N.lib().psk_table_info(self.handle, None, None, None))
+        return self.tensor.data_ptr()
+
+    @property
+    def exposed_ptr(self) -> int:
+        """the pointer as handed to code outside this package: from here on the engine keeps nothing derived from the table
+        (psk_table_info) until `written()` says the holder is done"""
         self.flush()
         p = C.c_void_p()
         N.check(N.lib().psk_table_info(self.handle, C.byref(p), None, None))
         return p.value
+
+    def written(self):
+        """the holder of a pointer / tensor handed out earlier has written what it wanted to (and takes the pointer again before it
+        writes any more): bounds are rescanned, derived state may be kept again (psk_rescan_bound)"""
+        N.check(N.lib().psk_rescan_bound(self.handle, self.stream))
+
+    def set_option(self, name: str, value: int):
+        """override an engine option for this sketch only (psk_sketch_set_option); value None: follow the process default"""
+        N.check(N.lib().psk_sketch_set_option(self.handle, name.encode(), -(2**63) if value is None else int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int64(0)
+        N.check(N.lib().psk_sketch_get_option(self.handle, name.encode(), C.byref(v)))
+        return v.value
 
     @property
     def nwords(self) -> int:

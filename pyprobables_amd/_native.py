@@ -52,6 +52,8 @@ PROTOTYPES = {
     "psk_get_counters": (_int, [_vp, C.POINTER(_i64), _vp]),
     "psk_reset_counters": (_int, [_vp, _vp]),
     "psk_rescan_bound": (_int, [_vp, _vp]),
+    "psk_sketch_set_option": (_int, [_vp, C.c_char_p, _i64]),
+    "psk_sketch_get_option": (_int, [_vp, C.c_char_p, C.POINTER(_i64)]),
     "psk_bloom_add": (_int, [_vp, *_KEYS, _int, _vp]),
     "psk_bloom_check": (_int, [_vp, *_KEYS, _int, _vp, _vp]),
     "psk_bloom_check_begin": (_int, [_vp, *_KEYS, _vp]),

@@ -158,11 +158,27 @@ class BloomFilter:
     @property
     def table_tensor(self):
         """the torch int32 tensor backing the table (padded to 16 B); what the multi-GPU merge reduces.  Handing it out tells the
-        engine that the table may be written from outside (``psk_table_info``): anything it derived from the table is dropped.
-        A caller that keeps the tensor and writes to it LATER must say so (``psk_rescan_bound`` / taking the property again)."""
+        engine that the table may be written from outside, now or later (``psk_table_info``): anything it derived from the table
+        is dropped, and nothing of the kind is kept again until :meth:`table_released` says the holder is done."""
         self._flush()
-        _ = self._tab.ptr
+        _ = self._tab.exposed_ptr
         return self._tab.tensor
+
+    def table_released(self) -> None:
+        """the caller no longer writes through a tensor obtained from :attr:`table_tensor` (it takes the property again before any
+        later write): the engine may keep state derived from the table again -- e.g. the 4-bit images of repeated
+        CountingBloomFilter lookups"""
+        self._flush()
+        self._tab.written()
+
+    def set_engine_option(self, name: str, value) -> None:
+        """override an engine tunable for THIS sketch (``psk_sketch_set_option``: "partition_min_keys", "cbf_lookup_shadow",
+        "auto_combine", "update_window", "update_window_keys", "scratch_budget_bytes", "remove_exact", "bloom_lookup"); ``None`` =
+        follow the process-wide default (``_native.set_option``) again"""
+        self._tab.set_option(name, value)
+
+    def get_engine_option(self, name: str) -> int:
+        return self._tab.get_option(name)
 
     @property
     def _fused(self) -> bool:

@@ -172,9 +172,14 @@ class CountingBloomFilter(BloomFilter):
             where = b.where
             if getattr(self, "_borrow", False) and where == N.DEVICE and w_addr is None:
                 where = N.DEVICE_BORROWED        # the engine keeps the POINTER: hold the buffers until the next flush
-                self._borrowed.append(b.keep)
-                if len(self._borrowed) >= 4000:  # (the engine flushes at 4096 batches; drop our references in step)
+                # Drop our references in step with the engine's own flushes (it flushes a list at 4096 batches or `combine_keys`
+                # keys), BEFORE this batch is handed over: a flush after the append would release the very batch the engine is about
+                # to be given a pointer to.
+                self._borrowed_keys = getattr(self, "_borrowed_keys", 0) + b.n
+                if len(self._borrowed) >= 4000 or self._borrowed_keys > N.get_option("combine_keys"):
                     self._flush()
+                    self._borrowed_keys = b.n
+                self._borrowed.append(b.keep)
             N.check(N.lib().psk_cbf_update_combined(self._tab.handle, *b.args(), w_addr, int(remove), where, self._tab.stream))
         else:
             fn = N.lib().psk_cbf_remove if remove else N.lib().psk_cbf_add

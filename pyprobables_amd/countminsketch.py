@@ -133,6 +133,13 @@ class CountMinSketch:
     def table_tensor(self):
         return self._tab.tensor
 
+    def set_engine_option(self, name: str, value) -> None:
+        """override an engine tunable for THIS sketch (``psk_sketch_set_option``); ``None`` = follow the process-wide default again"""
+        self._tab.set_option(name, value)
+
+    def get_engine_option(self, name: str) -> int:
+        return self._tab.get_option(name)
+
     @property
     def _bins(self):
         """host SNAPSHOT of the bins (int32, row-major by depth)"""

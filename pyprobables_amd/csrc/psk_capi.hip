@@ -98,6 +98,7 @@ static int create_common(int kind, uint64_t m, uint32_t k, uint64_t padded, uint
     s->padded_bytes = padded;
     s->logical_bytes = logical;
     s->owns_table = ext_table == nullptr;
+    s->shadow.exposed = ext_table != nullptr;  // (until the caller declares the table private to this handle: psk_sketch_set_option)
     s->table = ext_table;
     s->ctr = nullptr;
     if (s->owns_table) {
@@ -166,11 +167,40 @@ extern "C" int psk_destroy(psk_sketch *s)
     return PSK_OK;
 }
 
+// ---- per-sketch options (psk_host.hpp HandleOpt): process defaults, names, and the refresh every handle entry point does
+static const char *const kHoNames[HO_COUNT] = {"partition_min_keys", "cbf_lookup_shadow", "auto_combine", "update_window", "update_window_keys",
+                                                "scratch_budget_bytes", "remove_exact", "bloom_lookup"};
+static int64_t d_opt[HO_COUNT] = {1 << 16, 1, 1, 1, 1 << 27, 0, 1, 2};  // (== the thread-local variables' initial values)
+static int64_t *ho_var(int i)
+{
+    switch (i) {
+        case HO_PART_MIN_KEYS: return &g_part_min_keys;
+        case HO_CBF_SHADOW: return &g_cbf_shadow;
+        case HO_AUTO_COMBINE: return &g_auto_combine;
+        case HO_WINDOW: return &g_window;
+        case HO_WINDOW_KEYS: return &g_window_keys;
+        case HO_SCRATCH_BUDGET: return &g_scratch_budget;
+        case HO_REMOVE_EXACT: return &g_remove_exact;
+        default: return &g_bloom_lookup;
+    }
+}
+static int ho_index(const char *name)
+{
+    for (int i = 0; i < HO_COUNT; ++i)
+        if (!strcmp(name, kHoNames[i])) return i;
+    return -1;
+}
+static inline void ho_apply(const psk_sketch *s)
+{
+    for (int i = 0; i < HO_COUNT; ++i) *ho_var(i) = (s && s->opt[i] != kHoUnset) ? s->opt[i] : __atomic_load_n(&d_opt[i], __ATOMIC_RELAXED);
+}
+
 #define CHECK_HANDLE_RO(s, want_kind)                                                    \
     do {                                                                                 \
         if (!(s)) return fail(PSK_EINVAL, "sketch handle is NULL");                      \
         if ((want_kind) >= 0 && (s)->kind != (want_kind))                                \
             return fail(PSK_EINVAL, "wrong sketch kind %d for this call", (s)->kind);    \
+        ho_apply(s);                                                                     \
     } while (0);                                                                         \
     PSK_USE_DEVICE((s)->device)
 // every entry point that may change the table (or hands its pointer out) moves the table's version on: what was derived from the
@@ -230,6 +260,7 @@ extern "C" int psk_table_info(psk_sketch *s, void **dev_ptr, uint64_t *padded_by
 {
     if (!s) return fail(PSK_EINVAL, "sketch handle is NULL");
     ++s->table_version;  // the pointer leaves the engine: whoever holds it may write
+    if (dev_ptr) s->shadow.exposed = true;  // ... and later, too: no kept images until the holder says it is done (psk_rescan_bound)
     if (dev_ptr) *dev_ptr = s->table;
     if (padded_bytes) *padded_bytes = s->padded_bytes;
     if (logical_bytes) *logical_bytes = s->logical_bytes;
@@ -276,6 +307,9 @@ extern "C" int psk_write_table(psk_sketch *s, const void *src_host, uint64_t nby
 extern "C" int psk_rescan_bound(psk_sketch *s, void *stream)
 {
     CHECK_HANDLE(s, -1);
+    // "I wrote through the pointer I hold, and I am done": kept images may be built again (a holder of a caller-owned table must have
+    // promised to announce every outside write: option "table_private")
+    if (s->owns_table || s->table_private) s->shadow.exposed = false;
     if (s->kind == PSK_KIND_BLOOM) return PSK_OK;
     hipStream_t st = (hipStream_t)stream;
     PSK_TRY(flush_combined(s, st));
@@ -468,22 +502,23 @@ static int finish(int where, const OutBuf *o, hipStream_t st)
 
 // ------------------------------------------------- partitioned (large-batch) path: options
 int64_t g_part_mode = 1;
-int64_t g_part_min_keys = 1 << 16;   // x1 for Bloom inserts, x4 for lookups / counter adds (part_wanted)
+__thread int64_t g_part_min_keys = 1 << 16;   // x1 for Bloom inserts, x4 for lookups / counter adds (part_wanted)
 int64_t g_part_max_keys = 1 << 26;   // keys per partition round (bounds the bucket buffer: ~2 GB of scratch at k = 7; sized for 288 GB of HBM --
                                      // every round into a big table ends in a pass over the whole table, so fewer, larger rounds)
 int64_t g_part_cache_bytes = 240 << 20;  // bucket-buffer budget per round: the part of the 256 MB MALL we count on
 int64_t g_part_two_level_slices = 2048;     // tables cut into more slices than this take the two-level path (0 = never)
 int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGeom::dbg); 0 in production
-int64_t g_lookup_run_lanes = 0, g_bloom_lookup = 2, g_lookup_split = 1, g_part_tile_threads = 0, g_part_slice_bias = 0, g_part_wgs = 0, g_part_even_tiles = 1;
+__thread int64_t g_bloom_lookup = 2;
+int64_t g_lookup_run_lanes = 0, g_lookup_split = 1, g_part_tile_threads = 0, g_part_slice_bias = 0, g_part_wgs = 0, g_part_even_tiles = 1;
 int64_t g_lookup_half = 1;
 int64_t g_lookup_collect_threads = 1024;
 int64_t g_remove_dryrun = 1;   // validated unit-weight CBF removes into big tables: optimistic decrement first (psk_nibble.hpp), option "remove_optimistic"
-int64_t g_scratch_budget = 0;  // psk_set_option("scratch_budget_bytes"): cap on a handle's partition scratch (more, smaller rounds); 0 = none
+__thread int64_t g_scratch_budget = 0;  // psk_set_option("scratch_budget_bytes"): cap on a handle's partition scratch (more, smaller rounds); 0 = none
 int64_t g_lookup_nibble = 1;   // CBF lookups into 2^25 .. 2^29 counters: 4-bit slice images (psk_nibble.hpp) from cells / 16 probes on; 2 = always; 0 = the 32-bit / 16-bit slices or direct
 int64_t g_small_weights_used = 0;
 int64_t g_small_weights = 1;   // PayWeightSmall for weighted CountMinSketch adds (psk_sketch::wt)
 int64_t g_cbf_shadow_hits = 0;
-int64_t g_cbf_shadow = 1;  // nibble-slice lookups keep their 4-bit images while the table is unchanged (psk_sketch::shadow; cells / 2 bytes)
+__thread int64_t g_cbf_shadow = 1;  // nibble-slice lookups keep their 4-bit images while the table is unchanged (psk_sketch::shadow; cells / 2 bytes)
 int64_t g_nib_nt = 1;   // nontemporal table loads in k_nib_gather (1 GiB lookups 710 -> 656 us per 10 M keys); the fold of k_nib_apply re-writes what it
                         // reads and measured slower with them (795 -> 984 us): never there
 int64_t g_nib_min_lg_lookup = 23, g_nib_min_lg_update = 24;  // see nib_geometry (psk_host.hpp); measured crossovers: scripts/ab_nib_threshold.py
@@ -495,6 +530,12 @@ extern PSK_HIDDEN int64_t g_merge_single_rank;  // psk_merge.hip
 extern "C" int psk_set_option(const char *name, int64_t value)
 {
     if (!name) return fail(PSK_EINVAL, "option name is NULL");
+    if (const int i = ho_index(name); i >= 0) {  // a default of the per-sketch options (sketches without an override follow it)
+        if (i == HO_PART_MIN_KEYS && value < 1) value = 1;
+        __atomic_store_n(&d_opt[i], value, __ATOMIC_RELAXED);
+        *ho_var(i) = value;
+        return PSK_OK;
+    }
     if (!strcmp(name, "partition")) g_part_mode = value;
     else if (!strcmp(name, "partition_min_keys")) g_part_min_keys = value;
     else if (!strcmp(name, "partition_max_keys")) g_part_max_keys = value < 1024 ? 1024 : value;
@@ -547,9 +588,43 @@ extern "C" int psk_debug_phase_profile(psk_sketch *s, uint32_t nbuckets, uint32_
     return PSK_OK;
 }
 
+extern "C" int psk_sketch_set_option(psk_sketch *s, const char *name, int64_t value)
+{
+    if (!s || !name) return fail(PSK_EINVAL, "NULL argument");
+    if (!strcmp(name, "table_private")) {
+        s->table_private = value != 0;
+        if (s->table_private) s->shadow.exposed = false;  // (from here on the holder announces its writes)
+        else if (!s->owns_table) s->shadow.exposed = true;
+        ++s->table_version;
+        return PSK_OK;
+    }
+    const int i = ho_index(name);
+    if (i < 0) return fail(PSK_EINVAL, "%s is not a per-sketch option", name);
+    if (i == HO_PART_MIN_KEYS && value != kHoUnset && value < 1) value = 1;
+    s->opt[i] = value;  // (kHoUnset = INT64_MIN: follow the process default again)
+    return PSK_OK;
+}
+
+extern "C" int psk_sketch_get_option(psk_sketch *s, const char *name, int64_t *value)
+{
+    if (!s || !name || !value) return fail(PSK_EINVAL, "NULL argument");
+    if (!strcmp(name, "table_private")) {
+        *value = s->table_private ? 1 : 0;
+        return PSK_OK;
+    }
+    const int i = ho_index(name);
+    if (i < 0) return fail(PSK_EINVAL, "%s is not a per-sketch option", name);
+    *value = s->opt[i] != kHoUnset ? s->opt[i] : __atomic_load_n(&d_opt[i], __ATOMIC_RELAXED);
+    return PSK_OK;
+}
+
 extern "C" int psk_get_option(const char *name, int64_t *value)
 {
     if (!name || !value) return fail(PSK_EINVAL, "NULL argument");
+    if (const int i = ho_index(name); i >= 0) {
+        *value = __atomic_load_n(&d_opt[i], __ATOMIC_RELAXED);
+        return PSK_OK;
+    }
     if (!strcmp(name, "partition")) *value = g_part_mode;
     else if (!strcmp(name, "partition_min_keys")) *value = g_part_min_keys;
     else if (!strcmp(name, "partition_max_keys")) *value = g_part_max_keys;
@@ -810,7 +885,7 @@ int64_t g_fused_flush = 0;             // flush of both write-combined key lists
                                        // SLOWER on BASELINE cfg 4 (4.50 vs 3.80 ms per step: one workgroup per slice streams both lists and folds twice
                                        // back to back, nothing overlaps) -- off; option "combine_fused_flush"
 int64_t g_combine_scatter = 0;         // psk_cbf_update_combined: 1 = unit-weight batches wait as scattered probes instead of key lists (see there)
-int64_t g_auto_combine = 1;            // psk_cbf_add: small unit-weight batches into big tables wait as scattered probes (adds commute: exact)
+__thread int64_t g_auto_combine = 1;            // psk_cbf_add: small unit-weight batches into big tables wait as scattered probes (adds commute: exact)
 int64_t g_auto_combine_keys = 1 << 24; // keys per list in that mode (~0.8 GB of segments for k = 7, allocated on first use)
 
 // a flush (or drop) on another stream than the last append must not overtake it
@@ -905,9 +980,10 @@ static int scat_append(psk_sketch *s, const Batch &b, bool neg, uint64_t cap, hi
     if (l.n + b.n > cap) PSK_TRY(flush_combined(s, st));
     const PartGeom &g = s->scat.g;
     const uint64_t part_bytes = (uint64_t)g.nbuckets * g.nwg * g.segcap * 16 + 256, cnt_bytes = (uint64_t)g.nbuckets * g.nwg * 4 + 128;
+    if (neg) return PSK_OK;  // (decrements stay out of the persistent segments: an overflowing segment would apply them ahead of the window's adds)
     if (l.part.cap < part_bytes || l.cnt.cap < cnt_bytes) {  // first use (or released): allocate, counts start at zero
-        PSK_TRY(ensure(l.part, part_bytes));
-        PSK_TRY(ensure(l.cnt, cnt_bytes));
+        if (g_scratch_budget > 0 && (int64_t)(part_bytes + cnt_bytes) > g_scratch_budget) return PSK_OK;  // (not taken: the direct path serves)
+        if (ensure(l.part, part_bytes) != PSK_OK || ensure(l.cnt, cnt_bytes) != PSK_OK) return PSK_OK;    // out of memory costs the shortcut, not the add
         HIP_TRY(hipMemsetAsync(l.cnt.p, 0, cnt_bytes, st));
         l.n = 0;
     }
@@ -959,8 +1035,8 @@ static int borrowed_flush(psk_sketch *s, psk_sketch::BorrowList &bl, bool remove
 
 // ---- update windows (psk_window.hpp): small unit-weight add / remove batches of 16-byte keys into big tables wait, in arrival order,
 // as key copies; win_flush applies them in one pass over the table, proving the removes while it folds -- or replays them one by one
-int64_t g_window = 1;                // option "update_window"
-int64_t g_window_keys = 1 << 27;     // option "update_window_keys": most keys a window holds (16 bytes each); also cells / 2 and the scratch budget
+__thread int64_t g_window = 1;                // option "update_window"
+__thread int64_t g_window_keys = 1 << 27;     // option "update_window_keys": most keys a window holds (16 bytes each); also cells / 2 and the scratch budget
 int64_t g_window_folds = 0, g_window_replays = 0;  // windows applied by the fold / replayed batch by batch (tests, bench)
 int64_t g_window_force_fail = 0;     // tests: pretend the proof failed (exercises undo + replay on a well-formed stream)
 constexpr size_t kWinMaxBatches = 4096;
@@ -1230,8 +1306,11 @@ extern "C" int psk_cbf_add(psk_sketch *s, int layout, const void *data, const ui
     // Automatic write-combining (no opt-in): a unit-weight batch too small to pay for a pass over a big table would take one
     // fabric atomic per probe.  Adds commute (countingbloom.py:135-155; the clamp at 2^32-1 is applied by the fold just the
     // same), so the batch is scattered now and folded with its successors; every entry point that reads or removes flushes first.
+    // (16-byte keys wait in the update window above; the other layouts here.  An append launches min(256, tiles) workgroups and workgroup i
+    // always fills segment column i: batches of fewer than 256 tiles would pile the whole list into a few columns, which overflow long before
+    // the list is full -- such batches take the direct kernel, as before round 3.)
     if (!weights && g_auto_combine != 0 && s->win.n == 0 && s->comb.rem.n == 0 && s->comb.brem.n() == 0 && s->scat.rem.n == 0 && (int64_t)n >= g_part_min_keys &&
-        n * (uint64_t)s->k < s->m / 8 && g_auto_combine_keys > 0) {
+        n >= (256u * 2048u * 7u) / (s->k ? s->k : 1u) && n * (uint64_t)s->k < s->m / 8 && g_auto_combine_keys > 0) {
         bool taken = false;
         PSK_TRY(scat_append(s, b, false, (uint64_t)g_auto_combine_keys, st, &taken));
         if (taken) {
@@ -1289,7 +1368,7 @@ static __global__ void k_book_removed(long long *ctr, const long long *tmp)
 }
 
 int64_t g_cbf_ordered_replays = 0;  // remove batches whose result depended on the order inside them: undone, replayed in order (tests)
-int64_t g_remove_exact = 1;         // option "remove_exact": 0 = round 3's composition (clamps and tallies instead of replaying)
+__thread int64_t g_remove_exact = 1;         // option "remove_exact": 0 = round 3's composition (clamps and tallies instead of replaying)
 
 // The validated remove (countingbloom.py:186-208) of a device-resident batch, as a TRANSACTION.  Unordered execution gives the
 // reference's table whenever the result does not depend on the order inside the batch; here that is CHECKED and, where it fails, the
@@ -1456,7 +1535,7 @@ extern "C" int psk_cbf_check(psk_sketch *s, int layout, const void *data, const 
     const uint32_t kk = layout == PSK_KEYS_HASHES ? key_len : s->k;
     {
         bool done = false;
-        s->shadow.allow = true;  // (only here: a lookup INSIDE an updating entry point is followed by writes at the same table version)
+        s->shadow.allow = !s->shadow.exposed;  // (only here: a lookup INSIDE an updating entry point is followed by writes at the same table version)
         const int rc = cbf_check_partitioned(s, b, kk, (uint32_t *)o.dev, st, &done);
         s->shadow.allow = false;
         PSK_TRY(rc);

@@ -81,7 +81,15 @@ struct DevBuf {
 };
 constexpr uint64_t kPinBytes = 4096;
 
+// Per-sketch tunables (psk_sketch_set_option): the options below can differ between two sketches of one process.  The variables the
+// launchers read (g_part_min_keys ...) are THREAD-LOCAL effective values: every entry point that takes a handle sets them from the handle's
+// overrides, falling back to the process-wide defaults psk_set_option maintains (kHoUnset = inherit the default).
+enum HandleOpt { HO_PART_MIN_KEYS, HO_CBF_SHADOW, HO_AUTO_COMBINE, HO_WINDOW, HO_WINDOW_KEYS, HO_SCRATCH_BUDGET, HO_REMOVE_EXACT, HO_BLOOM_LOOKUP, HO_COUNT };
+constexpr int64_t kHoUnset = INT64_MIN;
+
 struct psk_sketch {
+    int64_t opt[HO_COUNT] = {kHoUnset, kHoUnset, kHoUnset, kHoUnset, kHoUnset, kHoUnset, kHoUnset, kHoUnset};
+    bool table_private = false;  // option "table_private": the holder of a caller-owned table announces every outside write (psk_table_info / psk_rescan_bound)
     int kind;
     int device;
     uint64_t m;        // bits (bloom), counters (cbf), width (cms)
@@ -191,6 +199,9 @@ struct psk_sketch {
         uint32_t seen_count = 0;  // nibble-eligible lookups in a row that found version `seen`
         hipStream_t stream = nullptr;
         bool allow = false;  // set by psk_cbf_check around its lookup
+        // the table's pointer is in somebody's hands who has not said that every outside write will be announced: no kept images (they
+        // would go stale silently).  Set by psk_table_info and for caller-owned tables; cleared by option "table_private" / psk_rescan_bound.
+        bool exposed = false;
     } shadow;
     // split lookup (psk_bloom_check_begin / _finish): pass 1 of the first round has run, the rest waits for the table
     struct {
@@ -215,14 +226,15 @@ static inline int grid_for_keys(uint64_t n)  // direct kernels: 256 CUs x 16 blo
 // ------------------------------------------------- partitioned (large-batch) path
 // Tunables (psk_set_option): the partitioned path is taken when the batch has at least g_part_min_keys keys and
 // the table geometry allows it; g_part_mode 0 = never, 1 = auto.
-extern PSK_HIDDEN int64_t g_part_mode, g_part_min_keys, g_part_max_keys, g_part_cache_bytes, g_part_two_level_slices, g_part_debug;
-extern PSK_HIDDEN int64_t g_bloom_lookup;      // Bloom lookups: 0 keyed probes + miss stores, 1 return trip (psk_lookup.hpp), 2 (default) by the observed miss rate
+extern PSK_HIDDEN __thread int64_t g_part_min_keys;
+extern PSK_HIDDEN int64_t g_part_mode, g_part_max_keys, g_part_cache_bytes, g_part_two_level_slices, g_part_debug;
+extern PSK_HIDDEN __thread int64_t g_bloom_lookup;      // Bloom lookups: 0 keyed probes + miss stores, 1 return trip (psk_lookup.hpp), 2 (default) by the observed miss rate
 extern PSK_HIDDEN int64_t g_part_slice_bias;     // bench knob: added to log2(cells per slice)
 extern PSK_HIDDEN int64_t g_part_tile_threads;   // pass 1 workgroup shape for k <= 8: 0 = auto (launch_scatter), 512 / 1024 = forced
 extern PSK_HIDDEN int64_t g_part_even_tiles;     // 1 (default): pass 1 evens the tile size out over the workgroups
 extern PSK_HIDDEN int64_t g_lookup_half;           // 1 (default): counter lookups into 2^26 .. 2^27 counters use 2^16-counter slices of 16-bit values
 extern PSK_HIDDEN int64_t g_small_weights;     // weighted CMS adds: 0 never the compact probe format, 1 by the hint, 2 always (tests)
-extern PSK_HIDDEN int64_t g_cbf_shadow;         // keep the nibble-slice lookup's images of an unchanged table
+extern PSK_HIDDEN __thread int64_t g_cbf_shadow;         // keep the nibble-slice lookup's images of an unchanged table
 extern PSK_HIDDEN int64_t g_nib_nt;             // nontemporal table loads in the nibble-slice kernels (bench A/B)
 extern PSK_HIDDEN int64_t g_nib_update_layout;  // delta-image layout of k_nib_apply: 0 pieces, 1 blocks (psk_nibble.hpp)
 extern PSK_HIDDEN int64_t g_lookup_nibble, g_update_nibble;  // CBF tables beyond one level of 32-bit slices: 4-bit slice images (psk_nibble.hpp)
@@ -460,7 +472,7 @@ static inline bool part_wanted(uint64_t n, uint32_t k, int64_t scale = 1)
 
 // Option "scratch_budget_bytes" (0 = none): caps the partition scratch of a handle by cutting a batch into more rounds.  per_key:
 // scratch bytes one key of a round occupies (bucket buffer incl. padding and slack, plus values / perm for lookups).
-extern PSK_HIDDEN int64_t g_scratch_budget;
+extern PSK_HIDDEN __thread int64_t g_scratch_budget;
 static inline uint64_t cap_round_by_budget(uint64_t rk, double per_key)
 {
     if (g_scratch_budget <= 0 || per_key <= 0) return rk;
@@ -603,7 +615,9 @@ struct WinPhaseHost {
     uint32_t remove;
 };
 PSK_DECLARE_VARIANTS(int, cbf_window_fold, (psk_sketch *s, const WinPhaseHost *ph, uint32_t nph, const void *keys_dev, uint64_t nlist, hipStream_t st, bool *launched, bool *ok))
-extern PSK_HIDDEN int64_t g_remove_exact, g_cbf_ordered_replays;
-extern PSK_HIDDEN int64_t g_window, g_window_keys, g_window_folds, g_window_replays, g_window_force_fail;
+extern PSK_HIDDEN __thread int64_t g_remove_exact, g_window, g_window_keys;
+extern PSK_HIDDEN int64_t g_cbf_ordered_replays;
+extern PSK_HIDDEN int64_t g_window_folds, g_window_replays, g_window_force_fail;
 extern PSK_HIDDEN int64_t g_remove_dryrun;
-extern PSK_HIDDEN int64_t g_auto_combine, g_auto_combine_keys, g_combine_keys, g_combine_scatter, g_fused_flush;
+extern PSK_HIDDEN __thread int64_t g_auto_combine;
+extern PSK_HIDDEN int64_t g_auto_combine_keys, g_combine_keys, g_combine_scatter, g_fused_flush;

@@ -415,12 +415,19 @@ def test_repeated_lookups_keep_the_4bit_images_until_the_table_changes(pa, oracl
     cbf.remove_many(_dev(big))                   # optimistic decrement of the whole batch
     oc.update_keys(big, -np.ones(big.shape[0], dtype=np.int64))
     looks(3, 1)
-    # a write from outside through the table tensor: taking the property tells the engine
+    # a write from outside through the table tensor: taking the property tells the engine -- and while somebody holds the tensor NOTHING is
+    # kept (round 4: a write at any later time would make kept images stale without the engine knowing) ...
     t = cbf.table_tensor
     idx = [int(h % m) for h in oracle.default_fnv_1a(bytes(probe[-1]), k)]
     for c in set(idx):
         t[c] += 2
         oc.bloom[c] += 2
+    looks(3, 0)
+    for c in set(idx):       # ... so a later write through the same tensor, never announced, is seen as well
+        t[c] += 1
+        oc.bloom[c] += 1
+    looks(3, 0)
+    cbf.table_released()     # the holder is done (it takes the property again before it writes any more): images are kept again
     looks(3, 1)
     # another stream: the images were built on the first one
     s2 = torch.cuda.Stream()
