@@ -302,7 +302,7 @@ def host_cores():
     return aff, note
 
 
-def cpu_baseline(n_sample: int, reps: int = 3):
+def cpu_baseline(n_sample: int, reps: int = 2):
     """(i) a pure-Python mirror of the reference's per-key loop on a 100k-key sample, (ii) the plain-C
     oracle (kind 'port') on one core and on all host cores (per-thread replica + OR merge).  ~20 s of host work."""
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -350,6 +350,70 @@ def cpu_baseline(n_sample: int, reps: int = 3):
     py = {"value": 2 * n_py / t_py / 1e6, "unit": "Mkeys/s", "cores": 1, "kind": "python-mirror", "seconds": t_py, "all_found": ok,
           "sample": f"insert {n_py} + check {n_py} keys through oracle/pymirror.py (interpreted per-key FNV-1a + add_alt/check_alt, bigint arithmetic like the reference)"}
     return {**one, "legs": {"port_1core": dict(one), "port_allcores": allc, "port_allcores_shared_table": shared, "python_mirror": py}}
+
+
+def cpu_baseline_cfg3(n_sample: int = 4_000_000):
+    """cfg 3 on the host: the plain-C oracle's CountMinSketch (countminsketch.py:257-288 restated) on a sample of the
+    same weighted stream -- one thread, and all cores as per-thread replicas summed at the end (exact while no bin reaches a rail:
+    cfg 3's weights are 1 .. 7).  Bounded to a few seconds."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import numpy as np
+    import oracle
+
+    keys, w = oracle.gen_keys16(0, n_sample), oracle.gen_weights(0, n_sample)
+    oc = oracle.OracleCMS(2**20, 5)
+    t0 = time.perf_counter()
+    oc.add_keys(keys, w)
+    t1 = time.perf_counter() - t0
+    one = {"value": n_sample / t1 / 1e6, "unit": "Mupdates/s", "cores": 1, "kind": "port", "seconds": t1,
+           "sample": f"{n_sample} weighted updates (16-byte keys, weights 1..7) into width=2^20 depth=5, oracle/psk_oracle.c (gcc -O2), 1 thread"}
+    t0 = time.perf_counter()
+    oc.check_keys(keys[: n_sample // 2])
+    t2 = time.perf_counter() - t0
+    one["check_Mkeys_s"] = n_sample // 2 / t2 / 1e6
+    cores, quota_note = host_cores()
+    per = max(1, (n_sample * 4) // cores)
+    reps = [oracle.OracleCMS(2**20, 5) for _ in range(cores)]
+    parts = [(oracle.gen_keys16(t * per, per), oracle.gen_weights(t * per, per)) for t in range(cores)]  # (generation outside the clock)
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=r.add_keys, args=p) for r, p in zip(reps, parts)]  # (ctypes drops the GIL inside the C call)
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    total = np.zeros(reps[0].bins.size, dtype=np.int64)
+    for r in reps:
+        total += r.bins  # (the merge of the replicas is part of the leg)
+    t3 = time.perf_counter() - t0
+    allc = {"value": per * cores / t3 / 1e6, "unit": "Mupdates/s", "cores": cores, "kind": "port", "seconds": t3,
+            "sum_of_bins_ok": int(total.sum()) == 5 * int(sum(int(p[1].sum()) for p in parts)),
+            "sample": f"{per * cores} weighted updates, {cores} threads ({quota_note}): per-thread 20 MiB replica + int64 sum of the replicas (exact below the rails)"}
+    return {**one, "legs": {"port_1core": dict(one), "port_allcores": allc}}
+
+
+def cpu_baseline_cfg4(batch: int = 1_000_000, nbatches: int = 3):
+    """cfg 4 on the host: the plain-C oracle's CountingBloomFilter (countingbloom.py:135-208 restated) on the first batches of the same
+    mixed stream into the same 2^28 x uint32 table (1 GiB), one thread.  The stream does not parallelise as it stands -- a remove must see
+    the adds before it -- so there is no all-cores leg."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import numpy as np
+    import oracle
+
+    keys = oracle.gen_keys16(0, batch * nbatches)
+    oc = oracle.OracleCBF(2**28, 7)
+    oc.bloom[:] = 0  # (first touch of the 1 GiB outside the clock)
+    ops = 0
+    t0 = time.perf_counter()
+    for b in range(nbatches):
+        oc.update_keys(keys[b * batch:(b + 1) * batch])
+        ops += batch
+        if b >= 1:
+            oc.update_keys(keys[(b - 1) * batch:(b - 1) * batch + batch // 2], -np.ones(batch // 2, dtype=np.int64))
+            ops += batch // 2
+    t1 = time.perf_counter() - t0
+    return {"value": ops / t1 / 1e6, "unit": "Mops/s", "cores": 1, "kind": "port", "seconds": t1, "elements_added": oc.els_added,
+            "sample": f"the first {nbatches} batches of the stream ({ops} operations: add {batch} keys, remove the first half of the previous batch) into the "
+                      "2^28 x uint32 table, oracle/psk_oracle.c (gcc -O2), 1 thread; the stream is order-dependent: no all-cores leg"}
 
 
 # ----------------------------------------------------------------------------------------------- cfg2
@@ -458,6 +522,21 @@ def side_measurements(ctx: Ctx, n, blm, keys):
 
     torch, dev = ctx.torch, ctx.dev
     out, rl = {}, {}
+    # Host buffers (SURVEY.md 8d / BASELINE.md 4: the copy reported separately, never `value`): the same 10 M keys handed over as a numpy
+    # array -- H2D copy over PCIe + insert / lookup, the call returns when the result is back
+    hk = keys.cpu().numpy()
+    hb = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01, device=dev)
+    hb.add_many(hk[: n // 10])  # (staging buffers exist)
+    hb.check_many(hk[: n // 10])
+    t0 = time.perf_counter()
+    hb.add_many(hk)
+    t_in = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    hres = hb.check_many(hk)
+    t_ck = time.perf_counter() - t0
+    out["bloom_host_buffers_Mkeys_s"] = {"insert": n / t_in / 1e6, "check": n / t_ck / 1e6, "all_found": bool(hres.all()),
+                                         "note": "PCIe inclusive: numpy keys in, results back on the host; not part of `value`"}
+    del hb, hk, hres
     # Bloom lookups that MISS (the timed step only looks up inserted keys: every probe hits).  blm holds keys [0, n).
     fresh = ctx.gen_keys(n, 10 * n)
     mixed = torch.cat([keys[: n // 2], fresh[: n - n // 2]])
@@ -867,7 +946,17 @@ def run(args):
         c3 = line["configs"]["cfg3"]
         line["cms"] = {"insert_Mupdates_s": c3["value"], "lookup_Mkeys_s": c3["detail"]["check_Mkeys_s"], "source": "configs.cfg3 (100M weighted updates in 10 passes; lookups of the 10M keys)"}
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(min(args.n, 10_000_000))
+        if args.config == "cfg2":
+            line["cpu_baseline"] = cpu_baseline(min(args.n, 10_000_000))
+            if "configs" in line:  # the other halves of the metric: their own host legs (bounded to ~3 s each)
+                line["configs"]["cfg3"]["cpu_baseline"] = cpu_baseline_cfg3()
+                line["configs"]["cfg4"]["cpu_baseline"] = cpu_baseline_cfg4()
+        elif args.config == "cfg3":
+            line["cpu_baseline"] = cpu_baseline_cfg3()
+        elif args.config == "cfg4":
+            line["cpu_baseline"] = cpu_baseline_cfg4()
+        else:
+            line["cpu_baseline"] = cpu_baseline(10_000_000)
     elif ctx.rank == 0:
         line["cpu_baseline"] = None
     if fails:
