@@ -103,6 +103,42 @@ def parse():
     return args
 
 
+# Which part of the run this rank is in -- a failure names it: {"rc": ..., "error": "rank 3 failed in phase 'merge (allreduce OR)': ..."}.
+# Every rank that fails also leaves a small file next to the rendezvous (one node: /tmp is shared), so that whoever prints the JSON line
+# -- rank 0, or the self-launching parent when rank 0 is the one that died -- can say WHICH rank failed WHERE, not just "a collective hung".
+PHASE = {"name": "start"}
+
+
+def phase(name: str) -> None:
+    PHASE["name"] = name
+
+
+def _err_dir() -> Path:
+    return Path(os.environ.get("TMPDIR", "/tmp")) / f"psk_bench_{os.environ.get('MASTER_PORT', 'single')}"
+
+
+def leave_error_note(rank: int, text: str) -> None:
+    try:
+        d = _err_dir()
+        d.mkdir(parents=True, exist_ok=True)
+        (d / f"rank{rank}.json").write_text(json.dumps({"rank": rank, "phase": PHASE["name"], "error": text[-1500:]}))
+    except OSError:
+        pass
+
+
+def collect_error_notes(skip_rank=None) -> str:
+    notes = []
+    try:
+        for f in sorted(_err_dir().glob("rank*.json")):
+            n = json.loads(f.read_text())
+            if n.get("rank") != skip_rank:
+                notes.append(f"rank {n['rank']} failed in phase '{n['phase']}': {n['error']}")
+            f.unlink()
+    except (OSError, ValueError):
+        pass
+    return " || ".join(notes)
+
+
 def error_line(args, rc: int, error: str) -> str:
     """the JSON line of a run that failed: same keys as a good line, value null, rc != 0"""
     return json.dumps({"metric": METRIC_CFG2 if args.config == "cfg2" else f"bench {args.config}", "value": None, "unit": None, "n_gpus": args.gpus,
@@ -131,7 +167,10 @@ def self_launch(args) -> None:
     last = out.strip().splitlines()[-1] if out.strip() else ""
     has_json = last.startswith("{") and last.endswith("}")
     if rc != 0 and not has_json:
-        print(error_line(args, rc, f"the ranks ended with rc {rc} and no result line" + (" (killed by the launcher's watchdog)" if rc in (-9, 137) else "")), flush=True)
+        os.environ["MASTER_PORT"] = str(port)  # (where the ranks left their notes)
+        notes = collect_error_notes()
+        print(error_line(args, rc, f"the ranks ended with rc {rc} and no result line" + (" (killed by the launcher's watchdog)" if rc in (-9, 137) else "")
+                         + (f" | {notes}" if notes else "")), flush=True)
     sys.exit(rc if rc >= 0 else 128 - rc)
 
 
@@ -171,6 +210,7 @@ class Ctx:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             from datetime import timedelta
 
+            phase("rendezvous (init_process_group)")
             tmo = timedelta(seconds=args.init_timeout)  # rendezvous + every collective: a dead rank raises instead of hanging
             if self.single_device:
                 dist.init_process_group("gloo", timeout=tmo)
@@ -460,6 +500,21 @@ class Cfg2:
     def instrumented(self):
         for _ in range(min(self.args.steps, 10)):
             self.step(True, every_phase=True)
+
+    def rank_times(self):
+        """(insert ms, merge ms, lookup ms, table bytes) of ONE un-overlapped step on this rank (multi_gpu_diagnostics)"""
+        torch, blm, keys = self.ctx.torch, self.blm, self.keys
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        blm.clear()
+        ev[0].record()
+        blm.add_many(keys)
+        ev[1].record()
+        self.parallel.merge_bloom(blm, sync_elements=False)
+        ev[2].record()
+        blm.check_many(keys)
+        ev[3].record()
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3]), 2**28 // 8
 
     def finish(self, ms_step):
         ctx, args, n, torch, timer, blm = self.ctx, self.args, self.n, self.ctx.torch, self.timer, self.blm
@@ -792,6 +847,23 @@ class Cfg5:
     def instrumented(self):
         pass
 
+    def rank_times(self):
+        """(insert ms, merge ms, lookup ms, table bytes) of one step on this rank (multi_gpu_diagnostics)"""
+        torch, blm = self.ctx.torch, self.blm
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        blm.clear()
+        ev[0].record()
+        for c in self.chunks:
+            blm.add_many(c)
+        ev[1].record()
+        self.parallel.merge_bloom(blm, sync_elements=False)
+        ev[2].record()
+        for c in self.chunks:
+            blm.check_many(c)
+        ev[3].record()
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3]), 2**31 // 8
+
     def finish(self, ms_step):
         ctx, torch = self.ctx, self.ctx.torch
         ok = all(bool(r.all().item()) for r in self.found)
@@ -839,11 +911,37 @@ UNITS = {"cfg2": "Mkeys/s", "cfg3": "Mupdates/s", "cfg4": "Mops/s", "cfg5": "Mke
 EXTRA_STEPS = {"cfg3": (5, 1), "cfg4": (3, 1), "cfg5": (2, 1)}  # (steps, warmup) of the extra configurations on the default line
 
 
+def multi_gpu_diagnostics(ctx: Ctx, args, wl):
+    """N > 1: what every rank measured for itself -- insert / merge / lookup of one un-overlapped step, HIP events on its own stream --
+    gathered on every rank, plus the merge's bus rate and the group size RCCL reports.  The first real 8-GPU run cannot be rehearsed on
+    the one-GPU boxes of this pool, so the line says where the time of each rank went."""
+    torch, dist = ctx.torch, ctx.dist
+    ins, mrg, chk, table_bytes = wl.rank_times()
+    mine = torch.tensor([ins, mrg, chk], dtype=torch.float64, device=f"cuda:{ctx.dev}")
+    everyone = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(everyone, mine)
+    seen = dist.get_world_size()
+    if seen != max(args.gpus, 1):
+        raise RuntimeError(f"the process group has {seen} ranks, --gpus says {args.gpus}")
+    per_rank = [{"rank": r, "insert_ms": float(t[0]), "merge_ms": float(t[1]), "check_ms": float(t[2])} for r, t in enumerate(everyone)]
+    worst = max(p["merge_ms"] for p in per_rank)
+    R = seen
+    # allreduce(OR) = slice exchange + all_gather: every GPU sends and receives (R - 1) / R of the table in each of the two steps
+    moved = 2.0 * (R - 1) / R * table_bytes
+    return {"ranks_seen_by_rccl": seen, "backend": dist.get_backend(), "per_rank": per_rank,
+            "merge_GBs_per_gpu": (moved / (worst * 1e-3) / 1e9) if worst > 0 and R > 1 else None,
+            "merge_bytes_per_gpu_each_way": moved, "table_bytes": table_bytes,
+            "note": "un-overlapped step after the timed region (clear, insert, merge, lookup one after the other); merge_GBs_per_gpu = bytes every "
+                    "GPU sends (= receives) in the slice exchange + all_gather, divided by the slowest rank's merge time"}
+
+
 def run_workload(ctx: Ctx, args, name: str, steps: int, warmup: int, spinup: float):
     """spin-up, `warmup` untimed steps, EXACTLY `steps` timed steps between two fences, per-phase pass, parity.
     -> (workload, body, fails, seconds per step (max over ranks), untimed spin-up steps)"""
     torch = ctx.torch
+    phase(f"{name}: set-up (keys, sketch)")
     wl = WORKLOADS[name](ctx, args)
+    phase(f"{name}: spin-up and warm-up steps")
     # clock ramp: a fresh process starts at idle clocks and the first tens of milliseconds after a fence run slow; spin
     # the same step untimed first so that short runs (the driver's --steps 20) measure the steady state
     t_spin = time.perf_counter()
@@ -856,15 +954,21 @@ def run_workload(ctx: Ctx, args, name: str, steps: int, warmup: int, spinup: flo
     for _ in range(warmup):
         wl.step(False)
     ctx.fence()
+    phase(f"{name}: timed steps")
     t0 = time.perf_counter()
     sample_every = max(1, min(20, steps // 3))  # the dominant launch is event-timed on every sample_every-th step (>= 3 samples)
     for it in range(steps):
         wl.step(it % sample_every == 0)
     ctx.fence()
     elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    phase(f"{name}: per-phase instrumented pass")
     wl.instrumented()  # per-phase HIP-event times (not part of `value`)
     ctx.fence()
+    phase(f"{name}: parity checks and result")
     body, fails = wl.finish(elapsed / steps * 1e3)
+    if ctx.distributed and hasattr(wl, "rank_times"):
+        phase(f"{name}: per-rank diagnostics")
+        body["multi_gpu"] = multi_gpu_diagnostics(ctx, args, wl)
     return wl, body, fails, elapsed / steps, spun
 
 
@@ -886,8 +990,11 @@ def main():
     rank = int(os.environ.get("RANK", 0))
 
     def give_up():  # a hang (a rank that died inside a collective, a wedged rendezvous): say so in the result line, then leave
+        leave_error_note(rank, f"watchdog: no result after {args.timeout:g} s")
         if rank == 0:
-            os.write(1, ("\n" + error_line(args, 124, f"watchdog: no result after {args.timeout:g} s (a rank failed or a collective hangs)") + "\n").encode())
+            notes = collect_error_notes(skip_rank=0)
+            os.write(1, ("\n" + error_line(args, 124, f"watchdog: rank 0 had no result after {args.timeout:g} s, phase '{PHASE['name']}' (a rank failed or a collective hangs)"
+                                           + (f" | {notes}" if notes else "")) + "\n").encode())
         os._exit(124)
 
     dog = threading.Timer(args.timeout, give_up)
@@ -897,10 +1004,15 @@ def main():
         rc = run(args)
     except SystemExit:
         raise
-    except BaseException as e:  # noqa: BLE001  -- the line must exist whatever happened (rank 0 reports; the others just fail)
+    except BaseException as e:  # noqa: BLE001  -- the line must exist whatever happened (rank 0 reports; the others leave a note)
+        text = f"{type(e).__name__}: {e} | " + traceback.format_exc(limit=4)
         if rank == 0:
+            time.sleep(0.5)  # (a rank that failed first has written its note by now)
+            notes = collect_error_notes(skip_rank=0)
             sys.stdout.flush()
-            print(error_line(args, 1, f"{type(e).__name__}: {e} | " + traceback.format_exc(limit=4)), flush=True)
+            print(error_line(args, 1, f"rank 0 failed in phase '{PHASE['name']}': {text}" + (f" | {notes}" if notes else "")), flush=True)
+        else:
+            leave_error_note(rank, text)
         os._exit(1)  # (not sys.exit: a failed rank must not wait in atexit handlers for collectives that will never complete)
     dog.cancel()
     if rc:

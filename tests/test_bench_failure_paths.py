@@ -39,3 +39,5 @@ def test_self_launched_ranks_that_fail_end_in_a_json_error_line():
     rc, line = _run(["--gpus", "2", "--timeout", "20", "--init-timeout", "10"], "raise:1", timeout=400)
     assert rc != 0
     assert line["rc"] != 0 and line["value"] is None and line["error"]
+    # (round 4) the line names the rank that failed and the phase it was in, whoever ends up printing it
+    assert "rank 1 failed in phase" in line["error"] and "injected failure" in line["error"], line["error"]

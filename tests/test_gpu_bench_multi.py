@@ -56,9 +56,14 @@ def test_eight_ranks_on_one_device():
     line = _run(cmd, env)
     assert line["n_gpus"] == 8 and line["rc"] == 0 and line["detail"]["all_inserted_found"] is True
     assert line["detail"]["merged_table_equals_single_stream"] is True
+    mg = line["multi_gpu"]  # what every rank measured for itself (round 4: the first real 8-GPU run must explain itself)
+    assert mg["ranks_seen_by_rccl"] == 8 and [p["rank"] for p in mg["per_rank"]] == list(range(8))
+    assert all(p["insert_ms"] > 0 and p["merge_ms"] > 0 and p["check_ms"] > 0 for p in mg["per_rank"])
+    assert mg["merge_GBs_per_gpu"] > 0 and mg["table_bytes"] == 2**28 // 8
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--config", "cfg5", "--n-total", "8000003", "--steps", "1", "--warmup", "1", "--spinup", "0"]
     line = _run(cmd, env)
     assert line["n_gpus"] == 8 and line["detail"]["all_inserted_found"] is True and line["detail"]["merged_prefix_equals_single_stream"] is True
+    assert line["multi_gpu"]["ranks_seen_by_rccl"] == 8 and len(line["multi_gpu"]["per_rank"]) == 8 and line["multi_gpu"]["table_bytes"] == 2**31 // 8
 
 
 def test_launched_under_torch_distributed_run():
