@@ -300,6 +300,12 @@ int psk_idx_test(const void *table_dev, const uint32_t *idx_dev, uint64_t n, uin
 int psk_idx_resolve_ordered(const void *table_dev, const uint32_t *idx_dev, const uint8_t *present_dev, uint64_t n, uint32_t k,
                             uint32_t *first_dev, uint8_t *flag_dev, uint64_t *count_dev, uint64_t *inserted_host, int device,
                             void *stream);
+/* the same resolution with the per-bit scratch replaced by a bounded hash map (round 4): slots_dev = uint32[2][2^lg_slots], all-ones on entry
+ * and on exit, 2^lg_slots >= 2 * n * k.  The caller walks an ordered chunk in sub-chunks of n keys -- resolve, insert, next -- so the scratch
+ * is a few MB whatever the filter's size (psk_idx_resolve_ordered needs 4 bytes per filter BIT).  count_dev[0] += keys to insert,
+ * count_dev[1] != 0: the map overflowed (cannot happen with the sizing above).  Enqueue only: no host synchronisation. */
+int psk_idx_resolve_ordered_hashed(const void *table_dev, const uint32_t *idx_dev, const uint8_t *present_dev, uint64_t n, uint32_t k,
+                                   void *slots_dev, uint32_t lg_slots, uint8_t *flag_dev, uint64_t *count_dev, int device, void *stream);
 int psk_idx_insert(void *table_dev, const uint32_t *idx_dev, const uint8_t *flag_dev, uint64_t n, uint32_t k, int device,
                    void *stream);
 int psk_bytes_or(void *dst_dev, const void *src_dev, uint64_t n, int device, void *stream);

@@ -87,6 +87,7 @@ PROTOTYPES = {
     "psk_bloom_indices": (_int, [_vp, _int, _vp, _vp, _u64, _u32, _int, _vp, _vp]),
     "psk_idx_test": (_int, [_vp, _vp, _u64, _u32, _vp, _int, _int, _vp]),
     "psk_idx_resolve_ordered": (_int, [_vp, _vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _int, _vp]),
+    "psk_idx_resolve_ordered_hashed": (_int, [_vp, _vp, _vp, _u64, _u32, _vp, _u32, _vp, _vp, _int, _vp]),
     "psk_idx_insert": (_int, [_vp, _vp, _vp, _u64, _u32, _int, _vp]),
     "psk_bytes_or": (_int, [_vp, _vp, _u64, _int, _vp]),
     "psk_gen_keys16": (_int, [_vp, _u64, _u64, _u64, _int, _vp]),

@@ -522,6 +522,7 @@ __thread int64_t g_cbf_shadow = 1;  // nibble-slice lookups keep their 4-bit ima
 int64_t g_nib_nt = 1;   // nontemporal table loads in k_nib_gather (1 GiB lookups 710 -> 656 us per 10 M keys); the fold of k_nib_apply re-writes what it
                         // reads and measured slower with them (795 -> 984 us): never there
 int64_t g_nib_min_lg_lookup = 23, g_nib_min_lg_update = 24;  // see nib_geometry (psk_host.hpp); measured crossovers: scripts/ab_nib_threshold.py
+int64_t g_nib_update_parts = 1;   // 1 = one workgroup per slice (default: two measured the same, 0.78-0.82 ms per 10 M adds either way), 2 = two, 0 = by slice size; see nib_update_lgparts
 int64_t g_nib_update_layout = 1;   // see psk_nibble.hpp (bench A/B)
 int64_t g_update_nibble = 1;   // CBF unit-weight adds / decrements into 2^26 .. 2^29 counters: 4-bit delta images, one level; 0 = two-level 32-bit path
 int64_t g_part_dense_groups = 40;   // pass 2: segments of fewer groups (mean) are walked end to end (for_each_batch_at); 0 = never
@@ -563,6 +564,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "lookup_nibble_slices")) g_lookup_nibble = value;
     else if (!strcmp(name, "update_nibble_slices")) g_update_nibble = value;
     else if (!strcmp(name, "nibble_update_layout")) g_nib_update_layout = value;
+    else if (!strcmp(name, "nibble_update_parts")) g_nib_update_parts = value;
     else if (!strcmp(name, "nibble_min_lg_lookup")) g_nib_min_lg_lookup = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_min_lg_update")) g_nib_min_lg_update = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_nt_loads")) g_nib_nt = value;
@@ -648,6 +650,7 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "lookup_nibble_slices")) *value = g_lookup_nibble;
     else if (!strcmp(name, "update_nibble_slices")) *value = g_update_nibble;
     else if (!strcmp(name, "nibble_update_layout")) *value = g_nib_update_layout;
+    else if (!strcmp(name, "nibble_update_parts")) *value = g_nib_update_parts;
     else if (!strcmp(name, "nibble_min_lg_lookup")) *value = g_nib_min_lg_lookup;
     else if (!strcmp(name, "nibble_min_lg_update")) *value = g_nib_min_lg_update;
     else if (!strcmp(name, "nibble_nt_loads")) *value = g_nib_nt;
@@ -938,13 +941,14 @@ static int scat_flush(psk_sketch *s, hipStream_t st)
     PartGeom g = s->scat.g;
     const uint64_t per_seg = (uint64_t)g.nbuckets * g.nwg * 6;
     g.dense = ((na > nr ? na : nr) * s->k / per_seg) < (uint64_t)g_part_dense_groups ? 1u : 0u;
-    const size_t lds = (size_t)1 << (g.shift - 1);
+    const uint32_t lgp = nib_update_lgparts(g);
+    const size_t lds = (size_t)1 << (g.shift - 1 - lgp);
     unsigned long long *sat = (unsigned long long *)(s->ctr + PSK_CTR_SATURATED);
     const bool pass_a = na * s->k >= s->m / 8, pass_r = nr * s->k >= s->m / 8;
     auto launch = [&](auto kern, const psk_sketch::ScatList *la, const psk_sketch::ScatList *lb, uint32_t direct) {
         PSK_TRY(set_dyn_lds(kern, lds));
-        hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint32_t *)la->cnt.p, (const uint4 *)la->part.p,
-                           (const uint32_t *)(lb ? lb->cnt.p : nullptr), (const uint4 *)(lb ? lb->part.p : nullptr), sat, direct, (uint32_t *)nullptr, g);
+        hipLaunchKernelGGL(kern, dim3(g.nbuckets << lgp), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint32_t *)la->cnt.p, (const uint4 *)la->part.p,
+                           (const uint32_t *)(lb ? lb->cnt.p : nullptr), (const uint4 *)(lb ? lb->part.p : nullptr), sat, direct | (lgp << 8), (uint32_t *)nullptr, g);
         HIP_TRY(hipGetLastError());
         return (int)PSK_OK;
     };
@@ -1183,11 +1187,12 @@ int flush_combined(psk_sketch *s, hipStream_t st)
             s->comb.add.n = s->comb.rem.n = 0;
             PSK_TRY(account_weights(s, (const uint32_t *)nullptr, na, PSK_CTR_ADDED, (long long)s->k, st, true));
             PSK_TRY(account_weights(s, (const uint32_t *)nullptr, nr, PSK_CTR_REMOVED, (long long)s->k, st, false));
-            const size_t lds = (size_t)1 << (ga.shift - 1);
+            const uint32_t lgp = nib_update_lgparts(ga);
+            const size_t lds = (size_t)1 << (ga.shift - 1 - lgp);
             auto launch2 = [&](auto kern) {
                 PSK_TRY(set_dyn_lds(kern, lds));
-                hipLaunchKernelGGL(kern, dim3(ga.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, ga, (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p,
-                                   (const uint32_t *)s->s_cnt2.p, (const uint4 *)s->s_part2.p, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED), 0u, (uint32_t *)nullptr, gr);
+                hipLaunchKernelGGL(kern, dim3(ga.nbuckets << lgp), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, ga, (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p,
+                                   (const uint32_t *)s->s_cnt2.p, (const uint4 *)s->s_part2.p, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED), lgp << 8, (uint32_t *)nullptr, gr);
                 HIP_TRY(hipGetLastError());
                 return (int)PSK_OK;
             };

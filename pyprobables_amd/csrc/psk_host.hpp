@@ -278,6 +278,15 @@ static inline bool nib_geometry(uint64_t cells, bool update, PartGeom *g)
     return part_slices(cells, kNibShift, 15, g, kPartMaxBuckets, 8);
 }
 
+// workgroups per slice of k_nib_apply (log2): 2 for the 2^18-counter slices (two 64 KiB delta images per CU: one streams probes while the
+// other folds -- psk_nibble.hpp nib_apply_list); option "nibble_update_parts": 0 = this rule, 1 / 2 = forced (bench A/B)
+extern PSK_HIDDEN int64_t g_nib_update_parts;
+static inline uint32_t nib_update_lgparts(const PartGeom &g)
+{
+    if (g_nib_update_parts > 0) return g_nib_update_parts >= 2 && g.shift >= 16 ? 1u : 0u;
+    return g.shift >= 18 ? 1u : 0u;
+}
+
 // A 4-bit DELTA image holds at most 15 hits per counter and round; a round that brings more than ~2.5 probes per counter on average
 // overflows some counter of nearly every slice and would run at the atomics' rate (measured: 10 M keys into 1.7e7 counters, 4.2 probes
 // per counter: 1.8 ms against 0.31 ms through the 32-bit slices).  At 2.5 the tail P(Poisson >= 16) is ~3e-9 per counter.

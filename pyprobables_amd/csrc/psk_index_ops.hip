@@ -93,6 +93,63 @@ __global__ __launch_bounds__(kBlock) void k_res_reset(const uint32_t *idx, const
     }
 }
 
+// ---- the same resolution with `first` as a bounded HASH MAP (round 4): a uint32 per bit POSITION is 4 bytes per filter bit -- 1 GiB of
+// scratch for a 32 MiB filter of 2^28 bits.  The host resolves an ordered chunk in sub-chunks (each sees the table as the previous one
+// left it: the claim above holds for any ordered piece), so the map only has to hold the clear bits ONE sub-chunk touches:
+// slots[2^lg] = (bit position, smallest candidate), open addressing, all-ones = empty; reset with one fill.
+__device__ __forceinline__ uint32_t slot_of(uint32_t b, uint32_t lg) { return (b * 0x9E3779B1u) >> (32 - lg); }
+
+__global__ __launch_bounds__(kBlock) void k_res_first_h(const uint32_t *tab, const uint32_t *idx, const uint8_t *present, uint64_t n, uint32_t k,
+                                                        uint2 *slots, uint32_t lg, uint32_t *full)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint32_t mask = (1u << lg) - 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        if (present && present[i]) continue;
+        for (uint32_t j = 0; j < k; ++j) {
+            const uint32_t b = idx[i * k + j];
+            if (bit_set(tab, b)) continue;
+            uint32_t s = slot_of(b, lg), tries = 0;
+            for (;; s = (s + 1) & mask) {
+                const uint32_t old = atomicCAS(&slots[s].x, kNone, b);
+                if (old == kNone || old == b) {
+                    atomicMin(&slots[s].y, (uint32_t)i);
+                    break;
+                }
+                if (++tries > mask) {  // (cannot happen with the host's sizing; never spin for ever)
+                    *full = 1u;
+                    break;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_res_classify_h(const uint32_t *tab, const uint32_t *idx, const uint8_t *present, uint64_t n, uint32_t k,
+                                                           const uint2 *slots, uint32_t lg, uint8_t *flag)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint32_t mask = (1u << lg) - 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        uint8_t f = kSkip;
+        if (!(present && present[i])) {
+            for (uint32_t j = 0; j < k; ++j) {
+                const uint32_t b = idx[i * k + j];
+                if (bit_set(tab, b)) continue;
+                for (uint32_t s = slot_of(b, lg), tries = 0; tries <= mask; s = (s + 1) & mask, ++tries) {
+                    const uint2 e = slots[s];
+                    if (e.x == b) {
+                        if (e.y == (uint32_t)i) f = kInsert;
+                        break;
+                    }
+                    if (e.x == kNone) break;
+                }
+            }
+        }
+        flag[i] = f;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_count_flag(const uint8_t *flag, uint64_t n, uint8_t value, unsigned long long *out)
 {
     __shared__ unsigned long long part[kBlock / 64];
@@ -176,6 +233,27 @@ extern "C" int psk_idx_resolve_ordered(const void *table_dev, const uint32_t *id
         HIP_TRY(hipStreamSynchronize(st));
         *inserted_host = host_cnt;
     }
+    return PSK_OK;
+}
+
+extern "C" int psk_idx_resolve_ordered_hashed(const void *table_dev, const uint32_t *idx_dev, const uint8_t *present_dev, uint64_t n, uint32_t k,
+                                              void *slots_dev, uint32_t lg_slots, uint8_t *flag_dev, uint64_t *count_dev, int device, void *stream)
+{
+    if (n && (!table_dev || !idx_dev || !slots_dev || !flag_dev || !count_dev)) return fail(PSK_EINVAL, "NULL argument");
+    if (k == 0) return fail(PSK_EINVAL, "k must be > 0");
+    if (lg_slots < 4 || lg_slots > 31 || n * (uint64_t)k * 2 > (1ULL << lg_slots)) return fail(PSK_EINVAL, "the slot table must hold at least 2 * n * k entries");
+    PSK_USE_DEVICE(device);
+    if (!n) return PSK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t *tab = (const uint32_t *)table_dev;
+    const dim3 grid(grid_keys(n)), block(kBlock);
+    // count_dev[0] += keys to insert, count_dev[1] = "the table was full" (checked by the caller with its one read-back)
+    hipLaunchKernelGGL(k_res_first_h, grid, block, 0, st, tab, idx_dev, present_dev, n, k, (uint2 *)slots_dev, lg_slots, (uint32_t *)(count_dev + 1));
+    hipLaunchKernelGGL(k_res_classify_h, grid, block, 0, st, tab, idx_dev, present_dev, n, k, (const uint2 *)slots_dev, lg_slots, flag_dev);
+    HIP_TRY(hipMemsetAsync(slots_dev, 0xFF, (size_t)8 << lg_slots, st));  // empty again for the next sub-chunk
+    hipLaunchKernelGGL(k_count_flag, dim3(grid_keys(n) > 1024 ? 1024 : grid_keys(n)), block, 0, st, (const uint8_t *)flag_dev, n, (uint8_t)kInsert,
+                       (unsigned long long *)count_dev);
+    HIP_TRY(hipGetLastError());
     return PSK_OK;
 }
 

@@ -283,43 +283,60 @@ __device__ __forceinline__ uint32_t dlt_bit(uint32_t cell) { return BLOCKS ? (((
 // one list (segcnt, buckets) into slice b; `direct`: skip the image and apply every probe with an atomic on the table (few probes:
 // a pass over the whole slice would cost more)
 // OPT 0: the reference's saturating add / checked decrement; 1 (NEG): optimistic decrement, see above; 2 (!NEG): its inverse
+// Round 4: a slice may be shared by 2^lgp workgroups (PARTS): workgroup h of a slice owns the counters [h << pshift, (h + 1) << pshift), pshift =
+// shift - lgp -- it streams ALL probe groups of the slice, applies those of its part and folds its part of the table.  With 2^17-counter
+// parts the delta image is 64 KiB, two workgroups fit one CU, and one of them streams probes (LDS-atomic bound) while the other folds
+// (HBM bound): the pass over a 1 GiB table was 3.0-3.7 TB/s with one 128 KiB workgroup per CU, whose phases only follow each other; the
+// probe groups are a tenth of the bytes, reading them twice costs little.
+constexpr int kNibDepth = 6;  // probe groups in flight per lane in k_nib_apply (two workgroups per CU share the latency hiding)
 template <bool NEG, bool BLOCKS, int OPT = 0>
 __device__ __forceinline__ void nib_apply_list(uint32_t *smem, uint32_t *carried, uint32_t *tab, uint64_t tab_cells, const PartGeom &g, const uint32_t *segcnt,
-                                               const uint4 *buckets, unsigned long long *sat_ctr, uint32_t b, bool direct, bool nt, uint32_t *flag = nullptr)
+                                               const uint4 *buckets, unsigned long long *sat_ctr, uint32_t b, bool direct, bool nt, uint32_t *flag = nullptr,
+                                               uint32_t lgp = 0, uint32_t h = 0)
 {
     uint32_t bad = 0;
-    const uint32_t pieces = 1u << (g.shift - 2);
-    const uint64_t c0 = (uint64_t)b << g.shift;
+    const uint32_t pshift = g.shift - lgp, pmask = (1u << pshift) - 1;
+    const uint32_t pieces = 1u << (pshift - 2);
+    const uint64_t c0 = ((uint64_t)b << g.shift) + ((uint64_t)h << pshift);
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     if (!direct) {
-        for (uint32_t w = threadIdx.x; w < (1u << (g.shift - 3)); w += kApplyThreads) smem[w] = 0;
+        for (uint32_t w = threadIdx.x; w < (1u << (pshift - 3)); w += kApplyThreads) smem[w] = 0;
         if (threadIdx.x == 0) *carried = 0;
         __syncthreads();
         uint32_t over = 0;
+        const uint32_t hpart = h;
         auto half = [&](uint32_t lo, uint32_t hi) {  // 3 x 20-bit slice-local indices, valid count in bits 60..63
             const unsigned long long h = ((unsigned long long)hi << 32) | lo;
             const uint32_t nv = hi >> 28;
-            const uint32_t x[3] = {(uint32_t)h & 0xFFFFFu, (uint32_t)(h >> 20) & 0xFFFFFu, (uint32_t)(h >> 40) & 0xFFFFFu};
-            uint32_t old[3] = {0, 0, 0};
+            const uint32_t xx[3] = {(uint32_t)h & 0xFFFFFu, (uint32_t)(h >> 20) & 0xFFFFFu, (uint32_t)(h >> 40) & 0xFFFFFu};
+            uint32_t old[3] = {0, 0, 0}, x[3];
+            bool mine[3];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                mine[e] = (uint32_t)e < nv && (xx[e] >> pshift) == hpart;
+                x[e] = xx[e] & pmask;
+            }
 #pragma unroll
             for (int e = 0; e < 3; ++e)
-                if ((uint32_t)e < nv) old[e] = atomicAdd(&smem[dlt_word<BLOCKS>(x[e])], 1u << dlt_bit<BLOCKS>(x[e]));  // ds_add_rtn_u32
+                if (mine[e]) old[e] = atomicAdd(&smem[dlt_word<BLOCKS>(x[e])], 1u << dlt_bit<BLOCKS>(x[e]));  // ds_add_rtn_u32
 #pragma unroll
             for (int e = 0; e < 3; ++e)
-                if ((uint32_t)e < nv) over |= (uint32_t)(((old[e] >> dlt_bit<BLOCKS>(x[e])) & 15u) == 15u);
+                if (mine[e]) over |= (uint32_t)(((old[e] >> dlt_bit<BLOCKS>(x[e])) & 15u) == 15u);
         };
-        for_each_group(buckets, segcnt, g, b, zero4, [&](const uint4 q) { half(q.x, q.y); half(q.z, q.w); });
+        for_each_group<kNibDepth>(buckets, segcnt, g, b, zero4, [&](const uint4 q) { half(q.x, q.y); half(q.z, q.w); });
         if (over) *carried = 1u;
         __syncthreads();
     }
     if (direct || *carried) {  // uniform: exact atomics for this slice, straight from its probe groups
+        const uint32_t hpart2 = h;
         auto slow = [&](uint32_t lo, uint32_t hi) {
             const unsigned long long h = ((unsigned long long)hi << 32) | lo;
             const uint32_t nv = hi >> 28;
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
-                if ((uint32_t)e < nv) {
-                    const uint64_t cell = c0 + ((uint32_t)(h >> (20 * e)) & 0xFFFFFu);
+                const uint32_t xe = (uint32_t)(h >> (20 * e)) & 0xFFFFFu;
+                if ((uint32_t)e < nv && (xe >> pshift) == hpart2) {
+                    const uint64_t cell = c0 + (xe & pmask);
                     if (OPT == 1) {
                         const uint32_t old = atomicSub(tab + cell, 1u);
                         bad |= (uint32_t)(old == 0u) | (uint32_t)(old == 0xFFFFFFFFu);
@@ -330,7 +347,7 @@ __device__ __forceinline__ void nib_apply_list(uint32_t *smem, uint32_t *carried
                 }
             }
         };
-        for_each_group(buckets, segcnt, g, b, zero4, [&](const uint4 q) { slow(q.x, q.y); slow(q.z, q.w); });
+        for_each_group<kNibDepth>(buckets, segcnt, g, b, zero4, [&](const uint4 q) { slow(q.x, q.y); slow(q.z, q.w); });
         if (OPT == 1 && bad) *flag = 1u;
         return;
     }
@@ -361,8 +378,8 @@ __device__ __forceinline__ void nib_apply_list(uint32_t *smem, uint32_t *carried
         if (gc + 2 < tab_cells) tab[gc + 2] = o.z;
     };
     if constexpr (BLOCKS) {
-        const uint32_t blocks = 1u << (g.shift - 13);
-        constexpr int U = 4;  // blocks (two 16-byte pieces per lane each) in flight
+        const uint32_t blocks = 1u << (pshift - 13);
+        constexpr int U = 2;  // blocks (two 16-byte pieces per lane each) in flight (two workgroups per CU: 64 VGPRs per lane)
         for (uint32_t k0 = 0; k0 < blocks; k0 += U) {
             uint32_t d[U];
             uint4 t[U][2];
@@ -383,7 +400,7 @@ __device__ __forceinline__ void nib_apply_list(uint32_t *smem, uint32_t *carried
         }
     } else {
         const uint16_t *half16 = reinterpret_cast<const uint16_t *>(smem);
-        constexpr int U = 8;  // 16-byte pieces in flight per lane
+        constexpr int U = 2;  // 16-byte pieces in flight per lane
         for (uint32_t p0 = threadIdx.x; p0 < pieces; p0 += kApplyThreads * U) {
             uint32_t d[U];
             uint4 t[U];
@@ -410,24 +427,28 @@ __device__ __forceinline__ void nib_apply_list(uint32_t *smem, uint32_t *carried
 // slice a workgroup has just folded is still on-die when it folds it again); 3: optimistic decrement (flag), 4: its inverse.
 // direct: see nib_apply_list.
 template <int MODE, bool BLOCKS>
-__global__ __launch_bounds__(kApplyThreads) void k_nib_apply(uint32_t *tab, uint64_t tab_cells, PartGeom g, const uint32_t *segcnt_a, const uint4 *buckets_a,
+__global__ __launch_bounds__(kApplyThreads, 8) void k_nib_apply(uint32_t *tab, uint64_t tab_cells, PartGeom g, const uint32_t *segcnt_a, const uint4 *buckets_a,
                                                              const uint32_t *segcnt_b, const uint4 *buckets_b, unsigned long long *sat_ctr, uint32_t direct,
                                                              uint32_t *flag, PartGeom gb)
 {
     // gb: geometry of list B (MODE 2; same slices as g, its own workgroup count / segment capacity)
+    // direct: bit 0 = atomics instead of the image, bit 1 = nontemporal table loads, bits 8.. = log2(workgroups per slice), see nib_apply_list
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t carried;
-    const uint32_t b = blockIdx.x;
-    if (MODE == 0 || MODE == 2) nib_apply_list<false, BLOCKS>(smem, &carried, tab, tab_cells, g, segcnt_a, buckets_a, sat_ctr, b, (direct & 1u) != 0, (direct & 2u) != 0);
+    const uint32_t lgp = direct >> 8;
+    const uint32_t b = blockIdx.x >> lgp, h = blockIdx.x & ((1u << lgp) - 1u);
+    if (((uint64_t)b << g.shift) + ((uint64_t)h << (g.shift - lgp)) >= tab_cells) return;  // (a part past the table's end)
+    if (MODE == 0 || MODE == 2) nib_apply_list<false, BLOCKS>(smem, &carried, tab, tab_cells, g, segcnt_a, buckets_a, sat_ctr, b, (direct & 1u) != 0, (direct & 2u) != 0, nullptr, lgp, h);
     if (MODE == 2) {
         __threadfence();   // my stores to the slice are visible to my loads below (same CU, but through L2: not the L1)
         __syncthreads();
     }
-    if (MODE == 1) nib_apply_list<true, BLOCKS>(smem, &carried, tab, tab_cells, g, segcnt_a, buckets_a, sat_ctr, b, (direct & 1u) != 0, (direct & 2u) != 0);
-    if (MODE == 2) nib_apply_list<true, BLOCKS>(smem, &carried, tab, tab_cells, gb, segcnt_b, buckets_b, sat_ctr, b, (direct & 1u) != 0, (direct & 2u) != 0);
-    if (MODE == 3) nib_apply_list<true, BLOCKS, 1>(smem, &carried, tab, tab_cells, g, segcnt_a, buckets_a, sat_ctr, b, (direct & 1u) != 0, (direct & 2u) != 0, flag);
-    if (MODE == 4) nib_apply_list<false, BLOCKS, 2>(smem, &carried, tab, tab_cells, g, segcnt_a, buckets_a, sat_ctr, b, (direct & 1u) != 0, (direct & 2u) != 0, flag);
+    if (MODE == 1) nib_apply_list<true, BLOCKS>(smem, &carried, tab, tab_cells, g, segcnt_a, buckets_a, sat_ctr, b, (direct & 1u) != 0, (direct & 2u) != 0, nullptr, lgp, h);
+    if (MODE == 2) nib_apply_list<true, BLOCKS>(smem, &carried, tab, tab_cells, gb, segcnt_b, buckets_b, sat_ctr, b, (direct & 1u) != 0, (direct & 2u) != 0, nullptr, lgp, h);
+    if (MODE == 3) nib_apply_list<true, BLOCKS, 1>(smem, &carried, tab, tab_cells, g, segcnt_a, buckets_a, sat_ctr, b, (direct & 1u) != 0, (direct & 2u) != 0, flag, lgp, h);
+    if (MODE == 4) nib_apply_list<false, BLOCKS, 2>(smem, &carried, tab, tab_cells, g, segcnt_a, buckets_a, sat_ctr, b, (direct & 1u) != 0, (direct & 2u) != 0, flag, lgp, h);
 }
+
 
 // segcnt[] of a persistent list back to zero after a flush (one launch for both lists)
 static __global__ __launch_bounds__(256) void k_zero_u32(uint32_t *a, uint64_t na, uint32_t *b, uint64_t nb)

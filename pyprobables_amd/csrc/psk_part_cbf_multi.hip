@@ -19,11 +19,12 @@ int PSK_VARIANT(cbf_unit_multi_partitioned)(psk_sketch *s, const void *const *ba
         return launch_scatter<KeysFixed16Multi, IdxBloom<kTuPow2>, PayNone, SpillCounter<false>, KT>(s, src, IdxBloom<kTuPow2>{s->md}, PayNone{}, spill, &g, n, st);
     }));
     // few probes: drain with atomics instead of a pass over the table (k_nib_apply's direct mode)
-    const uint32_t direct = n * (uint64_t)s->k < cells / 8 ? 1u : 0u;
-    const size_t lds = (size_t)1 << (g.shift - 1);
+    const uint32_t lgp = nib_update_lgparts(g);
+    const uint32_t direct = (n * (uint64_t)s->k < cells / 8 ? 1u : 0u) | (lgp << 8);
+    const size_t lds = (size_t)1 << (g.shift - 1 - lgp);
     auto launch = [&](auto kern) {
         PSK_TRY(set_dyn_lds(kern, lds));
-        hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p,
+        hipLaunchKernelGGL(kern, dim3(g.nbuckets << lgp), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p,
                            (const uint32_t *)nullptr, (const uint4 *)nullptr, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED), direct, (uint32_t *)nullptr, g);
         HIP_TRY(hipGetLastError());
         return (int)PSK_OK;

@@ -90,11 +90,12 @@ static inline int nib_scatter(psk_sketch *s, const Batch &sub, const uint32_t *m
 template <int MODE>
 static inline int nib_apply_mode(psk_sketch *s, const PartGeom &g, const void *cnt, const void *part, hipStream_t st, uint32_t *flag = nullptr)
 {
-    const size_t lds = (size_t)1 << (g.shift - 1);
+    const uint32_t lgp = nib_update_lgparts(g);
+    const size_t lds = (size_t)1 << (g.shift - 1 - lgp);
     auto kern = g_nib_update_layout ? k_nib_apply<MODE, true> : k_nib_apply<MODE, false>;
     PSK_TRY(set_dyn_lds(kern, lds));
-    hipLaunchKernelGGL(kern, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint32_t *)cnt, (const uint4 *)part,
-                       (const uint32_t *)nullptr, (const uint4 *)nullptr, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED), 0u, flag, g);
+    hipLaunchKernelGGL(kern, dim3(g.nbuckets << lgp), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint32_t *)cnt, (const uint4 *)part,
+                       (const uint32_t *)nullptr, (const uint4 *)nullptr, (unsigned long long *)(s->ctr + PSK_CTR_SATURATED), lgp << 8, flag, g);
     HIP_TRY(hipGetLastError());
     return PSK_OK;
 }

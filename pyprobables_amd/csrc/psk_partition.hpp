@@ -1161,13 +1161,13 @@ __device__ __forceinline__ void load_slice(uint32_t *smem, const uint32_t *tab, 
 }
 
 // consumers that only issue LDS atomics: one callback per group
-template <class F4>
+template <int DEPTH = kApplyDepth, class F4>
 __device__ __forceinline__ void for_each_group(const uint4 *buckets, const uint32_t *segcnt, const PartGeom &g, uint32_t b,
                                                const uint4 pad, F4 f4)
 {
-    for_each_batch<kApplyDepth>(buckets, segcnt, g, b, pad, [&](const uint4 (&q)[kApplyDepth]) {
+    for_each_batch<DEPTH>(buckets, segcnt, g, b, pad, [&](const uint4 (&q)[DEPTH]) {
 #pragma unroll
-        for (int d = 0; d < kApplyDepth; ++d) f4(q[d]);
+        for (int d = 0; d < DEPTH; ++d) f4(q[d]);
     });
 }
 

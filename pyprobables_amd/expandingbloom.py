@@ -134,7 +134,7 @@ class ExpandingBloomFilter:
     def _indices(self, b: KeyBatch):
         """the k bit positions of every key of the batch (bloom.py:247), hashed once for the whole stack"""
         last = self._blooms[-1]
-        if last.number_bits > 1 << 32:
+        if last.number_bits >= 1 << 32:  # (bit position 2^32 - 1 is the resolution map's "empty" marker)
             raise NotImplementedError("stacked filters need m <= 2^32 bits per filter on this engine")
         idx = self._buf("idx", b.n * self._k, torch.int32)
         N.check(N.lib().psk_bloom_indices(last._tab.handle, *b.args(), b.where, idx.data_ptr(), self._stream()))
@@ -154,18 +154,30 @@ class ExpandingBloomFilter:
                                        flag.data_ptr() if flag is not None else None, count, self._k, self._dev(),
                                        self._stream()))
 
-    def _resolve(self, blm: BloomFilter, idx, start: int, count: int, present):
-        """which keys of the ordered chunk the reference loop would insert into ``blm`` -> (flag tensor, inserted)"""
-        words = blm.number_bits  # one uint32 per bit position, all-ones between calls
-        first = self._buf("first", words, torch.int32, fill=-1)
-        flag = self._buf("flag", count, torch.uint8)
-        cnt = self._buf("count", 1, torch.int64)
-        ins = C.c_uint64(0)
-        N.check(N.lib().psk_idx_resolve_ordered(blm.table_tensor.data_ptr(), idx.data_ptr() + 4 * start * self._k,
-                                                present.data_ptr() if present is not None else None, count, self._k,
-                                                first.data_ptr(), flag.data_ptr(), cnt.data_ptr(), C.byref(ins), self._dev(),
-                                                self._stream()))
-        return flag, ins.value
+    _SUB = 1 << 18  # keys per resolution step: the scratch is a hash map over the clear bits ONE step touches (see _resolve_insert)
+
+    def _resolve_insert(self, blm: BloomFilter, idx, start: int, count: int, present) -> int:
+        """insert, into ``blm``, exactly the keys of the ordered chunk the reference loop would insert; -> how many.
+        The chunk is walked in steps of ``_SUB`` keys -- resolve (which of the step's keys find a clear bit first), insert, next: each
+        step sees the filter as the previous one left it, which is the sequential semantics.  Scratch: a 2^lg-slot map of
+        (bit position, first candidate) sized for one step -- 32 MiB for k = 7 -- where round 3 kept a uint32 per filter BIT (1 GiB for
+        m = 2^28)."""
+        k = self._k
+        lg = max(12, (2 * min(count, self._SUB) * k - 1).bit_length())
+        slots = self._buf(f"slots{lg}", 2 << lg, torch.int32, fill=-1)
+        flag = self._buf("flag", min(count, self._SUB), torch.uint8)
+        cnt = self._buf("count", 2, torch.int64)
+        cnt.zero_()
+        L, tab = N.lib(), blm.table_tensor.data_ptr()
+        for s in range(0, count, self._SUB):
+            n = min(self._SUB, count - s)
+            N.check(L.psk_idx_resolve_ordered_hashed(tab, idx.data_ptr() + 4 * (start + s) * k, (present.data_ptr() + s) if present is not None else None,
+                                                    n, k, slots.data_ptr(), lg, flag.data_ptr(), cnt.data_ptr(), self._dev(), self._stream()))
+            N.check(L.psk_idx_insert(tab, idx.data_ptr() + 4 * (start + s) * k, flag.data_ptr(), n, k, self._dev(), self._stream()))
+        inserted, full = (int(x) for x in cnt.tolist())
+        if full:
+            raise RuntimeError("stacked filter: the resolution map overflowed")
+        return inserted
 
     # ------------------------------------------------------------------ growth policy
     def _room(self, blm: BloomFilter):
@@ -230,8 +242,7 @@ class ExpandingBloomFilter:
             else:  # end the chunk right after the room-th candidate: no growth can happen inside it
                 csum = torch.cumsum(cand, 0)
                 e = int(torch.searchsorted(csum, torch.tensor([room], device=csum.device, dtype=csum.dtype)).item()) + 1
-            flag, inserted = self._resolve(last, idx, s, e, present)
-            self._insert(last, idx, s, e, flag)
+            inserted = self._resolve_insert(last, idx, s, e, present)
             last._els_added += inserted
             self._added_elements += e
             self.last_batch_stats["chunks"] += 1

@@ -229,3 +229,30 @@ def test_custom_hash_function_route(pa):
     for key in keys:
         one.add(key)
     assert bytes(m) == bytes(one) and all(m.check_many(keys))
+
+
+def test_stack_of_2p26_bit_filters_with_bounded_scratch(pa, oracle):
+    """filters of m ~ 2^26 bits (est 7 M at 1 %): the ordered insert resolves its chunks through a bounded hash map (32 MiB) instead of a
+    uint32 per filter bit (round 3: 256 MiB here, 1 GiB at m = 2^28) -- same stack as the sequential oracle, repeats and one growth included"""
+    est, fpr = 7_000_000, 0.01
+    blm = pa.ExpandingBloomFilter(est_elements=est, false_positive_rate=fpr)
+    assert abs(blm._blooms[-1].number_bits - 2**26) < 2**16  # (67 095 409 bits per filter)
+    n, pool = 12_000_000, 12_000_000
+    rng = np.random.default_rng(21)
+    sel = rng.integers(0, pool, size=n)
+    keys16 = oracle.gen_keys16(77_000_000, pool)
+    batch = np.ascontiguousarray(keys16[sel])
+    for w0 in range(0, n, 3_000_000):  # four ordered calls; the last one crosses the growth
+        blm.add_many(torch.from_numpy(batch[w0:w0 + 3_000_000]).cuda())
+    scratch = sum(t.numel() * t.element_size() for name, t in blm._scratch.items() if name.startswith("slots"))
+    assert 0 < scratch <= 64 << 20
+    st = oracle.OracleStack(est, fpr, max_filters=4)
+    blob = batch.reshape(-1)
+    offs = np.arange(0, 16 * (n + 1), 16, dtype=np.uint64)
+    import ctypes as C
+
+    rc = oracle.lib().psk_o_stack_add_varlen(st.stack.ctypes.data, st.filter_bytes, st.max_filters, C.byref(st._n), st.counts.ctypes.data,
+                                             st.m, st.k, st.est, st.queue, blob.ctypes.data, offs.ctypes.data, n, 0, C.byref(st._added))
+    assert rc == 0 and st.nfilters == 2
+    assert [b.elements_added for b in blm._blooms] == [int(c) for c in st.counts[: st.nfilters]]
+    assert bytes(blm) == st.export_bytes()
