@@ -66,9 +66,9 @@ SEED = 0x5EED
 # algorithmic bytes per unit of work (L = 16-byte key, k = 7, d = 5)
 BYTES = {"bloom_insert": 72, "bloom_check": 45, "cms_add": 60, "cms_check": 40, "cbf_add": 76, "cbf_remove": 76, "cbf_check": 48}
 DEFAULT_STEPS = {"cfg2": (200, 20), "cfg3": (20, 3), "cfg4": (10, 2), "cfg5": (5, 1)}
-PMC_FILE = next((f for f in (ROOT / "profiles" / "r03_pmc_traffic.json", ROOT / "profiles" / "r02_pmc_traffic.json") if f.exists()),
-                ROOT / "profiles" / "r03_pmc_traffic.json")
-L2_FILE = ROOT / "profiles" / "r03_l2_hit.json"
+PMC_FILE = next((f for f in (ROOT / "profiles" / "r04_pmc_traffic.json", ROOT / "profiles" / "r03_pmc_traffic.json") if f.exists()),
+                ROOT / "profiles" / "r04_pmc_traffic.json")
+L2_FILE = next((f for f in (ROOT / "profiles" / "r04_l2_hit.json", ROOT / "profiles" / "r03_l2_hit.json") if f.exists()), ROOT / "profiles" / "r04_l2_hit.json")
 METRIC_CFG2 = "million keys/sec insert+lookup (Bloom m=2^28 k=7, CMS 2^20x5)"
 
 
@@ -285,7 +285,7 @@ def timed_loop(torch, fn, iters, warm=2):
 
 def pmc_traffic(op: str, n: int):
     """HBM-side bytes per launch of `op` from the committed PMC profile of the same workload and kernels
-    (scripts/profile_r03.sh -> profiles/r03_pmc_traffic.json); None when there is no matching record.  A record measured
+    (scripts/profile_r04.sh -> profiles/r04_pmc_traffic.json); None when there is no matching record.  A record measured
     on chunks of the same kernels (`per_key_scalable`: cfg 5 inserts its shard in 2^25-key calls) is scaled by the key count."""
     try:
         pmc = json.loads(PMC_FILE.read_text())
@@ -300,8 +300,8 @@ def pmc_traffic(op: str, n: int):
 
 
 def l2_hit(op: str):
-    """L2 hit rate TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum) of the launch's kernels (profiles/r03_l2_hit.json,
-    scripts/profile_r03.sh: its own rocprofv3 --pmc pass); None when there is no record"""
+    """L2 hit rate TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum) of the launch's kernels (profiles/r04_l2_hit.json,
+    scripts/profile_r04.sh: its own rocprofv3 --pmc pass); None when there is no record"""
     try:
         return json.loads(L2_FILE.read_text())[op]["l2_hit"]
     except Exception:

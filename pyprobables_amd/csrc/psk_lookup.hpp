@@ -8,7 +8,7 @@
 //   pass 1  k_part_scatter (psk_partition.hpp), payload-free probes (8 x 16-bit slice-local cells per group, the unit
 //           counter-add format) + two by-products of its LDS counting sort:
 //             perm[key]      the position of each of the key's k probes inside the tile's sorted stage (16 bits each,
-//                            one 16-byte store per key and 8 probes)
+//                            ceil(k / 2) dwords per key: PermRec, psk_partition.hpp)
 //             runinfo[tile][slice] = (first group of the tile's run inside its (slice, workgroup) segment,
 //                                     stage offset << 16 | probe count)
 //   pass 2  k_counter_gather: one workgroup per slice keeps the slice (2^15 counters = 128 KiB) in LDS, streams the slice's
@@ -29,7 +29,7 @@ struct PayUnitLookup {  // as PayUnit (8 x 16-bit cells per group) + the by-prod
     static constexpr int mode = kModePlain;
     static constexpr int group = 8;
     static constexpr bool lookup = true;
-    uint4 *perm;       // [round keys][(KT + 7) / 8]
+    uint32_t *perm;    // [round keys][PermRec<KT>::PD dwords]
     uint2 *runinfo;    // [tiles][slices]
     __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
 };
@@ -38,7 +38,7 @@ struct PayBloomLookup {  // as PayNone (6 x 20-bit bit indices per group) + the 
     static constexpr int mode = kModePlain;
     static constexpr int group = 6;
     static constexpr bool lookup = true;
-    uint4 *perm;
+    uint32_t *perm;
     uint2 *runinfo;
     __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
 };
@@ -191,11 +191,11 @@ struct QueryCbfMin {   // countingbloom.py:166-174
 // dynamic LDS: runinfo[B] (uint2) | stage[stage_cap] (values in the tile's sorted order) | fmt[B] bytes
 // kCollectThreads: 1024 = two workgroups (tiles in flight) per CU, 512 = four (round 3 A/B: option "lookup_collect_threads")
 template <class Query, int KT, int kCollectThreads>
-__global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query, PartGeom g, uint64_t n, const uint4 *perm, const uint2 *runinfo,
+__global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query, PartGeom g, uint64_t n, const uint32_t *perm, const uint2 *runinfo,
                                                                     const uint32_t *vals, const uint8_t *fmt, uint32_t stage_cap, uint32_t run_lanes,
                                                                     typename Query::Out *out)
 {
-    constexpr int GS = 8, P4 = (KT + 7) / 8;
+    constexpr int GS = 8;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint2 *info = reinterpret_cast<uint2 *>(smem);
     uint32_t *stage = smem + 2 * g.nbuckets;
@@ -238,12 +238,11 @@ __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query,
                               : make_uint2((uint32_t)(seg + ri.x), (off << 16) | lim);
             }
         }
-        uint4 pw[kPre][P4];
+        PermRec<KT> pw[kPre];
 #pragma unroll
         for (int q = 0; q < kPre; ++q) {
             const uint64_t i = base + threadIdx.x + (uint64_t)q * kCollectThreads;
-#pragma unroll
-            for (int c = 0; c < P4; ++c) pw[q][c] = perm[(i < end ? i : base) * P4 + c];  // clamped, never branched around
+            pw[q] = perm_load<KT>(perm, i < end ? i : base);  // clamped, never branched around
         }
         __syncthreads();
         {
@@ -300,17 +299,13 @@ __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query,
         }
         __syncthreads();
         // ---- every key picks its k values through perm[]
-        auto finish_key = [&](uint64_t i, const uint4 (&w4)[P4]) {
-            uint32_t p[8 * P4];
-#pragma unroll
-            for (int c = 0; c < P4; ++c) {
-                const uint4 w = w4[c];
-                p[8 * c + 0] = w.x & 0xFFFFu; p[8 * c + 1] = w.x >> 16; p[8 * c + 2] = w.y & 0xFFFFu; p[8 * c + 3] = w.y >> 16;
-                p[8 * c + 4] = w.z & 0xFFFFu; p[8 * c + 5] = w.z >> 16; p[8 * c + 6] = w.w & 0xFFFFu; p[8 * c + 7] = w.w >> 16;
-            }
+        auto finish_key = [&](uint64_t i, const PermRec<KT> &rec) {
             uint32_t v[KT];
 #pragma unroll
-            for (int j = 0; j < KT; ++j) v[j] = (uint32_t)j < k ? stage[p[j] < stage_cap ? p[j] : 0] : 0u;
+            for (int j = 0; j < KT; ++j) {
+                const uint32_t pj = rec.pos(j);
+                v[j] = (uint32_t)j < k ? stage[pj < stage_cap ? pj : 0] : 0u;
+            }
             out[i] = query.template operator()<KT>(v, k);
         };
 #pragma unroll
@@ -318,12 +313,8 @@ __global__ __launch_bounds__(kCollectThreads) void k_lookup_collect(Query query,
             const uint64_t i = base + threadIdx.x + (uint64_t)q * kCollectThreads;
             if (i < end) finish_key(i, pw[q]);
         }
-        for (uint64_t i = base + threadIdx.x + (uint64_t)kPre * kCollectThreads; i < end; i += kCollectThreads) {  // tiles beyond 2048 keys (k <= 4)
-            uint4 w4[P4];
-#pragma unroll
-            for (int c = 0; c < P4; ++c) w4[c] = perm[i * P4 + c];
-            finish_key(i, w4);
-        }
+        for (uint64_t i = base + threadIdx.x + (uint64_t)kPre * kCollectThreads; i < end; i += kCollectThreads)  // tiles beyond 2048 keys (k <= 5)
+            finish_key(i, perm_load<KT>(perm, i));
         __syncthreads();
     }
 }
@@ -371,17 +362,28 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_gather(const uin
     }, mycnt);
 }
 
+constexpr int kBloomCollectThreads = 1024;
+// Keys per collect thread whose perm[] record is requested before the run copies: ceil(largest pass-1 tile / workgroup), at most 8.
+// (Rounds 1-3 asked for 8 per thread whatever k was: for k = 7 -- 2048-key tiles, two keys per thread -- six of the eight were clamped
+// re-reads of the tile's first record and 24 VGPRs of ballast.)
+template <int KT>
+__host__ __device__ constexpr int collect_prefetch_keys()
+{
+    constexpr int a = PartTile<PayBloomLookup, KT, 1024>::TILE, b = PartTile<PayBloomLookup, KT, kPartThreads>::TILE;
+    constexpr int per = ((a > b ? a : b) + kBloomCollectThreads - 1) / kBloomCollectThreads;
+    return per < 1 ? 1 : (per > 8 ? 8 : per);
+}
+
 // dynamic LDS: runinfo[B] (uint2) | stage bytes (one per group of the tile's sorted stage)
 // (1024-thread workgroups: 256-thread ones -- more tiles in flight per CU -- measured slower, 84 vs 64 us per 10 M keys: the
 // kernel is bound by the 16 bytes of perm[] per key, not by per-tile latency)
-constexpr int kBloomCollectThreads = 1024;
 
 template <int KT>
-__global__ __launch_bounds__(kBloomCollectThreads) void k_bloom_collect(PartGeom g, uint64_t n, const uint4 *perm, const uint2 *runinfo, const uint8_t *bits,
+__global__ __launch_bounds__(kBloomCollectThreads) void k_bloom_collect(PartGeom g, uint64_t n, const uint32_t *perm, const uint2 *runinfo, const uint8_t *bits,
                                                                    uint32_t stage_groups, uint32_t run_lanes, uint8_t *out, unsigned long long *miss_ctr)
 {
     uint32_t nmiss = 0;  // keys answered "absent" (feeds the host's choice of lookup scheme)
-    constexpr int GS = 6, P4 = (KT + 7) / 8;
+    constexpr int GS = 6;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint2 *info = reinterpret_cast<uint2 *>(smem);
     uint8_t *stage = reinterpret_cast<uint8_t *>(smem + 2 * g.nbuckets);
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(kBloomCollectThreads) void k_bloom_collect(PartGeom
     const uint32_t k = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
     const uint64_t ntiles = (n + g.tile - 1) / g.tile;
     constexpr int kInfoRegs = kPartMaxBuckets / kBloomCollectThreads;
-    constexpr int kPre = 8 / P4;  // keys per thread whose perm[] is prefetched (8 = a 2048-key tile)
+    constexpr int kPre = collect_prefetch_keys<KT>();  // keys per thread whose perm[] is prefetched: the whole tile
     uint2 nxt[kInfoRegs];
 #pragma unroll
     for (int r = 0; r < kInfoRegs; ++r) {
@@ -405,12 +407,11 @@ __global__ __launch_bounds__(kBloomCollectThreads) void k_bloom_collect(PartGeom
             const uint32_t b = threadIdx.x + (uint32_t)r * kBloomCollectThreads;
             if (b < B) info[b] = nxt[r];
         }
-        uint4 pw[kPre][P4];
+        PermRec<KT> pw[kPre];
 #pragma unroll
         for (int q = 0; q < kPre; ++q) {
             const uint64_t i = base + threadIdx.x + (uint64_t)q * kBloomCollectThreads;
-#pragma unroll
-            for (int c = 0; c < P4; ++c) pw[q][c] = perm[(i < end ? i : base) * P4 + c];
+            pw[q] = perm_load<KT>(perm, i < end ? i : base);
         }
         __syncthreads();
         {
@@ -434,19 +435,13 @@ __global__ __launch_bounds__(kBloomCollectThreads) void k_bloom_collect(PartGeom
         }
         __syncthreads();
         // ---- every key ANDs its k bits (bloom.py:269-271)
-        auto finish_key = [&](uint64_t i, const uint4 (&w4)[P4]) {
-            uint32_t p[8 * P4];
-#pragma unroll
-            for (int c = 0; c < P4; ++c) {
-                const uint4 w = w4[c];
-                p[8 * c + 0] = w.x & 0xFFFFu; p[8 * c + 1] = w.x >> 16; p[8 * c + 2] = w.y & 0xFFFFu; p[8 * c + 3] = w.y >> 16;
-                p[8 * c + 4] = w.z & 0xFFFFu; p[8 * c + 5] = w.z >> 16; p[8 * c + 6] = w.w & 0xFFFFu; p[8 * c + 7] = w.w >> 16;
-            }
+        auto finish_key = [&](uint64_t i, const PermRec<KT> &rec) {
             uint32_t ok = 1;
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
                 if ((uint32_t)j < k) {
-                    const uint32_t gi = p[j] / GS, e = p[j] - gi * GS;
+                    const uint32_t pj = rec.pos(j);
+                    const uint32_t gi = pj / GS, e = pj - gi * GS;
                     ok &= ((uint32_t)stage[gi < stage_groups ? gi : 0] >> e) & 1u;
                 }
             }
@@ -458,12 +453,8 @@ __global__ __launch_bounds__(kBloomCollectThreads) void k_bloom_collect(PartGeom
             const uint64_t i = base + threadIdx.x + (uint64_t)q * kBloomCollectThreads;
             if (i < end) finish_key(i, pw[q]);
         }
-        for (uint64_t i = base + threadIdx.x + (uint64_t)kPre * kBloomCollectThreads; i < end; i += kBloomCollectThreads) {
-            uint4 w4[P4];
-#pragma unroll
-            for (int c = 0; c < P4; ++c) w4[c] = perm[i * P4 + c];
-            finish_key(i, w4);
-        }
+        for (uint64_t i = base + threadIdx.x + (uint64_t)kPre * kBloomCollectThreads; i < end; i += kBloomCollectThreads)
+            finish_key(i, perm_load<KT>(perm, i));
         __syncthreads();
     }
     if (miss_ctr) {  // ONE atomic per workgroup: same-address device atomics serialise (~11 ns each; one per wave cost 90 us here)

@@ -138,10 +138,10 @@ static __global__ __launch_bounds__(kApplyThreads) void k_nib_gather(const uint3
 
 // dynamic LDS: runinfo[B] (uint2) | stage words (one per group of the tile's sorted stage)
 template <int KT>
-__global__ __launch_bounds__(kBloomCollectThreads) void k_nib_collect(PartGeom g, uint64_t n, const uint4 *perm, const uint2 *runinfo, const uint32_t *vals,
+__global__ __launch_bounds__(kBloomCollectThreads) void k_nib_collect(PartGeom g, uint64_t n, const uint32_t *perm, const uint2 *runinfo, const uint32_t *vals,
                                                                  uint32_t stage_groups, uint32_t run_lanes, uint32_t *out, uint32_t *flag)
 {
-    constexpr int GS = 6, P4 = (KT + 7) / 8;
+    constexpr int GS = 6;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint2 *info = reinterpret_cast<uint2 *>(smem);
     uint32_t *stage = smem + 2 * g.nbuckets;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kBloomCollectThreads) void k_nib_collect(PartGeom g
     const uint32_t k = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
     const uint64_t ntiles = (n + g.tile - 1) / g.tile;
     constexpr int kInfoRegs = kPartMaxBuckets / kBloomCollectThreads;
-    constexpr int kPre = 8 / P4;  // keys per thread whose perm[] is prefetched (see k_bloom_collect)
+    constexpr int kPre = collect_prefetch_keys<KT>();  // keys per thread whose perm[] is prefetched (see k_bloom_collect)
     uint2 nxt[kInfoRegs];
 #pragma unroll
     for (int r = 0; r < kInfoRegs; ++r) {
@@ -166,12 +166,11 @@ __global__ __launch_bounds__(kBloomCollectThreads) void k_nib_collect(PartGeom g
             const uint32_t b = threadIdx.x + (uint32_t)r * kBloomCollectThreads;
             if (b < B) info[b] = nxt[r];
         }
-        uint4 pw[kPre][P4];
+        PermRec<KT> pw[kPre];
 #pragma unroll
         for (int q = 0; q < kPre; ++q) {
             const uint64_t i = base + threadIdx.x + (uint64_t)q * kBloomCollectThreads;
-#pragma unroll
-            for (int c = 0; c < P4; ++c) pw[q][c] = perm[(i < end ? i : base) * P4 + c];
+            pw[q] = perm_load<KT>(perm, i < end ? i : base);
         }
         __syncthreads();
         {
@@ -195,19 +194,13 @@ __global__ __launch_bounds__(kBloomCollectThreads) void k_nib_collect(PartGeom g
         }
         __syncthreads();
         // ---- every key takes the min of its k nibbles (countingbloom.py:174)
-        auto finish_key = [&](uint64_t i, const uint4 (&w4)[P4]) {
-            uint32_t p[8 * P4];
-#pragma unroll
-            for (int c = 0; c < P4; ++c) {
-                const uint4 w = w4[c];
-                p[8 * c + 0] = w.x & 0xFFFFu; p[8 * c + 1] = w.x >> 16; p[8 * c + 2] = w.y & 0xFFFFu; p[8 * c + 3] = w.y >> 16;
-                p[8 * c + 4] = w.z & 0xFFFFu; p[8 * c + 5] = w.z >> 16; p[8 * c + 6] = w.w & 0xFFFFu; p[8 * c + 7] = w.w >> 16;
-            }
+        auto finish_key = [&](uint64_t i, const PermRec<KT> &rec) {
             uint32_t mn = 15;
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
                 if ((uint32_t)j < k) {
-                    const uint32_t gi = p[j] / GS, e = p[j] - gi * GS;
+                    const uint32_t pj = rec.pos(j);
+                    const uint32_t gi = pj / GS, e = pj - gi * GS;
                     const uint32_t v = (stage[gi < stage_groups ? gi : 0] >> (4 * e)) & 15u;
                     mn = v < mn ? v : mn;
                 }
@@ -220,12 +213,8 @@ __global__ __launch_bounds__(kBloomCollectThreads) void k_nib_collect(PartGeom g
             const uint64_t i = base + threadIdx.x + (uint64_t)q * kBloomCollectThreads;
             if (i < end) finish_key(i, pw[q]);
         }
-        for (uint64_t i = base + threadIdx.x + (uint64_t)kPre * kBloomCollectThreads; i < end; i += kBloomCollectThreads) {
-            uint4 w4[P4];
-#pragma unroll
-            for (int c = 0; c < P4; ++c) w4[c] = perm[i * P4 + c];
-            finish_key(i, w4);
-        }
+        for (uint64_t i = base + threadIdx.x + (uint64_t)kPre * kBloomCollectThreads; i < end; i += kBloomCollectThreads)
+            finish_key(i, perm_load<KT>(perm, i));
         __syncthreads();
     }
     if (ambiguous) *flag = 1u;

@@ -79,9 +79,9 @@ static int bloom_check_return_trip(psk_sketch *s, const Batch &b, uint8_t *out_d
                     if (tile_max * kq0 + (size_t)5 * g.nbuckets + 3 > 0xFFFFu) { fits = false; return (int)PSK_OK; }
                 }
                 const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE + 1024;  // (+ workgroups: evened tiles, launch_scatter_nt)
-                PSK_TRY(ensure(s->s_perm, cnt * P4 * 16));
+                PSK_TRY(ensure(s->s_perm, cnt * (uint64_t)PermRec<KT>::PD * 4 + 16));
                 PSK_TRY(ensure(s->s_run, max_tiles * g.nbuckets * 8));
-                PayBloomLookup pay{(uint4 *)s->s_perm.p, (uint2 *)s->s_run.p};
+                PayBloomLookup pay{(uint32_t *)s->s_perm.p, (uint2 *)s->s_run.p};
                 SpillRaiseFlag spill{flag};
                 PSK_TRY((launch_scatter<Src, IdxBloom<kTuPow2>, PayBloomLookup, SpillRaiseFlag, KT>(s, src, IdxBloom<kTuPow2>{s->md}, pay, spill, &g, cnt, st)));
                 PSK_TRY(ensure(s->s_vals, (uint64_t)g.nbuckets * g.nwg * g.segcap + 256));  // one result byte per group
@@ -99,7 +99,7 @@ static int bloom_check_return_trip(psk_sketch *s, const Batch &b, uint8_t *out_d
                 PSK_TRY(set_dyn_lds(kern, lds3));
                 uint32_t run_lanes = 2;  // lanes (one byte = one group of 6 probes each) per (tile, slice) run
                 while (run_lanes < 64 && (uint64_t)run_lanes * 6 * g.nbuckets < (uint64_t)g.tile * kq + 6ULL * g.nbuckets) run_lanes *= 2;
-                hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(kBloomCollectThreads), lds3, st, g, cnt, (const uint4 *)s->s_perm.p,
+                hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(kBloomCollectThreads), lds3, st, g, cnt, (const uint32_t *)s->s_perm.p,
                                    (const uint2 *)s->s_run.p, (const uint8_t *)s->s_vals.p, stage_groups, run_lanes, out_dev + start, s->lk.dev);
                 HIP_TRY(hipGetLastError());
                 return (int)PSK_OK;

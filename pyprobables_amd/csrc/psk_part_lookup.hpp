@@ -13,7 +13,7 @@ extern PSK_HIDDEN int64_t g_cbf_shadow_hits;  // nibble-slice lookups that loade
 static inline uint64_t lookup_round_keys(uint64_t n, uint32_t k)
 {
     uint64_t rk = (uint64_t)g_part_max_keys < n ? (uint64_t)g_part_max_keys : n;
-    rk = cap_round_by_budget(rk, (double)k * (2.0 + 4.0) * 1.5 + 16.0 * ((k + 7) / 8) + 8.0);  // probes + values + perm + runinfo
+    rk = cap_round_by_budget(rk, (double)k * (2.0 + 4.0) * 1.5 + 4.0 * ((k + 1) / 2) + 8.0);  // probes + values + perm + runinfo
     // pass 3 addresses a run's values by a 32-bit unit index (k_lookup_collect's run descriptors): at most 2^31 probes per round keeps the
     // round's groups, pads included, far below 2^31
     const uint64_t by_probes = (1ULL << 31) / (k ? k : 1);
@@ -61,9 +61,9 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
                     if (tile_max * kq0 + (size_t)7 * g.nbuckets + 3 > 0xFFFFu) { fits = false; return (int)PSK_OK; }
                 }
                 const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE + 1024;  // (+ workgroups: evened tiles, launch_scatter_nt)
-                PSK_TRY(ensure(s->s_perm, cnt * P4 * 16));
+                PSK_TRY(ensure(s->s_perm, cnt * (uint64_t)PermRec<KT>::PD * 4 + 16));
                 PSK_TRY(ensure(s->s_run, max_tiles * g.nbuckets * 8));
-                PayUnitLookup pay{(uint4 *)s->s_perm.p, (uint2 *)s->s_run.p};
+                PayUnitLookup pay{(uint32_t *)s->s_perm.p, (uint2 *)s->s_run.p};
                 SpillRaiseFlag spill{flag};
                 PSK_TRY((launch_scatter<Src, IDX<kTuPow2>, PayUnitLookup, SpillRaiseFlag, KT>(s, src, IDX<kTuPow2>{s->md}, pay, spill, &g, cnt, st)));
                 // pass 2: the counters behind every probe, in the probe buffer's shape
@@ -94,7 +94,7 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
                 if (g_lookup_run_lanes > 0) run_lanes = (uint32_t)g_lookup_run_lanes;
                 const uint64_t grid3 = narrow_wg ? 1024 : 512;
                 hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < grid3 ? ntiles : grid3)), dim3(narrow_wg ? 512 : 1024), lds3, st, query, g, cnt,
-                                   (const uint4 *)s->s_perm.p, (const uint2 *)s->s_run.p, (const uint32_t *)s->s_vals.p, (const uint8_t *)fmt, stage_cap, run_lanes,
+                                   (const uint32_t *)s->s_perm.p, (const uint2 *)s->s_run.p, (const uint32_t *)s->s_vals.p, (const uint8_t *)fmt, stage_cap, run_lanes,
                                    out_dev + start);
                 HIP_TRY(hipGetLastError());
                 return (int)PSK_OK;
@@ -175,9 +175,9 @@ static inline int cbf_check_nibble(psk_sketch *s, const Batch &b, uint32_t kk, u
                 const size_t tile_max = TileBig::TILE > TileSmall::TILE ? TileBig::TILE : TileSmall::TILE;
                 if (tile_max * kq + (size_t)5 * g.nbuckets + 3 > 0xFFFFu) { fits = false; return (int)PSK_OK; }
                 const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE + 1024;  // (+ workgroups: evened tiles, launch_scatter_nt)
-                PSK_TRY(ensure(s->s_perm, cnt * P4 * 16));
+                PSK_TRY(ensure(s->s_perm, cnt * (uint64_t)PermRec<KT>::PD * 4 + 16));
                 PSK_TRY(ensure(s->s_run, max_tiles * g.nbuckets * 8));
-                PayBloomLookup pay{(uint4 *)s->s_perm.p, (uint2 *)s->s_run.p};
+                PayBloomLookup pay{(uint32_t *)s->s_perm.p, (uint2 *)s->s_run.p};
                 SpillRaiseFlag spill{flag};
                 PSK_TRY((launch_scatter<Src, IdxBloom<kTuPow2>, PayBloomLookup, SpillRaiseFlag, KT>(s, src, IdxBloom<kTuPow2>{s->md}, pay, spill, &g, cnt, st)));
                 PSK_TRY(ensure(s->s_vals, (uint64_t)g.nbuckets * g.nwg * g.segcap * 4 + 256));  // one dword (six nibbles) per group
@@ -204,7 +204,7 @@ static inline int cbf_check_nibble(psk_sketch *s, const Batch &b, uint32_t kk, u
                 uint32_t run_lanes = 2;  // lanes (one dword = one group of 6 probes each) per (tile, slice) run
                 while (run_lanes < 64 && (uint64_t)run_lanes * 6 * g.nbuckets < (uint64_t)g.tile * kq + 6ULL * g.nbuckets) run_lanes *= 2;
                 if (g_lookup_run_lanes > 0) run_lanes = (uint32_t)g_lookup_run_lanes;
-                hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(kBloomCollectThreads), lds3, st, g, cnt, (const uint4 *)s->s_perm.p,
+                hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(kBloomCollectThreads), lds3, st, g, cnt, (const uint32_t *)s->s_perm.p,
                                    (const uint2 *)s->s_run.p, (const uint32_t *)s->s_vals.p, stage_groups, run_lanes, out_dev + start, amb);
                 HIP_TRY(hipGetLastError());
                 return (int)PSK_OK;

@@ -134,6 +134,52 @@ struct pay_is_phased { static constexpr bool value = false; };
 template <class Pay>
 struct pay_is_phased<Pay, decltype((void)Pay::phased)> { static constexpr bool value = Pay::phased; };
 
+// perm[] record of one key (the partitioned lookups, psk_lookup.hpp): the position of each of its KT probes inside the tile's sorted
+// stage, 16 bits each, in PD = ceil(KT / 2) dwords -- 12 bytes for k = 5 / 6, 8 for k <= 4 (round 4; rounds 1-3 wrote whole 16-byte
+// units: 16 bytes for every k <= 8, written by pass 1 and read back by pass 3).  Records are dword aligned; one wide access per <= 4 dwords.
+typedef uint32_t perm_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t perm_u32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t perm_u32x4 __attribute__((ext_vector_type(4)));
+typedef perm_u32x2 perm_u32x2a __attribute__((aligned(4)));
+typedef perm_u32x3 perm_u32x3a __attribute__((aligned(4)));
+typedef perm_u32x4 perm_u32x4a __attribute__((aligned(4)));
+template <int KT>
+struct PermRec {
+    static constexpr int PD = (KT + 1) / 2;
+    uint32_t w[PD];
+    __device__ __forceinline__ uint32_t pos(int j) const { return (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu; }
+};
+template <int PD, int C = 0>
+__device__ __forceinline__ void perm_load_chunks(uint32_t (&w)[PD], const uint32_t *p)
+{
+    if constexpr (PD - C >= 4) { const perm_u32x4 v = *reinterpret_cast<const perm_u32x4a *>(p + C); w[C] = v.x; w[C + 1] = v.y; w[C + 2] = v.z; w[C + 3] = v.w; }
+    else if constexpr (PD - C == 3) { const perm_u32x3 v = *reinterpret_cast<const perm_u32x3a *>(p + C); w[C] = v.x; w[C + 1] = v.y; w[C + 2] = v.z; }
+    else if constexpr (PD - C == 2) { const perm_u32x2 v = *reinterpret_cast<const perm_u32x2a *>(p + C); w[C] = v.x; w[C + 1] = v.y; }
+    else if constexpr (PD - C == 1) w[C] = p[C];
+    if constexpr (PD - C > 4) perm_load_chunks<PD, C + 4>(w, p);
+}
+template <int PD, int C = 0>
+__device__ __forceinline__ void perm_store_chunks(const uint32_t (&w)[PD], uint32_t *p)
+{
+    if constexpr (PD - C >= 4) { perm_u32x4 v; v.x = w[C]; v.y = w[C + 1]; v.z = w[C + 2]; v.w = w[C + 3]; *reinterpret_cast<perm_u32x4a *>(p + C) = v; }
+    else if constexpr (PD - C == 3) { perm_u32x3 v; v.x = w[C]; v.y = w[C + 1]; v.z = w[C + 2]; *reinterpret_cast<perm_u32x3a *>(p + C) = v; }
+    else if constexpr (PD - C == 2) { perm_u32x2 v; v.x = w[C]; v.y = w[C + 1]; *reinterpret_cast<perm_u32x2a *>(p + C) = v; }
+    else if constexpr (PD - C == 1) p[C] = w[C];
+    if constexpr (PD - C > 4) perm_store_chunks<PD, C + 4>(w, p);
+}
+template <int KT>
+__device__ __forceinline__ PermRec<KT> perm_load(const uint32_t *perm, uint64_t i)
+{
+    PermRec<KT> r;
+    perm_load_chunks<PermRec<KT>::PD>(r.w, perm + i * PermRec<KT>::PD);
+    return r;
+}
+template <int KT>
+__device__ __forceinline__ void perm_store(uint32_t *perm, uint64_t i, const PermRec<KT> &r)
+{
+    perm_store_chunks<PermRec<KT>::PD>(r.w, perm + i * PermRec<KT>::PD);
+}
+
 // payload functors: the second word a probe carries through the LDS sort (key i of a tile starting at base)
 struct PayNone {   // Bloom insert: 6 probes per group, 20-bit slice-local bit indices
     static constexpr int mode = kModePlain;
@@ -673,7 +719,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         for (int q = 0; q < KPT; ++q) {
             const uint64_t i = base + (uint64_t)q * NT + threadIdx.x;
             if (i < tile_end && kept(q)) {
-                uint32_t pos[LOOKUP ? 8 * ((KT + 7) / 8) : 1] = {};  // lookups: where each of my probes sits in the sorted stage
+                uint32_t pos[LOOKUP ? 2 * ((KT + 1) / 2) : 1] = {};  // lookups: where each of my probes sits in the sorted stage
                 if constexpr (pay_has_tally<Pay>::value) {
                     // (here, not where the weight is loaded: the sum would pin the load's latency into the hash phase --
                     // measured +19 us per 10 M keys -- while this phase consumes the weight anyway)
@@ -717,11 +763,11 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
                         }
                     }
                 }
-                if constexpr (LOOKUP) {  // perm[key]: 16-bit stage positions, one 16-byte store per 8 probes
+                if constexpr (LOOKUP) {  // perm[key]: 16-bit stage positions, ceil(k / 2) dwords per key (PermRec)
+                    PermRec<KT> rec;
 #pragma unroll
-                    for (int c = 0; c < (KT + 7) / 8; ++c)
-                        pay.perm[i * ((KT + 7) / 8) + c] = make_uint4(pos[8 * c] | (pos[8 * c + 1] << 16), pos[8 * c + 2] | (pos[8 * c + 3] << 16),
-                                                                      pos[8 * c + 4] | (pos[8 * c + 5] << 16), pos[8 * c + 6] | (pos[8 * c + 7] << 16));
+                    for (int c = 0; c < PermRec<KT>::PD; ++c) rec.w[c] = pos[2 * c] | (pos[2 * c + 1] << 16);
+                    perm_store<KT>(pay.perm, i, rec);
                 }
             }
         }
