@@ -21,24 +21,35 @@ constexpr int kGroup = 8;                                // hash chains interlea
 // ------------------------------------------------------------------ hashing
 // hashes.py:99-102  hval ^= e; hval *= prime (mod 2^64)
 // prime = 2^40 + 0x1B3 and e < 2^32, so with x = lo ^ e:  lo' = low32(x * 0x1B3),  hi' = hi * 0x1B3 + high32(x * 0x1B3) + (x << 8).
-// Four VALU instructions: v_xor_b32, v_mad_u64_u32 (lo' and the carry at once), v_lshl_add_u32, and a second
-// v_mad_u64_u32 as a 32-bit multiply-add (only the low word of its sum is used; the addend's high word is left undefined).
-// hipcc's own expansion of the 64-bit multiply is five (bitop3, lshlrev, mad_u64_u32, mul_lo_u32, add3_u32; 9.4 ns against
-// 7.5 ns per wave64 step and SIMD in scripts/ubench/alu.hip) -- the chains of a non-power-of-two table are VALU bound.
+// Four VALU instructions: v_xor_b32, v_mul_lo_u32 (hi * 0x1B3), v_lshl_add_u32 ((x << 8) + that), and ONE v_mad_u64_u32 that yields
+// lo' and hi' at once: x * 0x1B3 + {0, addend} -- the carry of the low product lands in the high word by itself.
+// scripts/ubench/alu.hip (profiles/r04_ubench_alu.txt; ns per step, wave64, 4 waves per SIMD): this order 7.40, rounds 1-3's order (two
+// v_mad_u64_u32: x * 0x1B3, then hi * 0x1B3 + addend) 7.99, a split low / high state (v_mul_hi_u32 + v_mul_lo_u32 + shift-add + add on the
+// high word) 10.85, hipcc's own expansion of the 64-bit multiply 9.4; the 32-bit chain of power-of-two tables 3.23.
+// The chains of a non-power-of-two table are VALU bound, and four instructions of which three are full-rate VOP3 is the floor.
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint64_t fnv_step(uint64_t h, uint32_t e)
+// `pair`: the chain's own {0, addend} register pair.  Its low word is zero and stays zero -- the step writes the high word only -- but the
+// asm names the pair as read-WRITE, so hipcc cannot know that and keeps the pair in place; told the truth it built a fresh {0, b} pair per
+// step and re-materialised the zero every time (a v_mov per step: five instructions, 8.5 ns).
+__device__ __forceinline__ uint64_t fnv_step(uint64_t h, uint32_t e, uint64_t &pair)
 {
     const uint32_t x = (uint32_t)h ^ e;
-    const uint64_t t = (uint64_t)x * 0x1B3u;
-    u32x2_t addend;
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wuninitialized"
-    addend.x = (x << 8) + (uint32_t)(t >> 32);
+    const uint32_t a = (uint32_t)(h >> 32) * 0x1B3u;
+    pair = (pair & 0xFFFFFFFFull) | ((uint64_t)((x << 8) + a) << 32);
     uint64_t u;
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(u) : "v"((uint32_t)(h >> 32)), "s"(0x1B3u), "v"(__builtin_bit_cast(uint64_t, addend)) : "vcc");
-#pragma clang diagnostic pop
-    return ((uint64_t)(uint32_t)u << 32) | (uint32_t)t;
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %1" : "=&v"(u), "+v"(pair) : "v"(x), "s"(0x1B3u) : "vcc");
+    return u;
 }
+// the {0, addend} pairs of G interleaved chains: declared once per key, handed to every step
+template <int G>
+struct FnvPairs {
+    uint64_t p[G];
+    __device__ __forceinline__ FnvPairs()
+    {
+#pragma unroll
+        for (int g = 0; g < G; ++g) p[g] = 0;
+    }
+};
 
 // hashes.py:96  seeded offset basis
 __device__ __forceinline__ uint64_t fnv_seed(uint32_t seed) { return kFnvBasis + 31ULL * (uint64_t)seed; }
@@ -51,14 +62,14 @@ __device__ __forceinline__ void fnv_init(uint64_t (&h)[G], uint32_t s0)
 }
 
 template <int G>
-__device__ __forceinline__ void fnv_word(uint64_t (&h)[G], uint32_t w)
+__device__ __forceinline__ void fnv_word(uint64_t (&h)[G], FnvPairs<G> &pr, uint32_t w)
 {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         uint32_t e = (w >> (8 * b)) & 0xFFu;
         asm volatile("" : "+v"(e));  // the byte once per key byte in a VGPR (see fnv_word32)
 #pragma unroll
-        for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e);
+        for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e, pr.p[g]);
     }
 }
 
@@ -101,10 +112,11 @@ struct KeysFixed16 {  // uint8[n][16], 16-byte aligned: one global_load_dwordx4 
     __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
     {
         fnv_init<G>(h, s0);
-        fnv_word<G>(h, k.w.x);
-        fnv_word<G>(h, k.w.y);
-        fnv_word<G>(h, k.w.z);
-        fnv_word<G>(h, k.w.w);
+        FnvPairs<G> pr;
+        fnv_word<G>(h, pr, k.w.x);
+        fnv_word<G>(h, pr, k.w.y);
+        fnv_word<G>(h, pr, k.w.z);
+        fnv_word<G>(h, pr, k.w.w);
     }
     template <int G>
     __device__ __forceinline__ void hash32(const Key &k, uint64_t, uint32_t s0, uint32_t (&h)[G]) const
@@ -153,14 +165,15 @@ struct KeysFixed {  // uint8[n][L]; DWORDS: L % 4 == 0 and base 4-byte aligned
     __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
     {
         fnv_init<G>(h, s0);
+        FnvPairs<G> pr;
         if (DWORDS) {
             const uint32_t *q = reinterpret_cast<const uint32_t *>(k.q);
-            for (uint32_t j = 0; j < L / 4; ++j) fnv_word<G>(h, q[j]);
+            for (uint32_t j = 0; j < L / 4; ++j) fnv_word<G>(h, pr, q[j]);
         } else {
             for (uint32_t j = 0; j < L; ++j) {
                 const uint32_t e = k.q[j];
 #pragma unroll
-                for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e);
+                for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e, pr.p[g]);
             }
         }
     }
@@ -196,10 +209,11 @@ struct KeysVarlen {  // elements T (uint8 bytes, or uint32 code points for str k
     __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
     {
         fnv_init<G>(h, s0);
+        FnvPairs<G> pr;
         for (uint64_t j = 0; j < k.len; ++j) {
             const uint32_t e = (uint32_t)k.q[j];
 #pragma unroll
-            for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e);
+            for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e, pr.p[g]);
         }
     }
     template <int G>
