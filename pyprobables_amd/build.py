@@ -33,7 +33,7 @@ PLAIN_SOURCES = ["psk_capi.hip", "psk_index_ops.hip", "psk_merge.hip", "psk_part
 # (source, object stem, extra flags); the heaviest units first so that the pool stays busy to the end
 SOURCES = [(f, Path(f).stem + f"_v{v}", [f"-DPSK_TU_POW2={v}"]) for f in VARIANT_SOURCES for v in (1, 0)] + \
           [(f, Path(f).stem, []) for f in PLAIN_SOURCES]
-HEADERS = ["psk_device.hpp", "psk_partition.hpp", "psk_host.hpp", "psk_part_counter.hpp", "psk_lookup.hpp", "psk_part_lookup.hpp", "psk_nibble.hpp", "psk_window.hpp", "psk_digest.hpp",
+HEADERS = ["psk_device.hpp", "psk_partition.hpp", "psk_host.hpp", "psk_part_counter.hpp", "psk_lookup.hpp", "psk_part_lookup.hpp", "psk_nibble.hpp", "psk_nibble_pipe.hpp", "psk_window.hpp", "psk_digest.hpp",
            "../../include/psk.h"]
 OUT = CSRC / "libpsk_hip.so"
 OBJ = CSRC / "build"

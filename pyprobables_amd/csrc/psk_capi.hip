@@ -524,6 +524,11 @@ int64_t g_nib_nt = 1;   // nontemporal table loads in k_nib_gather (1 GiB lookup
 int64_t g_nib_min_lg_lookup = 23, g_nib_min_lg_update = 24;  // see nib_geometry (psk_host.hpp); measured crossovers: scripts/ab_nib_threshold.py
 int64_t g_nib_update_parts = 1;   // 1 = one workgroup per slice (default: two measured the same, 0.78-0.82 ms per 10 M adds either way), 2 = two, 0 = by slice size; see nib_update_lgparts
 int64_t g_nib_update_layout = 1;   // see psk_nibble.hpp (bench A/B)
+int64_t g_nib_gather_pipe = 0;   // 1 = k_nib_gather_pipe (psk_nibble_pipe.hpp: the next slice's table load under this slice's probe walk) when no kept images exist.
+                                 // Measured on MI355X: 260 vs 257 us per 10 M keys -- no gain (the register budget allows one 4-piece load step in flight, which
+                                 // cannot keep the table stream busy; deeper variants spill: 366 us), so it stays off: k_nib_gather
+int64_t g_nib_update_pipe = 1;   // 1 = k_nib_apply_pipe (psk_nibble_pipe.hpp: persistent workgroups, fold of slice s under the probes of slice s + 1; nontemporal
+                                 // table accesses: 551 -> 514 us per 10 M adds), 3 = the same with plain accesses (A/B), 0 = k_nib_apply
 int64_t g_update_nibble = 1;   // CBF unit-weight adds / decrements into 2^26 .. 2^29 counters: 4-bit delta images, one level; 0 = two-level 32-bit path
 int64_t g_part_dense_groups = 40;   // pass 2: segments of fewer groups (mean) are walked end to end (for_each_batch_at); 0 = never
 extern PSK_HIDDEN int64_t g_merge_single_rank;  // psk_merge.hip
@@ -565,6 +570,8 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "update_nibble_slices")) g_update_nibble = value;
     else if (!strcmp(name, "nibble_update_layout")) g_nib_update_layout = value;
     else if (!strcmp(name, "nibble_update_parts")) g_nib_update_parts = value;
+    else if (!strcmp(name, "nibble_update_pipe")) g_nib_update_pipe = value;
+    else if (!strcmp(name, "nibble_lookup_pipe")) g_nib_gather_pipe = value;
     else if (!strcmp(name, "nibble_min_lg_lookup")) g_nib_min_lg_lookup = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_min_lg_update")) g_nib_min_lg_update = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_nt_loads")) g_nib_nt = value;
@@ -651,6 +658,8 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "update_nibble_slices")) *value = g_update_nibble;
     else if (!strcmp(name, "nibble_update_layout")) *value = g_nib_update_layout;
     else if (!strcmp(name, "nibble_update_parts")) *value = g_nib_update_parts;
+    else if (!strcmp(name, "nibble_update_pipe")) *value = g_nib_update_pipe;
+    else if (!strcmp(name, "nibble_lookup_pipe")) *value = g_nib_gather_pipe;
     else if (!strcmp(name, "nibble_min_lg_lookup")) *value = g_nib_min_lg_lookup;
     else if (!strcmp(name, "nibble_min_lg_update")) *value = g_nib_min_lg_update;
     else if (!strcmp(name, "nibble_nt_loads")) *value = g_nib_nt;

@@ -2,6 +2,7 @@
 #pragma once
 #include "psk_host.hpp"
 #include "psk_nibble.hpp"
+#include "psk_nibble_pipe.hpp"
 
 #include <utility>
 
@@ -86,11 +87,30 @@ static inline int nib_scatter(psk_sketch *s, const Batch &sub, const uint32_t *m
     });
 }
 
+extern PSK_HIDDEN int64_t g_nib_update_pipe;  // psk_capi.hip: option "nibble_update_pipe"
 // MODE: k_nib_apply's (0 adds, 1 decrements, 3 optimistic decrement with `flag`, 4 its inverse)
 template <int MODE>
 static inline int nib_apply_mode(psk_sketch *s, const PartGeom &g, const void *cnt, const void *part, hipStream_t st, uint32_t *flag = nullptr)
 {
     const uint32_t lgp = nib_update_lgparts(g);
+    // round 4: the pipelined pass (psk_nibble_pipe.hpp) -- persistent workgroups, the fold of one slice under the probe groups of the next;
+    // the blocks layout of the delta image, one workgroup per slice; option "nibble_update_pipe" (0 = k_nib_apply, the A/B partner)
+    if (g_nib_update_pipe != 0 && g_nib_update_layout != 0 && lgp == 0 && g.shift >= 15) {
+        static int ncu = 0;
+        if (ncu == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            ncu = v;
+        }
+        const size_t lds_p = (size_t)1 << (g.shift - 1);
+        auto kp = k_nib_apply_pipe<MODE>;
+        PSK_TRY(set_dyn_lds(kp, lds_p));
+        const uint32_t grid = g.nbuckets < (uint32_t)ncu ? g.nbuckets : (uint32_t)ncu;
+        hipLaunchKernelGGL(kp, dim3(grid), dim3(kApplyThreads), lds_p, st, (uint32_t *)s->table, s->m, g, (const uint32_t *)cnt, (const uint4 *)part,
+                           (unsigned long long *)(s->ctr + PSK_CTR_SATURATED), (uint32_t)(g_nib_update_pipe != 3), flag);  // (3: plain instead of nontemporal table accesses, bench A/B)
+        HIP_TRY(hipGetLastError());
+        return PSK_OK;
+    }
     const size_t lds = (size_t)1 << (g.shift - 1 - lgp);
     auto kern = g_nib_update_layout ? k_nib_apply<MODE, true> : k_nib_apply<MODE, false>;
     PSK_TRY(set_dyn_lds(kern, lds));

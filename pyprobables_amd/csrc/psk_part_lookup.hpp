@@ -4,7 +4,9 @@
 #include "psk_host.hpp"
 #include "psk_lookup.hpp"
 #include "psk_nibble.hpp"
+#include "psk_nibble_pipe.hpp"
 
+extern PSK_HIDDEN int64_t g_nib_gather_pipe;  // psk_capi.hip: option "nibble_lookup_pipe"
 extern PSK_HIDDEN int64_t g_cbf_shadow_hits;  // nibble-slice lookups that loaded kept images (psk_sketch::shadow)
 
 // Keys per round.  Measured on MI355X (10 M CMS lookups): one round of 10 M keys 432 us, two 446, three cache-sized ones 464
@@ -182,10 +184,26 @@ static inline int cbf_check_nibble(psk_sketch *s, const Batch &b, uint32_t kk, u
                 PSK_TRY((launch_scatter<Src, IdxBloom<kTuPow2>, PayBloomLookup, SpillRaiseFlag, KT>(s, src, IdxBloom<kTuPow2>{s->md}, pay, spill, &g, cnt, st)));
                 PSK_TRY(ensure(s->s_vals, (uint64_t)g.nbuckets * g.nwg * g.segcap * 4 + 256));  // one dword (six nibbles) per group
                 const size_t lds2 = (size_t)1 << (g.shift - 1);
-                PSK_TRY(set_dyn_lds(k_nib_gather, lds2));
-                hipLaunchKernelGGL(k_nib_gather, dim3(g.nbuckets), dim3(kApplyThreads), lds2, st, (const uint32_t *)s->table, cells, g,
-                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint32_t *)s->s_vals.p, (uint32_t)(g_nib_nt != 0), shadow_in,
-                                   shadow_out);
+                if (g_nib_gather_pipe != 0 && shadow_in == nullptr && g.shift >= 15) {
+                    // round 4: no kept images to load -- the pipelined pass (psk_nibble_pipe.hpp: the next slice's table load under this
+                    // slice's probe walk); option "nibble_lookup_pipe" (0 = k_nib_gather, the A/B partner)
+                    static int ncu = 0;
+                    if (ncu == 0) {
+                        int dev = 0, v = 0;
+                        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+                        ncu = v;
+                    }
+                    auto kp = k_nib_gather_pipe<0>;
+                    PSK_TRY(set_dyn_lds(kp, lds2));
+                    const uint32_t grid = g.nbuckets < (uint32_t)ncu ? g.nbuckets : (uint32_t)ncu;
+                    hipLaunchKernelGGL(kp, dim3(grid), dim3(kApplyThreads), lds2, st, (const uint32_t *)s->table, cells, g, (const uint32_t *)s->s_cnt.p,
+                                       (const uint4 *)s->s_part.p, (uint32_t *)s->s_vals.p, (uint32_t)(g_nib_nt != 0), shadow_out);
+                } else {
+                    PSK_TRY(set_dyn_lds(k_nib_gather, lds2));
+                    hipLaunchKernelGGL(k_nib_gather, dim3(g.nbuckets), dim3(kApplyThreads), lds2, st, (const uint32_t *)s->table, cells, g,
+                                       (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint32_t *)s->s_vals.p, (uint32_t)(g_nib_nt != 0), shadow_in,
+                                       shadow_out);
+                }
                 HIP_TRY(hipGetLastError());
                 shadow_used = shadow_used || shadow_in != nullptr;
                 if (shadow_out) {  // the images are complete behind this launch: the next round / lookup on this stream loads them

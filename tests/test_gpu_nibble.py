@@ -471,3 +471,44 @@ def test_repeated_lookups_keep_the_4bit_images_until_the_table_changes(pa, oracl
         looks(3, 0)
     finally:
         N.set_option("cbf_lookup_shadow", 1)
+
+
+@pytest.mark.parametrize("update_pipe,lookup_pipe", [(1, 0), (3, 1), (0, 1), (0, 0)])
+@pytest.mark.parametrize("est", [28005615, 10_000_000])
+def test_pipelined_table_passes_and_their_ab_partners_agree_with_the_oracle(pa, oracle, force_partition, est, update_pipe, lookup_pipe):
+    """Round 4: k_nib_apply_pipe (persistent workgroups, the fold of one slice under the probe groups of the next; options 1 =
+    nontemporal, 3 = plain table accesses) and k_nib_gather_pipe (option `nibble_lookup_pipe`), against k_nib_apply / k_nib_gather
+    (0) and the oracle: unit adds with a key repeated 41 times (its slices overflow their 4-bit deltas: exact atomics, and the slice
+    behind them goes in unpipelined), the optimistic decrement, its undo + exact path, lookups.  est = 10 M: 9.6e7 counters, Barrett,
+    the table ends inside the last slice.  countingbloom.py:135-208."""
+    N = force_partition
+    old = (N.get_option("nibble_update_pipe"), N.get_option("nibble_lookup_pipe"))
+    N.set_option("nibble_update_pipe", update_pipe)
+    N.set_option("nibble_lookup_pipe", lookup_pipe)
+    try:
+        cbf = pa.CountingBloomFilter(est_elements=est, false_positive_rate=0.01)
+        m, k = cbf.number_bits, cbf.number_hashes
+        n = max(2_400_000, m // (8 * k) + 200_000)   # more than cells / 8 probes: the pass over the table
+        oc = oracle.OracleCBF(m, k)
+        keys = oracle.gen_keys16(11, n)
+        keys[2000:2040] = keys[9]
+        cbf.add_many(_dev(keys))
+        oc.update_keys(keys)
+        assert np.array_equal(_table(cbf), oc.bloom), "unit add"
+        present = keys[2100 : n - 100_000]
+        cbf.remove_many(_dev(present))
+        oc.update_keys(present, -np.ones(present.shape[0], dtype=np.int64))
+        assert np.array_equal(_table(cbf), oc.bloom), "optimistic decrement"
+        absent = oracle.gen_keys16(700_000_000, n)
+        absent = absent[oc.check_keys(absent) == 0]
+        rm = np.concatenate([keys[n - 100_000 :], absent])
+        cbf.remove_many(_dev(rm))
+        oc.update_keys(rm, -np.ones(rm.shape[0], dtype=np.int64))
+        assert np.array_equal(_table(cbf), oc.bloom), "decrement undone, exact path"
+        assert cbf.elements_added == oc.els_added
+        probe = np.concatenate([keys[:400_000], absent[:400_000], keys[n - 400_000 :]])
+        for _ in range(2):  # (the second lookup of an unchanged table may load kept images: k_nib_gather either way)
+            assert np.array_equal(cbf.check_many(_dev(probe)).cpu().numpy().astype(np.uint32), oc.check_keys(probe))
+    finally:
+        N.set_option("nibble_update_pipe", old[0])
+        N.set_option("nibble_lookup_pipe", old[1])
