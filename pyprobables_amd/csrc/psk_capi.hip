@@ -524,6 +524,7 @@ int64_t g_nib_nt = 1;   // nontemporal table loads in k_nib_gather (1 GiB lookup
 int64_t g_nib_min_lg_lookup = 23, g_nib_min_lg_update = 24;  // see nib_geometry (psk_host.hpp); measured crossovers: scripts/ab_nib_threshold.py
 int64_t g_nib_update_parts = 1;   // 1 = one workgroup per slice (default: two measured the same, 0.78-0.82 ms per 10 M adds either way), 2 = two, 0 = by slice size; see nib_update_lgparts
 int64_t g_nib_update_layout = 1;   // see psk_nibble.hpp (bench A/B)
+int64_t g_window_nt = 1;   // nontemporal table loads / stores in the update windows' fold (k_win_fold); option "update_window_nt"
 int64_t g_nib_gather_pipe = 0;   // 1 = k_nib_gather_pipe (psk_nibble_pipe.hpp: the next slice's table load under this slice's probe walk) when no kept images exist.
                                  // Measured on MI355X: 260 vs 257 us per 10 M keys -- no gain (the register budget allows one 4-piece load step in flight, which
                                  // cannot keep the table stream busy; deeper variants spill: 366 us), so it stays off: k_nib_gather
@@ -572,6 +573,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "nibble_update_parts")) g_nib_update_parts = value;
     else if (!strcmp(name, "nibble_update_pipe")) g_nib_update_pipe = value;
     else if (!strcmp(name, "nibble_lookup_pipe")) g_nib_gather_pipe = value;
+    else if (!strcmp(name, "update_window_nt")) g_window_nt = value;
     else if (!strcmp(name, "nibble_min_lg_lookup")) g_nib_min_lg_lookup = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_min_lg_update")) g_nib_min_lg_update = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_nt_loads")) g_nib_nt = value;
@@ -660,6 +662,7 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "nibble_update_parts")) *value = g_nib_update_parts;
     else if (!strcmp(name, "nibble_update_pipe")) *value = g_nib_update_pipe;
     else if (!strcmp(name, "nibble_lookup_pipe")) *value = g_nib_gather_pipe;
+    else if (!strcmp(name, "update_window_nt")) *value = g_window_nt;
     else if (!strcmp(name, "nibble_min_lg_lookup")) *value = g_nib_min_lg_lookup;
     else if (!strcmp(name, "nibble_min_lg_update")) *value = g_nib_min_lg_update;
     else if (!strcmp(name, "nibble_nt_loads")) *value = g_nib_nt;

@@ -2,6 +2,8 @@
 #include "psk_part_counter.hpp"
 #include "psk_window.hpp"
 
+extern PSK_HIDDEN int64_t g_window_nt;  // psk_capi.hip: option "update_window_nt"
+
 template <int KT, int NT>
 static int window_scatter(psk_sketch *s, const WinPhaseHost *ph, uint32_t nph_host, const void *keys_dev, uint64_t nlist, PartGeom *g, uint32_t *flag,
                           hipStream_t st, uint32_t *nph_out)
@@ -90,7 +92,7 @@ int PSK_VARIANT(cbf_window_fold)(psk_sketch *s, const WinPhaseHost *ph, uint32_t
         auto kern = k_win_fold<false>;
         PSK_TRY(set_dyn_lds(kern, lds));
         hipLaunchKernelGGL(kern, dim3(parts), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint4 *)s->s_part.p, (const uint32_t *)s->s_snap.p,
-                           wp, (uint32_t *)s->s_wstat.p, flag);
+                           wp, (uint32_t *)s->s_wstat.p, flag, (uint32_t)(g_window_nt != 0));
         HIP_TRY(hipGetLastError());
     }
     if (g_window_force_fail) HIP_TRY(hipMemsetAsync(flag, 1, 4, st));  // (tests: the undo + replay path on a well-formed stream)
@@ -104,7 +106,7 @@ int PSK_VARIANT(cbf_window_fold)(psk_sketch *s, const WinPhaseHost *ph, uint32_t
     auto kern = k_win_fold<true>;  // the proof failed: put every part back where it was
     PSK_TRY(set_dyn_lds(kern, lds));
     hipLaunchKernelGGL(kern, dim3(parts), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint4 *)s->s_part.p, (const uint32_t *)s->s_snap.p, wp,
-                       (uint32_t *)s->s_wstat.p, flag);
+                       (uint32_t *)s->s_wstat.p, flag, (uint32_t)(g_window_nt != 0));
     HIP_TRY(hipGetLastError());
     return PSK_OK;
 }

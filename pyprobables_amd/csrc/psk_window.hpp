@@ -127,8 +127,10 @@ static inline size_t win_fold_lds(const PartGeom &g, uint32_t nph)
 // dynamic LDS: the byte image, 2^min(shift, 17) bytes | 4-bit group counts [phases][ceil(nwg / 2)] | phase types (win_fold_lds)
 template <bool UNDO>
 __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint64_t tab_cells, PartGeom g, const uint4 *buckets, const uint32_t *snap,
-                                                            WinPhases wp, uint32_t *status, uint32_t *flag)
+                                                            WinPhases wp, uint32_t *status, uint32_t *flag, uint32_t nt)
 {
+    // nt: nontemporal loads / stores of the table part (round 4; scripts/ubench/tabpass.hip: a pass over a table far larger than the
+    // Infinity Cache runs 8-12 % faster with them, and the window's probe groups keep the cache)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t s_viol, s_taint;
     const uint32_t pshift = g.shift < kWinPartShift ? g.shift : kWinPartShift;
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t pc = p0 + (uint32_t)u * kApplyThreads;
-                t[u] = pc < pieces ? nib_load_piece(tab, tab_cells, c0 + 4ULL * pc) : make_uint4(0, 0, 0, 0);
+                t[u] = pc < pieces ? nib_load_piece(tab, tab_cells, c0 + 4ULL * pc, nt != 0) : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -332,7 +334,13 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
         const uint32_t v[4] = {w & 255u, (w >> 8) & 255u, (w >> 16) & 255u, w >> 24};
         const bool marked = v[0] == 255u || v[1] == 255u || v[2] == 255u || v[3] == 255u;
         if (!marked && gc + 3 < tab_cells) {
-            *reinterpret_cast<uint4 *>(tab + gc) = make_uint4(v[0], v[1], v[2], v[3]);
+            if (nt) {
+                psk_u32x4 o;
+                o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+                __builtin_nontemporal_store(o, reinterpret_cast<psk_u32x4 *>(tab + gc));
+            } else {
+                *reinterpret_cast<uint4 *>(tab + gc) = make_uint4(v[0], v[1], v[2], v[3]);
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
