@@ -103,6 +103,11 @@ int psk_device_count(int *count);
  * round; 0 = none), "cms_small_weights" (weighted psk_cms_add: 1 (default) = weights 0 .. 15 travel as 20-bit fields once the previous batches
  * brought no other weight, 0 = never, 2 = always -- exact either way, a weight outside the range goes to the table directly); read-only
  * counters for tests: "cbf_lookup_shadow_hits", "cms_small_weights_used";
+ * round 4: "update_window" / "update_window_keys" (described with psk_cbf_add below), "update_window_nt" (default 1: nontemporal table accesses
+ * in the windows' fold), "nibble_update_pipe" (unit adds / decrements into tables of more than 2^24 counters: 1 (default) = the pipelined pass
+ * over the table -- persistent workgroups, the fold of one slice under the probe groups of the next, nontemporal table accesses; 3 = the same
+ * with plain accesses; 0 = the two-phase kernel of round 3), "nibble_lookup_pipe" (default 0: 1 = the pipelined form of the lookups' table pass,
+ * measured without gain), "remove_exact" (0: remove_many may tally violations instead of replaying order-dependent batches);
  * bench knobs: "lookup_split", "lookup_run_lanes", "tile_threads", "scatter_workgroups", "slice_bias" */
 int psk_set_option(const char *name, int64_t value);
 int psk_get_option(const char *name, int64_t *value);
@@ -167,9 +172,18 @@ int psk_bloom_check_begin(psk_sketch *s, int layout, const void *data, const uin
 int psk_bloom_check_finish(psk_sketch *s, uint8_t *out_dev, void *stream);
 
 /* ----------------------------------------------------- CountingBloomFilter
- * Unordered batches (weights: uint32[n] or NULL = all 1).  Bit-exact with the reference for
- * well-formed streams (no counter saturates; every remove targets a key with >= num_els live
- * inserts); anything else is counted in PSK_CTR_VIOLATIONS / PSK_CTR_SATURATED.
+ * Batches (weights: uint32[n] or NULL = all 1).  Round 4: the result of every batch equals the reference's per-key loop over it for ANY
+ * stream -- adds commute (the clamp at 2^32-1 included); psk_cbf_remove is a TRANSACTION: it runs unordered (optimistic decrement, or lookup
+ * -> amounts -> checked decrement) and proves on the way that the result does not depend on the order inside the batch; where it does
+ * (duplicates of a key with too few inserts, a false positive among absent keys, a frozen counter) the batch is undone and replayed in
+ * order on the device (k_cbf_ordered).  Option "remove_exact" = 0 restores the round-3 contract: exact for well-formed streams (no counter
+ * saturates; every remove targets a key with >= num_els live inserts), anything else tallied in PSK_CTR_VIOLATIONS / PSK_CTR_SATURATED.
+ * Update WINDOWS (round 4; tables of more than 2^24 counters, 16-byte keys, unit weights; options "update_window" = 0: off,
+ * "update_window_keys": capacity): add / remove batches too small to pay for a pass over the table wait on the device, in arrival order, as
+ * key copies (the caller's buffer is free when the call returns); the window reaches the table in ONE pass that walks it batch run by batch
+ * run and proves every deferred remove (it must meet a non-zero counter at its own position of the stream: countingbloom.py:198-201);
+ * a window that fails the proof is undone and replayed batch by batch through the transaction above.  Every entry point that reads the
+ * table applies what is waiting first (psk_flush before using psk_table_info's pointer).
  * add:    counters[h_i % m] = min(c + w, 2^32-1) for i<k        (countingbloom.py:125-155)
  * remove: conditional decrement                                 (countingbloom.py:176-208)
  * check:  out = min_i counters[h_i % m]                         (countingbloom.py:157-174)

@@ -4,7 +4,7 @@
 # between two tiles of its workgroup -- 32 workgroups per XCD x B slices x 128 B = 4 MiB (B = 1024: the whole L2) or 8 MiB (B = 2048) -- so
 # fewer workgroups might let the lines merge in L2.  Measured: pass 1 slows roughly in proportion to the workgroups taken away at every
 # geometry (profiles/r04_ab_scatter_workgroups.txt); per-workgroup work, not the L2, is what 1024+ slices cost.  The same table bounds what a
-# fused scatter + apply kernel could gain (DESIGN.md section 3.8): the Bloom insert's pass 1 with ONE 512-thread workgroup per CU.
+# fused scatter + apply kernel could gain (DESIGN.md section 3.7): the Bloom insert's pass 1 with ONE 512-thread workgroup per CU.
 #   scripts/ab_scatter_workgroups.sh -> gpurun_out/ab_scatter_workgroups.txt   (run on the GPU box)
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
