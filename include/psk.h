@@ -139,6 +139,11 @@ int psk_destroy(psk_sketch *s);                             /* ext_table: write-
 int psk_clear(psk_sketch *s, void *stream);                 /* bloom.py:217-221, countminsketch.py:240-244 */
 int psk_synchronize(psk_sketch *s, void *stream);
 int psk_release_scratch(psk_sketch *s);                     /* free staging + partition buffers (regrow on demand) */
+/* what the handle holds besides its table right now (round 4): bytes[0] = device scratch in all (staging, bucket buffers, values / perm,
+ * write-combining segments, update-window key list and snapshots, kept 4-bit images), bytes[1] = of which the update window / write-combining
+ * lists (they hold waiting updates: psk_flush applies them), bytes[2] = of which the kept 4-bit images; no stream work, no synchronisation.
+ * (The scratch is an implementation detail of the path behind countingbloom.py:135-208 / bloom.py:234-272: the reference has none.) */
+int psk_scratch_bytes(psk_sketch *s, uint64_t bytes[3]);
 /* device pointer + padded size + logical size (the reference's array byte length) */
 int psk_table_info(psk_sketch *s, void **dev_ptr, uint64_t *padded_bytes, uint64_t *logical_bytes);
 /* copy the first nbytes of the table to / from host memory in the reference's byte layout

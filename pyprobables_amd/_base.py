@@ -159,6 +159,13 @@ class DeviceTable:
         """free the engine's staging / partition buffers for this table (they regrow on the next large batch)"""
         N.check(N.lib().psk_release_scratch(self.handle))
 
+    def scratch_bytes(self) -> dict:
+        """device memory the engine holds for this table besides the table itself, in bytes: `total`, of which `waiting_updates` (update
+        window / write-combining lists) and `kept_images` (4-bit slice images of an unchanged CountingBloomFilter table)"""
+        out = (C.c_uint64 * 3)()
+        N.check(N.lib().psk_scratch_bytes(self.handle, out))
+        return {"total": int(out[0]), "waiting_updates": int(out[1]), "kept_images": int(out[2])}
+
     def synchronize(self):
         N.check(N.lib().psk_synchronize(self.handle, self.stream))
 

@@ -81,6 +81,7 @@ PROTOTYPES = {
     "psk_cbf_intersect": (_int, [_vp, _vp, _vp, _u64, C.POINTER(_u64), _int, _vp]),
     "psk_cbf_jaccard_counts": (_int, [_vp, _vp, _u64, C.POINTER(_u64), _int, _vp]),
     "psk_release_scratch": (_int, [_vp]),
+    "psk_scratch_bytes": (_int, [_vp, C.POINTER(C.c_uint64)]),
     "psk_or_reduce_slices": (_int, [_vp, _vp, _u32, _u64, _int, _vp]),
     "psk_merge_or": (_int, [_vp, _vp, _vp]),
     "psk_merge_sum": (_int, [_vp, _vp, _vp]),

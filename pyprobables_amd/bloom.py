@@ -180,6 +180,16 @@ class BloomFilter:
     def get_engine_option(self, name: str) -> int:
         return self._tab.get_option(name)
 
+    def scratch_bytes(self) -> dict:
+        """device memory the engine holds for this sketch besides its table (``psk_scratch_bytes``): ``total``, of which
+        ``waiting_updates`` (update window / write-combining lists) and ``kept_images`` (4-bit slice images of an unchanged table)"""
+        return self._tab.scratch_bytes()
+
+    def release_scratch(self) -> None:
+        """apply what is waiting and free the engine's scratch for this sketch (it regrows on demand)"""
+        self._flush()
+        self._tab.release_scratch()
+
     @property
     def _fused(self) -> bool:
         """True when the kernel computes the hashes itself (default FNV-1a family)"""

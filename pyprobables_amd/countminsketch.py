@@ -140,6 +140,13 @@ class CountMinSketch:
     def get_engine_option(self, name: str) -> int:
         return self._tab.get_option(name)
 
+    def scratch_bytes(self) -> dict:
+        """device memory the engine holds for this sketch besides its table (``psk_scratch_bytes``)"""
+        return self._tab.scratch_bytes()
+
+    def release_scratch(self) -> None:
+        self._tab.release_scratch()
+
     @property
     def _bins(self):
         """host SNAPSHOT of the bins (int32, row-major by depth)"""

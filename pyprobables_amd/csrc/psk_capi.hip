@@ -524,6 +524,7 @@ int64_t g_nib_nt = 1;   // nontemporal table loads in k_nib_gather (1 GiB lookup
 int64_t g_nib_min_lg_lookup = 23, g_nib_min_lg_update = 24;  // see nib_geometry (psk_host.hpp); measured crossovers: scripts/ab_nib_threshold.py
 int64_t g_nib_update_parts = 1;   // 1 = one workgroup per slice (default: two measured the same, 0.78-0.82 ms per 10 M adds either way), 2 = two, 0 = by slice size; see nib_update_lgparts
 int64_t g_nib_update_layout = 1;   // see psk_nibble.hpp (bench A/B)
+int64_t g_big_table_nt = 1;   // nontemporal table sweeps in the Bloom pass-2 kernels for tables of 128 MiB and more (BASELINE cfg 5); option "big_table_nt"
 int64_t g_window_nt = 1;   // nontemporal table loads / stores in the update windows' fold (k_win_fold); option "update_window_nt"
 int64_t g_nib_gather_pipe = 0;   // 1 = k_nib_gather_pipe (psk_nibble_pipe.hpp: the next slice's table load under this slice's probe walk) when no kept images exist.
                                  // Measured on MI355X: 260 vs 257 us per 10 M keys -- no gain (the register budget allows one 4-piece load step in flight, which
@@ -574,6 +575,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "nibble_update_pipe")) g_nib_update_pipe = value;
     else if (!strcmp(name, "nibble_lookup_pipe")) g_nib_gather_pipe = value;
     else if (!strcmp(name, "update_window_nt")) g_window_nt = value;
+    else if (!strcmp(name, "big_table_nt")) g_big_table_nt = value;
     else if (!strcmp(name, "nibble_min_lg_lookup")) g_nib_min_lg_lookup = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_min_lg_update")) g_nib_min_lg_update = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_nt_loads")) g_nib_nt = value;
@@ -663,6 +665,7 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "nibble_update_pipe")) *value = g_nib_update_pipe;
     else if (!strcmp(name, "nibble_lookup_pipe")) *value = g_nib_gather_pipe;
     else if (!strcmp(name, "update_window_nt")) *value = g_window_nt;
+    else if (!strcmp(name, "big_table_nt")) *value = g_big_table_nt;
     else if (!strcmp(name, "nibble_min_lg_lookup")) *value = g_nib_min_lg_lookup;
     else if (!strcmp(name, "nibble_min_lg_update")) *value = g_nib_min_lg_update;
     else if (!strcmp(name, "nibble_nt_loads")) *value = g_nib_nt;
@@ -1927,6 +1930,23 @@ extern "C" int psk_cbf_jaccard_counts(const void *a, const void *b, uint64_t n, 
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     hipFree(d);
     if (e != hipSuccess) return fail(PSK_EHIP, "cbf jaccard failed: %s", hipGetErrorString(e));
+    return PSK_OK;
+}
+
+// per-handle accounting of the device scratch (the write-combining / window lists are large and allocated on first use)
+extern "C" int psk_scratch_bytes(psk_sketch *s, uint64_t bytes[3])
+{
+    if (!s || !bytes) return fail(PSK_EINVAL, "psk_scratch_bytes: NULL argument");
+    uint64_t all = 0, waiting = 0;
+    for (const DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
+                            &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->s_brw, &s->shadow.img,
+                            &s->win.keys, &s->s_snap, &s->s_wstat, &s->s_phase})
+        if (b->p) all += b->cap;
+    for (const DevBuf *b : {&s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->win.keys, &s->s_snap})
+        if (b->p) waiting += b->cap;
+    bytes[0] = all;
+    bytes[1] = waiting;
+    bytes[2] = s->shadow.img.p ? s->shadow.img.cap : 0;
     return PSK_OK;
 }
 

@@ -335,7 +335,7 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_gather(const uin
     const uint32_t slice_words = 1u << (g.shift - 5);
     const uint64_t w0 = (uint64_t)b * slice_words;
     const uint32_t mycnt = lane_segment_count(segcnt, g, b);
-    load_slice(smem, tab, tab_words, w0, slice_words);
+    load_slice(smem, tab, tab_words, w0, slice_words, (g.dbg & kGeomNtBit) != 0);
     __syncthreads();
     // (8 groups in flight per lane: 48 LDS words + the 8 groups stay inside the 128 VGPRs of a 1024-thread workgroup; with 12
     // the kernel spilled and ran 3x slower)

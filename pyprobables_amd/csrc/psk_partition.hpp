@@ -1174,10 +1174,21 @@ __device__ __forceinline__ void for_each_batch(const uint4 *buckets, const uint3
 constexpr int kApplyDepth = 12;  // 16-byte loads in flight per lane
 
 // The 16-byte piece `w` (in words) of a table slice that starts at word w0; words at or beyond tab_words read as 0.
-__device__ __forceinline__ uint4 slice_piece(const uint32_t *tab, uint64_t tab_words, uint64_t w0, uint32_t w)
+// Tables far beyond the 256 MB Infinity Cache (BASELINE cfg 5: 256 MiB of bits per replica) are swept once per call: nontemporal accesses
+// keep the sweep from pushing the probe stream out of the cache (scripts/ubench/tabpass.hip: + 10 % on such a pass; round 4)
+constexpr uint64_t kNtTableWords = 1ULL << 25;  // 128 MiB
+constexpr uint32_t kGeomNtBit = 0x80000000u;    // PartGeom::dbg bit 31 (a production bit, not a bench knob): option "big_table_nt" is on
+__device__ __forceinline__ uint4 slice_piece(const uint32_t *tab, uint64_t tab_words, uint64_t w0, uint32_t w, bool nt = false)
 {
     const uint64_t gw = w0 + w;
-    if (gw + 3 < tab_words) return *reinterpret_cast<const uint4 *>(tab + gw);
+    if (gw + 3 < tab_words) {
+        if (nt) {
+            typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
+            const nt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(tab + gw));
+            return make_uint4(v.x, v.y, v.z, v.w);
+        }
+        return *reinterpret_cast<const uint4 *>(tab + gw);
+    }
     uint4 t = make_uint4(0, 0, 0, 0);
     if (gw + 0 < tab_words) t.x = tab[gw + 0];
     if (gw + 1 < tab_words) t.y = tab[gw + 1];
@@ -1189,14 +1200,15 @@ __device__ __forceinline__ uint4 slice_piece(const uint32_t *tab, uint64_t tab_w
 // pieces a lane moves for a 128 KiB slice were 8 DEPENDENT round trips -- load, wait, LDS store -- in front of every pass-2
 // workgroup's work: round 3)
 constexpr int kSliceLoads = 8;
-__device__ __forceinline__ void load_slice(uint32_t *smem, const uint32_t *tab, uint64_t tab_words, uint64_t w0, uint32_t slice_words)
+__device__ __forceinline__ void load_slice(uint32_t *smem, const uint32_t *tab, uint64_t tab_words, uint64_t w0, uint32_t slice_words, bool nt_on = false)
 {
+    const bool nt = nt_on && tab_words >= kNtTableWords;
     for (uint32_t wb = threadIdx.x * 4; wb < slice_words; wb += kApplyThreads * 4 * kSliceLoads) {
         uint4 t[kSliceLoads];
 #pragma unroll
         for (int u = 0; u < kSliceLoads; ++u) {
             const uint32_t w = wb + (uint32_t)u * kApplyThreads * 4;
-            t[u] = w < slice_words ? slice_piece(tab, tab_words, w0, w) : make_uint4(0, 0, 0, 0);
+            t[u] = w < slice_words ? slice_piece(tab, tab_words, w0, w, nt) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < kSliceLoads; ++u) {
@@ -1254,6 +1266,8 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *
     __syncthreads();
     // merge: this workgroup is the only writer of its slice
     const uint64_t w0 = (uint64_t)b * slice_words;
+    const bool nt = (g.dbg & kGeomNtBit) != 0 && tab_words >= kNtTableWords;  // (see slice_piece)
+    typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
     constexpr int kFold = 4;  // 16-byte pieces in flight per lane (one at a time was a chain of HBM round trips)
     for (uint32_t wb = threadIdx.x * 4; wb < slice_words; wb += kApplyThreads * 4 * kFold) {
         uint4 t[kFold], add[kFold];
@@ -1265,7 +1279,14 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *
             full[u] = w < slice_words && gw + 3 < tab_words;
             add[u] = w < slice_words ? *reinterpret_cast<const uint4 *>(smem + w) : make_uint4(0, 0, 0, 0);
             t[u] = make_uint4(0, 0, 0, 0);
-            if (full[u] && (add[u].x | add[u].y | add[u].z | add[u].w)) t[u] = *reinterpret_cast<const uint4 *>(tab + gw);
+            if (full[u] && (add[u].x | add[u].y | add[u].z | add[u].w)) {
+                if (nt) {
+                    const nt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(tab + gw));
+                    t[u] = make_uint4(v.x, v.y, v.z, v.w);
+                } else {
+                    t[u] = *reinterpret_cast<const uint4 *>(tab + gw);
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < kFold; ++u) {
@@ -1274,7 +1295,13 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_apply(uint32_t *
             if (!(add[u].x | add[u].y | add[u].z | add[u].w)) continue;
             if (full[u]) {
                 t[u].x |= add[u].x; t[u].y |= add[u].y; t[u].z |= add[u].z; t[u].w |= add[u].w;
-                *reinterpret_cast<uint4 *>(tab + gw) = t[u];
+                if (nt) {
+                    nt_u32x4 v;
+                    v.x = t[u].x; v.y = t[u].y; v.z = t[u].z; v.w = t[u].w;
+                    __builtin_nontemporal_store(v, reinterpret_cast<nt_u32x4 *>(tab + gw));
+                } else {
+                    *reinterpret_cast<uint4 *>(tab + gw) = t[u];
+                }
             } else if (w < slice_words) {
                 const uint32_t aa[4] = {add[u].x, add[u].y, add[u].z, add[u].w};
                 for (uint32_t e = 0; e < 4; ++e)
@@ -1300,7 +1327,7 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint3
     const uint64_t w0 = (uint64_t)b * slice_words;
     const uint32_t dbg = kBenchKnobs ? g.dbg : 0u;
     const uint32_t mycnt = lane_segment_count(segcnt, g, b);  // (requested before the slice: see lane_segment_count)
-    if (!(dbg & 128)) load_slice(smem, tab, tab_words, w0, slice_words);
+    if (!(dbg & 128)) load_slice(smem, tab, tab_words, w0, slice_words, (g.dbg & kGeomNtBit) != 0);
     __syncthreads();
     const uint32_t kmask = (1u << (31 - g.shift)) - 1;
     for_each_batch_at<kApplyDepth>(buckets, segcnt, g, b, make_uint4(0, 0, 0, 0), [&](const uint4 (&q)[kApplyDepth], const uint64_t (&at)[kApplyDepth],
