@@ -210,27 +210,20 @@ static inline void ho_apply(const psk_sketch *s)
     ++(s)->table_version
 
 // table (padded to 16 bytes) and the handle's counter block, zeroed by one kernel
-// NT: nontemporal stores -- a table far beyond the 256 MB Infinity Cache (the 1 GiB counter table of BASELINE cfg 4) need not pass through it
-template <bool NT>
+// (round 4: nontemporal stores measured SLOWER for this write-only sweep -- 247 vs 215 us for the 1 GiB table of cfg 4 -- unlike the
+// read-modify-write passes; plain stores stay)
 static __global__ __launch_bounds__(kBlock) void k_clear(uint4 *tab, uint64_t nvec, long long *ctr)
 {
-    typedef unsigned int clr_u32x4 __attribute__((ext_vector_type(4)));
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const uint4 z = make_uint4(0, 0, 0, 0);
-    clr_u32x4 zz;
-    zz.x = zz.y = zz.z = zz.w = 0;
-    auto put = [&](uint64_t i) {
-        if (NT) __builtin_nontemporal_store(zz, reinterpret_cast<clr_u32x4 *>(tab + i));
-        else tab[i] = z;
-    };
     uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     for (; i + 3 * stride < nvec; i += 4 * stride) {  // four 16-byte stores in flight per lane
-        put(i);
-        put(i + stride);
-        put(i + 2 * stride);
-        put(i + 3 * stride);
+        tab[i] = z;
+        tab[i + stride] = z;
+        tab[i + 2 * stride] = z;
+        tab[i + 3 * stride] = z;
     }
-    for (; i < nvec; i += stride) put(i);
+    for (; i < nvec; i += stride) tab[i] = z;
     if (blockIdx.x == 0 && threadIdx.x < PSK_CTR_COUNT) ctr[threadIdx.x] = 0;
 }
 
@@ -252,8 +245,7 @@ extern "C" int psk_clear(psk_sketch *s, void *stream)
     uint64_t grid = (nvec + kBlock * 4 - 1) / (kBlock * 4);
     if (grid > 2048) grid = 2048;
     if (grid == 0) grid = 1;
-    if (s->padded_bytes >= (512ULL << 20) && g_big_table_nt != 0) hipLaunchKernelGGL(k_clear<true>, dim3((unsigned)grid), dim3(kBlock), 0, st, (uint4 *)s->table, nvec, s->ctr);
-    else hipLaunchKernelGGL(k_clear<false>, dim3((unsigned)grid), dim3(kBlock), 0, st, (uint4 *)s->table, nvec, s->ctr);
+    hipLaunchKernelGGL(k_clear, dim3((unsigned)grid), dim3(kBlock), 0, st, (uint4 *)s->table, nvec, s->ctr);
     HIP_TRY(hipGetLastError());
     return PSK_OK;
 }
