@@ -2,7 +2,8 @@
 #include "psk_part_counter.hpp"
 #include "psk_window.hpp"
 
-extern PSK_HIDDEN int64_t g_window_nt;  // psk_capi.hip: option "update_window_nt"
+extern PSK_HIDDEN int64_t g_window_nt;     // psk_capi.hip: option "update_window_nt"
+extern PSK_HIDDEN int64_t g_window_image;  // psk_capi.hip: option "update_window_image"
 
 template <int KT, int NT>
 static int window_scatter(psk_sketch *s, const WinPhaseHost *ph, uint32_t nph_host, const void *keys_dev, uint64_t nlist, PartGeom *g, uint32_t *flag,
@@ -83,13 +84,14 @@ int PSK_VARIANT(cbf_window_fold)(psk_sketch *s, const WinPhaseHost *ph, uint32_t
     if (nph_dev == 0) return PSK_OK;
     *launched = true;
     const WinPhases wp{nph_dev, (const PhaseDesc *)s->s_phase.p};
-    const uint32_t pshift = g.shift < kWinPartShift ? g.shift : kWinPartShift;
+    const bool nib = g_window_image != 8;  // option "update_window_image": 4 (default) = nibble images, one workgroup per slice; 8 = byte images, two
+    const uint32_t pshift = win_part_shift(g.shift, nib);
     const uint32_t parts = g.nbuckets << (g.shift - pshift);
-    const size_t lds = win_fold_lds(g, nph_dev);
+    const size_t lds = win_fold_lds(g, nph_dev, nib);
     if (lds > 160 * 1024) return fail(PSK_EINVAL, "update window: %u phases of %u segments do not fit the fold's LDS", nph_dev, g.nwg);
     PSK_TRY(ensure(s->s_wstat, (uint64_t)parts * 4));
     {
-        auto kern = k_win_fold<false>;
+        auto kern = nib ? k_win_fold<false, true> : k_win_fold<false, false>;
         PSK_TRY(set_dyn_lds(kern, lds));
         hipLaunchKernelGGL(kern, dim3(parts), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint4 *)s->s_part.p, (const uint32_t *)s->s_snap.p,
                            wp, (uint32_t *)s->s_wstat.p, flag, (uint32_t)(g_window_nt != 0));
@@ -103,7 +105,7 @@ int PSK_VARIANT(cbf_window_fold)(psk_sketch *s, const WinPhaseHost *ph, uint32_t
         *ok = true;
         return PSK_OK;
     }
-    auto kern = k_win_fold<true>;  // the proof failed: put every part back where it was
+    auto kern = nib ? k_win_fold<true, true> : k_win_fold<true, false>;  // the proof failed: put every part back where it was
     PSK_TRY(set_dyn_lds(kern, lds));
     hipLaunchKernelGGL(kern, dim3(parts), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint4 *)s->s_part.p, (const uint32_t *)s->s_snap.p, wp,
                        (uint32_t *)s->s_wstat.p, flag, (uint32_t)(g_window_nt != 0));

@@ -27,7 +27,13 @@
 
 namespace psk {
 
-constexpr uint32_t kWinPartShift = 17;  // log2(counters of one workgroup's byte image): 128 KiB
+constexpr uint32_t kWinPartShift = 17;  // log2(counters of one workgroup's BYTE image): 128 KiB
+constexpr uint32_t kWinNibShift = 18;   // ... of its NIBBLE image (round 4, second form): a whole 2^18-counter slice in 128 KiB
+__host__ __device__ __forceinline__ uint32_t win_part_shift(uint32_t slice_shift, bool nib)
+{
+    const uint32_t cap = nib ? kWinNibShift : kWinPartShift;
+    return slice_shift < cap ? slice_shift : cap;
+}
 constexpr int kWinMaxPhases = 192;   // (their 4-bit group counts sit next to the image: 192 x 128 bytes for 256 pass-1 workgroups)
 struct WinPhases {
     uint32_t nph;
@@ -116,16 +122,20 @@ __device__ __forceinline__ void win_walk_simple(const PartGeom &g, const uint4 *
     }
 }
 
-static inline size_t win_fold_lds(const PartGeom &g, uint32_t nph)
+static inline size_t win_fold_lds(const PartGeom &g, uint32_t nph, bool nib)
 {
-    const uint32_t pshift = g.shift < kWinPartShift ? g.shift : kWinPartShift;
-    return ((size_t)1 << pshift) + (((size_t)nph * ((g.nwg + 1) / 2) + 3) & ~(size_t)3) + (((size_t)nph + 31) / 32) * 4 + 16;
+    const uint32_t pshift = win_part_shift(g.shift, nib);
+    return ((size_t)1 << (nib ? pshift - 1 : pshift)) + (((size_t)nph * ((g.nwg + 1) / 2) + 3) & ~(size_t)3) + (((size_t)nph + 31) / 32) * 4 + 16;
 }
 
 // UNDO = false: apply the window to my table part (blockIdx.x = slice * parts + part); flag: a remove met a zero / a counter
 // would freeze -- the window has to be undone and replayed.  UNDO = true: the exact inverse of what the forward launch did.
 // dynamic LDS: the byte image, 2^min(shift, 17) bytes | 4-bit group counts [phases][ceil(nwg / 2)] | phase types (win_fold_lds)
-template <bool UNDO>
+// NIB (round 4): the image holds min(counter, 15) in four bits, so ONE workgroup takes a whole 2^18-counter slice and every probe group is
+// decoded once -- with byte images two workgroups per slice each decoded all of the slice's groups and applied half (the walk is bound by
+// that decoding).  Same proof: adds must meet 0 .. 13, removes 1 .. 14 (15 = a counter the image cannot follow: atomics on the table); a
+// nibble that carries or borrows into its neighbour has raised the taint / violation flag first, and either flag discards the image.
+template <bool UNDO, bool NIB>
 __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint64_t tab_cells, PartGeom g, const uint4 *buckets, const uint32_t *snap,
                                                             WinPhases wp, uint32_t *status, uint32_t *flag, uint32_t nt)
 {
@@ -133,10 +143,13 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
     // Infinity Cache runs 8-12 % faster with them, and the window's probe groups keep the cache)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t s_viol, s_taint;
-    const uint32_t pshift = g.shift < kWinPartShift ? g.shift : kWinPartShift;
+    const uint32_t pshift = win_part_shift(g.shift, NIB);
     const uint32_t nparts = 1u << (g.shift - pshift);
     const uint32_t b = blockIdx.x / nparts, h = blockIdx.x % nparts;
-    const uint32_t pieces = 1u << (pshift - 2);  // 16-byte pieces of my table part = words of the image
+    const uint32_t pieces = 1u << (pshift - 2);  // 16-byte pieces of my table part = words (bytes) / 16-bit halves (nibbles) of the image
+    const uint32_t img_words = NIB ? pieces / 2 : pieces;
+    constexpr uint32_t kTop = NIB ? 15u : 255u;   // the marker: a counter the image cannot follow
+    uint16_t *half16 = reinterpret_cast<uint16_t *>(smem);
     const uint32_t pmask = (1u << pshift) - 1;
     const uint64_t c0 = ((uint64_t)b << g.shift) + ((uint64_t)h << pshift);
     if (c0 >= tab_cells) {
@@ -186,7 +199,10 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
             for (int u = 0; u < U; ++u) {
                 const uint32_t pc = p0 + (uint32_t)u * kApplyThreads;
                 auto by = [](uint32_t c) -> uint32_t { return c < 255u ? c : 255u; };
-                if (pc < pieces) smem[pc] = by(t[u].x) | (by(t[u].y) << 8) | (by(t[u].z) << 16) | (by(t[u].w) << 24);
+                if (pc < pieces) {
+                    if (NIB) half16[pc] = (uint16_t)nib_pack4(t[u]);
+                    else smem[pc] = by(t[u].x) | (by(t[u].y) << 8) | (by(t[u].z) << 16) | (by(t[u].w) << 24);
+                }
             }
         }
     }
@@ -196,9 +212,10 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
         // where it started (all of them were below 255 when the forward launch wrote them)
         win_walk_simple(g, buckets, snap, wp, b, false, [&](uint32_t x, bool rem) {
             if ((x >> pshift) != h) return;
-            const uint32_t c = x & pmask, one = 1u << ((c & 3u) * 8u);
-            if (rem) atomicAdd(&smem[c >> 2], one);
-            else atomicSub(&smem[c >> 2], one);
+            const uint32_t c = x & pmask, one = NIB ? 1u << ((c & 7u) * 4u) : 1u << ((c & 3u) * 8u);
+            uint32_t *word = &smem[NIB ? c >> 3 : c >> 2];
+            if (rem) atomicAdd(word, one);
+            else atomicSub(word, one);
         });
         __syncthreads();
     } else {
@@ -214,8 +231,8 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
         const WinLane wl = win_lane(g);
         const uint4 *src = buckets + seg_index(g, b, wl.active ? wl.seg : 0) * g.segcap;
         const uint32_t nph = wp.nph;
-        uint8_t *cnt4 = reinterpret_cast<uint8_t *>(smem + pieces);     // [nph][ceil(nwg / 2)]: two segments per byte
-        uint32_t *types = smem + pieces + ((nph * ((g.nwg + 1) / 2) + 3) / 4);  // bit p: phase p removes
+        uint8_t *cnt4 = reinterpret_cast<uint8_t *>(smem + img_words);     // [nph][ceil(nwg / 2)]: two segments per byte
+        uint32_t *types = smem + img_words + ((nph * ((g.nwg + 1) / 2) + 3) / 4);  // bit p: phase p removes
         const uint32_t row = (g.nwg + 1) / 2;
         for (uint32_t i = threadIdx.x; i < (nph + 31) / 32; i += kApplyThreads) types[i] = 0;
         __syncthreads();
@@ -249,7 +266,8 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
         // a slot -- a fully branch-free version that added 0 for those took 3.3 us per phase, as long as the waits it replaced.
         // (per group: ~12 VALU per probe -- the fold is bound by VALU issue, 4 cycles per wave64 instruction with four waves per SIMD,
         // not by its waits: three applies per lane and phase at ~130 instructions each were 2.7 us per phase)
-        const uint32_t amask = pmask & ~3u;          // byte address of the counter's word in the image
+        const uint32_t amask = pmask & ~3u;          // byte address of the counter's word in the byte image
+        const uint32_t hmask = (1u << (20 - pshift)) - 1u;  // which part of the slice a 20-bit index belongs to
         auto apply = [&](const win_u32x4 &q, uint32_t rm) {
             const uint32_t n0 = q.y >> 28, n1 = q.w >> 28;
             const uint32_t x[6] = {q.x, __builtin_amdgcn_alignbit(q.y, q.x, 20), q.y >> 8, q.z, __builtin_amdgcn_alignbit(q.w, q.z, 20), q.w >> 8};
@@ -257,18 +275,19 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
             uint32_t ob[6];
 #pragma unroll
             for (int e = 0; e < 6; ++e) {
-                const bool mine = (uint32_t)(e % 3) < (e < 3 ? n0 : n1) && ((x[e] >> pshift) & ((1u << (20 - kWinPartShift)) - 1u)) == h;
-                const uint32_t sh = (x[e] & 3u) * 8u;
-                uint32_t old = 0x01010101u;          // (a probe that is not mine: an old byte nobody objects to)
-                if (mine) old = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(smem) + (x[e] & amask)), pm << sh);  // ds_add_rtn_u32
-                ob[e] = (old >> sh) & 255u;
+                const bool mine = (uint32_t)(e % 3) < (e < 3 ? n0 : n1) && ((x[e] >> pshift) & hmask) == h;
+                const uint32_t sh = NIB ? (x[e] & 7u) * 4u : (x[e] & 3u) * 8u;
+                const uint32_t waddr = NIB ? ((x[e] & pmask) >> 1) & ~3u : x[e] & amask;  // byte address of the counter's image word
+                uint32_t old = NIB ? 0x11111111u : 0x01010101u;  // (a probe that is not mine: an old value nobody objects to)
+                if (mine) old = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(smem) + waddr), pm << sh);  // ds_add_rtn_u32
+                ob[e] = (old >> sh) & kTop;
             }
             // removes: every old byte must be 1 .. 254 (0: the key is not there -- countingbloom.py:200-201; 255: beyond the image);
             // adds: 0 .. 253 (254 would become the marker)
             const uint32_t mn = min(min(min(ob[0], ob[1]), min(ob[2], ob[3])), min(ob[4], ob[5]));
             const uint32_t mx = max(max(max(ob[0], ob[1]), max(ob[2], ob[3])), max(ob[4], ob[5]));
             viol |= rm & (uint32_t)(mn == 0u);
-            taint |= (uint32_t)(mx >= 254u + (rm & 1u));
+            taint |= (uint32_t)(mx >= (kTop - 1u) + (rm & 1u));
         };
         // the R groups of a phase that brings `d` groups from `lo` on in my segment; a lane without a group re-reads the phase's
         // first one and remembers that it has none (qv: applied where the group is used)
@@ -327,12 +346,18 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
         }
         if (threadIdx.x == 0) status[blockIdx.x] = kWinWritten;
     }
-    // ---- image -> table (a byte of 255 is a counter nobody touched: it keeps its value)
+    // ---- image -> table (a value of 255 / 15 is a counter nobody touched: it keeps its value)
     for (uint32_t pc = threadIdx.x; pc < pieces; pc += kApplyThreads) {
-        const uint32_t w = smem[pc];
         const uint64_t gc = c0 + 4ULL * pc;
-        const uint32_t v[4] = {w & 255u, (w >> 8) & 255u, (w >> 16) & 255u, w >> 24};
-        const bool marked = v[0] == 255u || v[1] == 255u || v[2] == 255u || v[3] == 255u;
+        uint32_t v[4];
+        if (NIB) {
+            const uint32_t w = half16[pc];
+            v[0] = w & 15u; v[1] = (w >> 4) & 15u; v[2] = (w >> 8) & 15u; v[3] = w >> 12;
+        } else {
+            const uint32_t w = smem[pc];
+            v[0] = w & 255u; v[1] = (w >> 8) & 255u; v[2] = (w >> 16) & 255u; v[3] = w >> 24;
+        }
+        const bool marked = v[0] == kTop || v[1] == kTop || v[2] == kTop || v[3] == kTop;
         if (!marked && gc + 3 < tab_cells) {
             if (nt) {
                 psk_u32x4 o;
@@ -344,7 +369,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (v[e] != 255u && gc + e < tab_cells) tab[gc + e] = v[e];
+                if (v[e] != kTop && gc + e < tab_cells) tab[gc + e] = v[e];
         }
     }
 }

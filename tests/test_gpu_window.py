@@ -21,12 +21,15 @@ def pa():
     return pyprobables_amd
 
 
-@pytest.fixture()
-def N():
+@pytest.fixture(params=[4, 8], ids=["nibble-image", "byte-image"])
+def N(request):
+    """every case runs under both forms of the fold's LDS image (option update_window_image): 4 bits per counter, one workgroup per
+    2^18-counter slice (default), and 8 bits, two workgroups per slice"""
     from pyprobables_amd import _native as N
 
-    names = ("update_window", "update_window_keys", "update_window_force_fail")
+    names = ("update_window", "update_window_keys", "update_window_force_fail", "update_window_image")
     old = [N.get_option(k) for k in names]
+    N.set_option("update_window_image", request.param)
     yield N
     for k, v in zip(names, old):
         N.set_option(k, v)
@@ -202,3 +205,26 @@ def test_option_off_and_host_batches(pa, oracle, N):
     _run(cbf, oc, ops[:8])
     _same(cbf, oc)
     assert N.get_option("update_window_folds") == folds + 1
+
+
+def test_counters_around_the_nibble_image_limit(pa, oracle, N):
+    """keys added 12 .. 17 times inside ONE window and partly removed again: counters that end at 13, 14 (the last values a 4-bit image
+    follows), 15 and beyond (the slice drops its image and takes the atomics), next to ordinary traffic; then a second window that removes
+    from those counters (loaded as 15 = "cannot follow" by the nibble image) -- countingbloom.py:135-155, :186-208"""
+    cbf = pa.CountingBloomFilter(est_elements=3_600_000, false_positive_rate=0.01)
+    m, k = cbf.number_bits, cbf.number_hashes
+    oc = oracle.OracleCBF(m, k)
+    base = oracle.gen_keys16(71, 300_000)
+    hot = base[:6]
+    ops = [(False, base[:150_000])]
+    for r in range(17):  # key i of `hot` is added 12 + i times in all (one copy came with the first batch)
+        sel = np.concatenate([hot[i:i + 1] for i in range(6) if r < 11 + i] + [base[150_000 + r * 5_000:150_000 + (r + 1) * 5_000]])
+        ops.append((False, sel))
+        if r % 4 == 3:
+            ops.append((True, base[r * 2_000:(r + 1) * 2_000 + 6]))  # ordinary removes in between (keys 6.. of the first batch)
+    ops.append((True, np.concatenate([hot, hot])))  # two copies of each hot key leave again, still in the same window
+    _run(cbf, oc, ops)
+    _same(cbf, oc)
+    ops2 = [(True, hot), (False, base[200_000:260_000]), (True, hot), (True, base[200_000:230_000])]
+    _run(cbf, oc, ops2)
+    _same(cbf, oc)
