@@ -513,7 +513,7 @@ int64_t g_part_debug = 0;            // ablation bits for bench runs (see PartGe
 __thread int64_t g_bloom_lookup = 2;
 int64_t g_lookup_run_lanes = 0, g_lookup_split = 1, g_part_tile_threads = 0, g_part_slice_bias = 0, g_part_wgs = 0, g_part_even_tiles = 1;
 int64_t g_lookup_half = 1;
-int64_t g_lookup_collect_threads = 1024;
+int64_t g_lookup_collect_threads = 0;   // pass 3 of the counter lookups: 0 = 512-thread workgroups up to 256 slices, 1024 beyond (psk_part_lookup.hpp); 512 / 1024 = forced
 int64_t g_remove_dryrun = 1;   // validated unit-weight CBF removes into big tables: optimistic decrement first (psk_nibble.hpp), option "remove_optimistic"
 __thread int64_t g_scratch_budget = 0;  // psk_set_option("scratch_budget_bytes"): cap on a handle's partition scratch (more, smaller rounds); 0 = none
 int64_t g_lookup_nibble = 1;   // CBF lookups into 2^25 .. 2^29 counters: 4-bit slice images (psk_nibble.hpp) from cells / 16 probes on; 2 = always; 0 = the 32-bit / 16-bit slices or direct

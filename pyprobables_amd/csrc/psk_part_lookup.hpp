@@ -77,7 +77,17 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
                 PSK_TRY(set_dyn_lds(gather, lds2));
                 // slice counts that do not fill the 256 CUs evenly: two workgroups share a slice's segments (each loads the slice)
                 PartGeom g2 = g;
-                g2.split = (g.nbuckets % 256 != 0 && g.nbuckets < 1024 && g_lookup_split != 0) ? 2 : 1;
+                // Round 4 (same-box A/B over four CMS geometries, scripts/ab_cms_check_lib.py): up to 256 slices the split is the largest power
+                // of two that still fits ONE wave of workgroups (32 slices: 8 per slice; 160 slices, BASELINE cfg 3: none -- two per slice
+                // were 320 workgroups, a second wave of 64); between 256 and 1024 slices two per slice as before.
+                g2.split = 1;
+                if (g_lookup_split != 0) {
+                    if (g.nbuckets <= 256) {
+                        while (g2.split < 8 && g.nbuckets * g2.split * 2 <= 256) g2.split *= 2;
+                    } else if (g.nbuckets % 256 != 0 && g.nbuckets < 1024) {
+                        g2.split = 2;
+                    }
+                }
                 hipLaunchKernelGGL(gather, dim3(g.nbuckets * g2.split), dim3(kApplyThreads), lds2, st, (const uint32_t *)s->table, cells, g2,
                                    (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, (uint4 *)s->s_vals.p, fmt, flag);
                 HIP_TRY(hipGetLastError());
@@ -86,7 +96,9 @@ static inline int counter_check_partitioned(psk_sketch *s, const Batch &b, uint3
                 const uint32_t stage_cap = (uint32_t)(((size_t)g.tile * kq + (size_t)7 * g.nbuckets + 3) & ~(size_t)3);
                 const size_t lds3 = ((size_t)2 * g.nbuckets + stage_cap) * 4 + ((g.nbuckets + 15) & ~(size_t)15);
                 const uint64_t ntiles = (cnt + g.tile - 1) / g.tile;
-                const bool narrow_wg = g_lookup_collect_threads == 512;
+                // pass 3 as 512-thread workgroups (four tiles in flight per CU) pays up to 256 slices (cfg 3: 270 -> 259 us per 10 M lookups) and
+                // costs 15 % at 1024 (twice the runinfo reads per key): option "lookup_collect_threads" 0 = this rule, 512 / 1024 = forced
+                const bool narrow_wg = g_lookup_collect_threads == 512 || (g_lookup_collect_threads == 0 && g.nbuckets <= 256);
                 auto kern = narrow_wg ? k_lookup_collect<Query, KT, 512> : k_lookup_collect<Query, KT, 1024>;
                 PSK_TRY(set_dyn_lds(kern, lds3));
                 // lanes that copy one (tile, slice) run of values: the power of two at or above HALF the mean run -- a lane moves two

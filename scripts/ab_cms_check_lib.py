@@ -11,7 +11,9 @@ print("package:", pa.__file__)
 n = 10_000_000
 keys = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device="cuda")
 w = torch.randint(1, 8, (n,), dtype=torch.int32, device="cuda")
-cms = pa.CountMinSketch(width=2**20, depth=5)
+import os
+W, D = int(os.environ.get("CMS_W", 2**20)), int(os.environ.get("CMS_D", 5))  # geometry (default: BASELINE cfg 3)
+cms = pa.CountMinSketch(width=W, depth=D)
 cms.add_many(keys, w)
 for _ in range(3): cms.check_many(keys)
 torch.cuda.synchronize()
