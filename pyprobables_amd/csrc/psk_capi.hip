@@ -527,6 +527,10 @@ int64_t g_nib_min_lg_lookup = 23, g_nib_min_lg_update = 24;  // see nib_geometry
 int64_t g_nib_update_parts = 1;   // 1 = one workgroup per slice (default: two measured the same, 0.78-0.82 ms per 10 M adds either way), 2 = two, 0 = by slice size; see nib_update_lgparts
 int64_t g_nib_update_layout = 1;   // see psk_nibble.hpp (bench A/B)
 int64_t g_big_table_nt = 1;   // nontemporal table sweeps in the Bloom pass-2 kernels for tables of 128 MiB and more (BASELINE cfg 5); option "big_table_nt"
+int64_t g_window_shadow = 0;   // 1 = a successful window fold leaves the lookups' kept 4-bit images up to date (when they exist) instead of stale.  Measured on the
+                               // 1 GiB table (scripts/ab_window_shadow.py: rounds of 15 M window updates + a 10 M-key lookup): 2.99 vs 3.00 ms per round -- the
+                               // 0.1 ms the lookup saves is within the noise of the round and is partly paid by the fold's 128 MiB of image stores: off
+int64_t g_window_shadow_writes = 0;  // folds that did (tests)
 int64_t g_window_image = 4;   // update windows' fold: 4 = nibble images, one workgroup per 2^18-counter slice; 8 = byte images, two per slice (round 4 A/B)
 int64_t g_window_nt = 1;   // nontemporal table loads / stores in the update windows' fold (k_win_fold); option "update_window_nt"
 int64_t g_nib_gather_pipe = 0;   // 1 = k_nib_gather_pipe (psk_nibble_pipe.hpp: the next slice's table load under this slice's probe walk) when no kept images exist.
@@ -579,6 +583,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "nibble_lookup_pipe")) g_nib_gather_pipe = value;
     else if (!strcmp(name, "update_window_nt")) g_window_nt = value;
     else if (!strcmp(name, "update_window_image")) g_window_image = value;
+    else if (!strcmp(name, "update_window_shadow")) g_window_shadow = value;
     else if (!strcmp(name, "big_table_nt")) g_big_table_nt = value;
     else if (!strcmp(name, "nibble_min_lg_lookup")) g_nib_min_lg_lookup = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_min_lg_update")) g_nib_min_lg_update = value < 20 ? 20 : value;
@@ -670,6 +675,8 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "nibble_lookup_pipe")) *value = g_nib_gather_pipe;
     else if (!strcmp(name, "update_window_nt")) *value = g_window_nt;
     else if (!strcmp(name, "update_window_image")) *value = g_window_image;
+    else if (!strcmp(name, "update_window_shadow")) *value = g_window_shadow;
+    else if (!strcmp(name, "update_window_shadow_writes")) *value = g_window_shadow_writes;
     else if (!strcmp(name, "big_table_nt")) *value = g_big_table_nt;
     else if (!strcmp(name, "nibble_min_lg_lookup")) *value = g_nib_min_lg_lookup;
     else if (!strcmp(name, "nibble_min_lg_update")) *value = g_nib_min_lg_update;

@@ -4,6 +4,7 @@
 
 extern PSK_HIDDEN int64_t g_window_nt;     // psk_capi.hip: option "update_window_nt"
 extern PSK_HIDDEN int64_t g_window_image;  // psk_capi.hip: option "update_window_image"
+extern PSK_HIDDEN int64_t g_window_shadow, g_window_shadow_writes;  // options "update_window_shadow" / "update_window_shadow_writes" (read-only tally)
 
 template <int KT, int NT>
 static int window_scatter(psk_sketch *s, const WinPhaseHost *ph, uint32_t nph_host, const void *keys_dev, uint64_t nlist, PartGeom *g, uint32_t *flag,
@@ -17,7 +18,10 @@ static int window_scatter(psk_sketch *s, const WinPhaseHost *ph, uint32_t nph_ho
     const uint32_t nwg = 256;  // one 1024-thread workgroup per CU (k <= 8), every one of them writes its snapshots
     // A phase of the fold is at most two tiles per pass-1 workgroup (longer runs of same-type batches are cut: k_win_fold holds a
     // phase's probe groups of a segment in a fixed number of registers).
-    const uint64_t cut = 2ULL * nwg * tk;
+    // (tables of few slices bring long runs per tile -- 2048 keys x k / B probes: 6.5 groups at 366 slices -- so there one tile per workgroup
+    // and phase: with two, nearly every slice of a 9.6e7-counter table overflowed the fold's 12 groups per segment and phase and took the atomics)
+    const double groups_per_tile = (double)tk * (g->k < (uint32_t)KT ? g->k : (uint32_t)KT) / (double)g->nbuckets / 6.0 + 0.5;
+    const uint64_t cut = (groups_per_tile > 4.0 ? 1ULL : 2ULL) * nwg * tk;
     uint64_t tiles = 0;
     uint32_t nph = 0;
     for (uint32_t p = 0; p < nph_host; ++p) {
@@ -70,8 +74,8 @@ int PSK_VARIANT(cbf_window_fold)(psk_sketch *s, const WinPhaseHost *ph, uint32_t
     if (g_update_nibble == 0 || nph == 0 || nlist == 0 || s->k > 32 || !nib_geometry(s->m, true, &g)) return PSK_OK;
     g.k = s->k;
     PSK_TRY(ensure(s->s_flag, 8));
-    uint32_t *flag = (uint32_t *)s->s_flag.p;
-    HIP_TRY(hipMemsetAsync(flag, 0, 4, st));
+    uint32_t *flag = (uint32_t *)s->s_flag.p;  // [0] a remove met a zero (undo + replay), [1] a slice took the atomics (its 4-bit image is void)
+    HIP_TRY(hipMemsetAsync(flag, 0, 8, st));
     uint32_t nph_dev = 0;  // phases of the fold (0: the window does not fit -- nothing was launched)
     PSK_TRY(with_kt<KeysFixed16>(s->k, [&](auto kt) {
         constexpr int KT = decltype(kt)::value;
@@ -90,25 +94,38 @@ int PSK_VARIANT(cbf_window_fold)(psk_sketch *s, const WinPhaseHost *ph, uint32_t
     const size_t lds = win_fold_lds(g, nph_dev, nib);
     if (lds > 160 * 1024) return fail(PSK_EINVAL, "update window: %u phases of %u segments do not fit the fold's LDS", nph_dev, g.nwg);
     PSK_TRY(ensure(s->s_wstat, (uint64_t)parts * 4));
+    // Kept 4-bit images (psk_sketch::shadow): when the lookups already keep them, the fold -- which ends with the very image of every slice
+    // in LDS -- leaves them up to date instead of stale: the lookup behind a flush loads 128 MiB instead of reading the 1 GiB table again.
+    const uint64_t shadow_words = (uint64_t)g.nbuckets << (g.shift - 3);
+    uint32_t *shadow_out = nullptr;
+    if (nib && pshift == g.shift && g_cbf_shadow != 0 && g_window_shadow != 0 && !s->shadow.exposed && s->shadow.img.p && s->shadow.words == shadow_words &&
+        s->shadow.img.cap >= shadow_words * 4)
+        shadow_out = (uint32_t *)s->shadow.img.p;
+    if (shadow_out) s->shadow.built = ~0ULL;  // (being overwritten: valid again only once the verdict is in)
     {
         auto kern = nib ? k_win_fold<false, true> : k_win_fold<false, false>;
         PSK_TRY(set_dyn_lds(kern, lds));
         hipLaunchKernelGGL(kern, dim3(parts), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint4 *)s->s_part.p, (const uint32_t *)s->s_snap.p,
-                           wp, (uint32_t *)s->s_wstat.p, flag, (uint32_t)(g_window_nt != 0));
+                           wp, (uint32_t *)s->s_wstat.p, flag, (uint32_t)(g_window_nt != 0), shadow_out);
         HIP_TRY(hipGetLastError());
     }
     if (g_window_force_fail) HIP_TRY(hipMemsetAsync(flag, 1, 4, st));  // (tests: the undo + replay path on a well-formed stream)
-    uint32_t verdict = 1;
-    HIP_TRY(hipMemcpyAsync(&verdict, flag, 4, hipMemcpyDeviceToHost, st));
+    uint32_t verdict[2] = {1, 1};
+    HIP_TRY(hipMemcpyAsync(verdict, flag, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (verdict == 0) {
+    if (verdict[0] == 0) {
         *ok = true;
+        if (shadow_out) {  // every slice wrote its image (from LDS, or from the table behind its atomics): the kept images mirror the table as it is now
+            s->shadow.built = s->table_version;
+            s->shadow.stream = st;
+            ++g_window_shadow_writes;
+        }
         return PSK_OK;
     }
     auto kern = nib ? k_win_fold<true, true> : k_win_fold<true, false>;  // the proof failed: put every part back where it was
     PSK_TRY(set_dyn_lds(kern, lds));
     hipLaunchKernelGGL(kern, dim3(parts), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint4 *)s->s_part.p, (const uint32_t *)s->s_snap.p, wp,
-                       (uint32_t *)s->s_wstat.p, flag, (uint32_t)(g_window_nt != 0));
+                       (uint32_t *)s->s_wstat.p, flag, (uint32_t)(g_window_nt != 0), (uint32_t *)nullptr);
     HIP_TRY(hipGetLastError());
     return PSK_OK;
 }

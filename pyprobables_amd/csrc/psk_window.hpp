@@ -137,8 +137,11 @@ static inline size_t win_fold_lds(const PartGeom &g, uint32_t nph, bool nib)
 // nibble that carries or borrows into its neighbour has raised the taint / violation flag first, and either flag discards the image.
 template <bool UNDO, bool NIB>
 __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint64_t tab_cells, PartGeom g, const uint4 *buckets, const uint32_t *snap,
-                                                            WinPhases wp, uint32_t *status, uint32_t *flag, uint32_t nt)
+                                                            WinPhases wp, uint32_t *status, uint32_t *flag, uint32_t nt, uint32_t *shadow_out)
 {
+    // shadow_out (forward fold with nibble images only; may be null): the kept 4-bit images of the lookups (psk_sketch::shadow) -- the fold
+    // ends with exactly that image of every slice in LDS, so the lookups that follow a flush need not read the table again.  flag[1] tells
+    // the host when a slice took the atomics instead (its image is void: the kept images are dropped).
     // nt: nontemporal loads / stores of the table part (round 4; scripts/ubench/tabpass.hip: a pass over a table far larger than the
     // Infinity Cache runs 8-12 % faster with them, and the window's probe groups keep the cache)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -333,8 +336,36 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
         if (taint) s_taint = 1u;
         __syncthreads();
         if (s_taint) {  // a counter of 254 or more in play: the image is void (bytes may have carried); the table part is still untouched
-            if (threadIdx.x == 0) status[blockIdx.x] = kWinAtomics;
+            if (threadIdx.x == 0) {
+                status[blockIdx.x] = kWinAtomics;
+                flag[1] = 1u;  // (a tally for tests: slices that took the atomics)
+            }
             atomics_pass(false);
+            if constexpr (NIB) {
+                if (shadow_out) {
+                    // the kept image of this slice from the table itself, now that the atomics are through: every lane's atomics have
+                    // returned (they are returning ones), the barrier collects the workgroup, and the loads go past this CU's L1, which
+                    // still holds the lines of the first load
+                    __threadfence();
+                    __syncthreads();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    uint16_t *dst = reinterpret_cast<uint16_t *>(shadow_out + (uint64_t)blockIdx.x * img_words);
+                    constexpr int U = 8;
+                    for (uint32_t p0 = threadIdx.x; p0 < pieces; p0 += kApplyThreads * U) {
+                        uint4 t[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const uint32_t pc = p0 + (uint32_t)u * kApplyThreads;
+                            t[u] = pc < pieces ? nib_load_piece(tab, tab_cells, c0 + 4ULL * pc, true) : make_uint4(0, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const uint32_t pc = p0 + (uint32_t)u * kApplyThreads;
+                            if (pc < pieces) dst[pc] = (uint16_t)nib_pack4(t[u]);
+                        }
+                    }
+                }
+            }
             return;
         }
         if (s_viol) {  // a remove met a zero: nothing of this part reaches the table; the host undoes the others and replays the window
@@ -370,6 +401,13 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (v[e] != kTop && gc + e < tab_cells) tab[gc + e] = v[e];
+        }
+    }
+    if constexpr (NIB && !UNDO) {
+        if (shadow_out) {  // (nparts == 1: blockIdx.x is the slice; the image is read-only from here on)
+            uint4 *dst = reinterpret_cast<uint4 *>(shadow_out + (uint64_t)blockIdx.x * img_words);
+            const uint4 *src = reinterpret_cast<const uint4 *>(smem);
+            for (uint32_t v = threadIdx.x; v < img_words / 4; v += kApplyThreads) dst[v] = src[v];
         }
     }
 }

@@ -228,3 +228,41 @@ def test_counters_around_the_nibble_image_limit(pa, oracle, N):
     ops2 = [(True, hot), (False, base[200_000:260_000]), (True, hot), (True, base[200_000:230_000])]
     _run(cbf, oc, ops2)
     _same(cbf, oc)
+
+
+def test_a_fold_leaves_the_lookups_kept_images_up_to_date(pa, oracle, N):
+    """lookups of a big table keep 4-bit slice images while it does not change (psk_sketch::shadow); a window fold with nibble images ends
+    with exactly those images in LDS and writes them back, so the lookup behind the flush loads them instead of reading the table again --
+    and must answer exactly (countingbloom.py:166-174) for present, removed and absent keys.  The byte-image fold leaves them stale.
+    (Option update_window_shadow; off by default -- the saving measured within the noise of a round of updates + lookups.)"""
+    cbf = pa.CountingBloomFilter(est_elements=20_000_000, false_positive_rate=0.01)   # 1.9e8 counters, 732 slices: runs short enough for the image path
+    m, k = cbf.number_bits, cbf.number_hashes
+    oc = oracle.OracleCBF(m, k)
+    _run(cbf, oc, _stream(oracle, 6, 200_000, seed=91))
+    probe = np.concatenate([oracle.gen_keys16(91, 500_000), oracle.gen_keys16(999_000_000, 200_000)])
+    dp = _dev(probe)
+    old = N.get_option("lookup_nibble_slices")
+    old_sh = N.get_option("update_window_shadow")
+    N.set_option("lookup_nibble_slices", 2)  # (the 4-bit lookup path whatever the batch size)
+    N.set_option("update_window_shadow", 1)  # (off by default: measured without gain)
+    try:
+        for _ in range(3):  # plain, build the images, load them
+            assert np.array_equal(cbf.check_many(dp).cpu().numpy().astype(np.uint32), oc.check_keys(probe))
+        hits, writes = N.get_option("cbf_lookup_shadow_hits"), N.get_option("update_window_shadow_writes")
+        folds = N.get_option("update_window_folds")
+        for rnd in range(3):
+            ops = _stream(oracle, 12, 400_000, seed=120 + rnd)     # fresh keys: adds + removes of half of them; 7 M operations: one window, one fold
+            _run(cbf, oc, ops)
+            got = cbf.check_many(dp).cpu().numpy().astype(np.uint32)   # the flush folds the window, then the lookup runs
+            assert np.array_equal(got, oc.check_keys(probe))
+            more = np.concatenate([ops[0][1][:50_000], ops[2][1][:50_000]])  # keys of this window: removed ones and live ones
+            assert np.array_equal(cbf.check_many(_dev(more)).cpu().numpy().astype(np.uint32), oc.check_keys(more))
+        assert N.get_option("update_window_folds") == folds + 3
+        nib = N.get_option("update_window_image") != 8
+        assert N.get_option("update_window_shadow_writes") - writes == (3 if nib else 0)
+        if nib:
+            assert N.get_option("cbf_lookup_shadow_hits") - hits >= 3   # the lookup behind every fold loaded the images it left
+        _same(cbf, oc)
+    finally:
+        N.set_option("lookup_nibble_slices", old)
+        N.set_option("update_window_shadow", old_sh)
