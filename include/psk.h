@@ -104,7 +104,8 @@ int psk_device_count(int *count);
  * brought no other weight, 0 = never, 2 = always -- exact either way, a weight outside the range goes to the table directly); read-only
  * counters for tests: "cbf_lookup_shadow_hits", "cms_small_weights_used";
  * round 4: "update_window" / "update_window_keys" (described with psk_cbf_add below), "update_window_nt" (default 1: nontemporal table accesses
- * in the windows' fold), "update_window_shadow" (default 0: 1 = a fold leaves the lookups' kept 4-bit images up to date; measured without gain),
+ * in the windows' fold), "update_window_wide" (default 1: tables of few slices take the fold with five probe groups per lane and phase),
+ * "update_window_shadow" (default 0: 1 = a fold leaves the lookups' kept 4-bit images up to date; measured without gain),
  * "update_window_image" (the fold's LDS image of the counters: 4 (default) = four bits per counter, one workgroup per
  * 2^18-counter slice; 8 = a byte per counter, two workgroups per slice -- exact either way), "nibble_update_pipe" (unit adds / decrements into tables of more than 2^24 counters: 1 (default) = the pipelined pass
  * over the table -- persistent workgroups, the fold of one slice under the probe groups of the next, nontemporal table accesses; 3 = the same

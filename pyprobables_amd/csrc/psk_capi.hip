@@ -531,6 +531,7 @@ int64_t g_window_shadow = 0;   // 1 = a successful window fold leaves the lookup
                                // 1 GiB table (scripts/ab_window_shadow.py: rounds of 15 M window updates + a 10 M-key lookup): 2.99 vs 3.00 ms per round -- the
                                // 0.1 ms the lookup saves is within the noise of the round and is partly paid by the fold's 128 MiB of image stores: off
 int64_t g_window_shadow_writes = 0;  // folds that did (tests)
+int64_t g_window_wide = 1;    // update windows on tables of few slices: the fold with five probe groups per lane and phase and byte-wide group counts (0: three, nibbles)
 int64_t g_window_image = 4;   // update windows' fold: 4 = nibble images, one workgroup per 2^18-counter slice; 8 = byte images, two per slice (round 4 A/B)
 int64_t g_window_nt = 1;   // nontemporal table loads / stores in the update windows' fold (k_win_fold); option "update_window_nt"
 int64_t g_nib_gather_pipe = 0;   // 1 = k_nib_gather_pipe (psk_nibble_pipe.hpp: the next slice's table load under this slice's probe walk) when no kept images exist.
@@ -583,6 +584,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "nibble_lookup_pipe")) g_nib_gather_pipe = value;
     else if (!strcmp(name, "update_window_nt")) g_window_nt = value;
     else if (!strcmp(name, "update_window_image")) g_window_image = value;
+    else if (!strcmp(name, "update_window_wide")) g_window_wide = value;
     else if (!strcmp(name, "update_window_shadow")) g_window_shadow = value;
     else if (!strcmp(name, "big_table_nt")) g_big_table_nt = value;
     else if (!strcmp(name, "nibble_min_lg_lookup")) g_nib_min_lg_lookup = value < 20 ? 20 : value;
@@ -675,6 +677,7 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "nibble_lookup_pipe")) *value = g_nib_gather_pipe;
     else if (!strcmp(name, "update_window_nt")) *value = g_window_nt;
     else if (!strcmp(name, "update_window_image")) *value = g_window_image;
+    else if (!strcmp(name, "update_window_wide")) *value = g_window_wide;
     else if (!strcmp(name, "update_window_shadow")) *value = g_window_shadow;
     else if (!strcmp(name, "update_window_shadow_writes")) *value = g_window_shadow_writes;
     else if (!strcmp(name, "big_table_nt")) *value = g_big_table_nt;

@@ -4,6 +4,7 @@
 
 extern PSK_HIDDEN int64_t g_window_nt;     // psk_capi.hip: option "update_window_nt"
 extern PSK_HIDDEN int64_t g_window_image;  // psk_capi.hip: option "update_window_image"
+extern PSK_HIDDEN int64_t g_window_wide;   // option "update_window_wide"
 extern PSK_HIDDEN int64_t g_window_shadow, g_window_shadow_writes;  // options "update_window_shadow" / "update_window_shadow_writes" (read-only tally)
 
 template <int KT, int NT>
@@ -91,7 +92,11 @@ int PSK_VARIANT(cbf_window_fold)(psk_sketch *s, const WinPhaseHost *ph, uint32_t
     const bool nib = g_window_image != 8;  // option "update_window_image": 4 (default) = nibble images, one workgroup per slice; 8 = byte images, two
     const uint32_t pshift = win_part_shift(g.shift, nib);
     const uint32_t parts = g.nbuckets << (g.shift - pshift);
-    const size_t lds = win_fold_lds(g, nph_dev, nib);
+    // tables of few slices (a 2048-key tile brings more than 4 probe groups per slice: below ~600 slices): the WIDE fold -- five groups per lane
+    // and phase, byte-wide group counts -- when its count table still fits the LDS next to the image
+    const double groups_per_tile = 2048.0 * (double)(s->k < 8 ? s->k : 8) / (double)g.nbuckets / 6.0 + 0.5;
+    const bool wide = nib && g_window_wide != 0 && groups_per_tile > 4.0 && win_fold_lds(g, nph_dev, nib, true) <= 160 * 1024;
+    const size_t lds = win_fold_lds(g, nph_dev, nib, wide);
     if (lds > 160 * 1024) return fail(PSK_EINVAL, "update window: %u phases of %u segments do not fit the fold's LDS", nph_dev, g.nwg);
     PSK_TRY(ensure(s->s_wstat, (uint64_t)parts * 4));
     // Kept 4-bit images (psk_sketch::shadow): when the lookups already keep them, the fold -- which ends with the very image of every slice
@@ -103,7 +108,7 @@ int PSK_VARIANT(cbf_window_fold)(psk_sketch *s, const WinPhaseHost *ph, uint32_t
         shadow_out = (uint32_t *)s->shadow.img.p;
     if (shadow_out) s->shadow.built = ~0ULL;  // (being overwritten: valid again only once the verdict is in)
     {
-        auto kern = nib ? k_win_fold<false, true> : k_win_fold<false, false>;
+        auto kern = wide ? k_win_fold<false, true, 5> : (nib ? k_win_fold<false, true> : k_win_fold<false, false>);
         PSK_TRY(set_dyn_lds(kern, lds));
         hipLaunchKernelGGL(kern, dim3(parts), dim3(kApplyThreads), lds, st, (uint32_t *)s->table, s->m, g, (const uint4 *)s->s_part.p, (const uint32_t *)s->s_snap.p,
                            wp, (uint32_t *)s->s_wstat.p, flag, (uint32_t)(g_window_nt != 0), shadow_out);

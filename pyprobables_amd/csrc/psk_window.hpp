@@ -75,6 +75,18 @@ __device__ __forceinline__ void win_wait(win_u32x4 &a, win_u32x4 &b, win_u32x4 &
 {
     asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
 }
+template <int N>
+__device__ __forceinline__ void win_wait(win_u32x4 &a, win_u32x4 &b, win_u32x4 &c, win_u32x4 &d, win_u32x4 &e)
+{
+    asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N) : "memory");
+}
+template <int N, int R>
+__device__ __forceinline__ void win_wait_all(win_u32x4 (&q)[R])
+{
+    static_assert(R == 3 || R == 5, "win_wait names three or five registers");
+    if constexpr (R == 3) win_wait<N>(q[0], q[1], q[2]);
+    else win_wait<N>(q[0], q[1], q[2], q[3], q[4]);
+}
 
 // Which segment (pass-1 workgroup) of the slice a lane walks: wave w owns segments [w * spw, (w + 1) * spw), L lanes each.
 struct WinLane {
@@ -122,10 +134,13 @@ __device__ __forceinline__ void win_walk_simple(const PartGeom &g, const uint4 *
     }
 }
 
-static inline size_t win_fold_lds(const PartGeom &g, uint32_t nph, bool nib)
+// wide: five instead of three probe groups per lane and phase, whole bytes instead of nibbles for the per-(phase, segment) group counts --
+// tables of few slices, whose tiles bring long runs per slice (host's choice, psk_part_cbf_window.hip)
+static inline size_t win_fold_lds(const PartGeom &g, uint32_t nph, bool nib, bool wide = false)
 {
     const uint32_t pshift = win_part_shift(g.shift, nib);
-    return ((size_t)1 << (nib ? pshift - 1 : pshift)) + (((size_t)nph * ((g.nwg + 1) / 2) + 3) & ~(size_t)3) + (((size_t)nph + 31) / 32) * 4 + 16;
+    const size_t row = wide ? g.nwg : (g.nwg + 1) / 2;
+    return ((size_t)1 << (nib ? pshift - 1 : pshift)) + (((size_t)nph * row + 3) & ~(size_t)3) + (((size_t)nph + 31) / 32) * 4 + 16;
 }
 
 // UNDO = false: apply the window to my table part (blockIdx.x = slice * parts + part); flag: a remove met a zero / a counter
@@ -135,7 +150,7 @@ static inline size_t win_fold_lds(const PartGeom &g, uint32_t nph, bool nib)
 // decoded once -- with byte images two workgroups per slice each decoded all of the slice's groups and applied half (the walk is bound by
 // that decoding).  Same proof: adds must meet 0 .. 13, removes 1 .. 14 (15 = a counter the image cannot follow: atomics on the table); a
 // nibble that carries or borrows into its neighbour has raised the taint / violation flag first, and either flag discards the image.
-template <bool UNDO, bool NIB>
+template <bool UNDO, bool NIB, int RG = 3>
 __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint64_t tab_cells, PartGeom g, const uint4 *buckets, const uint32_t *snap,
                                                             WinPhases wp, uint32_t *status, uint32_t *flag, uint32_t nt, uint32_t *shadow_out)
 {
@@ -230,27 +245,29 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
         // has a group is applied where the group is used): hipcc can then count the loads in flight and wait for the oldest only
         // (s_waitcnt vmcnt(n) counts in order; with loads under branches, or loaded registers copied / selected before their phase,
         // it drains every load at every phase -- the first version: 3.3 us per phase).
-        constexpr int K = 3, R = 3;  // phases in flight; groups per lane and phase
+        constexpr int K = 3, R = RG;  // phases in flight; groups per lane and phase
+        constexpr bool WIDE = RG > 3;  // (byte-wide group counts: up to R * L = 20 groups per segment and phase)
         const WinLane wl = win_lane(g);
         const uint4 *src = buckets + seg_index(g, b, wl.active ? wl.seg : 0) * g.segcap;
         const uint32_t nph = wp.nph;
-        uint8_t *cnt4 = reinterpret_cast<uint8_t *>(smem + img_words);     // [nph][ceil(nwg / 2)]: two segments per byte
-        uint32_t *types = smem + img_words + ((nph * ((g.nwg + 1) / 2) + 3) / 4);  // bit p: phase p removes
-        const uint32_t row = (g.nwg + 1) / 2;
+        uint8_t *cnt4 = reinterpret_cast<uint8_t *>(smem + img_words);     // [nph][ceil(nwg / 2)]: two segments per byte (WIDE: [nph][nwg], one each)
+        const uint32_t row = WIDE ? g.nwg : (g.nwg + 1) / 2;
+        uint32_t *types = smem + img_words + ((nph * row + 3) / 4);  // bit p: phase p removes
         for (uint32_t i = threadIdx.x; i < (nph + 31) / 32; i += kApplyThreads) types[i] = 0;
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < nph * row; i += kApplyThreads) {
-            const uint32_t p = i / row, s2 = (i - p * row) * 2;
+            const uint32_t p = i / row, s2 = (i - p * row) * (WIDE ? 1u : 2u);
             uint32_t byte = 0, ty = 0;
 #pragma unroll
-            for (uint32_t e = 0; e < 2; ++e) {
+            for (uint32_t e = 0; e < (WIDE ? 1u : 2u); ++e) {
                 if (s2 + e < g.nwg) {
                     const uint32_t cur = snap[((uint64_t)p * g.nbuckets + b) * g.nwg + s2 + e];
                     const uint32_t prev = p ? snap[((uint64_t)(p - 1) * g.nbuckets + b) * g.nwg + s2 + e] & 0x7FFFFFFFu : 0u;
                     ty = cur >> 31;
                     const uint32_t c1 = cur & 0x7FFFFFFFu, hi = c1 < g.segcap ? c1 : g.segcap, lo = prev < g.segcap ? prev : g.segcap;
                     const uint32_t d = hi - lo;
-                    byte |= (d < 15u ? d : 15u) << (4 * e);
+                    if (WIDE) byte = d < 255u ? d : 255u;
+                    else byte |= (d < 15u ? d : 15u) << (4 * e);
                 }
             }
             cnt4[i] = (uint8_t)byte;
@@ -260,7 +277,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
         uint32_t viol = 0, taint = 0;
         auto count = [&](uint32_t p) -> uint32_t {  // groups of my segment in phase p (0 past the end / for an idle lane)
             if (p >= nph || !wl.active) return 0u;
-            const uint32_t d = (cnt4[p * row + (wl.seg >> 1)] >> (4 * (wl.seg & 1))) & 15u;
+            const uint32_t d = WIDE ? (uint32_t)cnt4[p * row + wl.seg] : (cnt4[p * row + (wl.seg >> 1)] >> (4 * (wl.seg & 1))) & 15u;
             return d;
         };
         // one probe group: the returning LDS atomics of its probes (mine: valid slot, my half of the slice) issue back to back, then the
@@ -294,7 +311,6 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
         };
         // the R groups of a phase that brings `d` groups from `lo` on in my segment; a lane without a group re-reads the phase's
         // first one and remembers that it has none (qv: applied where the group is used)
-        static_assert(R == 3, "win_wait names three registers");
         auto fetch = [&](win_u32x4 (&q)[R], uint32_t (&qv)[R], uint32_t lo, uint32_t d) {
             const uint32_t safe = lo < g.segcap ? lo : g.segcap - 1;
 #pragma unroll
@@ -321,7 +337,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_win_fold(uint32_t *tab, uint6
                 if (p < nph) {  // (uniform)
                     const uint32_t rm = 0u - ((types[p >> 5] >> (p & 31)) & 1u);
                     const uint32_t d = count(p + K);
-                    win_wait<(K - 1) * R>(Q[j][0], Q[j][1], Q[j][2]);  // K * R loads in flight: this phase's are the oldest R
+                    win_wait_all<(K - 1) * R, R>(Q[j]);  // K * R loads in flight: this phase's are the oldest R
 #pragma unroll
                     for (int r = 0; r < R; ++r)
                         if (QV[j][r]) apply(Q[j][r], rm);  // (a lane without an r-th group sits it out; a wave without one skips it)
