@@ -617,7 +617,7 @@ def side_measurements(ctx: Ctx, n, blm, keys):
     cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, device=dev)  # 2^28 x u32 = 1 GiB
     ms = timed_loop(torch, lambda: cbf.add_many(keys[:ncbf]), 3, warm=1)
     out["cbf_add_Mops_s"] = ncbf / ms / 1e3
-    rl["cbf_add"] = roofline("cbf_add", "CBF unit add into the 1 GiB table (one level of 2^18-counter nibble-delta slices: k_part_scatter + k_nib_apply<0>)",
+    rl["cbf_add"] = roofline("cbf_add", "CBF unit add into the 1 GiB table (one level of 2^18-counter nibble-delta slices: k_part_scatter + k_nib_apply_pipe<0>, the pipelined pass over the table)",
                              ncbf, ms, "the fold read-modify-writes the whole 1 GiB table")
     from pyprobables_amd import _native as _N
     _N.set_option("cbf_lookup_shadow", 0)  # `cbf_check` = a lookup of a table that has just changed: the whole 32-bit table is read
@@ -640,7 +640,7 @@ def side_measurements(ctx: Ctx, n, blm, keys):
     torch.cuda.synchronize()
     ms = rm.mean_ms("remove")
     out["cbf_remove_Mops_s"] = ncbf / ms / 1e3
-    rl["cbf_remove"] = roofline("cbf_remove", "validated CBF remove of present keys, 1 GiB table: k_part_scatter + k_nib_apply<3> (optimistic decrement, one pass over the table)",
+    rl["cbf_remove"] = roofline("cbf_remove", "validated CBF remove of present keys, 1 GiB table: k_part_scatter + k_nib_apply_pipe<3> (optimistic decrement, one pipelined pass over the table)",
                                 ncbf, ms, "the pass over the table (2 GiB read + written) whatever the batch brings")
     del cbf
     # random-access ceilings at the headline table size (2^23 words = 32 MiB) and at 1 GiB
