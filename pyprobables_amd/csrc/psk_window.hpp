@@ -9,17 +9,19 @@
 //   * pass 1 (k_part_scatter<..., PayNonePhased>) runs once over the window's key list; a tile never straddles two phases, and a
 //     (slice, workgroup) segment receives its tiles in order, so the end-of-phase fill counts (snap[phase][slice][workgroup]) cut
 //     every segment into per-phase pieces;
-//   * the fold (k_win_fold) keeps a BYTE image of the real counters of its table part in LDS (min(counter, 255); 2^17 counters =
-//     128 KiB, two workgroups per 2^18-counter slice, each applying the probes of its half) and walks the slice's probes phase by
-//     phase: adds with a returning ds_add, barrier, removes with a returning ds_sub whose old byte must be 1 .. 254.
+//   * the fold (k_win_fold) keeps an image of the real counters of its table part in LDS -- four bits per counter (min(counter, 15)), a
+//     whole 2^18-counter slice per workgroup (default), or a byte per counter (min(counter, 255)), 2^17 counters, two workgroups per slice
+//     each applying the probes of its half -- and walks the slice's probes phase by phase: adds with a returning ds_add, barrier, removes
+//     with a returning ds_sub whose old value must be 1 .. 14 (1 .. 254).
 //     With T[c] the counter before a remove phase and R[c] the phase's probes on it:  T[c] >= R[c] for every c, none frozen  ==>
 //     every key of the phase is removed whatever the order inside it (each of its counters holds >= 1 just before its own
 //     decrement), and the result is T - R.  By induction over the phases the window's result is the sequential one.
 //   * a remove that meets a zero (or a frozen / saturating counter) raises the window's flag: the host then UNDOES the fold
 //     (k_win_fold<true>: the inverse net delta, wrapping arithmetic, exact) and replays the window batch by batch through the
 //     validated per-batch path -- the reference's semantics for any stream, automatically.
-// Counters of 254 and more do not fit the image's arithmetic: a part that touches one drops its image and applies its probes, phase
-// by phase, with wrapping atomics on the table itself (the part is its alone) -- same checks, exact.
+// Counters of 14 (254) and more do not fit the image's arithmetic: a part that touches one drops its image and applies its probes, phase
+// by phase, with wrapping atomics on the table itself (the part is its alone) -- same checks, exact.  The same for a (segment, phase) piece
+// of more probe groups than the walk keeps in registers (12; 20 in the wide form that tables of few slices take).
 #pragma once
 #include "psk_nibble.hpp"
 
