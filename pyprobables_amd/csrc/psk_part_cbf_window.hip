@@ -95,7 +95,9 @@ int PSK_VARIANT(cbf_window_fold)(psk_sketch *s, const WinPhaseHost *ph, uint32_t
     // tables of few slices (a 2048-key tile brings more than 4 probe groups per slice: below ~600 slices): the WIDE fold -- five groups per lane
     // and phase, byte-wide group counts -- when its count table still fits the LDS next to the image
     const double groups_per_tile = 2048.0 * (double)(s->k < 8 ? s->k : 8) / (double)g.nbuckets / 6.0 + 0.5;
-    const bool wide = nib && g_window_wide != 0 && groups_per_tile > 4.0 && win_fold_lds(g, nph_dev, nib, true) <= 160 * 1024;
+    // (per segment and phase the narrow fold holds 12 groups: one tile of more than 4 groups per slice, or two tiles of more than 3.25 -- 732 slices:
+    // 2 x 3.8, most slices overflowed, 9.4 -> 15.9 G ops/s with the wide fold; 1024 slices, BASELINE cfg 4: 2 x 2.8 fit, and the wide fold costs 5 %)
+    const bool wide = nib && g_window_wide != 0 && (groups_per_tile > 3.25 || g_window_wide == 2) && win_fold_lds(g, nph_dev, nib, true) <= 160 * 1024;  // (2: wherever it fits, A/B)
     const size_t lds = win_fold_lds(g, nph_dev, nib, wide);
     if (lds > 160 * 1024) return fail(PSK_EINVAL, "update window: %u phases of %u segments do not fit the fold's LDS", nph_dev, g.nwg);
     PSK_TRY(ensure(s->s_wstat, (uint64_t)parts * 4));
