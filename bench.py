@@ -64,11 +64,11 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SEED = 0x5EED
 # algorithmic bytes per unit of work (L = 16-byte key, k = 7, d = 5)
-BYTES = {"bloom_insert": 72, "bloom_check": 45, "cms_add": 60, "cms_check": 40, "cbf_add": 76, "cbf_remove": 76, "cbf_check": 48}
+BYTES = {"bloom_insert": 72, "bloom_check": 45, "cms_add": 60, "cms_check": 40, "cbf_add": 76, "cbf_remove": 76, "cbf_check": 48,
+         "bloom_step": 72 + 45}  # one key inserted AND looked up: what one unit of cfg 2 / cfg 5's `value` moves
 DEFAULT_STEPS = {"cfg2": (200, 20), "cfg3": (20, 3), "cfg4": (10, 2), "cfg5": (5, 1)}
-PMC_FILE = next((f for f in (ROOT / "profiles" / "r04_pmc_traffic.json", ROOT / "profiles" / "r03_pmc_traffic.json") if f.exists()),
-                ROOT / "profiles" / "r04_pmc_traffic.json")
-L2_FILE = next((f for f in (ROOT / "profiles" / "r04_l2_hit.json", ROOT / "profiles" / "r03_l2_hit.json") if f.exists()), ROOT / "profiles" / "r04_l2_hit.json")
+PMC_FILE = next((f for f in (ROOT / "profiles" / f"r0{r}_pmc_traffic.json" for r in (5, 4, 3)) if f.exists()), ROOT / "profiles" / "r05_pmc_traffic.json")
+L2_FILE = next((f for f in (ROOT / "profiles" / f"r0{r}_l2_hit.json" for r in (5, 4, 3)) if f.exists()), ROOT / "profiles" / "r05_l2_hit.json")
 METRIC_CFG2 = "million keys/sec insert+lookup (Bloom m=2^28 k=7, CMS 2^20x5)"
 
 
@@ -83,6 +83,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1_000_000, help="cfg4: keys per batch")
     ap.add_argument("--batches", type=int, default=50, help="cfg4: batches per step")
     ap.add_argument("--spinup", type=float, default=1.0, help="seconds of untimed steps before warm-up (clock ramp)")
+    ap.add_argument("--repeats", type=int, default=5, help="the block of --steps timed steps is run this many times, each between its own fences; "
+                    "`ms_per_step` / `value` are the MEDIAN block's, min / max are reported next to it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-detail", action="store_true", help="skip the CMS / CBF / GUPS side measurements")
     ap.add_argument("--no-combine", action="store_true", help="cfg4: apply every 1M-key batch at once (update windows off: psk_set_option update_window=0)")
@@ -322,6 +324,20 @@ def roofline(op: str, kernel: str, units: int, ms: float, limiter: str, traffic_
     }
 
 
+def step_roofline(kernel: str, units: int, step_ms: float, launches: dict, limiter: str):
+    """roofline object of a whole timed STEP (what `value` measures): `units` keys each inserted and looked up (BYTES["bloom_step"] algorithmic
+    bytes) in `step_ms` -- HIP events around whole steps of the timed region, everything the step enqueues included (clear, merge) --
+    with the objects of its launches nested under `launches` (each timed between its own events on other steps of the timed region)"""
+    r = roofline("bloom_step", kernel, units, step_ms, limiter)
+    tr = [v.get("traffic") for v in launches.values()]
+    r["traffic"] = sum(tr) if tr and all(t is not None for t in tr) else None
+    r["traffic_source"] = next((v["traffic_source"] for v in launches.values() if v.get("traffic_source")), None) if r["traffic"] else None
+    r["l2_hit"] = {k: v.get("l2_hit") for k, v in launches.items()}
+    r["launch_ms_sum"] = sum(v["avg_kernel_ms"] for v in launches.values())
+    r["launches"] = launches
+    return r
+
+
 # ----------------------------------------------------------------------------------------------- CPU baseline
 
 
@@ -476,11 +492,15 @@ class Cfg2:
     # A timing-enabled HIP event is a barrier packet: the next kernel cannot be dispatched ahead of it, ~7 us of bubble
     # each.  The timed steps therefore carry only the ONE event pair the roofline needs (around the insert launch), and
     # only on a sample of the steps; the other phases are timed in a separate instrumented pass after the timed region.
-    def step(self, record=False, every_phase=False):
+    def step(self, record=0, every_phase=False):
+        """record: 0 no events; 1 one event pair around the WHOLE step (-> roofline of the step); 2 events between the launches (-> their
+        nested objects) -- on different steps, so that the whole-step sample carries no event bubbles inside"""
         plain = lambda _n, f: f()  # noqa: E731
         t = self.timer.time if (record and every_phase) else plain
-        ti = self.timer.time if record else plain
+        ti = self.timer.time if (record == 2 or (record and every_phase)) else plain
         blm, keys, ctx = self.blm, self.keys, self.ctx
+        if record == 1 and not every_phase:
+            return self.timer.time("step", lambda: self.step(0))
         t("clear", blm.clear)
         ti("insert" if not every_phase else "insert_detail", lambda: blm.add_many(keys))
         if ctx.distributed and not self.args.no_overlap:
@@ -491,11 +511,11 @@ class Cfg2:
                 h.wait()
                 return blm.check_many_finish()
 
-            self.state["res"] = t("merge+check", merge_and_check)
+            self.state["res"] = ti("merge+check", merge_and_check)
         else:
             if ctx.distributed:
-                t("merge", lambda: self.parallel.merge_bloom(blm, sync_elements=False))  # table merge only: no host sync
-            self.state["res"] = t("check", lambda: blm.check_many(keys))
+                ti("merge", lambda: self.parallel.merge_bloom(blm, sync_elements=False))  # table merge only: no host sync
+            self.state["res"] = ti("check" if not every_phase else "check_detail", lambda: blm.check_many(keys))
 
     def instrumented(self):
         for _ in range(min(self.args.steps, 10)):
@@ -516,6 +536,16 @@ class Cfg2:
         torch.cuda.synchronize()
         return ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3]), 2**28 // 8
 
+    def predicted(self, body):
+        """the weak-scaling curve of cfg 2 from this run's per-key times (per-rank figures of the un-overlapped diagnostic step when N > 1)"""
+        mg, d = body.get("multi_gpu"), body["detail"]
+        if mg:
+            ins = max(p["insert_ms"] for p in mg["per_rank"])
+            chk = max(p["check_ms"] for p in mg["per_rank"])
+        else:
+            ins, chk = self.n / d["insert_Mkeys_s"] / 1e3, self.n / d["check_Mkeys_s"] / 1e3
+        return predicted_scaling("weak", 2**28 // 8, ins / (self.n / 1e6), chk / (self.n / 1e6), self.n, d.get("clear_ms") or 0.0, 0.68, _worst_merge(body))
+
     def finish(self, ms_step):
         ctx, args, n, torch, timer, blm = self.ctx, self.args, self.n, self.ctx.torch, self.timer, self.blm
         ok = bool(self.state["res"].all().item())  # every inserted key must be found (size-independent parity property)
@@ -528,8 +558,8 @@ class Cfg2:
                 ref.add_many(ctx.gen_keys(n, r * n))
             merged_ok = bool(torch.equal(ref.table_tensor, blm.table_tensor))
             del ref
-        ins_ms, chk_ms = timer.mean_ms("insert"), timer.mean_ms("check")
         overlapped = ctx.distributed and not args.no_overlap
+        ins_ms, chk_ms = timer.mean_ms("insert"), timer.mean_ms("merge+check" if overlapped else "check")
         detail = {
             "insert_Mkeys_s": n / ins_ms / 1e3,
             "check_Mkeys_s": None if overlapped else n / chk_ms / 1e3,
@@ -538,16 +568,23 @@ class Cfg2:
             "merge_ms": timer.mean_ms("merge") if ctx.distributed and not overlapped else None,
             "all_inserted_found": ok, "merged_table_equals_single_stream": merged_ok, "bits_set": bits_set,
         }
-        rooflines = {}
+        launches = {"bloom_insert": roofline(
+            "bloom_insert", "Bloom insert = k_part_scatter<KeysFixed16,IdxBloom<pow2>,PayNone,SpillBloomOr,7> + k_bloom_apply "
+            "(one insert launch = both kernels; avg_kernel_ms is their sum between two HIP events)", n, ins_ms,
+            "pass 1 is co-limited by VALU (the k FNV-1a chains) and the LDS counting sort, not by HBM; pass 2 streams at ~5.5 TB/s")}
         if not overlapped:
-            rooflines["bloom_check"] = roofline(
-                "bloom_check", "Bloom lookup = rounds x (k_part_scatter<KeysFixed16,IdxBloom<pow2>,PayKeyId,SpillBloomTest,7> + k_bloom_test)",
-                n, chk_ms, "pass 1 as the insert's (hash + LDS counting sort) with keyed probes; pass 2 streams the probes back "
+            launches["bloom_check"] = roofline(
+                "bloom_check", "Bloom lookup of present keys = k_part_scatter<KeysFixed16,IdxBloom<pow2>,PayTileTag,SpillBloomFlag,7> + k_bloom_test_flag + "
+                "k_bloom_flag_finish (tile flags; keyed probes / return trip for batches with absent keys: detail.check_*_fresh)",
+                n, chk_ms, "pass 1 is the insert's (hash + LDS counting sort, 2.67-byte probes); pass 2 streams the probes back "
                 "from the Infinity Cache against an LDS-resident slice")
+        rooflines = {k: v for k, v in launches.items() if k != "bloom_insert"}
         if ctx.rank == 0 and ctx.world == 1 and not args.no_detail:
             side, rl = side_measurements(ctx, n, blm, self.keys)
             detail.update(side)
             rooflines.update(rl)
+        step_ms = timer.mean_ms("step")
+        detail["step_ms_events"] = step_ms
         line = {
             "metric": METRIC_CFG2,
             "config": {
@@ -556,10 +593,12 @@ class Cfg2:
                 "keys_per_rank": n, "key_bytes": 16, "m_bits": 2**28, "k": 7,
                 "parallelism": f"key-range x{ctx.world}, replica per GPU, allreduce(OR)" if ctx.world > 1 else "single GPU",
             },
-            "roofline": roofline(
-                "bloom_insert", "Bloom insert = k_part_scatter<KeysFixed16,IdxBloom<pow2>,PayNone,SpillBloomOr,7> + k_bloom_apply "
-                "(one insert launch = both kernels; avg_kernel_ms is their sum between two HIP events)", n, ins_ms,
-                "pass 1 is co-limited by VALU (the k FNV-1a chains) and the LDS counting sort, not by HBM; pass 2 streams at ~5.5 TB/s"),
+            "roofline": step_roofline(
+                "one timed STEP = clear + Bloom insert (k_part_scatter + k_bloom_apply) + " + ("allreduce(OR) + " if ctx.distributed else "") +
+                "Bloom lookup (k_part_scatter + k_bloom_test_flag + k_bloom_flag_finish); avg_kernel_ms = HIP events around whole steps of the timed region",
+                n, step_ms, launches,
+                "both pass 1s are co-limited by VALU (the k FNV-1a chains, ~75 of ~130 us) and the LDS counting sort, not by HBM; the pass 2s "
+                "stream the probes back at 4-5 TB/s"),
             "rooflines": rooflines, "detail": detail,
         }
         fails = []
@@ -568,6 +607,11 @@ class Cfg2:
         if merged_ok is False:
             fails.append("parity property violated: the merged table differs from the single-stream filter")
         return line, fails
+
+
+def _worst_merge(body):
+    mg = body.get("multi_gpu")
+    return {"world": mg["ranks_seen_by_rccl"], "merge_ms": max(p["merge_ms"] for p in mg["per_rank"])} if mg else None
 
 
 def side_measurements(ctx: Ctx, n, blm, keys):
@@ -674,7 +718,8 @@ class Cfg3:
         self.timer = EventTimer(ctx.torch)
         self.ops_per_step = self.n * self.PASSES * ctx.world
 
-    def step(self, record=False, every_phase=False):
+    def step(self, record=0, every_phase=False):
+        record = record == 1
         t = self.timer.time if record else (lambda _n, f: f())
         self.cms.clear()
         for p in range(self.PASSES):
@@ -758,11 +803,11 @@ class Cfg4:
         self.ops_per_step = self.adds + self.removes
         self.timer = EventTimer(ctx.torch)
 
-    def step(self, record=False, every_phase=False):
+    def step(self, record=0, every_phase=False):
         cbf, keys, B = self.cbf, self.keys, self.B
         run = lambda: self._stream(cbf, keys, B)  # noqa: E731
         cbf.clear()
-        if record:
+        if record == 1:
             self.timer.time("stream", run)
         else:
             run()
@@ -835,8 +880,10 @@ class Cfg5:
         self.ops_per_step = 2 * args.n_total
         self.found = None
 
-    def step(self, record=False, every_phase=False):
-        t = self.timer.time if record else (lambda _n, f: f())
+    def step(self, record=0, every_phase=False):
+        if record == 1:  # one event pair around the whole step; the launches are timed on other steps (record == 2)
+            return self.timer.time("step", lambda: self.step(0))
+        t = self.timer.time if record == 2 else (lambda _n, f: f())
         blm = self.blm
         blm.clear()
         t("insert", lambda: [blm.add_many(c) for c in self.chunks])
@@ -864,6 +911,13 @@ class Cfg5:
         torch.cuda.synchronize()
         return ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3]), 2**31 // 8
 
+    def predicted(self, body):
+        """the strong-scaling curve of cfg 5: per-key insert / lookup times of this run's shard, applied to n_total / N keys per rank"""
+        d, mg = body["detail"], body.get("multi_gpu")
+        ins = max(p["insert_ms"] for p in mg["per_rank"]) if mg else d["insert_ms"]
+        chk = max(p["check_ms"] for p in mg["per_rank"]) if mg else d["check_ms"]
+        return predicted_scaling("strong", 2**31 // 8, ins / (self.n / 1e6), chk / (self.n / 1e6), self.args.n_total, 0.05, 0.0, _worst_merge(body))
+
     def finish(self, ms_step):
         ctx, torch = self.ctx, self.ctx.torch
         ok = all(bool(r.all().item()) for r in self.found)
@@ -887,9 +941,14 @@ class Cfg5:
                                    "key range + allreduce(OR) + check the rank's key range",
                        "keys_total": self.args.n_total, "keys_per_rank": self.n, "m_bits": 2**31, "k": 7,
                        "parallelism": f"key-range x{ctx.world}, replica per GPU, allreduce(OR) = all_to_all + OR kernel + all_gather"},
-            "roofline": roofline("bloom_insert", "Bloom insert, m=2^31 (2048 slices): k_part_scatter + k_bloom_apply per 32M-key chunk", self.n, ins,
-                                 "short (tile, slice) runs at 2048 slices: pass 1 is write-out bound", "bloom31_insert"),
-            "rooflines": {"bloom_check": roofline("bloom_check", "Bloom lookup, m=2^31", self.n, chk, "as the insert", "bloom31_check")},
+            "roofline": step_roofline(
+                "one timed STEP = clear + insert the shard (k_part_scatter + k_bloom_apply per 32M-key chunk) + " + ("allreduce(OR) + " if ctx.distributed else "") +
+                "check the shard; avg_kernel_ms = HIP events around whole steps of the timed region", self.n, self.timer.mean_ms("step"),
+                {"bloom_insert": roofline("bloom_insert", "Bloom insert, m=2^31 (2048 slices): k_part_scatter + k_bloom_apply per 32M-key chunk", self.n, ins,
+                                          "short (tile, slice) runs at 2048 slices: pass 1 is write-out bound", "bloom31_insert"),
+                 "bloom_check": roofline("bloom_check", "Bloom lookup, m=2^31", self.n, chk, "as the insert", "bloom31_check")},
+                "short (tile, slice) runs at 2048 slices: both pass 1s are write-out bound"),
+            "rooflines": {},
             "detail": {"insert_ms": ins, "merge_ms": None if mrg != mrg else mrg, "check_ms": chk,
                        "insert_Mkeys_s_per_gpu": self.n / ins / 1e3, "check_Mkeys_s_per_gpu": self.n / chk / 1e3,
                        "merge_GBs_per_gpu": None if mrg != mrg else 2**28 / mrg / 1e6,
@@ -901,6 +960,50 @@ class Cfg5:
         if merged_ok is False:
             fails.append("parity property violated: merged prefix differs from the single-stream filter")
         return line, fails
+
+
+# ----------------------------------------------------------------------------------------------- the scaling curve this line predicts
+XGMI_LINK_GBS = 153.0      # per link and direction; an MI355X node is fully connected, 7 links per GPU
+RCCL_CALL_US = 25.0        # fixed cost assumed per RCCL call of the merge (all_to_all_single, all_gather_into_tensor): launch + handshake
+OR_KERNEL_GBS = 4000.0     # psk_or_reduce_slices streams its R input slices and writes one (measured 3.6-4.9 TB/s on the streaming kernels)
+
+
+def predicted_merge_ms(table_bytes: int, R: int) -> float:
+    """allreduce(OR) over R fully connected GPUs: slice exchange (every GPU sends slice j straight to owner j, all R - 1 links busy at once:
+    table / R bytes per link), the OR kernel over R slices of table / R bytes, all_gather (table / R per link again)"""
+    if R <= 1:
+        return 0.0
+    per_link = table_bytes / R
+    return 2.0 * (per_link / (XGMI_LINK_GBS * 1e9) * 1e3 + RCCL_CALL_US * 1e-3) + (table_bytes + per_link) / (OR_KERNEL_GBS * 1e9) * 1e3
+
+
+def predicted_scaling(kind: str, table_bytes: int, insert_ms_per_Mkey: float, check_ms_per_Mkey: float, keys_1gpu: int, clear_ms: float,
+                      scatter_share: float, measured=None):
+    """What the 1/2/4/8-GPU curve of this configuration should look like, from THIS run's per-key insert / lookup times and the link model
+    above -- so that the driver's SCALE_rNN.json can be read against a number: `value_Mkeys_s` per N, `efficiency` against N x the N = 1 value.
+    kind "weak": every rank owns keys_1gpu keys (cfg 2); "strong": keys_1gpu keys are split over the ranks (cfg 5).
+    scatter_share: the part of a lookup that is its pass 1 (never reads the table: it runs under the merge when bench.py overlaps them).
+    measured = {"world": R, "merge_ms": ...}: this run's own merge next to the model's."""
+    out = {"model": f"step(N) = clear + insert + allreduce(OR) + lookup; allreduce(OR) = 2 x (table/N bytes per xGMI link at {XGMI_LINK_GBS:g} GB/s + "
+                    f"{RCCL_CALL_US:g} us per RCCL call) + OR kernel over (N + 1) x table/N bytes at {OR_KERNEL_GBS:g} GB/s; the lookup's pass 1 "
+                    f"({scatter_share:.2f} of a lookup) hides under the merge; insert / lookup per key as measured in this run",
+           "table_bytes": table_bytes, "per_N": {}}
+    base = None
+    for R in (1, 2, 4, 8):
+        keys_rank = keys_1gpu if kind == "weak" else -(-keys_1gpu // R)
+        ins, chk = insert_ms_per_Mkey * keys_rank / 1e6, check_ms_per_Mkey * keys_rank / 1e6
+        mrg = predicted_merge_ms(table_bytes, R)
+        hidden = min(mrg, scatter_share * chk) if R > 1 else 0.0
+        step = clear_ms + ins + mrg + chk - hidden
+        total_keys = keys_rank * R if kind == "weak" else keys_1gpu
+        val = 2 * total_keys / step / 1e3
+        base = val if R == 1 else base
+        out["per_N"][str(R)] = {"ms_per_step": step, "merge_ms": mrg, "value_Mkeys_s": val, "efficiency": val / (R * base)}
+    if measured and measured.get("world", 1) > 1 and measured.get("merge_ms"):
+        R = measured["world"]
+        out["measured_vs_model"] = {"world": R, "merge_ms_measured": measured["merge_ms"], "merge_ms_model": predicted_merge_ms(table_bytes, R),
+                                    "ratio": measured["merge_ms"] / predicted_merge_ms(table_bytes, R)}
+    return out
 
 
 WORKLOADS = {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5}
@@ -935,9 +1038,9 @@ def multi_gpu_diagnostics(ctx: Ctx, args, wl):
                     "GPU sends (= receives) in the slice exchange + all_gather, divided by the slowest rank's merge time"}
 
 
-def run_workload(ctx: Ctx, args, name: str, steps: int, warmup: int, spinup: float):
-    """spin-up, `warmup` untimed steps, EXACTLY `steps` timed steps between two fences, per-phase pass, parity.
-    -> (workload, body, fails, seconds per step (max over ranks), untimed spin-up steps)"""
+def run_workload(ctx: Ctx, args, name: str, steps: int, warmup: int, spinup: float, repeats: int = 1):
+    """spin-up, `warmup` untimed steps, `repeats` blocks of EXACTLY `steps` timed steps between two fences each, per-phase pass, parity.
+    -> (workload, body, fails, seconds per step of the median block (max over ranks), untimed spin-up steps)"""
     torch = ctx.torch
     phase(f"{name}: set-up (keys, sketch)")
     wl = WORKLOADS[name](ctx, args)
@@ -955,12 +1058,20 @@ def run_workload(ctx: Ctx, args, name: str, steps: int, warmup: int, spinup: flo
         wl.step(False)
     ctx.fence()
     phase(f"{name}: timed steps")
-    t0 = time.perf_counter()
-    sample_every = max(1, min(20, steps // 3))  # the dominant launch is event-timed on every sample_every-th step (>= 3 samples)
-    for it in range(steps):
-        wl.step(it % sample_every == 0)
-    ctx.fence()
-    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    # The block of EXACTLY `steps` steps, each block between its own fences, `repeats` times: the median block is the result, min / max say
+    # how far one block may lie from it.  Events: every sample_every-th step carries ONE pair around the whole step (the step's roofline),
+    # the steps half-way between them carry the events between the launches (their nested objects) -- the whole-step samples hold no bubbles.
+    sample_every = max(2, min(20, steps // 3))  # (>= 3 samples of either kind per block when steps >= 6)
+    blocks = []
+    for _rep in range(max(1, repeats)):
+        ctx.fence()
+        t0 = time.perf_counter()
+        for it in range(steps):
+            wl.step(1 if it % sample_every == 0 else (2 if it % sample_every == sample_every // 2 else 0))
+        ctx.fence()
+        blocks.append(ctx.max_over_ranks(time.perf_counter() - t0))
+    srt = sorted(blocks)
+    elapsed = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
     phase(f"{name}: per-phase instrumented pass")
     wl.instrumented()  # per-phase HIP-event times (not part of `value`)
     ctx.fence()
@@ -969,13 +1080,19 @@ def run_workload(ctx: Ctx, args, name: str, steps: int, warmup: int, spinup: flo
     if ctx.distributed and hasattr(wl, "rank_times"):
         phase(f"{name}: per-rank diagnostics")
         body["multi_gpu"] = multi_gpu_diagnostics(ctx, args, wl)
+    if name in ("cfg2", "cfg5") and ctx.rank == 0:
+        body["predicted"] = wl.predicted(body)
+    body["config"]["timed_blocks"] = {
+        "repeats": len(blocks), "steps_per_block": steps, "ms_per_step_median": elapsed / steps * 1e3, "ms_per_step_min": srt[0] / steps * 1e3,
+        "ms_per_step_max": srt[-1] / steps * 1e3, "ms_per_step_blocks": [b / steps * 1e3 for b in blocks],
+        "note": "every block is `steps` steps between a barrier + synchronize on both sides (max over ranks); ms_per_step / value are the median block's"}
     return wl, body, fails, elapsed / steps, spun
 
 
 def extra_config(ctx: Ctx, args, name: str):
     """one of cfg3 / cfg4 / cfg5 (N = 1) as written, a few steps: the object reported under `configs.<name>`"""
     steps, warmup = EXTRA_STEPS[name]
-    wl, body, fails, sec, spun = run_workload(ctx, args, name, steps, warmup, min(args.spinup, 0.3))
+    wl, body, fails, sec, spun = run_workload(ctx, args, name, steps, warmup, min(args.spinup, 0.3), repeats=min(args.repeats, 3))
     obj = {"metric": body.pop("metric"), "value": wl.ops_per_step / sec / 1e6, "unit": UNITS[name], "ms_per_step": sec * 1e3, "steps": steps,
            "warmup": warmup, "scaling": body.pop("scaling", "weak"), "dtype": DTYPES[name], "parity_ok": not fails, "parity_failures": fails}
     obj.update(body)
@@ -1033,7 +1150,7 @@ def run(args):
         from pyprobables_amd import _native as _n
         name, _, value = opt.partition("=")
         _n.set_option(name, int(value, 0))
-    wl, body, fails, sec, spun = run_workload(ctx, args, args.config, args.steps, args.warmup, args.spinup)
+    wl, body, fails, sec, spun = run_workload(ctx, args, args.config, args.steps, args.warmup, args.spinup, repeats=args.repeats)
 
     line = {
         "metric": body.pop("metric"),
@@ -1043,6 +1160,8 @@ def run(args):
         "higher_is_better": True, "scaling": body.pop("scaling", "weak"), "vs_baseline": None, "dtype": DTYPES[args.config],
         "data": "synthetic", "rc": 0,
     }
+    tb = body["config"]["timed_blocks"]
+    line.update({"repeats": tb["repeats"], "ms_per_step_min": tb["ms_per_step_min"], "ms_per_step_max": tb["ms_per_step_max"]})
     body["config"]["clock_spinup"] = f"{spun} untimed steps (~{args.spinup:g} s) before the {args.warmup} warm-up steps"
     line.update(body)
     if args.config == "cfg2" and ctx.world == 1 and not ctx.distributed and not args.no_extra_configs and not args.no_detail:

@@ -155,7 +155,7 @@ extern "C" int psk_destroy(psk_sketch *s)
     if (s->lk.dev) hipFree(s->lk.dev);
     if (s->lk.pin) hipHostFree((void *)s->lk.pin);
     if (s->wt.pin) hipHostFree((void *)s->wt.pin);
-    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_tflag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
                       &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->s_brw, &s->shadow.img,
                       &s->win.keys, &s->s_snap, &s->s_wstat, &s->s_phase}) {
         if (b->p) hipFree(b->p);
@@ -1954,7 +1954,7 @@ extern "C" int psk_scratch_bytes(psk_sketch *s, uint64_t bytes[3])
 {
     if (!s || !bytes) return fail(PSK_EINVAL, "psk_scratch_bytes: NULL argument");
     uint64_t all = 0, waiting = 0;
-    for (const DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
+    for (const DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_tflag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
                             &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->s_brw, &s->shadow.img,
                             &s->win.keys, &s->s_snap, &s->s_wstat, &s->s_phase})
         if (b->p) all += b->cap;
@@ -1974,7 +1974,7 @@ extern "C" int psk_release_scratch(psk_sketch *s)
     if (s->pend.active) return fail(PSK_EINVAL, "a split lookup is pending: finish it before releasing the scratch buffers");
     PSK_TRY(flush_combined(s, nullptr));
     HIP_TRY(hipDeviceSynchronize());
-    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
+    for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_tflag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,
                       &s->comb.add.keys, &s->comb.add.w, &s->comb.rem.keys, &s->comb.rem.w, &s->scat.add.part, &s->scat.add.cnt, &s->scat.rem.part, &s->scat.rem.cnt, &s->s_brw, &s->shadow.img,
                       &s->win.keys, &s->s_snap, &s->s_wstat, &s->s_phase}) {
         if (b->p) HIP_TRY(hipFree(b->p));

@@ -103,6 +103,8 @@ struct psk_sketch {
     DevBuf s_keys, s_offs, s_w, s_out, s_aux;  // staging for PSK_HOST buffers
     DevBuf s_part, s_cnt;                      // partitioned path: bucket buffer + per-bucket fill counts
     DevBuf s_flag;                             // split lookup: "a segment overflowed" flag
+    DevBuf s_tflag;                            // tile-flag Bloom lookups: one uint32 per pass-1 tile of a round; "flagged" = holds the round's
+    uint32_t tflag_gen = 0;                    // generation number (never 0), so the flags are never reset
     DevBuf s_part2, s_cnt2;                    // two-level path: bucket buffer + fill counts after the second split
     DevBuf s_merge;                            // multi-GPU merge (psk_merge_or / _sum): exchange buffers
     DevBuf s_tally;                            // weighted pass 1: (sum w, sum |w|) per workgroup, folded by k_tally_fold
@@ -123,8 +125,10 @@ struct psk_sketch {
     // when the call ends and read -- without any synchronisation, so possibly one call late -- when the next one starts.
     struct {
         unsigned long long *dev = nullptr;           // [0] misses of the call in flight
-        volatile unsigned long long *pin = nullptr;  // [0] misses, [1] units (probes or keys), [2] scheme that produced them
-        int mode = 0;                                // 0 keyed probes + miss stores, 1 return trip
+        volatile unsigned long long *pin = nullptr;  // [0] misses, [1] units (probes or keys), [2] scheme that produced them, [3] calls published
+        unsigned long long seen_seq = 0;             // pin[3] when the choice last looked
+        uint32_t clean = 0;                          // finished calls in a row that missed (almost) nothing
+        int mode = 0;                                // 0 keyed probes + miss stores, 1 return trip, 3 tile flags (PayTileTag)
     } lk;
     // write-combined CBF updates (psk_cbf_update_combined): key batches wait here until a list is full, then each list is
     // applied as ONE partitioned update (the fold of a big table read-modify-writes the whole table whatever the batch size)
@@ -385,8 +389,8 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
     const double mean = (double)tiles_per_wg * (double)tk * kk / (double)g->nbuckets;  // probes per segment
     // 16-byte groups per segment: mean/GS, + ~half a group of padding per (tile, slice) run, + 8 sigma
     uint64_t segcap = (uint64_t)(mean / Tile::GS + 0.5 * (double)tiles_per_wg + 8.0 * __builtin_sqrt(mean) / Tile::GS + 16.0);
-    if constexpr (Pay::mode == kModeKeyed) {
-        if (tiles_per_wg > 16) return fail(PSK_EINVAL, "keyed lookup round of %llu keys needs %llu tiles per workgroup (max 16)",
+    if constexpr (Pay::mode == kModeKeyed || pay_tile_tag<Pay>::value) {
+        if (tiles_per_wg > 16) return fail(PSK_EINVAL, "lookup round of %llu keys needs %llu tiles per workgroup (max 16)",
                                            (unsigned long long)n, (unsigned long long)tiles_per_wg);
     }
     // (pass 1 addresses a group as wg_base + slice * segcap + slot with a 24-bit multiply and a 32-bit sum)
@@ -407,6 +411,36 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
     return PSK_OK;
 }
 
+// The workgroup shape launch_scatter picks for (Pay, KT) on geometry g: threads per workgroup, and the pass-1 workgroups
+// launch_scatter_nt starts by default (before it clamps them to the number of tiles)
+template <class Pay, int KT>
+static int scatter_threads(const PartGeom *g)
+{
+    if constexpr (KT <= 8) {
+        const bool fits1024 = scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget;
+        const bool two_per_cu = pay_fat512<Pay>::value && scatter_lds_bytes<Pay, KT, kPartThreads>(g) <= kScatterLdsTwoPerCu;
+        bool use1024 = fits1024 && !two_per_cu;
+        if (g_part_tile_threads == 1024) use1024 = fits1024;
+        if (g_part_tile_threads == 512 || (kBenchKnobs && (g->dbg & 16))) use1024 = false;
+        if (use1024) return 1024;
+    }
+    return kPartThreads;
+}
+// largest round (keys) whose tiles number at most `max_tiles` per pass-1 workgroup (probes that spell the tile's ordinal in 4 bits)
+template <class Pay, int KT>
+static uint64_t scatter_round_cap(const PartGeom *g, uint32_t want_wgs, uint32_t max_tiles)
+{
+    const bool big = scatter_threads<Pay, KT>(g) == 1024;
+    const size_t lds = big ? scatter_lds_bytes<Pay, KT, 1024>(g) : scatter_lds_bytes<Pay, KT, kPartThreads>(g);
+    const uint64_t tile = big ? (uint64_t)PartTile<Pay, KT, 1024>::TILE : (uint64_t)PartTile<Pay, KT, kPartThreads>::TILE;
+    uint64_t nwg = 256 * (uint64_t)(big ? 1 : (lds > kScatterLdsTwoPerCu ? 1 : 2));
+    if (kBenchKnobs && (g->dbg & 8)) nwg = 256;
+    if (want_wgs) nwg = want_wgs;
+    if (g_part_wgs > 0) nwg = (uint64_t)g_part_wgs;
+    if (nwg > 64u * kApplyWaves) nwg = 64u * kApplyWaves;
+    return nwg * max_tiles * tile;
+}
+
 // Workgroup shape (PartTile): k <= 8 takes one 1024-thread workgroup per CU; the Bloom insert (Pay::fat512) two 512-thread
 // workgroups per CU with 32 probes per thread when two LDS stages fit (tables of up to ~512 slices); larger k runs 512 threads
 // with one key per thread.
@@ -423,12 +457,7 @@ static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, con
         // tile must stay within 2^(31 - shift) keys (PayKeyId::max_tile caps it at 2048 keys)
         if constexpr (Pay::mode == kModeKeyed)
             static_assert(((uint64_t)PartTile<Pay, KT, 1024>::TILE << Pay::slice_shift) <= (1ULL << 31), "keyed tile too large");
-        const bool fits1024 = scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget;
-        const bool two_per_cu = pay_fat512<Pay>::value && scatter_lds_bytes<Pay, KT, kPartThreads>(g) <= kScatterLdsTwoPerCu;
-        bool use1024 = fits1024 && !two_per_cu;
-        if (g_part_tile_threads == 1024) use1024 = fits1024;
-        if (g_part_tile_threads == 512 || (kBenchKnobs && (g->dbg & 16))) use1024 = false;
-        if (use1024) return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st, want_wgs, fixed);
+        if (scatter_threads<Pay, KT>(g) == 1024) return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st, want_wgs, fixed);
     }
     return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, kPartThreads>(s, src, idxfn, pay, spill, g, n, st, want_wgs, fixed);
 }

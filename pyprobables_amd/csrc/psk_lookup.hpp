@@ -478,6 +478,7 @@ static __global__ void k_lookup_publish(unsigned long long *tally, volatile unsi
         pin[1] = units;
         pin[2] = scheme;
         pin[0] = tally[0];
+        pin[3] = pin[3] + 1;
         tally[0] = 0;
     }
 }

@@ -121,26 +121,108 @@ static int bloom_check_return_trip(psk_sketch *s, const Batch &b, uint8_t *out_d
     return PSK_OK;
 }
 
+// Tile-flag lookups (round 5; PayTileTag, k_bloom_test_flag, k_bloom_flag_finish): for batches whose keys are (nearly) all present.  Pass 1 and
+// the probe stream are the insert's (2.67-byte probes, two 512-thread workgroups per CU, one round of up to 16 tiles per workgroup); pass 2
+// raises a flag per TILE that met a clear bit and the finishing kernel answers unflagged tiles wholesale, flagged ones key by key from the
+// table.  Exact for any batch; a batch with absent keys in most tiles costs the direct kernel's gathers on top -- the automatic choice
+// (choose_scheme) only comes here while the previous lookups on the handle missed (almost) nothing.
+static int bloom_check_tile_flags(psk_sketch *s, const Batch &b, uint8_t *out_dev, hipStream_t st, bool *done)
+{
+    *done = false;
+    if (!part_wanted(b.n, s->k, 4)) return PSK_OK;
+    PartGeom g;
+    if (!part_slices(s->m, 20, 7, &g)) return PSK_OK;
+    g.k = s->k;
+    uint64_t round_keys = part_round_keys_big_table(b.n, s->k, PayTileTag::group, s->padded_bytes);
+    {   // 4 bits of tile ordinal per group: at most 16 tiles per pass-1 workgroup and round
+        bool handled = false;
+        uint64_t cap = 0;
+        PSK_TRY(with_part_source(b, &handled, [&](auto src) {
+            using Src = decltype(src);
+            return with_kt<Src>(s->k, [&](auto kt) {
+                constexpr int KT = decltype(kt)::value;
+                cap = scatter_round_cap<PayTileTag, KT>(&g, 0, PayTileTag::max_tiles_per_wg);
+                return (int)PSK_OK;
+            });
+        }));
+        if (!handled || cap == 0) return PSK_OK;
+        if (round_keys > cap) {  // equal rounds
+            const uint64_t rounds = (b.n + cap - 1) / cap;
+            round_keys = ((b.n + rounds - 1) / rounds + 4095) & ~4095ULL;
+            if (round_keys > cap) round_keys = cap;
+        }
+    }
+    for (uint64_t start = 0; start < b.n; start += round_keys) {
+        const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
+        const Batch sub = sub_batch(b, start, cnt);
+        bool handled = false;
+        PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
+            using Src = decltype(src);
+            return with_kt<Src>(s->k, [&](auto kt) {
+                constexpr int KT = decltype(kt)::value;
+                // one flag per tile; tiles are at least 64 keys (evened tiles are multiples of 64)
+                const uint64_t flag_bytes = (cnt / 64 + 2048) * 4;
+                if (flag_bytes > s->s_tflag.cap || s->tflag_gen == 0xFFFFFFFFu) {
+                    PSK_TRY(ensure(s->s_tflag, flag_bytes));
+                    HIP_TRY(hipMemsetAsync(s->s_tflag.p, 0, s->s_tflag.cap, st));  // once (and when the generation number wraps)
+                    s->tflag_gen = 0;
+                }
+                const uint32_t gen = ++s->tflag_gen;
+                uint32_t *tflag = (uint32_t *)s->s_tflag.p;
+                SpillBloomFlag spill{(const uint32_t *)s->table, tflag, gen};
+                PSK_TRY((launch_scatter<Src, IdxBloom<kTuPow2>, PayTileTag, SpillBloomFlag, KT>(s, src, IdxBloom<kTuPow2>{s->md}, PayTileTag{}, spill, &g, cnt, st)));
+                const size_t lds = (size_t)1 << (g.shift - 3);
+                PSK_TRY(set_dyn_lds(k_bloom_test_flag, lds));
+                hipLaunchKernelGGL(k_bloom_test_flag, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (const uint32_t *)s->table, s->padded_bytes / 4, g,
+                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, tflag, gen, s->lk.dev);
+                HIP_TRY(hipGetLastError());
+                const uint64_t ntiles = (cnt + g.tile - 1) / g.tile;
+                const uint32_t chunks = (g.tile + kFinishKeys - 1) / kFinishKeys;
+                LookupPublish pub;
+                if (start + cnt == b.n && g_bloom_lookup == 2 && s->lk.dev) pub = LookupPublish{s->lk.dev, s->lk.pin, b.n * (uint64_t)s->k, 3};
+                hipLaunchKernelGGL((k_bloom_flag_finish<Src, kTuPow2>), dim3((unsigned)(ntiles * chunks)), dim3(kFinishThreads), 0, st, src,
+                                   (const uint32_t *)s->table, s->md, s->k, (const uint32_t *)tflag, gen, g.tile, chunks, cnt, out_dev + start, pub);
+                HIP_TRY(hipGetLastError());
+                return (int)PSK_OK;
+            });
+        }));
+        if (!handled) return start == 0 ? (int)PSK_OK : fail(PSK_EHIP, "tile-flag lookup: layout lost its partitioned instantiation");
+    }
+    *done = true;
+    return PSK_OK;
+}
+
 // Which scheme?  Keyed probes cost ~240 us per 10 M all-hit keys but one scattered byte store per probe that misses (~450 us
 // when every key is absent); the return trip costs ~300 us whatever the answers.  Mode 2 follows what the previous large
 // lookups on this handle saw: the tally of the last finished call sits in a pinned page (no synchronisation: it may be one
 // call late, and the very first call is keyed).
 static int choose_scheme(psk_sketch *s, hipStream_t st)
 {
-    if (g_bloom_lookup != 2) return g_bloom_lookup != 0;
+    if (g_bloom_lookup != 2) return (int)g_bloom_lookup;   // forced: 0 keyed, 1 return trip, 3 tile flags
     if (!s->lk.dev) {
         HIP_TRY(hipMalloc((void **)&s->lk.dev, 8));
         void *pin = nullptr;
         HIP_TRY(hipHostMalloc(&pin, 32, hipHostMallocDefault));
         s->lk.pin = (volatile unsigned long long *)pin;
-        s->lk.pin[0] = s->lk.pin[1] = s->lk.pin[2] = 0;
+        s->lk.pin[0] = s->lk.pin[1] = s->lk.pin[2] = s->lk.pin[3] = 0;
         HIP_TRY(hipMemsetAsync(s->lk.dev, 0, 8, st));  // once: k_lookup_publish re-zeroes the tally at the end of every call
     }
-    const unsigned long long miss = s->lk.pin[0], units = s->lk.pin[1], by = s->lk.pin[2];
+    const unsigned long long miss = s->lk.pin[0], units = s->lk.pin[1], by = s->lk.pin[2], seq = s->lk.pin[3];
     if (units) {
         const double f = (double)miss / (double)units;
-        if (by == 0) s->lk.mode = f > 0.22 ? 1 : 0;   // keyed: fraction of PROBES that missed; beyond ~1/4 the stores cost more than the return trip
-        else s->lk.mode = f < 0.12 ? 0 : 1;          // return trip: fraction of KEYS answered absent (each misses one probe or more)
+        // consecutive finished calls that missed (almost) nothing; an alternating hit / miss workload never gets to the tile flags
+        const bool clean_call = by == 1 ? f == 0.0 : f <= 1e-6;
+        if (seq != s->lk.seen_seq) {
+            s->lk.seen_seq = seq;
+            s->lk.clean = clean_call ? s->lk.clean + 1 : 0;
+        }
+        const bool flags_ok = clean_call && s->lk.clean >= 2;
+        // keyed (0) and tile flags (3) tally PROBES that missed, the return trip (1) KEYS answered absent (each misses one probe or more).
+        // Tile flags pay a direct re-check of every ~2000-key tile that holds one miss: only while (almost) nothing misses -- one probe
+        // in a million flags ~1 % of the tiles.  Keyed probes pay a scattered byte store per miss: beyond ~1/4 of the probes the return
+        // trip, whose cost does not depend on the answers, is cheaper.
+        if (by == 1) s->lk.mode = flags_ok ? 3 : (f < 0.12 ? 0 : 1);
+        else s->lk.mode = flags_ok ? 3 : (f > 0.22 ? 1 : 0);
     }
     return s->lk.mode;
 }
@@ -166,6 +248,10 @@ int PSK_VARIANT(bloom_check_partitioned)(psk_sketch *s, const Batch &b, uint8_t 
         PSK_TRY(bloom_check_return_trip(s, b, out_dev, st, done));
         if (*done) return publish_tally(s, b.n, 1, st);
         // (not eligible -- e.g. a tile too large for 16-bit stage positions: the keyed kernels below take the batch)
+    }
+    if (scheme == 3) {
+        PSK_TRY(bloom_check_tile_flags(s, b, out_dev, st, done));
+        if (*done) return PSK_OK;  // (the finishing kernel of the last round has published the tally)
     }
     *done = false;
     PartGeom g;

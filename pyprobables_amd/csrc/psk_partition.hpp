@@ -130,6 +130,11 @@ template <class Pay>
 struct pay_is_lookup<Pay, decltype((void)Pay::lookup)> { static constexpr bool value = Pay::lookup; };
 
 template <class Pay, class = void>
+struct pay_tile_tag { static constexpr bool value = false; };
+template <class Pay>
+struct pay_tile_tag<Pay, decltype((void)Pay::tile_tag)> { static constexpr bool value = Pay::tile_tag; };
+
+template <class Pay, class = void>
 struct pay_is_phased { static constexpr bool value = false; };
 template <class Pay>
 struct pay_is_phased<Pay, decltype((void)Pay::phased)> { static constexpr bool value = Pay::phased; };
@@ -185,6 +190,19 @@ struct PayNone {   // Bloom insert: 6 probes per group, 20-bit slice-local bit i
     static constexpr int mode = kModePlain;
     static constexpr int group = 6;
     static constexpr bool fat512 = true;  // PartTile: two 512-thread workgroups per CU with 32 probes per thread (measured: -3.5 %)
+    __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
+};
+// Bloom lookups of batches whose keys are (nearly) all present (round 5): PayNone's 2.67-byte probes -- the lookup's pass 1 is then the
+// insert's, not the keyed one with its 4-byte probes -- and the two spare bits of each half's count nibble spell the tile's ORDINAL inside
+// its workgroup's sequence (tile = ordinal * workgroups + the segment's workgroup, as for PayKeyId: at most 16 tiles per workgroup and
+// round).  A hit needs no way back to its key: pass 2 (k_bloom_test_flag) only raises tileflag[tile] when a probe of the tile finds its bit
+// clear, and k_bloom_flag_finish answers every key of an unflagged tile "present" and re-checks the keys of a flagged one directly.
+struct PayTileTag {
+    static constexpr int mode = kModePlain;
+    static constexpr int group = 6;
+    static constexpr bool fat512 = true;
+    static constexpr bool tile_tag = true;
+    static constexpr uint32_t max_tiles_per_wg = 16;
     __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
 };
 struct PayUnitMasked {  // PayNone's probes, for the keys with amount[i] != 0 only: the decrement of the validated CBF remove, whose
@@ -315,6 +333,16 @@ struct SpillBloomTest {  // lookup probe: test it directly (bloom.py:269-271); `
     }
 };
 
+struct SpillBloomFlag {  // PayTileTag probe of an overflowing segment: test it directly (bloom.py:269-271), a clear bit flags the probe's tile
+    const uint32_t *tab;
+    uint32_t *tileflag;
+    uint32_t gen;  // the round's generation number: "flagged" = holds this value (k_bloom_test_flag)
+    __device__ __forceinline__ void operator()(uint32_t idx, uint32_t tile) const
+    {
+        if (((tab[idx >> 5] >> (idx & 31)) & 1u) == 0) tileflag[tile] = gen;
+    }
+};
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a fence, for which hipcc emits
 // s_waitcnt vmcnt(0): every barrier of pass 1 would then drain the key prefetch (a full HBM latency per tile)
 // and the previous tile's write-out stores.  Pass 1 exchanges data between waves through LDS only.
@@ -419,8 +447,10 @@ __device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t
                 auto fld = [&](uint32_t x) -> unsigned long long {
                     return WP ? (unsigned long long)(((x & mask) | ((x >> kSmallWeightShift) << 15)) & ~(uint32_t)((int32_t)x >> 31)) : (unsigned long long)(x & mask);
                 };
-                const unsigned long long h0 = fld(c[0]) | (fld(c[1]) << 20) | ((fld(c[2]) & 0xFFFFFull) << 40) | ((unsigned long long)n0 << 60);
-                const unsigned long long h1 = fld(c[3]) | (fld(c[4]) << 20) | ((fld(c[5]) & 0xFFFFFull) << 40) | ((unsigned long long)n1 << 60);
+                // (PayTileTag: `tile` is the tile's ordinal inside this workgroup's sequence, two bits of it above each half's count)
+                const uint32_t t0 = pay_tile_tag<Pay>::value ? ((uint32_t)tile & 3u) << 2 : 0u, t1 = pay_tile_tag<Pay>::value ? (uint32_t)tile & 12u : 0u;
+                const unsigned long long h0 = fld(c[0]) | (fld(c[1]) << 20) | ((fld(c[2]) & 0xFFFFFull) << 40) | ((unsigned long long)(n0 | t0) << 60);
+                const unsigned long long h1 = fld(c[3]) | (fld(c[4]) << 20) | ((fld(c[5]) & 0xFFFFFull) << 40) | ((unsigned long long)(n1 | t1) << 60);
                 o = make_uint4((uint32_t)h0, (uint32_t)(h0 >> 32), (uint32_t)h1, (uint32_t)(h1 >> 32));
             } else {
                 auto h16 = [&](uint32_t x) -> uint32_t { return (x & mask) | ((uint32_t)((int32_t)x >> 31) & 0xFFFFu); };  // pad (all ones) -> 0xFFFF
@@ -433,6 +463,7 @@ __device__ __forceinline__ void emit_group(const uint32_t *stage, const uint32_t
             for (int e = 0; e < GS; ++e)
                 if (c[e] != kPadProbe) {
                     if constexpr (WP) spill(c[e] & kSmallCellMask, c[e] >> kSmallWeightShift);
+                    else if constexpr (pay_tile_tag<Pay>::value) spill(c[e], (uint32_t)tile * gridDim.x + blockIdx.x);
                     else spill(c[e], 0u);
                 }
         }
@@ -791,7 +822,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         if (!(dbg & 1)) {
             const uint32_t ngroups = tile_probes / GS;
             for (uint32_t gi = threadIdx.x; gi < ngroups; gi += NT) {
-                emit_group<Pay, Spill>(stage, gb, delta, g, mask, gi, Pay::mode == kModeKeyed ? (uint64_t)ordinal : tile, base, spill, wg_buckets);
+                emit_group<Pay, Spill>(stage, gb, delta, g, mask, gi, (Pay::mode == kModeKeyed || pay_tile_tag<Pay>::value) ? (uint64_t)ordinal : tile, base, spill, wg_buckets);
             }
         }
         // (pipelined form) no barrier needed here: the next iteration touches only hist (last read two barriers
@@ -1367,6 +1398,117 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint3
             for (int w = 0; w < kApplyWaves; ++w) t += smem[w];
             if (t) atomicAdd(miss_ctr, t);
         }
+    }
+}
+
+// Bloom lookup, tile-flag scheme (round 5; PayTileTag): the probes are the insert's 6 x 20-bit groups, so pass 1 and the probe stream cost what
+// the insert's do (18.7 instead of 28 bytes per key).  A probe that finds its bit SET needs no way back to its key; one that finds it clear
+// flags its tile: tileflag[tile] = gen, the round's generation number (plain stores of the same value; a flag of an older round is not a
+// flag, so nothing ever resets them; the tile = ordinal in the groups' spare bits x workgroups + the segment's workgroup).
+// k_bloom_flag_finish then answers whole tiles.  miss_ctr as in k_bloom_test (probes that found their bit clear).
+constexpr int kFlagDepth = 8;  // 16-byte groups in flight per lane: 8 x (4 + 6 LDS words) registers
+static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test_flag(const uint32_t *tab, uint64_t tab_words, PartGeom g,
+                                                                   const uint32_t *segcnt, const uint4 *buckets, uint32_t *tileflag, uint32_t gen,
+                                                                   unsigned long long *miss_ctr)
+{
+    uint32_t nmiss = 0;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t b = blockIdx.x;
+    const uint32_t slice_words = 1u << (g.shift - 5);
+    const uint64_t w0 = (uint64_t)b * slice_words;
+    const uint32_t mycnt = lane_segment_count(segcnt, g, b);  // (requested before the slice: see lane_segment_count)
+    load_slice(smem, tab, tab_words, w0, slice_words, (g.dbg & kGeomNtBit) != 0);
+    __syncthreads();
+    for_each_batch_at<kFlagDepth>(buckets, segcnt, g, b, make_uint4(0, 0, 0, 0), [&](const uint4 (&q)[kFlagDepth], const uint64_t (&)[kFlagDepth],
+                                                                                   const uint32_t (&wg)[kFlagDepth]) {
+        // a pad field (all ones inside the slice) and the fields of an absent group (all zero, counts 0) address the slice: every read is safe
+        uint32_t f[kFlagDepth][6], w[kFlagDepth][6];
+#pragma unroll
+        for (int d = 0; d < kFlagDepth; ++d) {
+            f[d][0] = q[d].x & 0xFFFFFu;
+            f[d][1] = __builtin_amdgcn_alignbit(q[d].y, q[d].x, 20) & 0xFFFFFu;
+            f[d][2] = (q[d].y >> 8) & 0xFFFFFu;
+            f[d][3] = q[d].z & 0xFFFFFu;
+            f[d][4] = __builtin_amdgcn_alignbit(q[d].w, q[d].z, 20) & 0xFFFFFu;
+            f[d][5] = (q[d].w >> 8) & 0xFFFFFu;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) w[d][e] = smem[f[d][e] >> 5];
+        }
+#pragma unroll
+        for (int d = 0; d < kFlagDepth; ++d) {
+            uint32_t clear = 0;  // bit e: probe e's table bit is clear
+#pragma unroll
+            for (int e = 0; e < 6; ++e) clear |= (((w[d][e] >> (f[d][e] & 31)) & 1u) ^ 1u) << e;
+            const uint32_t n0 = (q[d].y >> 28) & 3u, n1 = (q[d].w >> 28) & 3u;
+            const uint32_t valid = ((1u << n0) - 1u) | (((1u << n1) - 1u) << 3);
+            clear &= valid;
+            if (clear) {  // rare on the batches this scheme is chosen for
+                nmiss += (uint32_t)__builtin_popcount(clear);
+                const uint32_t ordinal = (q[d].y >> 30) | ((q[d].w >> 30) << 2);
+                tileflag[ordinal * g.nwg + wg[d]] = gen;
+            }
+        }
+    }, mycnt);
+    if (miss_ctr) {  // one atomic per workgroup
+        for (int o = 32; o > 0; o >>= 1) nmiss += __shfl_down(nmiss, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = nmiss;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (int w = 0; w < kApplyWaves; ++w) t += smem[w];
+            if (t) atomicAdd(miss_ctr, t);
+        }
+    }
+}
+
+// Last step of the tile-flag lookup: the keys of a tile none of whose probes met a clear bit are present; the keys of a flagged tile are
+// checked one by one against the table (bloom.py:261-272: the direct kernel's loop) -- exact whatever the batch holds, fast when flagged
+// tiles are rare.  One workgroup per kFinishKeys keys of one tile (a flagged tile is shared by several workgroups: its gathers are
+// latency-bound).  publish (last round of a call under the automatic scheme choice): workgroup 0 copies the call's miss tally to the
+// pinned page the next call's choice reads (what the one-thread k_lookup_publish launch does for the other schemes).
+constexpr int kFinishThreads = 256, kFinishKeys = 512;
+struct LookupPublish {
+    unsigned long long *tally = nullptr;         // device: [0] misses of the call
+    volatile unsigned long long *pin = nullptr;  // pinned host page: see psk_sketch::lk
+    unsigned long long units = 0, scheme = 0;
+};
+template <class Src, bool POW2>
+__global__ __launch_bounds__(kFinishThreads) void k_bloom_flag_finish(Src src, const uint32_t *tab, Mod md, uint32_t k, const uint32_t *tileflag, uint32_t gen,
+                                                                      uint32_t tile, uint32_t chunks, uint64_t n, uint8_t *out, LookupPublish pub)
+{
+    if (pub.tally && blockIdx.x == 0 && threadIdx.x == 0) {
+        pub.pin[1] = pub.units;
+        pub.pin[2] = pub.scheme;
+        pub.pin[0] = pub.tally[0];
+        pub.pin[3] = pub.pin[3] + 1;
+        pub.tally[0] = 0;
+    }
+    const uint32_t t = blockIdx.x / chunks, c = blockIdx.x - t * chunks;
+    const uint64_t tbase = (uint64_t)t * tile;
+    const uint32_t tcnt = (uint32_t)(n - tbase < tile ? n - tbase : tile);   // keys of this tile
+    const uint32_t lo = c * kFinishKeys;
+    if (lo >= tcnt) return;
+    const uint32_t cnt = tcnt - lo < (uint32_t)kFinishKeys ? tcnt - lo : (uint32_t)kFinishKeys;
+    const uint64_t base = tbase + lo;
+    const bool flagged = __builtin_amdgcn_readfirstlane(tileflag[t]) == gen;
+    if (!flagged) {
+        uint8_t *o = out + base;
+        if (((uintptr_t)o & 3) == 0) {
+            for (uint32_t i = threadIdx.x * 4; i + 4 <= cnt; i += kFinishThreads * 4) *reinterpret_cast<uint32_t *>(o + i) = 0x01010101u;
+            for (uint32_t i = (cnt & ~3u) + threadIdx.x; i < cnt; i += kFinishThreads) o[i] = 1;
+        } else {
+            for (uint32_t i = threadIdx.x; i < cnt; i += kFinishThreads) o[i] = 1;
+        }
+        return;
+    }
+    BloomCheck<POW2> op{tab, md, k, out};
+    for (uint32_t j = threadIdx.x; j < cnt; j += kFinishThreads) {
+        const uint64_t i = base + j;
+        const typename Src::Key key = src.load(i);
+        typename BloomCheck<POW2>::State st = op.begin(i);
+        for_each_hash(src, key, i, k, [&](uint32_t jj, uint64_t h) { op.apply(st, jj, h); });
+        op.end(st, i);
     }
 }
 

@@ -424,7 +424,7 @@ def test_pass2_segment_walks_agree_with_the_oracle(pa, oracle, force_partition, 
             blm.add_many(dk[n // 3:])
             ob.add_keys(keys)
             assert np.array_equal(_table(blm), ob.bloom)
-            for scheme in (0, 1):
+            for scheme in (0, 1, 3):
                 force_partition.set_option("bloom_lookup", scheme)
                 assert np.array_equal(blm.check_many(dk).cpu().numpy().astype(np.uint8), ob.check_keys(keys))
                 assert np.array_equal(blm.check_many(df).cpu().numpy().astype(np.uint8), ob.check_keys(fresh))
@@ -605,10 +605,11 @@ def test_cbf_unchecked_remove_direct_and_partitioned_agree(pa, oracle, force_par
 
 
 # ------------------------------------------------------------------ Bloom lookups: return trip vs keyed probes
-@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("mode", [1, 0, 3])
 def test_bloom_lookup_modes_vs_oracle(pa, oracle, force_partition, mode):
-    """option bloom_lookup: 1 = pass 1 with perm / runinfo + k_bloom_gather + k_bloom_collect (default), 0 = keyed probes +
-    k_bloom_test; both against the oracle over hits, misses, k classes, table sizes, layouts, rounds and segment overflow"""
+    """option bloom_lookup: 1 = pass 1 with perm / runinfo + k_bloom_gather + k_bloom_collect, 0 = keyed probes + k_bloom_test, 3 = the
+    insert's compact probes + a flag per tile that met a clear bit + k_bloom_flag_finish (round 5); all against the oracle over hits, misses,
+    k classes, table sizes, layouts, rounds and segment overflow"""
     force_partition.set_option("bloom_lookup", mode)
     try:
         n = 160_000
@@ -644,8 +645,26 @@ def test_bloom_lookup_modes_vs_oracle(pa, oracle, force_partition, mode):
         ob.add_hashes(hs[:20_000])
         assert np.array_equal(np.asarray(blm.check_many(words)).astype(np.uint8), ob.check_hashes(hs))
         assert np.array_equal(np.asarray(blm.check_alt_many(hs)).astype(np.uint8), ob.check_hashes(hs))
+        if mode == 3:
+            # what the scheme is for: every key present (no tile flagged), then ONE absent key in the middle (one tile re-checked), several
+            # rounds of 16 tiles per workgroup, and the flags left clean for the next call
+            blm = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01)
+            ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+            blm.add_many(_dev(keys))
+            ob.add_keys(keys)
+            assert blm.check_many(_dev(keys)).cpu().numpy().all()
+            one = keys.copy()
+            one[77_777] = fresh[0]
+            want = ob.check_keys(one)
+            assert not want[77_777]
+            assert np.array_equal(blm.check_many(_dev(one)).cpu().numpy().astype(np.uint8), want)
+            assert blm.check_many(_dev(keys)).cpu().numpy().all()
+            force_partition.set_option("partition_max_keys", 40_000)
+            assert np.array_equal(blm.check_many(_dev(one)).cpu().numpy().astype(np.uint8), want)
+            force_partition.set_option("partition_max_keys", 1 << 25)
+            assert np.array_equal(blm.check_many(_dev(one[:-5])).cpu().numpy().astype(np.uint8), want[:-5])
     finally:
-        force_partition.set_option("bloom_lookup", 1)
+        force_partition.set_option("bloom_lookup", 2)
 
 
 def test_bloom_lookup_auto_mode_follows_the_miss_rate_and_stays_exact(pa, oracle, force_partition):
