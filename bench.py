@@ -575,7 +575,7 @@ class Cfg2:
         if not overlapped:
             launches["bloom_check"] = roofline(
                 "bloom_check", "Bloom lookup of present keys = k_part_scatter<KeysFixed16,IdxBloom<pow2>,PayTileTag,SpillBloomFlag,7> + k_bloom_test_flag + "
-                "k_bloom_flag_finish (tile flags; keyed probes / return trip for batches with absent keys: detail.check_*_fresh)",
+                "k_bloom_flag_resolve (tile flags; keyed probes / return trip for batches with absent keys: detail.check_*_fresh)",
                 n, chk_ms, "pass 1 is the insert's (hash + LDS counting sort, 2.67-byte probes); pass 2 streams the probes back "
                 "from the Infinity Cache against an LDS-resident slice")
         rooflines = {k: v for k, v in launches.items() if k != "bloom_insert"}
@@ -595,7 +595,7 @@ class Cfg2:
             },
             "roofline": step_roofline(
                 "one timed STEP = clear + Bloom insert (k_part_scatter + k_bloom_apply) + " + ("allreduce(OR) + " if ctx.distributed else "") +
-                "Bloom lookup (k_part_scatter + k_bloom_test_flag + k_bloom_flag_finish); avg_kernel_ms = HIP events around whole steps of the timed region",
+                "Bloom lookup (k_part_scatter + k_bloom_test_flag + k_bloom_flag_resolve); avg_kernel_ms = HIP events around whole steps of the timed region",
                 n, step_ms, launches,
                 "both pass 1s are co-limited by VALU (the k FNV-1a chains, ~75 of ~130 us) and the LDS counting sort, not by HBM; the pass 2s "
                 "stream the probes back at 4-5 TB/s"),

@@ -79,6 +79,11 @@ def _compile(item, force: bool, verbose: bool, objdir: Path, extra: list) -> Pat
     extra = [*extra, *flags]
     obj = objdir / (stem + ".o")
     dep = max([(CSRC / src).stat().st_mtime] + [f.stat().st_mtime for f in _deps(CSRC / src)])
+    # PSK_BUILD_ONLY="bloom_check,capi" (development only): recompile just the matching units, keep the other objects as they are -- for
+    # experiments inside one kernel family; never for a change of anything two units share (psk_sketch, PartGeom, the launchers' signatures)
+    only = [t for t in os.environ.get("PSK_BUILD_ONLY", "").split(",") if t]
+    if only and obj.exists() and not any(t in stem for t in only):
+        return obj
     if force or not obj.exists() or obj.stat().st_mtime < dep:
         cmd = [hipcc(), *FLAGS, *extra, "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:

@@ -142,12 +142,14 @@ extern "C" int psk_cms_create(uint64_t width, uint32_t depth, int device, void *
                          device, ext_table, out);
 }
 
+static inline void ho_apply(const psk_sketch *s);  // (the handle's option overrides -> this thread's effective values; defined with the options below)
 extern "C" int psk_destroy(psk_sketch *s)
 {
     if (!s) return PSK_OK;
     DeviceScope scope;
     (void)scope.enter(s->device);
     if (!s->owns_table && s->table) {  // the caller's table outlives the handle: write-combined updates still waiting must reach it
+        ho_apply(s);  // (under THIS sketch's options, not those of whatever handle the thread used last: remove_exact, update_window ...)
         if (flush_combined(s, nullptr) == PSK_OK) (void)hipStreamSynchronize(nullptr);
     }
     if (s->owns_table && s->table) hipFree(s->table);
@@ -1147,9 +1149,38 @@ static int win_flush(psk_sketch *s, hipStream_t st)
     return win_replay(s, keys, batches, st);
 }
 
-// hand a batch over to the window (eligible: win_eligible); host batches are copied straight from the caller's buffer
-static int win_append(psk_sketch *s, const void *data, uint64_t n, bool remove, int where, hipStream_t st)
+// Room for `want` keys in the window's key list (16 bytes each).  The list grows in steps -- 2^22 keys (64 MiB) first, then doubling up to
+// the window's capacity, the waiting keys copied over -- instead of cap x 16 bytes (2 GiB for a 2^28-counter table) on the first small
+// batch.  *ok = false: the memory is not there (the HIP error is cleared): the caller takes the paths that need no list.
+static int win_reserve(psk_sketch *s, uint64_t want, uint64_t cap, hipStream_t st, bool *ok)
 {
+    *ok = true;
+    if (want * 16 <= s->win.keys.cap) return PSK_OK;
+    uint64_t keys = s->win.keys.cap / 16 ? s->win.keys.cap / 16 : (1ULL << 22);
+    while (keys < want) keys *= 2;
+    if (keys > cap) keys = cap;
+    void *p = nullptr;
+    if (hipMalloc(&p, keys * 16) != hipSuccess) {
+        (void)hipGetLastError();
+        *ok = false;
+        return PSK_OK;
+    }
+    if (s->win.n) {
+        PSK_TRY(comb_order(s, st));
+        HIP_TRY(hipMemcpyAsync(p, s->win.keys.p, s->win.n * 16, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));  // (the old list is freed below)
+    }
+    if (s->win.keys.p) HIP_TRY(hipFree(s->win.keys.p));
+    s->win.keys.p = p;
+    s->win.keys.cap = keys * 16;
+    return PSK_OK;
+}
+
+// hand a batch over to the window (eligible: win_eligible); host batches are copied straight from the caller's buffer.
+// *taken = false: no memory for the key list -- nothing was appended, what waited has been applied, the caller applies this batch itself.
+static int win_append(psk_sketch *s, const void *data, uint64_t n, bool remove, int where, hipStream_t st, bool *taken)
+{
+    *taken = true;
     const uint64_t cap = win_capacity(s);
     if (s->win.cap != cap && s->win.n) PSK_TRY(win_flush(s, st));
     if (s->win.n + n > cap || s->win.batches.size() >= kWinMaxBatches) PSK_TRY(win_flush(s, st));
@@ -1159,7 +1190,16 @@ static int win_append(psk_sketch *s, const void *data, uint64_t n, bool remove, 
         if (phases >= (size_t)kWinMaxPhases) PSK_TRY(win_flush(s, st));
     }
     s->win.cap = cap;
-    PSK_TRY(ensure(s->win.keys, cap * 16));  // full capacity at once: growing would drop the waiting keys
+    bool room = false;
+    PSK_TRY(win_reserve(s, s->win.n + n, cap, st, &room));
+    if (!room && s->win.n) {  // what waits fits what there is: apply it, then this batch may fit too
+        PSK_TRY(win_flush(s, st));
+        room = n * 16 <= s->win.keys.cap;
+    }
+    if (!room) {
+        *taken = false;
+        return PSK_OK;
+    }
     PSK_TRY(comb_order(s, st));
     // (round 4: an own copy kernel with nontemporal loads / stores measured slower than the runtime's blit: 3.60 vs 3.55 ms per cfg-4 step)
     HIP_TRY(hipMemcpyAsync((uint8_t *)s->win.keys.p + s->win.n * 16, data, n * 16, where == PSK_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
@@ -1258,6 +1298,9 @@ extern "C" int psk_cbf_update_combined(psk_sketch *s, int layout, const void *da
     if (where != PSK_HOST && where != PSK_DEVICE && where != PSK_DEVICE_BORROWED) return fail(PSK_EINVAL, "`where` must be PSK_HOST, PSK_DEVICE or PSK_DEVICE_BORROWED");
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) return PSK_OK;
+    // Batches that wait in the update window (psk_cbf_add / psk_cbf_remove on this handle) arrived EARLIER than this one: they reach the
+    // table first.  (flush_combined applies the lists below before the window: the window may only ever hold what came after them.)
+    if (s->win.n) PSK_TRY(flush_combined(s, st));
     const uint64_t cap = g_combine_keys > 0 ? (uint64_t)g_combine_keys : 0;
     if (where == PSK_DEVICE_BORROWED) {
         // 16-byte unit-weight keys into a table with the nibble geometry: remember WHERE they are, nothing else.  The flush hashes all
@@ -1335,7 +1378,9 @@ extern "C" int psk_cbf_add(psk_sketch *s, int layout, const void *data, const ui
     if (win_eligible(s, layout, data, key_len, weights, n)) {
         // (what the older write-combining mechanisms hold arrived earlier: it goes first)
         if (s->comb.add.n || s->comb.rem.n || s->comb.badd.n() || s->comb.brem.n() || (s->scat.ready && (s->scat.add.n || s->scat.rem.n))) PSK_TRY(flush_combined(s, st));
-        return win_append(s, data, n, false, where, st);
+        bool taken = false;
+        PSK_TRY(win_append(s, data, n, false, where, st, &taken));
+        if (taken) return PSK_OK;  // (else: no memory for the window's key list -- the batch goes on below like any other)
     }
     Batch b;
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
@@ -1544,7 +1589,9 @@ extern "C" int psk_cbf_remove(psk_sketch *s, int layout, const void *data, const
         // A small batch into a big table: it waits in the update window (with the adds around it, in order) for a shared pass over
         // the table; the flush proves that it would have removed every key at this point of the stream, or replays it right here.
         if (s->comb.add.n || s->comb.rem.n || s->comb.badd.n() || s->comb.brem.n() || (s->scat.ready && (s->scat.add.n || s->scat.rem.n))) PSK_TRY(flush_combined(s, st));
-        return win_append(s, data, n, true, where, st);
+        bool taken = false;
+        PSK_TRY(win_append(s, data, n, true, where, st, &taken));
+        if (taken) return PSK_OK;
     }
     PSK_TRY(flush_combined(s, st));  // write-combined updates reach the table before anything else touches it
     Batch b;
@@ -1972,6 +2019,7 @@ extern "C" int psk_release_scratch(psk_sketch *s)
     if (!s) return fail(PSK_EINVAL, "sketch handle is NULL");
     PSK_USE_DEVICE(s->device);
     if (s->pend.active) return fail(PSK_EINVAL, "a split lookup is pending: finish it before releasing the scratch buffers");
+    ho_apply(s);  // (what is waiting is applied under this sketch's own options)
     PSK_TRY(flush_combined(s, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     for (DevBuf *b : {&s->s_keys, &s->s_offs, &s->s_w, &s->s_out, &s->s_aux, &s->s_part, &s->s_cnt, &s->s_flag, &s->s_tflag, &s->s_part2, &s->s_cnt2, &s->s_merge, &s->s_vals, &s->s_perm, &s->s_run, &s->s_tally,

@@ -213,6 +213,8 @@ struct psk_sketch {
         Batch b{};            // device-resident batch (the caller keeps it alive until finish)
         PartGeom g{};
         uint64_t round_keys = 0;
+        int scheme = 0;       // 0 keyed probes, 3 tile flags
+        uint32_t gen = 0;     // tile flags: generation number of the scattered round
     } pend;
 };
 

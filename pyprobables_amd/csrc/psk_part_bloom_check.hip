@@ -121,72 +121,102 @@ static int bloom_check_return_trip(psk_sketch *s, const Batch &b, uint8_t *out_d
     return PSK_OK;
 }
 
-// Tile-flag lookups (round 5; PayTileTag, k_bloom_test_flag, k_bloom_flag_finish): for batches whose keys are (nearly) all present.  Pass 1 and
+// Tile-flag lookups (round 5; PayTileTag, k_bloom_test_flag, k_bloom_flag_resolve): for batches whose keys are (nearly) all present.  Pass 1 and
 // the probe stream are the insert's (2.67-byte probes, two 512-thread workgroups per CU, one round of up to 16 tiles per workgroup); pass 2
-// raises a flag per TILE that met a clear bit and the finishing kernel answers unflagged tiles wholesale, flagged ones key by key from the
-// table.  Exact for any batch; a batch with absent keys in most tiles costs the direct kernel's gathers on top -- the automatic choice
+// answers every key "present" and raises a flag per TILE that met a clear bit; the resolving kernel re-checks the keys of flagged tiles
+// against the table.  Exact for any batch; a batch with absent keys in most tiles costs the direct kernel's gathers on top -- the automatic choice
 // (choose_scheme) only comes here while the previous lookups on the handle missed (almost) nothing.
-static int bloom_check_tile_flags(psk_sketch *s, const Batch &b, uint8_t *out_dev, hipStream_t st, bool *done)
+// geometry and round size of a tile-flag lookup of b; false: not eligible
+static bool tile_flag_geometry(psk_sketch *s, const Batch &b, PartGeom *g, uint64_t *round_keys_out)
 {
-    *done = false;
-    if (!part_wanted(b.n, s->k, 4)) return PSK_OK;
-    PartGeom g;
-    if (!part_slices(s->m, 20, 7, &g)) return PSK_OK;
-    g.k = s->k;
+    if (!part_wanted(b.n, s->k, 4)) return false;
+    if (!part_slices(s->m, 20, 7, g)) return false;
+    g->k = s->k;
     uint64_t round_keys = part_round_keys_big_table(b.n, s->k, PayTileTag::group, s->padded_bytes);
-    {   // 4 bits of tile ordinal per group: at most 16 tiles per pass-1 workgroup and round
-        bool handled = false;
-        uint64_t cap = 0;
-        PSK_TRY(with_part_source(b, &handled, [&](auto src) {
+    // 4 bits of tile ordinal per group: at most 16 tiles per pass-1 workgroup and round
+    bool handled = false;
+    uint64_t cap = 0;
+    if (with_part_source(b, &handled, [&](auto src) {
             using Src = decltype(src);
             return with_kt<Src>(s->k, [&](auto kt) {
                 constexpr int KT = decltype(kt)::value;
-                cap = scatter_round_cap<PayTileTag, KT>(&g, 0, PayTileTag::max_tiles_per_wg);
+                cap = scatter_round_cap<PayTileTag, KT>(g, 0, PayTileTag::max_tiles_per_wg);
                 return (int)PSK_OK;
             });
-        }));
-        if (!handled || cap == 0) return PSK_OK;
-        if (round_keys > cap) {  // equal rounds
-            const uint64_t rounds = (b.n + cap - 1) / cap;
-            round_keys = ((b.n + rounds - 1) / rounds + 4095) & ~4095ULL;
-            if (round_keys > cap) round_keys = cap;
-        }
+        }) != PSK_OK || !handled || cap == 0) return false;
+    if (round_keys > cap) {  // equal rounds
+        const uint64_t rounds = (b.n + cap - 1) / cap;
+        round_keys = ((b.n + rounds - 1) / rounds + 4095) & ~4095ULL;
+        if (round_keys > cap) round_keys = cap;
     }
+    *round_keys_out = round_keys;
+    return true;
+}
+
+// pass 1 of one round (keys [0, cnt) of `sub`); defer: split lookup, the table is not consulted
+static int tile_flag_scatter(psk_sketch *s, const Batch &sub, uint64_t cnt, bool defer, PartGeom *g, uint32_t *gen_out, hipStream_t st, bool *handled)
+{
+    return with_part_source(sub, handled, [&](auto src) {
+        using Src = decltype(src);
+        return with_kt<Src>(s->k, [&](auto kt) {
+            constexpr int KT = decltype(kt)::value;
+            // one flag per tile; tiles are at least 64 keys (evened tiles are multiples of 64)
+            const uint64_t flag_bytes = (cnt / 64 + 2048) * 4;
+            if (flag_bytes > s->s_tflag.cap || s->tflag_gen == 0xFFFFFFFFu) {
+                PSK_TRY(ensure(s->s_tflag, flag_bytes));
+                HIP_TRY(hipMemsetAsync(s->s_tflag.p, 0, s->s_tflag.cap, st));  // once (and when the generation number wraps)
+                s->tflag_gen = 0;
+            }
+            const uint32_t gen = ++s->tflag_gen;
+            *gen_out = gen;
+            SpillBloomFlag spill{(const uint32_t *)s->table, (uint32_t *)s->s_tflag.p, gen, defer ? 1u : 0u};
+            return launch_scatter<Src, IdxBloom<kTuPow2>, PayTileTag, SpillBloomFlag, KT>(s, src, IdxBloom<kTuPow2>{s->md}, PayTileTag{}, spill, g, cnt, st);
+        });
+    });
+}
+
+// pass 2 + the re-check of flagged tiles for one scattered round; publish_units != 0: last round of a call, the tally goes to the pinned page
+static int tile_flag_test(psk_sketch *s, const Batch &sub, uint64_t cnt, const PartGeom &g, uint32_t gen, uint8_t *out, unsigned long long publish_units, hipStream_t st)
+{
+    bool handled = false;
+    PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
+        using Src = decltype(src);
+        uint32_t *tflag = (uint32_t *)s->s_tflag.p;
+        const size_t lds = (size_t)1 << (g.shift - 3);
+        PSK_TRY(set_dyn_lds(k_bloom_test_flag, lds));
+        hipLaunchKernelGGL(k_bloom_test_flag, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (const uint32_t *)s->table, s->padded_bytes / 4, g,
+                           (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, tflag, gen, s->lk.dev, out, cnt);
+        HIP_TRY(hipGetLastError());
+        const uint64_t ntiles = (cnt + g.tile - 1) / g.tile;
+        LookupPublish pub;
+        if (publish_units && g_bloom_lookup == 2 && s->lk.dev) pub = LookupPublish{s->lk.dev, s->lk.pin, publish_units, 3};
+        hipLaunchKernelGGL((k_bloom_flag_resolve<Src, kTuPow2>), dim3((unsigned)(ntiles < 1024 ? ntiles : 1024)), dim3(kResolveThreads), 0, st, src,
+                           (const uint32_t *)s->table, s->md, s->k, (const uint32_t *)tflag, gen, g.tile, cnt, out, pub);
+        HIP_TRY(hipGetLastError());
+        return (int)PSK_OK;
+    }));
+    return handled ? (int)PSK_OK : fail(PSK_EHIP, "tile-flag lookup: layout lost its partitioned instantiation");
+}
+
+// Tile-flag lookups (round 5; PayTileTag, k_bloom_test_flag, k_bloom_flag_resolve): for batches whose keys are (nearly) all present.  Pass 1 and
+// the probe stream are the insert's (2.67-byte probes, two 512-thread workgroups per CU, one round of up to 16 tiles per workgroup); pass 2
+// answers every key "present" and raises a flag per TILE that met a clear bit; the resolving kernel re-checks the keys of flagged tiles
+// against the table.  Exact for any batch; a batch with absent keys in most tiles costs the direct kernel's gathers on top -- the automatic
+// choice (choose_scheme) only comes here while the previous lookups on the handle missed (almost) nothing.
+static int bloom_check_tile_flags(psk_sketch *s, const Batch &b, uint8_t *out_dev, hipStream_t st, bool *done)
+{
+    *done = false;
+    PartGeom g;
+    uint64_t round_keys = 0;
+    if (!tile_flag_geometry(s, b, &g, &round_keys)) return PSK_OK;
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
         const Batch sub = sub_batch(b, start, cnt);
         bool handled = false;
-        PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
-            using Src = decltype(src);
-            return with_kt<Src>(s->k, [&](auto kt) {
-                constexpr int KT = decltype(kt)::value;
-                // one flag per tile; tiles are at least 64 keys (evened tiles are multiples of 64)
-                const uint64_t flag_bytes = (cnt / 64 + 2048) * 4;
-                if (flag_bytes > s->s_tflag.cap || s->tflag_gen == 0xFFFFFFFFu) {
-                    PSK_TRY(ensure(s->s_tflag, flag_bytes));
-                    HIP_TRY(hipMemsetAsync(s->s_tflag.p, 0, s->s_tflag.cap, st));  // once (and when the generation number wraps)
-                    s->tflag_gen = 0;
-                }
-                const uint32_t gen = ++s->tflag_gen;
-                uint32_t *tflag = (uint32_t *)s->s_tflag.p;
-                SpillBloomFlag spill{(const uint32_t *)s->table, tflag, gen};
-                PSK_TRY((launch_scatter<Src, IdxBloom<kTuPow2>, PayTileTag, SpillBloomFlag, KT>(s, src, IdxBloom<kTuPow2>{s->md}, PayTileTag{}, spill, &g, cnt, st)));
-                const size_t lds = (size_t)1 << (g.shift - 3);
-                PSK_TRY(set_dyn_lds(k_bloom_test_flag, lds));
-                hipLaunchKernelGGL(k_bloom_test_flag, dim3(g.nbuckets), dim3(kApplyThreads), lds, st, (const uint32_t *)s->table, s->padded_bytes / 4, g,
-                                   (const uint32_t *)s->s_cnt.p, (const uint4 *)s->s_part.p, tflag, gen, s->lk.dev);
-                HIP_TRY(hipGetLastError());
-                const uint64_t ntiles = (cnt + g.tile - 1) / g.tile;
-                const uint32_t chunks = (g.tile + kFinishKeys - 1) / kFinishKeys;
-                LookupPublish pub;
-                if (start + cnt == b.n && g_bloom_lookup == 2 && s->lk.dev) pub = LookupPublish{s->lk.dev, s->lk.pin, b.n * (uint64_t)s->k, 3};
-                hipLaunchKernelGGL((k_bloom_flag_finish<Src, kTuPow2>), dim3((unsigned)(ntiles * chunks)), dim3(kFinishThreads), 0, st, src,
-                                   (const uint32_t *)s->table, s->md, s->k, (const uint32_t *)tflag, gen, g.tile, chunks, cnt, out_dev + start, pub);
-                HIP_TRY(hipGetLastError());
-                return (int)PSK_OK;
-            });
-        }));
+        uint32_t gen = 0;
+        PSK_TRY(tile_flag_scatter(s, sub, cnt, false, &g, &gen, st, &handled));
         if (!handled) return start == 0 ? (int)PSK_OK : fail(PSK_EHIP, "tile-flag lookup: layout lost its partitioned instantiation");
+        PSK_TRY(tile_flag_test(s, sub, cnt, g, gen, out_dev + start, start + cnt == b.n ? b.n * (uint64_t)s->k : 0ULL, st));
     }
     *done = true;
     return PSK_OK;
@@ -279,6 +309,21 @@ int PSK_VARIANT(bloom_check_begin_partitioned)(psk_sketch *s, const Batch &b, hi
     s->pend.active = true;
     s->pend.scattered = false;
     s->pend.b = b;
+    s->pend.scheme = 0;
+    if (!part_wanted(b.n, s->k, 4)) return PSK_OK;
+    const int scheme = choose_scheme(s, st);
+    if (scheme < 0) return scheme;
+    if (scheme == 3 && tile_flag_geometry(s, b, &s->pend.g, &s->pend.round_keys)) {
+        // tile flags: a probe of an overflowing segment cannot be tested yet -- it flags its tile, whose keys the finish re-checks
+        const uint64_t cnt = b.n < s->pend.round_keys ? b.n : s->pend.round_keys;
+        bool handled = false;
+        PSK_TRY(tile_flag_scatter(s, sub_batch(b, 0, cnt), cnt, true, &s->pend.g, &s->pend.gen, st, &handled));
+        if (handled) {
+            s->pend.scattered = true;
+            s->pend.scheme = 3;
+            return PSK_OK;
+        }
+    }
     if (!check_geometry(s, b.n, &s->pend.g, &s->pend.round_keys)) return PSK_OK;
     PSK_TRY(ensure(s->s_flag, 8));
     uint32_t *flag = (uint32_t *)s->s_flag.p;
@@ -299,8 +344,22 @@ int PSK_VARIANT(bloom_check_finish_partitioned)(psk_sketch *s, uint8_t *out_dev,
     if (!s->pend.scattered) return PSK_OK;
     const uint64_t round_keys = s->pend.round_keys;
     const uint64_t cnt0 = b.n < round_keys ? b.n : round_keys;
+    if (s->pend.scheme == 3) {
+        PartGeom g = s->pend.g;
+        PSK_TRY(tile_flag_test(s, sub_batch(b, 0, cnt0), cnt0, g, s->pend.gen, out_dev, cnt0 == b.n ? b.n * (uint64_t)s->k : 0ULL, st));
+        for (uint64_t start = cnt0; start < b.n; start += round_keys) {
+            const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
+            const Batch sub = sub_batch(b, start, cnt);
+            bool handled = false;
+            uint32_t gen = 0;
+            PSK_TRY(tile_flag_scatter(s, sub, cnt, false, &g, &gen, st, &handled));
+            if (!handled) return fail(PSK_EHIP, "split lookup: layout lost its partitioned instantiation");
+            PSK_TRY(tile_flag_test(s, sub, cnt, g, gen, out_dev + start, start + cnt == b.n ? b.n * (uint64_t)s->k : 0ULL, st));
+        }
+        return PSK_OK;
+    }
     HIP_TRY(hipMemsetAsync(out_dev, 1, cnt0, st));
-    PSK_TRY(check_round_test(s, s->pend.g, out_dev, st));
+    PSK_TRY(check_round_test(s, s->pend.g, out_dev, st, s->lk.dev));
     *redo_flag_possible = true;
     PartGeom g = s->pend.g;
     for (uint64_t start = cnt0; start < b.n; start += round_keys) {
@@ -311,7 +370,7 @@ int PSK_VARIANT(bloom_check_finish_partitioned)(psk_sketch *s, uint8_t *out_dev,
         HIP_TRY(hipMemsetAsync(out, 1, cnt, st));
         PSK_TRY(check_round_scatter(s, sub, cnt, out, nullptr, &g, st, &handled));
         if (!handled) return fail(PSK_EHIP, "split lookup: layout lost its partitioned instantiation");
-        PSK_TRY(check_round_test(s, g, out, st));
+        PSK_TRY(check_round_test(s, g, out, st, s->lk.dev));
     }
-    return PSK_OK;
+    return publish_tally(s, b.n * (uint64_t)s->k, 0, st);
 }

@@ -196,7 +196,7 @@ struct PayNone {   // Bloom insert: 6 probes per group, 20-bit slice-local bit i
 // insert's, not the keyed one with its 4-byte probes -- and the two spare bits of each half's count nibble spell the tile's ORDINAL inside
 // its workgroup's sequence (tile = ordinal * workgroups + the segment's workgroup, as for PayKeyId: at most 16 tiles per workgroup and
 // round).  A hit needs no way back to its key: pass 2 (k_bloom_test_flag) only raises tileflag[tile] when a probe of the tile finds its bit
-// clear, and k_bloom_flag_finish answers every key of an unflagged tile "present" and re-checks the keys of a flagged one directly.
+// clear, and k_bloom_flag_resolve re-checks the keys of the flagged tiles directly.
 struct PayTileTag {
     static constexpr int mode = kModePlain;
     static constexpr int group = 6;
@@ -337,9 +337,11 @@ struct SpillBloomFlag {  // PayTileTag probe of an overflowing segment: test it 
     const uint32_t *tab;
     uint32_t *tileflag;
     uint32_t gen;  // the round's generation number: "flagged" = holds this value (k_bloom_test_flag)
+    uint32_t defer;  // split lookup (psk_bloom_check_begin): the table is not final yet -- flag the tile whatever the table says (it is then
+                     // re-checked key by key at the finish: exact)
     __device__ __forceinline__ void operator()(uint32_t idx, uint32_t tile) const
     {
-        if (((tab[idx >> 5] >> (idx & 31)) & 1u) == 0) tileflag[tile] = gen;
+        if (defer || ((tab[idx >> 5] >> (idx & 31)) & 1u) == 0) tileflag[tile] = gen;
     }
 };
 
@@ -1405,15 +1407,33 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test(const uint3
 // the insert's do (18.7 instead of 28 bytes per key).  A probe that finds its bit SET needs no way back to its key; one that finds it clear
 // flags its tile: tileflag[tile] = gen, the round's generation number (plain stores of the same value; a flag of an older round is not a
 // flag, so nothing ever resets them; the tile = ordinal in the groups' spare bits x workgroups + the segment's workgroup).
-// k_bloom_flag_finish then answers whole tiles.  miss_ctr as in k_bloom_test (probes that found their bit clear).
+// k_bloom_flag_resolve then re-checks the flagged tiles.  miss_ctr as in k_bloom_test (probes that found their bit clear).
 constexpr int kFlagDepth = 8;  // 16-byte groups in flight per lane: 8 x (4 + 6 LDS words) registers
+// out[0 .. n): the round's answers; every workgroup first presets its share to 1 ("present") -- fire-and-forget stores under its slice
+// load, instead of a fill launch -- and k_bloom_flag_resolve, the next kernel, overwrites the answers of the flagged tiles' keys.
 static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test_flag(const uint32_t *tab, uint64_t tab_words, PartGeom g,
                                                                    const uint32_t *segcnt, const uint4 *buckets, uint32_t *tileflag, uint32_t gen,
-                                                                   unsigned long long *miss_ctr)
+                                                                   unsigned long long *miss_ctr, uint8_t *out, uint64_t n)
 {
     uint32_t nmiss = 0;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = blockIdx.x;
+    {   // my share of out[]: 16-byte pieces between the 16-byte boundaries of the buffer, single bytes at its two ends
+        const uintptr_t a0 = (uintptr_t)out, a1 = a0 + n;
+        const uintptr_t m0 = (a0 + 15) & ~(uintptr_t)15, m1 = a1 & ~(uintptr_t)15;
+        if (m0 < m1) {
+            const uint64_t pieces = (m1 - m0) >> 4, per = (pieces + gridDim.x - 1) / gridDim.x;
+            const uint64_t lo = (uint64_t)b * per, hi = lo + per < pieces ? lo + per : pieces;
+            const uint4 ones = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+            for (uint64_t i = lo + threadIdx.x; i < hi; i += kApplyThreads) reinterpret_cast<uint4 *>(m0)[i] = ones;
+            if (b == 0) {
+                if (threadIdx.x < (uint32_t)(m0 - a0)) out[threadIdx.x] = 1;
+                if (threadIdx.x < (uint32_t)(a1 - m1)) reinterpret_cast<uint8_t *>(m1)[threadIdx.x] = 1;
+            }
+        } else if (b == 0) {
+            for (uint64_t i = threadIdx.x; i < n; i += kApplyThreads) out[i] = 1;
+        }
+    }
     const uint32_t slice_words = 1u << (g.shift - 5);
     const uint64_t w0 = (uint64_t)b * slice_words;
     const uint32_t mycnt = lane_segment_count(segcnt, g, b);  // (requested before the slice: see lane_segment_count)
@@ -1462,20 +1482,20 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test_flag(const 
     }
 }
 
-// Last step of the tile-flag lookup: the keys of a tile none of whose probes met a clear bit are present; the keys of a flagged tile are
-// checked one by one against the table (bloom.py:261-272: the direct kernel's loop) -- exact whatever the batch holds, fast when flagged
-// tiles are rare.  One workgroup per kFinishKeys keys of one tile (a flagged tile is shared by several workgroups: its gathers are
-// latency-bound).  publish (last round of a call under the automatic scheme choice): workgroup 0 copies the call's miss tally to the
-// pinned page the next call's choice reads (what the one-thread k_lookup_publish launch does for the other schemes).
-constexpr int kFinishThreads = 256, kFinishKeys = 512;
+// Last step of the tile-flag lookup: pass 2 has answered every key "present"; the keys of a FLAGGED tile are checked one by one against
+// the table here (bloom.py:261-272: the direct kernel's loop) -- exact whatever the batch holds, next to nothing when no tile is flagged
+// (every workgroup reads its few flags and leaves).  Workgroup w owns the tiles w, w + gridDim.x, ...
+// publish (last round of a call under the automatic scheme choice): workgroup 0 copies the call's miss tally to the pinned page the next
+// call's choice reads (what the one-thread k_lookup_publish launch does for the other schemes).
+constexpr int kResolveThreads = 1024;  // (a flagged tile is re-checked by ONE workgroup: two keys per thread, latency-bound gathers)
 struct LookupPublish {
     unsigned long long *tally = nullptr;         // device: [0] misses of the call
     volatile unsigned long long *pin = nullptr;  // pinned host page: see psk_sketch::lk
     unsigned long long units = 0, scheme = 0;
 };
 template <class Src, bool POW2>
-__global__ __launch_bounds__(kFinishThreads) void k_bloom_flag_finish(Src src, const uint32_t *tab, Mod md, uint32_t k, const uint32_t *tileflag, uint32_t gen,
-                                                                      uint32_t tile, uint32_t chunks, uint64_t n, uint8_t *out, LookupPublish pub)
+__global__ __launch_bounds__(kResolveThreads) void k_bloom_flag_resolve(Src src, const uint32_t *tab, Mod md, uint32_t k, const uint32_t *tileflag, uint32_t gen,
+                                                                       uint32_t tile, uint64_t n, uint8_t *out, LookupPublish pub)
 {
     if (pub.tally && blockIdx.x == 0 && threadIdx.x == 0) {
         pub.pin[1] = pub.units;
@@ -1484,31 +1504,25 @@ __global__ __launch_bounds__(kFinishThreads) void k_bloom_flag_finish(Src src, c
         pub.pin[3] = pub.pin[3] + 1;
         pub.tally[0] = 0;
     }
-    const uint32_t t = blockIdx.x / chunks, c = blockIdx.x - t * chunks;
-    const uint64_t tbase = (uint64_t)t * tile;
-    const uint32_t tcnt = (uint32_t)(n - tbase < tile ? n - tbase : tile);   // keys of this tile
-    const uint32_t lo = c * kFinishKeys;
-    if (lo >= tcnt) return;
-    const uint32_t cnt = tcnt - lo < (uint32_t)kFinishKeys ? tcnt - lo : (uint32_t)kFinishKeys;
-    const uint64_t base = tbase + lo;
-    const bool flagged = __builtin_amdgcn_readfirstlane(tileflag[t]) == gen;
-    if (!flagged) {
-        uint8_t *o = out + base;
-        if (((uintptr_t)o & 3) == 0) {
-            for (uint32_t i = threadIdx.x * 4; i + 4 <= cnt; i += kFinishThreads * 4) *reinterpret_cast<uint32_t *>(o + i) = 0x01010101u;
-            for (uint32_t i = (cnt & ~3u) + threadIdx.x; i < cnt; i += kFinishThreads) o[i] = 1;
-        } else {
-            for (uint32_t i = threadIdx.x; i < cnt; i += kFinishThreads) o[i] = 1;
-        }
-        return;
-    }
+    const uint64_t ntiles = (n + tile - 1) / tile;
     BloomCheck<POW2> op{tab, md, k, out};
-    for (uint32_t j = threadIdx.x; j < cnt; j += kFinishThreads) {
-        const uint64_t i = base + j;
-        const typename Src::Key key = src.load(i);
-        typename BloomCheck<POW2>::State st = op.begin(i);
-        for_each_hash(src, key, i, k, [&](uint32_t jj, uint64_t h) { op.apply(st, jj, h); });
-        op.end(st, i);
+    // 64 of my tiles at a time: lane l of every wave reads the flag of tile (t0 + l) * gridDim.x + blockIdx.x
+    for (uint64_t t0 = 0; t0 * gridDim.x + blockIdx.x < ntiles; t0 += 64) {
+        const uint64_t mine = (t0 + (threadIdx.x & 63)) * gridDim.x + blockIdx.x;
+        unsigned long long todo = __ballot(mine < ntiles && tileflag[mine < ntiles ? mine : 0] == gen);
+        while (todo) {  // (uniform)
+            const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint64_t t = (t0 + l) * gridDim.x + blockIdx.x, base = t * tile;
+            const uint32_t cnt = (uint32_t)(n - base < tile ? n - base : tile);
+            for (uint32_t j = threadIdx.x; j < cnt; j += kResolveThreads) {
+                const uint64_t i = base + j;
+                const typename Src::Key key = src.load(i);
+                typename BloomCheck<POW2>::State st = op.begin(i);
+                for_each_hash(src, key, i, k, [&](uint32_t jj, uint64_t h) { op.apply(st, jj, h); });
+                op.end(st, i);
+            }
+        }
     }
 }
 

@@ -330,7 +330,15 @@ def test_lookup_key_ids_fit_the_probe_word(pa, oracle, force_partition, est, fpr
 
 
 # ------------------------------------------------------------------ split lookup (pass 1 before the table is final)
-def test_split_lookup_sees_the_table_at_finish_time(pa, oracle, force_partition):
+@pytest.fixture(params=[0, 3], ids=["keyed", "tile-flags"])
+def split_scheme(request, force_partition):
+    """the split lookups under both schemes that have a split form: keyed probes and tile flags (round 5)"""
+    force_partition.set_option("bloom_lookup", request.param)
+    yield request.param
+    force_partition.set_option("bloom_lookup", 2)
+
+
+def test_split_lookup_sees_the_table_at_finish_time(pa, oracle, force_partition, split_scheme):
     n = 600_000
     keys = oracle.gen_keys16(21, n)
     dk = _dev(keys)
@@ -349,7 +357,7 @@ def test_split_lookup_sees_the_table_at_finish_time(pa, oracle, force_partition)
             blm.check_many_finish()                # nothing pending any more
 
 
-def test_split_lookup_rounds_and_small_batches(pa, oracle, force_partition):
+def test_split_lookup_rounds_and_small_batches(pa, oracle, force_partition, split_scheme):
     keys = oracle.gen_keys16(2, 50_000)
     dk = _dev(keys)
     blm = pa.BloomFilter(est_elements=400_000, false_positive_rate=0.01)
@@ -367,7 +375,7 @@ def test_split_lookup_rounds_and_small_batches(pa, oracle, force_partition):
     assert np.array_equal(np.asarray(blm.check_many_finish(), dtype=np.uint8), want)
 
 
-def test_split_lookup_segment_overflow_is_redone_exactly(pa, oracle, force_partition):
+def test_split_lookup_segment_overflow_is_redone_exactly(pa, oracle, force_partition, split_scheme):
     # all keys identical: their probes overflow <= k segments during begin; finish must re-check the round on the device
     key = oracle.gen_keys16(9, 1)
     keys = np.repeat(key, 150_000, axis=0)
@@ -383,7 +391,7 @@ def test_split_lookup_segment_overflow_is_redone_exactly(pa, oracle, force_parti
     assert got[1] == 1 and got.sum() >= 150_000 - 300
 
 
-def test_split_lookup_overflow_in_later_rounds(pa, oracle, force_partition):
+def test_split_lookup_overflow_in_later_rounds(pa, oracle, force_partition, split_scheme):
     # six rounds; the duplicate-heavy stretch sits in rounds 1 and 2 (begin scatters round 0 only: the later rounds run in full
     # at finish, their overflowing probes take the exact direct test), and the table changes while the lookup is pending
     n = 260_000
@@ -608,7 +616,7 @@ def test_cbf_unchecked_remove_direct_and_partitioned_agree(pa, oracle, force_par
 @pytest.mark.parametrize("mode", [1, 0, 3])
 def test_bloom_lookup_modes_vs_oracle(pa, oracle, force_partition, mode):
     """option bloom_lookup: 1 = pass 1 with perm / runinfo + k_bloom_gather + k_bloom_collect, 0 = keyed probes + k_bloom_test, 3 = the
-    insert's compact probes + a flag per tile that met a clear bit + k_bloom_flag_finish (round 5); all against the oracle over hits, misses,
+    insert's compact probes + a flag per tile that met a clear bit + k_bloom_flag_resolve (round 5); all against the oracle over hits, misses,
     k classes, table sizes, layouts, rounds and segment overflow"""
     force_partition.set_option("bloom_lookup", mode)
     try:

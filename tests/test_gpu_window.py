@@ -266,3 +266,28 @@ def test_a_fold_leaves_the_lookups_kept_images_up_to_date(pa, oracle, N):
     finally:
         N.set_option("lookup_nibble_slices", old)
         N.set_option("update_window_shadow", old_sh)
+
+
+def test_combined_update_after_window_batches_keeps_the_order(pa, oracle, N):
+    """a C caller may mix psk_cbf_add / psk_cbf_remove (update window) with psk_cbf_update_combined (key lists) on ONE handle.
+    The window's batches arrived first, so they reach the table first: a windowed remove of an ABSENT key X is a no-op
+    (countingbloom.py:198-201) and the combined add of X that follows leaves X present -- not removed."""
+    n = 120_000
+    keys = oracle.gen_keys16(4242, n)
+    dk = _dev(keys)
+    cbf = pa.CountingBloomFilter(est_elements=7_100_000, false_positive_rate=0.01)
+    oc = oracle.OracleCBF(cbf.number_bits, cbf.number_hashes)
+    L, h = N.lib(), cbf._tab.handle
+    st = cbf._tab.stream
+    args = (N.KEYS_FIXED, dk.data_ptr(), None, n, 16)
+    N.check(L.psk_cbf_remove(h, *args, None, N.DEVICE, st))               # absent keys: waits in the window, removes nothing
+    N.check(L.psk_cbf_update_combined(h, *args, None, 0, N.DEVICE, st))    # the same keys, added through the combined path
+    N.check(L.psk_cbf_add(h, N.KEYS_FIXED, dk[: n // 2].data_ptr(), None, n // 2, 16, None, N.DEVICE, st))   # window again
+    N.check(L.psk_cbf_update_combined(h, N.KEYS_FIXED, dk[: n // 4].data_ptr(), None, n // 4, 16, None, 1, N.DEVICE, st))  # combined remove
+    oc.update_keys(keys, -np.ones(n, dtype=np.int64))
+    oc.update_keys(keys)
+    oc.update_keys(keys[: n // 2])
+    oc.update_keys(keys[: n // 4], -np.ones(n // 4, dtype=np.int64))
+    cbf._dirty = True
+    assert np.array_equal(_table(cbf), oc.bloom)
+    assert np.array_equal(cbf.check_many(dk).cpu().numpy().astype(np.uint32), oc.check_keys(keys))
