@@ -20,10 +20,8 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 VARIANT_SOURCES = [
     "psk_part_bloom_add.hip",
     "psk_part_bloom_check.hip",
-    "psk_part_cms_add.hip",
-    "psk_part_cms_remove.hip",
     "psk_part_cbf.hip",
-    "psk_part_cbf_remove.hip",
+    "psk_part_cms.hip",
     "psk_part_cms_check.hip",
     "psk_part_cbf_check.hip",
     "psk_part_cbf_multi.hip",

@@ -329,12 +329,13 @@ static int set_dyn_lds(K kernel, size_t bytes)
 // Pass 1 for one concrete (Src, IdxFn, Pay, Spill, KT, NT): sizes the (slice, workgroup) segments for `n` keys,
 // grows the handle's bucket buffer, launches.  g->nwg / g->segcap are filled in for pass 2.
 template <class Pay, int KT, int NT>
-static size_t scatter_lds_bytes(const PartGeom *g)
+static size_t scatter_lds_bytes(const PartGeom *g, uint64_t tile = 0)  // tile: keys per tile (0 = the shape's full tile)
 {
     using Tile = PartTile<Pay, KT, NT>;
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
+    const size_t tk = tile ? (size_t)tile : (size_t)Tile::TILE;
     // stage (one word per probe in every mode) + one slice id per group for the payload modes
-    const size_t stage_cap = (((size_t)Tile::TILE * kk + (size_t)(Tile::GS - 1) * g->nbuckets) + 3) & ~(size_t)3;
+    const size_t stage_cap = ((tk * kk + (size_t)(Tile::GS - 1) * g->nbuckets) + 3) & ~(size_t)3;
     const size_t stage_words = stage_cap + (Tile::pair ? stage_cap / Tile::GS + 4 : 0);
     return (5 * (size_t)g->nbuckets + 16 + 24 + stage_words) * 4;
 }
@@ -352,27 +353,32 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
                              uint64_t n, hipStream_t st, uint32_t want_wgs, const ScatterTarget *fixed = nullptr)
 {
     using Tile = PartTile<Pay, KT, NT>;
-    const uint64_t ntiles = (n + Tile::TILE - 1) / Tile::TILE;
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
-    const size_t lds = scatter_lds_bytes<Pay, KT, NT>(g);
+    // keys per tile: the shape's, cut down (whole waves) where its LDS stage would not fit -- 8-probe groups at 2048 slices carry 7 pad
+    // slots per slice: 1984-key tiles instead of 2048 (the kernel sizes its stage by PartGeom::tile)
+    uint64_t tile_full = Tile::TILE;
+    while (tile_full > 64 && scatter_lds_bytes<Pay, KT, NT>(g, tile_full) > kScatterLdsBudget) tile_full -= 64;
+    if (scatter_lds_bytes<Pay, KT, NT>(g, tile_full) > kScatterLdsBudget) return fail(PSK_EINVAL, "pass 1: %u slices do not fit the LDS stage", g->nbuckets);
+    const uint64_t ntiles = (n + tile_full - 1) / tile_full;
     if (fixed) {  // append behind what the segments already hold: the first min(nwg, tiles) workgroups each take their share of tiles
         if (Pay::mode != kModePlain) return fail(PSK_EINVAL, "persistent segments carry payload-free probes");
         const uint64_t grid = g->nwg < ntiles ? g->nwg : ntiles;
         if (grid == 0) return PSK_OK;
         const uint64_t per_wg = (ntiles + grid - 1) / grid;
-        uint64_t tk = Tile::TILE;
+        uint64_t tk = tile_full;
         if (g_part_even_tiles != 0 && grid * per_wg > ntiles) {
             tk = ((n + grid * per_wg - 1) / (grid * per_wg) + 63) & ~63ULL;
-            if (tk > (uint64_t)Tile::TILE) tk = Tile::TILE;
+            if (tk > tile_full) tk = tile_full;
         }
         g->tile = (uint32_t)tk;
+        const size_t lds = scatter_lds_bytes<Pay, KT, NT>(g, tk);
         auto kern = k_part_scatter<Src, IdxFn, Pay, Spill, KT, NT>;
         PSK_TRY(set_dyn_lds(kern, lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, src, idxfn, pay, spill, *g, n, fixed->cnt, fixed->part);
         HIP_TRY(hipGetLastError());
         return PSK_OK;
     }
-    uint64_t per_cu = NT > 512 ? 1 : (lds > kScatterLdsTwoPerCu ? 1 : 2);
+    uint64_t per_cu = NT > 512 ? 1 : (scatter_lds_bytes<Pay, KT, NT>(g, tile_full) > kScatterLdsTwoPerCu ? 1 : 2);
     if (kBenchKnobs && (g->dbg & 8)) per_cu = 1;  // ablation: one workgroup per CU
     uint64_t nwg = 256 * per_cu;
     if (want_wgs) nwg = want_wgs;  // caller's choice (keyed lookups into big tables: twice the keys per round)
@@ -383,11 +389,12 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
     // Even tiles: 10 M keys are 4883 tiles of 2048, i.e. 19 rounds of all 256 workgroups and a 20th of only 19 of them --
     // every workgroup takes ceil(tiles / workgroups) tiles of the same, slightly smaller size instead (a multiple of 64 keys:
     // whole waves), the last one short.  Pass 2 and the lookups' pass 3 read the tile size from the geometry.
-    uint64_t tk = Tile::TILE;
+    uint64_t tk = tile_full;
     if (g_part_even_tiles != 0 && nwg * tiles_per_wg > ntiles) {
         tk = ((n + nwg * tiles_per_wg - 1) / (nwg * tiles_per_wg) + 63) & ~63ULL;
-        if (tk > (uint64_t)Tile::TILE) tk = Tile::TILE;
+        if (tk > tile_full) tk = tile_full;
     }
+    const size_t lds = scatter_lds_bytes<Pay, KT, NT>(g, tk);
     const double mean = (double)tiles_per_wg * (double)tk * kk / (double)g->nbuckets;  // probes per segment
     // 16-byte groups per segment: mean/GS, + ~half a group of padding per (tile, slice) run, + 8 sigma
     uint64_t segcap = (uint64_t)(mean / Tile::GS + 0.5 * (double)tiles_per_wg + 8.0 * __builtin_sqrt(mean) / Tile::GS + 16.0);
@@ -418,6 +425,10 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
 template <class Pay, int KT>
 static int scatter_threads(const PartGeom *g)
 {
+    // k <= 8 without the two-per-CU shape (every payload but the Bloom insert's / the tile-flag lookup's): 1024 threads, always -- its stage fits the
+    // LDS for every geometry the single-level path takes (at most 2048 slices, at most 16 K probes per tile: <= 154 KB), so the 512-thread
+    // form of these kernels is not even instantiated (round 5: it was a third of the library's device code and never selected)
+    if constexpr (KT <= 8 && !pay_fat512<Pay>::value) return 1024;
     if constexpr (KT <= 8) {
         const bool fits1024 = scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget;
         const bool two_per_cu = pay_fat512<Pay>::value && scatter_lds_bytes<Pay, KT, kPartThreads>(g) <= kScatterLdsTwoPerCu;
@@ -459,9 +470,15 @@ static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, con
         // tile must stay within 2^(31 - shift) keys (PayKeyId::max_tile caps it at 2048 keys)
         if constexpr (Pay::mode == kModeKeyed)
             static_assert(((uint64_t)PartTile<Pay, KT, 1024>::TILE << Pay::slice_shift) <= (1ULL << 31), "keyed tile too large");
-        if (scatter_threads<Pay, KT>(g) == 1024) return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st, want_wgs, fixed);
+        if constexpr (!pay_fat512<Pay>::value) {  // one shape only (scatter_threads; launch_scatter_nt cuts the tile where the stage would not fit)
+            return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st, want_wgs, fixed);
+        } else {
+            if (scatter_threads<Pay, KT>(g) == 1024) return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st, want_wgs, fixed);
+            return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, kPartThreads>(s, src, idxfn, pay, spill, g, n, st, want_wgs, fixed);
+        }
+    } else {
+        return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, kPartThreads>(s, src, idxfn, pay, spill, g, n, st, want_wgs, fixed);
     }
-    return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, kPartThreads>(s, src, idxfn, pay, spill, g, n, st, want_wgs, fixed);
 }
 
 // compile-time hash count: exact for the common small k on the 16-byte fast layout, rounded up otherwise
@@ -481,7 +498,9 @@ static int with_kt(uint32_t k, F &&f)
         }
     }
     if (k <= 8) return f(std::integral_constant<int, 8>{});
-    if (k <= 16) return f(std::integral_constant<int, 16>{});
+    // (k = 9 .. 16 on the other layouts runs the 32-chain instantiation, whose chains go four at a time and stop at k: both forms hash one key
+    // per thread and tile, so a separate 16-chain kernel per layout and payload bought nothing but device code)
+    if (fast && k <= 16) return f(std::integral_constant<int, 16>{});
     return f(std::integral_constant<int, 32>{});
 }
 
@@ -637,6 +656,10 @@ PSK_DECLARE_VARIANTS(int, cbf_remove_partitioned, (psk_sketch *s, const Batch &b
 // lookups (psk_lookup.hpp): query = psk_query; out_dev int32 (min / mean) or int64 (mean-min); kk = hashes per key
 PSK_DECLARE_VARIANTS(int, cms_check_partitioned, (psk_sketch *s, const Batch &b, int query, int64_t els_added, void *out_dev, hipStream_t st, bool *done))
 PSK_DECLARE_VARIANTS(int, cbf_check_partitioned, (psk_sketch *s, const Batch &b, uint32_t kk, uint32_t *out_dev, hipStream_t st, bool *done))
+// pass 1 of the return-trip lookups over a BLOOM-indexed table (IdxBloom, PayBloomLookup: perm[] / runinfo[] in s_perm / s_run, probes in
+// s_part / s_cnt; an overflowing segment raises *flag): shared by the Bloom return trip and the CountingBloomFilter's 4-bit-slice lookups --
+// ONE set of instantiations (psk_part_cbf_check.hip) instead of one per caller.  *fits = false: a tile too large for 16-bit stage positions.
+PSK_DECLARE_VARIANTS(int, bloomidx_lookup_scatter, (psk_sketch *s, const Batch &sub, uint64_t cnt, uint32_t kk, PartGeom *g, uint32_t *flag, hipStream_t st, bool *handled, bool *fits))
 PSK_HIDDEN int flush_combined(psk_sketch *s, hipStream_t st);  // apply the write-combined CBF updates, if any (psk_capi.hip)
 // pass 1 of a unit-weight CBF batch, appended to the handle's persistent add (neg = 0) / decrement (neg = 1) list; *done = false:
 // the batch / table is not eligible (nothing was launched)

@@ -67,23 +67,14 @@ static int bloom_check_return_trip(psk_sketch *s, const Batch &b, uint8_t *out_d
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
         const Batch sub = sub_batch(b, start, cnt);
         bool handled = false, fits = true;
+        // pass 1 with the perm[] / runinfo[] by-products (shared with the CountingBloomFilter's 4-bit-slice lookups); 16-bit stage positions:
+        // decided before anything is enqueued (else: not eligible, the keyed kernels take the batch)
+        PSK_TRY(PSK_VARIANT(bloomidx_lookup_scatter)(s, sub, cnt, s->k, &g, flag, st, &handled, &fits));
+        if (!handled || !fits) return PSK_OK;
         PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
             using Src = decltype(src);
             return with_kt<Src>(s->k, [&](auto kt) {
                 constexpr int KT = decltype(kt)::value;
-                constexpr int P4 = (KT + 7) / 8;
-                using TileSmall = PartTile<PayBloomLookup, KT, kPartThreads>;
-                {   // 16-bit stage positions: decided before anything is enqueued (else: not eligible, the keyed kernels take the batch)
-                    const size_t tile_max = PartTile<PayBloomLookup, KT, 1024>::TILE > TileSmall::TILE ? PartTile<PayBloomLookup, KT, 1024>::TILE : TileSmall::TILE;
-                    const uint32_t kq0 = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
-                    if (tile_max * kq0 + (size_t)5 * g.nbuckets + 3 > 0xFFFFu) { fits = false; return (int)PSK_OK; }
-                }
-                const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE + 1024;  // (+ workgroups: evened tiles, launch_scatter_nt)
-                PSK_TRY(ensure(s->s_perm, cnt * (uint64_t)PermRec<KT>::PD * 4 + 16));
-                PSK_TRY(ensure(s->s_run, max_tiles * g.nbuckets * 8));
-                PayBloomLookup pay{(uint32_t *)s->s_perm.p, (uint2 *)s->s_run.p};
-                SpillRaiseFlag spill{flag};
-                PSK_TRY((launch_scatter<Src, IdxBloom<kTuPow2>, PayBloomLookup, SpillRaiseFlag, KT>(s, src, IdxBloom<kTuPow2>{s->md}, pay, spill, &g, cnt, st)));
                 PSK_TRY(ensure(s->s_vals, (uint64_t)g.nbuckets * g.nwg * g.segcap + 256));  // one result byte per group
                 const size_t lds2 = (size_t)1 << (g.shift - 3);
                 PSK_TRY(set_dyn_lds(k_bloom_gather, lds2));

@@ -177,23 +177,13 @@ static inline int cbf_check_nibble(psk_sketch *s, const Batch &b, uint32_t kk, u
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
         const Batch sub = sub_batch(b, start, cnt);
         bool handled = false, fits = true;
+        PSK_TRY(PSK_VARIANT(bloomidx_lookup_scatter)(s, sub, cnt, kk, &g, flag, st, &handled, &fits));  // pass 1 (perm[] / runinfo[] by-products)
+        if (!handled || !fits) return PSK_OK;  // (only ever on the first round: nothing was launched)
         PSK_TRY(with_part_source(sub, &handled, [&](auto src) {
             using Src = decltype(src);
             return with_kt<Src>(kk, [&](auto kt) {
                 constexpr int KT = decltype(kt)::value;
-                constexpr int P4 = (KT + 7) / 8;
-                using TileSmall = PartTile<PayBloomLookup, KT, kPartThreads>;
-                using TileBig = PartTile<PayBloomLookup, KT, 1024>;
                 const uint32_t kq = g.k < (uint32_t)KT ? g.k : (uint32_t)KT;
-                // 16-bit stage positions (perm[]): the largest tile pass 1 may choose must fit -- else not eligible, nothing launched
-                const size_t tile_max = TileBig::TILE > TileSmall::TILE ? TileBig::TILE : TileSmall::TILE;
-                if (tile_max * kq + (size_t)5 * g.nbuckets + 3 > 0xFFFFu) { fits = false; return (int)PSK_OK; }
-                const uint64_t max_tiles = (cnt + TileSmall::TILE - 1) / TileSmall::TILE + 1024;  // (+ workgroups: evened tiles, launch_scatter_nt)
-                PSK_TRY(ensure(s->s_perm, cnt * (uint64_t)PermRec<KT>::PD * 4 + 16));
-                PSK_TRY(ensure(s->s_run, max_tiles * g.nbuckets * 8));
-                PayBloomLookup pay{(uint32_t *)s->s_perm.p, (uint2 *)s->s_run.p};
-                SpillRaiseFlag spill{flag};
-                PSK_TRY((launch_scatter<Src, IdxBloom<kTuPow2>, PayBloomLookup, SpillRaiseFlag, KT>(s, src, IdxBloom<kTuPow2>{s->md}, pay, spill, &g, cnt, st)));
                 PSK_TRY(ensure(s->s_vals, (uint64_t)g.nbuckets * g.nwg * g.segcap * 4 + 256));  // one dword (six nibbles) per group
                 const size_t lds2 = (size_t)1 << (g.shift - 1);
                 if (g_nib_gather_pipe != 0 && shadow_in == nullptr && g.shift >= 15) {

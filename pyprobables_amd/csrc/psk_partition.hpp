@@ -524,7 +524,8 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     unsigned long long *t_acc = reinterpret_cast<unsigned long long *>(wave_tot + 16);  // phase profile (dbg & 32), 12 slots
     uint32_t *stage = wave_tot + 16 + 24;
     // slice id of every stage group (payload modes); sits behind the stage: TILE * k probes + (GS - 1) pads per slice
-    const uint32_t stage_cap = ((uint32_t)TILE * (g.k < (uint32_t)KT ? g.k : (uint32_t)KT) + (uint32_t)(GS - 1) * B + 3u) & ~3u;
+    // (sized by the tile the host chose -- g.tile <= TILE: evened tiles, or tiles cut down so that the stage fits the LDS at 2048 slices)
+    const uint32_t stage_cap = (g.tile * (g.k < (uint32_t)KT ? g.k : (uint32_t)KT) + (uint32_t)(GS - 1) * B + 3u) & ~3u;
     uint32_t *gb = stage + stage_cap;
     // KT other than the round-up sizes 8 / 16 / 32 is an exact instantiation (with_kt): k == KT, and every per-probe
     // "j < k" test below folds away (28 exec-mask branch sequences per tile for k = 7)
