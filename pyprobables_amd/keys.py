@@ -93,10 +93,66 @@ def _pack_homogeneous(keys: list, n: int):
     return KeyBatch(N.KEYS_VARLEN8, _np_ptr(blob), _np_ptr(offs), n, 0, N.HOST, None, [blob, offs, blob8])
 
 
+def _is_array(x) -> bool:
+    return isinstance(x, np.ndarray) or (torch is not None and isinstance(x, torch.Tensor))
+
+
+def _pack_ragged(blob, offsets) -> KeyBatch:
+    """a ragged batch handed over as it lies in memory: ``blob`` = the keys' elements end to end (uint8 bytes, or 4-byte code points
+    for str keys -- hashes.py:98 XORs whole code points), ``offsets`` = n + 1 ascending 8-byte positions, key i = blob[offsets[i]:offsets[i+1]].
+    Both on the host, or both on one device (zero-copy: the C ABI takes ``offsets`` from either side)."""
+    is_t = [torch is not None and isinstance(x, torch.Tensor) for x in (blob, offsets)]
+    cuda = [t and x.is_cuda for t, x in zip(is_t, (blob, offsets))]
+    if cuda[0] != cuda[1]:
+        raise TypeError("(blob, offsets): both on the host or both on one device")
+    if cuda[0]:
+        if blob.device != offsets.device:
+            raise TypeError("(blob, offsets): both tensors must live on the same device")
+        if blob.dim() != 1 or offsets.dim() != 1 or offsets.numel() < 1:
+            raise TypeError("(blob, offsets): 1-D blob and 1-D offsets of n + 1 entries")
+        if offsets.element_size() != 8 or offsets.dtype.is_floating_point:
+            raise TypeError("(blob, offsets): offsets must be 64-bit integers")
+        if blob.dtype == torch.uint8:
+            layout = N.KEYS_VARLEN8
+        elif blob.element_size() == 4 and not blob.dtype.is_floating_point:
+            layout = N.KEYS_VARLEN32
+        else:
+            raise TypeError("(blob, offsets): blob must be uint8 bytes or 4-byte code points")
+        b, o = blob.contiguous(), offsets.contiguous()
+        if b.numel() == 0:
+            b = torch.zeros(1, dtype=blob.dtype, device=blob.device)  # (all keys empty: the engine still wants an address)
+        return KeyBatch(layout, b.data_ptr(), o.data_ptr(), o.numel() - 1, 0, N.DEVICE, b.device.index, [b, o])
+    b = blob.numpy() if is_t[0] else np.asarray(blob)
+    o = offsets.numpy() if is_t[1] else np.asarray(offsets)
+    if b.ndim != 1 or o.ndim != 1 or o.size < 1:
+        raise TypeError("(blob, offsets): 1-D blob and 1-D offsets of n + 1 entries")
+    if o.dtype.kind not in "iu" or o.dtype.itemsize != 8:
+        raise TypeError("(blob, offsets): offsets must be 64-bit integers")
+    if b.dtype == np.uint8:
+        layout = N.KEYS_VARLEN8
+    elif b.dtype.kind in "iu" and b.dtype.itemsize == 4:
+        layout = N.KEYS_VARLEN32
+    else:
+        raise TypeError("(blob, offsets): blob must be uint8 bytes or 4-byte code points")
+    o = np.ascontiguousarray(o).view(np.uint64)
+    # (offsets need not start at 0: a window into a larger blob is fine)
+    if o.size > 1 and (np.diff(o.view(np.int64)) < 0).any():
+        raise ValueError("(blob, offsets): offsets must ascend")
+    if int(o[-1]) > b.size:
+        raise ValueError("(blob, offsets): offsets reach past the blob")
+    b = np.ascontiguousarray(b)
+    if b.size == 0:
+        b = np.zeros(1, dtype=b.dtype)
+    return KeyBatch(layout, _np_ptr(b), _np_ptr(o), o.size - 1, 0, N.HOST, None, [b, o])
+
+
 def pack_keys(keys) -> KeyBatch:
-    """one key, a sequence of keys, a (n, L) uint8 array or a (n, L) uint8 torch tensor -> KeyBatch"""
+    """one key, a sequence of keys, a (n, L) uint8 array or a (n, L) uint8 torch tensor, or a ragged ``(blob, offsets)`` pair of
+    arrays / tensors (host or device) -> KeyBatch"""
     if _is_key(keys):
         keys = [keys]
+    if isinstance(keys, tuple) and len(keys) == 2 and _is_array(keys[0]) and _is_array(keys[1]):
+        return _pack_ragged(keys[0], keys[1])
     if torch is not None and isinstance(keys, torch.Tensor):
         if keys.dtype != torch.uint8 or keys.dim() != 2:
             raise TypeError("tensor key batches must be uint8 of shape (n, key_len)")
@@ -185,6 +241,8 @@ def _pack_bytes_utf8(keys) -> KeyBatch:
         keys = [keys]
     if (torch is not None and isinstance(keys, torch.Tensor)) or isinstance(keys, np.ndarray):
         return pack_keys(keys)  # raw (n, L) byte matrices
+    if isinstance(keys, tuple) and len(keys) == 2 and _is_array(keys[0]) and _is_array(keys[1]):
+        return pack_keys(keys)  # ragged (blob, offsets): bytes as they lie
     keys = list(keys)
     try:
         if "".join(keys).isascii():  # ASCII: UTF-8 bytes == code points, the vectorised packing applies as is

@@ -52,6 +52,67 @@ k13 = torch.randint(0, 256, (n, 13), dtype=torch.uint8, device="cuda")
 bloom_case("bloom 8-byte keys", 28005615, 0.01, k8)
 bloom_case("bloom 32-byte keys", 28005615, 0.01, k32)
 bloom_case("bloom 13-byte keys (unaligned)", 28005615, 0.01, k13)
+# ---- the reference's native key type: variable-length byte / str keys (hashes.py:98 walks code points) ----
+def ragged(kind, nn, seed=7):
+    """(blob, offsets) on the device.  wide: 4 + min(36, floor(Exp(12.6))) bytes, mean ~16; narrow: 4 + min(36, Poisson(12));
+    words: 2 .. 15 lowercase letters, mean ~8; wide32: the wide lengths as 4-byte code points, one per key above 255"""
+    rng = np.random.default_rng(seed)
+    if kind in ("wide", "wide32"):
+        lens = 4 + np.minimum(36, np.floor(rng.exponential(12.6, nn))).astype(np.int64)
+    elif kind == "narrow":
+        lens = 4 + np.minimum(36, rng.poisson(12, nn)).astype(np.int64)
+    else:
+        lens = np.clip(np.round(rng.normal(8, 2.5, nn)), 2, 15).astype(np.int64)
+    offs = np.zeros(nn + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    tot = int(offs[-1])
+    if kind == "words":
+        blob = rng.integers(97, 123, tot, dtype=np.uint8)
+    elif kind == "wide32":
+        blob = rng.integers(32, 127, tot, dtype=np.uint32)
+        blob[offs[:-1]] = rng.integers(0x400, 0x2000, nn, dtype=np.uint32)
+    else:
+        blob = rng.integers(0, 256, tot, dtype=np.uint8)
+    return blob, offs, float(lens.mean()), int(lens.max())
+
+
+for kind, label in [("wide", "bloom ragged bytes 4-40 (exp, device)"), ("narrow", "bloom ragged bytes 4-40 (poisson, device)"),
+                    ("words", "bloom ascii words 2-15 (device)"), ("wide32", "bloom str code points > 255 (device)")]:
+    blob, offs, mean, mx = ragged(kind, n)
+    dk = (torch.from_numpy(blob.view(np.int32) if blob.dtype == np.uint32 else blob).cuda(), torch.from_numpy(offs).cuda())
+    f = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    a = t(lambda: f.add_many(dk))
+    c = t(lambda: f.check_many(dk))
+    rows.append((label, f"mean {mean:.1f} max {mx}", n / a / 1e3, n / c / 1e3))
+    del f, dk
+# host lists of bytes / str (packing + PCIe inclusive), 1 M keys
+nh = 1_000_000
+blob, offs, mean, mx = ragged("wide", nh)
+raw = blob.tobytes()
+lst = [raw[offs[i]:offs[i + 1]] for i in range(nh)]
+f = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01)
+a = t(lambda: f.add_many(lst), 3)
+c = t(lambda: f.check_many(lst), 3)
+rows.append(("bloom list of ragged bytes (host, 1 M)", f"mean {mean:.1f}", nh / a / 1e3, nh / c / 1e3))
+blob, offs, mean, mx = ragged("words", nh)
+raw = blob.tobytes().decode("ascii")
+lst = [raw[offs[i]:offs[i + 1]] for i in range(nh)]
+a = t(lambda: f.add_many(lst), 3)
+c = t(lambda: f.check_many(lst), 3)
+rows.append(("bloom list of ascii str words (host, 1 M)", f"mean {mean:.1f}", nh / a / 1e3, nh / c / 1e3))
+del f, lst
+blob, offs, mean, mx = ragged("wide", n)
+dk = (torch.from_numpy(blob).cuda(), torch.from_numpy(offs).cuda())
+cms = pa.CountMinSketch(width=2**20, depth=5)
+a = t(lambda: cms.add_many(dk, w))
+c = t(lambda: cms.check_many(dk))
+rows.append(("cms 2^20 x 5 ragged bytes 4-40 (device)", f"mean {mean:.1f}", n / a / 1e3, n / c / 1e3))
+del cms
+cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01)
+a = t(lambda: cbf.add_many(dk), 3)
+c = t(lambda: cbf.check_many(dk), 3)
+rows.append(("cbf 2^28 ragged bytes 4-40 (device)", f"mean {mean:.1f}", n / a / 1e3, n / c / 1e3))
+del cbf, dk
 # host-staged (PCIe inclusive) 16-byte keys
 kh = keys16.cpu().numpy()
 f = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01)
