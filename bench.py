@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--borrow-keys", action="store_true", help="cfg4: the resident, never overwritten key batches are BORROWED (PSK_DEVICE_BORROWED): the "
                     "engine keeps pointers and hashes them where they lie at the flush, instead of copying every batch into its key lists "
                     "(same throughput, no 2 x 1.25 GiB of lists)")
+    ap.add_argument("--borrow-window", action="store_true", help="cfg4: the default API with CountingBloomFilter(borrow_keys=True): the update window keeps the "
+                    "resident, never overwritten key batches where they are instead of copying them (exact for any stream, like the default)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="psk_set_option before the run (A/B of engine tunables)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: merge, then look up (no lookup pass 1 under the merge)")
     ap.add_argument("--no-extra-configs", action="store_true", help="default run: skip the short cfg3 / cfg4 / cfg5 steps reported under `configs`")
@@ -791,13 +793,13 @@ class Cfg4:
         self.keys = ctx.gen_keys(self.B * self.nb, 0)   # 50M keys = 800 MB resident
         # default: the plain API (add_many / remove_many, no opt-in) -- the engine's update windows (psk_window.hpp) make the small
         # batches share passes over the table and keep the reference's semantics for any stream
-        self.mode = "off" if args.no_combine else ("borrow" if args.borrow_keys else (True if args.legacy_combine else "window"))
+        self.mode = "off" if args.no_combine else ("borrow" if args.borrow_keys else (True if args.legacy_combine else ("window_borrow" if args.borrow_window else "window")))
         if self.mode == "off":
             from pyprobables_amd import _native as N
 
             N.set_option("update_window", 0)
         self.cbf = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, device=ctx.dev,
-                                          combine_updates=self.mode if self.mode in (True, "borrow") else False)
+                                          combine_updates=self.mode if self.mode in (True, "borrow") else False, borrow_keys=self.mode == "window_borrow")
         assert self.cbf.number_bits == 2**28
         self.adds, self.removes = self.B * self.nb, (self.nb - 1) * (self.B // 2)
         self.ops_per_step = self.adds + self.removes
@@ -842,6 +844,7 @@ class Cfg4:
                                    f"add {self.B} keys, remove the first {self.B // 2} keys of the previous batch",
                        "batch_keys": self.B, "batches": self.nb, "ops_per_step": self.ops_per_step, "parallelism": "single GPU",
                        "api": {"window": "default (add_many / remove_many, no opt-in)", "off": "default API, update windows off",
+                               "window_borrow": "default API + borrow_keys=True (the update window hashes the caller's key tensors where they lie: no key copies; exact for any stream)",
                                True: "opt-in combine_updates=True", "borrow": "opt-in combine_updates='borrow'"}[self.mode],
                        "combine_updates": self.mode if self.mode in (True, "borrow") else False,
                        "note": "default API: the engine lets the 1M-key batches wait, in arrival order, in an update window and applies them in one "
@@ -851,7 +854,7 @@ class Cfg4:
                                "--no-combine: update windows off, every batch at once"},
             "roofline": roofline("cbf_add", "CBF stream = per window: key copies + k_part_scatter<PayNonePhased> + k_win_fold over the 1 GiB table",
                                  self.ops_per_step, ms, "the fold read-modify-writes the whole 1 GiB table; batches are combined before it",
-                                 {True: "cfg4_stream", "borrow": "cfg4_stream_borrow", "off": "cfg4_stream_nocombine", "window": "cfg4_stream_window"}[self.mode]),
+                                 {True: "cfg4_stream", "borrow": "cfg4_stream_borrow", "off": "cfg4_stream_nocombine", "window": "cfg4_stream_window", "window_borrow": "cfg4_stream_window"}[self.mode]),
             "rooflines": {},
             "detail": {"elements_added": els, "expected_elements": expect, "sum_counters_equals_k_x_live": total == 7 * expect, "diagnostics": diag,
                        "update_window_folds": self._opt("update_window_folds"), "update_window_replays": self._opt("update_window_replays")},

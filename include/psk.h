@@ -56,10 +56,12 @@ enum psk_status {
 enum psk_where {
     PSK_HOST = 0,
     PSK_DEVICE = 1,
-    /* psk_cbf_update_combined only: a device buffer that stays valid AND UNCHANGED until the handle's next flush (any entry point
-     * that applies the waiting updates, psk_flush, psk_clear).  16-byte fixed-length keys are then not copied into the
-     * write-combining list: the flush hashes them where they lie, all borrowed batches in one pass (no key copy, one key read).
-     * Other layouts are copied as with PSK_DEVICE. */
+    /* psk_cbf_add / psk_cbf_remove / psk_cbf_update_combined: a device buffer that stays valid AND UNCHANGED until the handle's next
+     * flush (any entry point that applies the waiting updates, psk_flush, psk_clear; psk_sketch_get_option "window_pending_batches"
+     * tells how many of the latest batches still wait).  16-byte-aligned 16-byte fixed-length unit-weight keys that the engine defers
+     * (update windows, write-combining lists) are then not copied: the flush hashes them where they lie, all waiting batches in one
+     * pass (no key copy, one key read; round 5: BASELINE cfg 4 spent 22 % of its step copying keys).  Everything else -- other layouts,
+     * batches applied at once -- is treated as PSK_DEVICE: nothing is kept. */
     PSK_DEVICE_BORROWED = 2
 };
 

@@ -37,7 +37,7 @@ class CountingBloomFilter(BloomFilter):
     _MISMATCH = "The parameter second must be of type CountingBloomFilter"
 
     def __init__(self, est_elements=None, false_positive_rate=None, filepath=None, hex_string=None, hash_function=None,
-                 device=None, combine_updates: bool = False):
+                 device=None, combine_updates: bool = False, borrow_keys: bool = False):
         """Small unit-weight ``add_many`` batches into big tables (more than 2^26 counters) are write-combined by the engine
         on its own: adds commute, so each batch is hashed and partitioned when it is handed over and the probes are folded
         into the table together with their successors -- exact, no opt-in (``psk_set_option("auto_combine", 0)`` turns it
@@ -52,9 +52,16 @@ class CountingBloomFilter(BloomFilter):
 
         ``combine_updates="borrow"``: as above, and device batches of 16-byte keys are not even copied -- the sketch keeps a
         reference to the key tensor and hashes it where it lies at the flush (``PSK_DEVICE_BORROWED``).  The caller must not
-        OVERWRITE such a tensor before the next read of the sketch (``check*``, ``elements_added``, ``flush()`` ...)."""
+        OVERWRITE such a tensor before the next read of the sketch (``check*``, ``elements_added``, ``flush()`` ...).
+
+        ``borrow_keys=True`` (extra, off by default) is the same promise for the DEFAULT path: small ``add_many`` / ``remove_many`` batches
+        of 16-byte keys into big tables wait in the engine's update window (exact for any stream: the flush proves every deferred remove
+        or replays the window in order) as copies of their keys -- 22 % of BASELINE config 4's step.  With the promise that a device
+        key tensor handed over is not overwritten until the sketch is next read, the window keeps a reference instead and hashes the
+        batches where they lie.  Results are the same bit for bit; only the copy goes."""
         self._combine = bool(combine_updates)
         self._borrow = combine_updates == "borrow"
+        self._borrow_window = bool(borrow_keys)
         self._borrowed: list = []
         super().__init__(est_elements, false_positive_rate, filepath, hex_string, hash_function, device)
 
@@ -63,6 +70,7 @@ class CountingBloomFilter(BloomFilter):
         inst = super().frombytes(b, hash_function, device)
         inst._combine = False
         inst._borrow = False
+        inst._borrow_window = False
         inst._borrowed = []
         return inst
 
@@ -183,7 +191,19 @@ class CountingBloomFilter(BloomFilter):
             N.check(N.lib().psk_cbf_update_combined(self._tab.handle, *b.args(), w_addr, int(remove), where, self._tab.stream))
         else:
             fn = N.lib().psk_cbf_remove if remove else N.lib().psk_cbf_add
-            N.check(fn(self._tab.handle, *b.args(), w_addr, b.where, self._tab.stream))
+            where = b.where
+            lend = (getattr(self, "_borrow_window", False) and where == N.DEVICE and w_addr is None and b.layout == N.KEYS_FIXED and b.key_len == 16
+                    and b.data % 16 == 0 and b.n)
+            if lend:
+                where = N.DEVICE_BORROWED  # the engine may keep the POINTER (update window): hold the tensor until the window is applied
+                self._borrowed.append(b.keep)
+            N.check(fn(self._tab.handle, *b.args(), w_addr, where, self._tab.stream))
+            if len(self._borrowed) >= 128 or (self._borrowed and not lend):
+                # the window holds its latest `pending` batches, ours among them: everything older has been hashed and may go
+                # (asked every 128 lent batches, not every call: the question is a ctypes round trip on a path that is enqueue-bound)
+                pending = self._tab.get_option("window_pending_batches")
+                if pending < len(self._borrowed):
+                    del self._borrowed[: len(self._borrowed) - pending]
         self._dirty = True
 
     def _add_batch(self, b: KeyBatch, num_els=None) -> None:  # type: ignore[override]

@@ -239,7 +239,7 @@ extern "C" int psk_clear(psk_sketch *s, void *stream)
     s->comb.add.unit = s->comb.rem.unit = true;
     s->comb.badd.clear();
     s->comb.brem.clear();
-    s->win.n = 0;  // (the update window too; a window's back-off is a property of the stream and stays)
+    s->win.n = s->win.copied = 0;  // (the update window too; a window's back-off is a property of the stream and stays)
     s->win.batches.clear();
     PSK_TRY(scat_drop(s, st));
     // one launch for the table AND the counter block (two fills are two ~5 us launches; clear sits in every bench step)
@@ -291,7 +291,7 @@ extern "C" int psk_write_table(psk_sketch *s, const void *src_host, uint64_t nby
     s->comb.add.unit = s->comb.rem.unit = true;
     s->comb.badd.clear();
     s->comb.brem.clear();
-    s->win.n = 0;
+    s->win.n = s->win.copied = 0;
     s->win.batches.clear();
     PSK_TRY(scat_drop(s, st));
     HIP_TRY(hipMemsetAsync(s->table, 0, s->padded_bytes, st));
@@ -423,10 +423,10 @@ static int with_source(const Batch &b, F &&f)
     switch (b.layout) {
         case PSK_KEYS_FIXED:
             if (b.key_len == 16 && ((uintptr_t)b.data & 15) == 0) return f(KeysFixed16{(const uint4 *)b.data});
-            if (b.key_len % 4 == 0 && ((uintptr_t)b.data & 3) == 0) return f(KeysFixed<true>{(const uint8_t *)b.data, b.key_len});
-            return f(KeysFixed<false>{(const uint8_t *)b.data, b.key_len});
-        case PSK_KEYS_VARLEN8: return f(KeysVarlen<uint8_t>{(const uint8_t *)b.data, b.offs});
-        case PSK_KEYS_VARLEN32: return f(KeysVarlen<uint32_t>{(const uint32_t *)b.data, b.offs});
+            if (b.key_len % 4 == 0 && ((uintptr_t)b.data & 3) == 0) return f(KeysFixed<true>{(const uint8_t *)b.data, b.key_len, b.n});
+            return f(KeysFixed<false>{(const uint8_t *)b.data, b.key_len, b.n});
+        case PSK_KEYS_VARLEN8: return f(KeysVarlen<uint8_t>{(const uint8_t *)b.data, b.offs, b.n});
+        case PSK_KEYS_VARLEN32: return f(KeysVarlen<uint32_t>{(const uint32_t *)b.data, b.offs, b.n});
         case PSK_KEYS_HASHES: return f(KeysHashes{(const uint64_t *)b.data, b.key_len});
     }
     return fail(PSK_EINVAL, "unknown key layout");
@@ -636,6 +636,10 @@ extern "C" int psk_sketch_get_option(psk_sketch *s, const char *name, int64_t *v
     if (!s || !name || !value) return fail(PSK_EINVAL, "NULL argument");
     if (!strcmp(name, "table_private")) {
         *value = s->table_private ? 1 : 0;
+        return PSK_OK;
+    }
+    if (!strcmp(name, "window_pending_batches")) {  // read-only: batches the update window still holds (borrowed ones among them must stay as they are)
+        *value = s->win.n ? (int64_t)s->win.batches.size() : 0;
         return PSK_OK;
     }
     const int i = ho_index(name);
@@ -1102,7 +1106,7 @@ static int win_replay(psk_sketch *s, const void *keys, const std::vector<psk_ske
     ++s->win.replays;
     ++g_window_replays;
     for (const auto &wb : batches) {
-        const Batch b{PSK_KEYS_FIXED, (const uint8_t *)keys + wb.start * 16, nullptr, wb.n, 16};
+        const Batch b{PSK_KEYS_FIXED, wb.ext ? wb.ext : (const void *)((const uint8_t *)keys + wb.start * 16), nullptr, wb.n, 16};
         if (wb.remove) PSK_TRY(cbf_remove_device(s, b, nullptr, st));
         else PSK_TRY(cbf_apply_device(s, b, nullptr, false, st));
     }
@@ -1117,25 +1121,30 @@ static int win_flush(psk_sketch *s, hipStream_t st)
     batches.swap(s->win.batches);  // (cleared first: a failure must not re-apply the window on the next call)
     const uint64_t n = s->win.n;
     s->win.n = 0;
+    s->win.copied = 0;
     const void *keys = s->win.keys.p;
     // runs of same-type batches are the fold's phases
-    std::vector<WinPhaseHost> ph;
+    std::vector<WinBatchHost> wbh;
+    wbh.reserve(batches.size());
     uint64_t n_add = 0, n_rem = 0;
+    size_t phases = 0;
+    bool borrowed = false;
     for (const auto &wb : batches) {
-        if (!ph.empty() && ph.back().remove == wb.remove) ph.back().n += wb.n;
-        else ph.push_back(WinPhaseHost{wb.start, wb.n, wb.remove});
+        phases += wbh.empty() || wbh.back().remove != wb.remove;
+        wbh.push_back(WinBatchHost{wb.ext ? wb.ext : (const void *)((const uint8_t *)keys + wb.start * 16), wb.n, wb.remove});
+        borrowed = borrowed || wb.ext != nullptr;
         (wb.remove ? n_rem : n_add) += wb.n;
     }
-    // One phase: a plain batch (the partitioned add / the validated remove take it as a whole).  Too few probes for a pass over the
-    // table, or a recent window whose proof failed: batch by batch.
-    if (ph.size() == 1) {
-        const Batch b{PSK_KEYS_FIXED, keys, nullptr, n, 16};
-        return ph[0].remove ? cbf_remove_device(s, b, nullptr, st) : cbf_apply_device(s, b, nullptr, false, st);
+    // One phase of keys that lie end to end (copies in the list, or one borrowed batch): a plain batch (the partitioned add / the validated
+    // remove take it as a whole).  Too few probes for a pass over the table, or a recent window whose proof failed: batch by batch.
+    if (phases == 1 && (!borrowed || batches.size() == 1)) {
+        const Batch b{PSK_KEYS_FIXED, wbh[0].keys, nullptr, n, 16};
+        return wbh[0].remove ? cbf_remove_device(s, b, nullptr, st) : cbf_apply_device(s, b, nullptr, false, st);
     }
-    const bool worth = n * (uint64_t)s->k >= s->m / 8 && ph.size() <= (size_t)kWinMaxPhases;
+    const bool worth = n * (uint64_t)s->k >= s->m / 8 && phases <= (size_t)kWinMaxPhases;
     if (worth && s->win.backoff == 0) {
         bool launched = false, ok = false;
-        PSK_TRY(cbf_window_fold(s, ph.data(), (uint32_t)ph.size(), keys, n, st, &launched, &ok));
+        PSK_TRY(cbf_window_fold(s, wbh.data(), (uint32_t)wbh.size(), st, &launched, &ok));
         if (launched && ok) {
             ++s->win.folds;
             ++g_window_folds;
@@ -1165,9 +1174,9 @@ static int win_reserve(psk_sketch *s, uint64_t want, uint64_t cap, hipStream_t s
         *ok = false;
         return PSK_OK;
     }
-    if (s->win.n) {
+    if (s->win.copied) {
         PSK_TRY(comb_order(s, st));
-        HIP_TRY(hipMemcpyAsync(p, s->win.keys.p, s->win.n * 16, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(p, s->win.keys.p, s->win.copied * 16, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));  // (the old list is freed below)
     }
     if (s->win.keys.p) HIP_TRY(hipFree(s->win.keys.p));
@@ -1176,7 +1185,9 @@ static int win_reserve(psk_sketch *s, uint64_t want, uint64_t cap, hipStream_t s
     return PSK_OK;
 }
 
-// hand a batch over to the window (eligible: win_eligible); host batches are copied straight from the caller's buffer.
+// hand a batch over to the window (eligible: win_eligible); host batches are copied straight from the caller's buffer, PSK_DEVICE batches
+// device to device, PSK_DEVICE_BORROWED ones stay where they are (the caller keeps them unchanged until the window has been applied:
+// psk_flush_combined, any entry point that reads the table, or psk_sketch_get_option "window_pending_batches" back at 0).
 // *taken = false: no memory for the key list -- nothing was appended, what waited has been applied, the caller applies this batch itself.
 static int win_append(psk_sketch *s, const void *data, uint64_t n, bool remove, int where, hipStream_t st, bool *taken)
 {
@@ -1190,8 +1201,13 @@ static int win_append(psk_sketch *s, const void *data, uint64_t n, bool remove, 
         if (phases >= (size_t)kWinMaxPhases) PSK_TRY(win_flush(s, st));
     }
     s->win.cap = cap;
+    if (where == PSK_DEVICE_BORROWED) {  // (16-byte aligned: win_eligible's caller checked)
+        s->win.batches.push_back(psk_sketch::WinBatch{0, n, remove ? 1u : 0u, data});
+        s->win.n += n;
+        return comb_appended(s, st);  // (a flush on another stream waits for this one: the keys may still be in the making on it)
+    }
     bool room = false;
-    PSK_TRY(win_reserve(s, s->win.n + n, cap, st, &room));
+    PSK_TRY(win_reserve(s, s->win.copied + n, cap, st, &room));
     if (!room && s->win.n) {  // what waits fits what there is: apply it, then this batch may fit too
         PSK_TRY(win_flush(s, st));
         room = n * 16 <= s->win.keys.cap;
@@ -1202,8 +1218,9 @@ static int win_append(psk_sketch *s, const void *data, uint64_t n, bool remove, 
     }
     PSK_TRY(comb_order(s, st));
     // (round 4: an own copy kernel with nontemporal loads / stores measured slower than the runtime's blit: 3.60 vs 3.55 ms per cfg-4 step)
-    HIP_TRY(hipMemcpyAsync((uint8_t *)s->win.keys.p + s->win.n * 16, data, n * 16, where == PSK_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
-    s->win.batches.push_back(psk_sketch::WinBatch{s->win.n, n, remove ? 1u : 0u});
+    HIP_TRY(hipMemcpyAsync((uint8_t *)s->win.keys.p + s->win.copied * 16, data, n * 16, where == PSK_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+    s->win.batches.push_back(psk_sketch::WinBatch{s->win.copied, n, remove ? 1u : 0u, nullptr});
+    s->win.copied += n;
     s->win.n += n;
     PSK_TRY(comb_appended(s, st));
     if (where == PSK_HOST) HIP_TRY(hipStreamSynchronize(st));  // the caller may reuse its buffer on return
@@ -1218,11 +1235,12 @@ int flush_combined(psk_sketch *s, hipStream_t st)
         if (s->comb.add.n || s->comb.rem.n || s->comb.badd.n() || s->comb.brem.n() || (s->scat.ready && (s->scat.add.n || s->scat.rem.n))) {
             std::vector<psk_sketch::WinBatch> keep;
             keep.swap(s->win.batches);
-            const uint64_t wn = s->win.n;
+            const uint64_t wn = s->win.n, wc = s->win.copied;
             s->win.n = 0;
             PSK_TRY(flush_combined(s, st));
             s->win.batches.swap(keep);
             s->win.n = wn;
+            s->win.copied = wc;
         }
         PSK_TRY(win_flush(s, st));
     }
@@ -1374,14 +1392,15 @@ extern "C" int psk_cbf_add(psk_sketch *s, int layout, const void *data, const ui
     CHECK_HANDLE(s, PSK_KIND_CBF);
     PSK_TRY(check_hashes_width(s, layout, key_len));
     hipStream_t st = (hipStream_t)stream;
-    if (where != PSK_HOST && where != PSK_DEVICE) return fail(PSK_EINVAL, "`where` must be PSK_HOST or PSK_DEVICE");
+    if (where != PSK_HOST && where != PSK_DEVICE && where != PSK_DEVICE_BORROWED) return fail(PSK_EINVAL, "`where` must be PSK_HOST, PSK_DEVICE or PSK_DEVICE_BORROWED");
     if (win_eligible(s, layout, data, key_len, weights, n)) {
         // (what the older write-combining mechanisms hold arrived earlier: it goes first)
         if (s->comb.add.n || s->comb.rem.n || s->comb.badd.n() || s->comb.brem.n() || (s->scat.ready && (s->scat.add.n || s->scat.rem.n))) PSK_TRY(flush_combined(s, st));
         bool taken = false;
-        PSK_TRY(win_append(s, data, n, false, where, st, &taken));
+        PSK_TRY(win_append(s, data, n, false, where == PSK_DEVICE_BORROWED && ((uintptr_t)data & 15) ? PSK_DEVICE : where, st, &taken));
         if (taken) return PSK_OK;  // (else: no memory for the window's key list -- the batch goes on below like any other)
     }
+    if (where == PSK_DEVICE_BORROWED) where = PSK_DEVICE;  // (applied before this call returns: nothing is kept)
     Batch b;
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));
     // Automatic write-combining (no opt-in): a unit-weight batch too small to pay for a pass over a big table would take one
@@ -1584,15 +1603,16 @@ extern "C" int psk_cbf_remove(psk_sketch *s, int layout, const void *data, const
     CHECK_HANDLE(s, PSK_KIND_CBF);
     PSK_TRY(check_hashes_width(s, layout, key_len));
     hipStream_t st = (hipStream_t)stream;
-    if (where != PSK_HOST && where != PSK_DEVICE) return fail(PSK_EINVAL, "`where` must be PSK_HOST or PSK_DEVICE");
+    if (where != PSK_HOST && where != PSK_DEVICE && where != PSK_DEVICE_BORROWED) return fail(PSK_EINVAL, "`where` must be PSK_HOST, PSK_DEVICE or PSK_DEVICE_BORROWED");
     if (win_eligible(s, layout, data, key_len, weights, n)) {
         // A small batch into a big table: it waits in the update window (with the adds around it, in order) for a shared pass over
         // the table; the flush proves that it would have removed every key at this point of the stream, or replays it right here.
         if (s->comb.add.n || s->comb.rem.n || s->comb.badd.n() || s->comb.brem.n() || (s->scat.ready && (s->scat.add.n || s->scat.rem.n))) PSK_TRY(flush_combined(s, st));
         bool taken = false;
-        PSK_TRY(win_append(s, data, n, true, where, st, &taken));
+        PSK_TRY(win_append(s, data, n, true, where == PSK_DEVICE_BORROWED && ((uintptr_t)data & 15) ? PSK_DEVICE : where, st, &taken));
         if (taken) return PSK_OK;
     }
+    if (where == PSK_DEVICE_BORROWED) where = PSK_DEVICE;
     PSK_TRY(flush_combined(s, st));  // write-combined updates reach the table before anything else touches it
     Batch b;
     PSK_TRY(stage_batch(s->s_keys, s->s_offs, layout, data, offsets, n, key_len, where, st, &b));

@@ -154,12 +154,123 @@ struct KeysFixed16Multi {
     __device__ __forceinline__ void hash32(const Key &k, uint64_t i, uint32_t s0, uint32_t (&h)[G]) const { KeysFixed16{nullptr}.template hash32<G>(k, i, s0, h); }
 };
 
+// ---- keys that start anywhere: 16-byte windows of the blob per lane
+// A key of `len` bytes at any address is read as 4-byte-aligned global_load_dwordx4 windows (adjacent lanes hold adjacent keys, so a wave's
+// windows cover one contiguous stretch of the blob just as the fixed-16 layout's loads do), the next window requested before the current
+// one is hashed, and the key's words are cut out of neighbouring dwords with v_alignbyte_b32 -- instead of one dependent
+// global_load_ubyte in front of every step of the k chains (rounds 1-4).
+// `room`: bytes from the key's first byte to the end of the whole blob.  A dword is only ever requested if it holds a byte of the
+// blob (it then lies in a mapped page); the last windows of the batch fall back to dword loads clamped to the blob's last dword.
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+struct ByteWindows {
+    const uint32_t *w;  // the dword that holds the key's first byte
+    uint32_t a;         // that byte's position in it
+    uint32_t safe;      // dwords from w on that may be loaded
+    __device__ __forceinline__ ByteWindows(const uint8_t *q, uint32_t room)
+    {
+        const uintptr_t addr = (uintptr_t)q;
+        a = (uint32_t)addr & 3u;
+        w = reinterpret_cast<const uint32_t *>(addr - a);
+        safe = (a + room + 3u) >> 2;
+    }
+    __device__ __forceinline__ uint4 load(uint32_t t) const
+    {
+        const uint32_t d0 = 4u * t;
+        if (d0 + 4u <= safe) {
+            const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(w + d0);
+            return make_uint4(v.x, v.y, v.z, v.w);
+        }
+        const uint32_t last = safe - 1u;  // (safe >= 1: the caller holds at least one byte)
+        return make_uint4(w[d0 < last ? d0 : last], w[d0 + 1 < last ? d0 + 1 : last], w[d0 + 2 < last ? d0 + 2 : last], w[d0 + 3 < last ? d0 + 3 : last]);
+    }
+};
+
+// word(w): four key bytes (little endian); byte(e): one.  len < 2^31.  `cur`: the key's first window (bw.load(0); a caller that hashes
+// several keys requests all their first windows before it walks the first key)
+template <class WordFn, class ByteFn>
+__device__ __forceinline__ void walk_key_bytes(const ByteWindows &bw, uint4 cur, uint32_t len, WordFn &&word, ByteFn &&byte)
+{
+    if (len == 0) return;
+    const uint32_t nwin = (bw.a + len + 15u) >> 4;
+    uint32_t left = len;
+    for (uint32_t t = 0; t < nwin; ++t) {
+        uint4 nxt = cur;
+        if (t + 1 < nwin) nxt = bw.load(t + 1);
+        const uint32_t d[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t kw = __builtin_amdgcn_alignbyte(d[e + 1], d[e], bw.a);
+            if (left >= 4) {
+                word(kw);
+                left -= 4;
+            } else {
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                    if ((uint32_t)b < left) byte((kw >> (8 * b)) & 0xFFu);
+                left = 0;
+            }
+        }
+        cur = nxt;
+    }
+}
+
+template <class WordFn, class ByteFn>
+__device__ __forceinline__ void walk_key_bytes(const uint8_t *q, uint32_t len, uint32_t room, WordFn &&word, ByteFn &&byte)
+{
+    if (len == 0) return;
+    const ByteWindows bw(q, room);
+    walk_key_bytes(bw, bw.load(0), len, word, byte);
+}
+
+// 4-byte elements (code points of str keys): windows of four elements, `room` in elements (>= 1)
+__device__ __forceinline__ uint4 elem_window(const uint32_t *q, uint32_t room, uint32_t t)
+{
+    const uint32_t d0 = 4u * t;
+    if (d0 + 4u <= room) {
+        const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(q + d0);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    const uint32_t last = room - 1u;
+    return make_uint4(q[d0 < last ? d0 : last], q[d0 + 1 < last ? d0 + 1 : last], q[d0 + 2 < last ? d0 + 2 : last], q[d0 + 3 < last ? d0 + 3 : last]);
+}
+template <class ElemFn>
+__device__ __forceinline__ void walk_key_elems(const uint32_t *q, uint4 cur, uint32_t len, uint32_t room, ElemFn &&elem)
+{
+    if (len == 0) return;
+    auto loadwin = [&](uint32_t t) -> uint4 { return elem_window(q, room, t); };
+    const uint32_t nwin = (len + 3u) >> 2;
+    for (uint32_t t = 0; t < nwin; ++t) {
+        uint4 nxt = cur;
+        if (t + 1 < nwin) nxt = loadwin(t + 1);
+        const uint32_t d[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4u * t + (uint32_t)e < len) elem(d[e]);
+        cur = nxt;
+    }
+}
+template <class ElemFn>
+__device__ __forceinline__ void walk_key_elems(const uint32_t *q, uint32_t len, uint32_t room, ElemFn &&elem)
+{
+    if (len == 0) return;
+    walk_key_elems(q, elem_window(q, room, 0), len, room, elem);
+}
+
+constexpr uint32_t kKeyLenBig = 0xFFFFFFFFu;  // Key::len of a key of 2^31 elements or more: walked element by element from off[]
+constexpr uint64_t kKeyRoomMax = 0x7FFFFFF0ull;
+
 template <bool DWORDS>
 struct KeysFixed {  // uint8[n][L]; DWORDS: L % 4 == 0 and base 4-byte aligned
     const uint8_t *p;
     uint32_t L;
-    struct Key { const uint8_t *q; };
-    __device__ __forceinline__ Key load(uint64_t i) const { return Key{p + i * (uint64_t)L}; }
+    uint64_t n;  // keys the matrix holds (bounds the windows of the last keys)
+    struct Key { const uint8_t *q; uint32_t room; };
+    __device__ __forceinline__ Key load(uint64_t i) const
+    {
+        const uint64_t room = (n - i) * (uint64_t)L;
+        return Key{p + i * (uint64_t)L, (uint32_t)(room < kKeyRoomMax ? room : kKeyRoomMax)};
+    }
     static __device__ __forceinline__ void pin(Key &) {}
     template <int G>
     __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
@@ -170,11 +281,11 @@ struct KeysFixed {  // uint8[n][L]; DWORDS: L % 4 == 0 and base 4-byte aligned
             const uint32_t *q = reinterpret_cast<const uint32_t *>(k.q);
             for (uint32_t j = 0; j < L / 4; ++j) fnv_word<G>(h, pr, q[j]);
         } else {
-            for (uint32_t j = 0; j < L; ++j) {
-                const uint32_t e = k.q[j];
+            walk_key_bytes(k.q, L, k.room, [&](uint32_t w) { fnv_word<G>(h, pr, w); },
+                           [&](uint32_t e) {
 #pragma unroll
-                for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e, pr.p[g]);
-            }
+                               for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e, pr.p[g]);
+                           });
         }
     }
     template <int G>
@@ -185,11 +296,11 @@ struct KeysFixed {  // uint8[n][L]; DWORDS: L % 4 == 0 and base 4-byte aligned
             const uint32_t *q = reinterpret_cast<const uint32_t *>(k.q);
             for (uint32_t j = 0; j < L / 4; ++j) fnv_word32<G>(h, q[j]);
         } else {
-            for (uint32_t j = 0; j < L; ++j) {
-                const uint32_t e = k.q[j];
+            walk_key_bytes(k.q, L, k.room, [&](uint32_t w) { fnv_word32<G>(h, w); },
+                           [&](uint32_t e) {
 #pragma unroll
-                for (int g = 0; g < G; ++g) h[g] = fnv_step32(h[g], e);
-            }
+                               for (int g = 0; g < G; ++g) h[g] = fnv_step32(h[g], e);
+                           });
         }
     }
 };
@@ -198,34 +309,72 @@ template <class T>
 struct KeysVarlen {  // elements T (uint8 bytes, or uint32 code points for str keys: hashes.py:98)
     const T *p;
     const uint64_t *off;
-    struct Key { const T *q; uint64_t len; };
+    uint64_t n;  // keys of the batch: off[n] is the end of the blob
+    struct Key { const T *q; uint32_t len; uint32_t room; };
+    static constexpr bool sorted = true;  // pass 1 hands a tile's keys to its lanes in order of length (psk_partition.hpp, src_sorted)
+    // length class of the sort (0 .. 62): the exact length below 48 elements -- the lanes of a wave then agree on every step of the walk --,
+    // steps of 16 up to 272, one class for the rest
+    static __device__ __forceinline__ uint32_t len_class(const Key &k)
+    {
+        return k.len < 48u ? k.len : (k.len < 48u + 14u * 16u ? 48u + ((k.len - 48u) >> 4) : 62u);
+    }
+    // the key's first window (requested for all keys of a thread before the first one is walked)
+    __device__ __forceinline__ uint4 first(const Key &k) const
+    {
+        if (k.len == 0) return make_uint4(0, 0, 0, 0);
+        if constexpr (sizeof(T) == 1) return ByteWindows(reinterpret_cast<const uint8_t *>(k.q), k.room).load(0);
+        else return elem_window(reinterpret_cast<const uint32_t *>(k.q), k.room, 0);
+    }
     __device__ __forceinline__ Key load(uint64_t i) const
     {
-        const uint64_t a = off[i], b = off[i + 1];
-        return Key{p + a, b - a};
+        const uint64_t a = off[i], b = off[i + 1], e = off[n];  // (off[n]: one address for the whole wave, a scalar load)
+        const uint64_t len = b - a, room = e - a;
+        return Key{p + a, len < 0x80000000ull ? (uint32_t)len : kKeyLenBig, (uint32_t)(room < kKeyRoomMax ? room : kKeyRoomMax)};
     }
     static __device__ __forceinline__ void pin(Key &) {}
     template <int G>
-    __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
+    __device__ __forceinline__ void hash_first(const Key &k, const uint4 &w0, uint64_t i, uint32_t s0, uint64_t (&h)[G]) const
     {
         fnv_init<G>(h, s0);
         FnvPairs<G> pr;
-        for (uint64_t j = 0; j < k.len; ++j) {
-            const uint32_t e = (uint32_t)k.q[j];
+        auto step = [&](uint32_t e) {
 #pragma unroll
             for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e, pr.p[g]);
+        };
+        if (k.len == kKeyLenBig) {  // 2 G elements in one key: the plain walk
+            const uint64_t len = off[i + 1] - off[i];
+            for (uint64_t j = 0; j < len; ++j) step((uint32_t)k.q[j]);
+            return;
+        }
+        if constexpr (sizeof(T) == 1) {
+            if (k.len) walk_key_bytes(ByteWindows(reinterpret_cast<const uint8_t *>(k.q), k.room), w0, k.len, [&](uint32_t w) { fnv_word<G>(h, pr, w); }, step);
+        } else {
+            walk_key_elems(reinterpret_cast<const uint32_t *>(k.q), w0, k.len, k.room, step);
         }
     }
     template <int G>
-    __device__ __forceinline__ void hash32(const Key &k, uint64_t, uint32_t s0, uint32_t (&h)[G]) const
+    __device__ __forceinline__ void hash32_first(const Key &k, const uint4 &w0, uint64_t i, uint32_t s0, uint32_t (&h)[G]) const
     {
         fnv_init32<G>(h, s0);
-        for (uint64_t j = 0; j < k.len; ++j) {
-            const uint32_t e = (uint32_t)k.q[j];  // code points > 255 XOR whole into the low word as well
+        auto step = [&](uint32_t e) {  // code points > 255 XOR whole into the low word as well
 #pragma unroll
             for (int g = 0; g < G; ++g) h[g] = fnv_step32(h[g], e);
+        };
+        if (k.len == kKeyLenBig) {
+            const uint64_t len = off[i + 1] - off[i];
+            for (uint64_t j = 0; j < len; ++j) step((uint32_t)k.q[j]);
+            return;
+        }
+        if constexpr (sizeof(T) == 1) {
+            if (k.len) walk_key_bytes(ByteWindows(reinterpret_cast<const uint8_t *>(k.q), k.room), w0, k.len, [&](uint32_t w) { fnv_word32<G>(h, w); }, step);
+        } else {
+            walk_key_elems(reinterpret_cast<const uint32_t *>(k.q), w0, k.len, k.room, step);
         }
     }
+    template <int G>
+    __device__ __forceinline__ void hash(const Key &k, uint64_t i, uint32_t s0, uint64_t (&h)[G]) const { hash_first<G>(k, first(k), i, s0, h); }
+    template <int G>
+    __device__ __forceinline__ void hash32(const Key &k, uint64_t i, uint32_t s0, uint32_t (&h)[G]) const { hash32_first<G>(k, first(k), i, s0, h); }
 };
 
 struct KeysHashes {  // uint64[n][stride] pre-computed hashes (add_alt / check_alt, custom hash_function)

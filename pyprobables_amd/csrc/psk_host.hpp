@@ -178,12 +178,14 @@ struct psk_sketch {
     // arrival order, as key copies; the flush proves while it folds that every remove would have succeeded at its own position of the
     // stream (else: undo + batch-by-batch replay), so the result is the reference's for ANY stream -- no opt-in, no contract.
     struct WinBatch {
-        uint64_t start, n;   // keys [start, start + n) of the list
+        uint64_t start, n;   // keys [start, start + n) of the list ...
         uint32_t remove;
+        const void *ext;     // ... or n keys the caller keeps where they are until the window is applied (PSK_DEVICE_BORROWED); null: copied
     };
     struct {
         DevBuf keys;         // uint8[cap][16]
-        uint64_t n = 0, cap = 0;
+        uint64_t n = 0, cap = 0;   // keys waiting (copied + borrowed), the window's capacity
+        uint64_t copied = 0;       // keys of the list in use
         std::vector<WinBatch> batches;
         uint32_t backoff = 0;      // windows left that are replayed batch by batch without trying the fold (after a failed proof)
         void *pin = nullptr;       // pinned staging of the phase table
@@ -329,8 +331,9 @@ static int set_dyn_lds(K kernel, size_t bytes)
 // Pass 1 for one concrete (Src, IdxFn, Pay, Spill, KT, NT): sizes the (slice, workgroup) segments for `n` keys,
 // grows the handle's bucket buffer, launches.  g->nwg / g->segcap are filled in for pass 2.
 template <class Pay, int KT, int NT>
-static size_t scatter_lds_bytes(const PartGeom *g, uint64_t tile = 0)  // tile: keys per tile (0 = the shape's full tile)
+static size_t scatter_lds_bytes(const PartGeom *g, uint64_t tile = 0, bool sorted = false)  // tile: keys per tile (0 = the shape's full tile)
 {
+    if (sorted) return scatter_lds_bytes<Pay, KT, NT>(g, tile, false) + 16 + 512 + 18 * (size_t)PartTile<Pay, KT, NT>::TILE;  // length sort (src_sorted): counts, descriptors, slots
     using Tile = PartTile<Pay, KT, NT>;
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
     const size_t tk = tile ? (size_t)tile : (size_t)Tile::TILE;
@@ -353,12 +356,13 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
                              uint64_t n, hipStream_t st, uint32_t want_wgs, const ScatterTarget *fixed = nullptr)
 {
     using Tile = PartTile<Pay, KT, NT>;
+    constexpr bool kSorted = src_sorted<Src>::value;  // (keys of different lengths: + the LDS of the tile's length sort)
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
     // keys per tile: the shape's, cut down (whole waves) where its LDS stage would not fit -- 8-probe groups at 2048 slices carry 7 pad
     // slots per slice: 1984-key tiles instead of 2048 (the kernel sizes its stage by PartGeom::tile)
     uint64_t tile_full = Tile::TILE;
-    while (tile_full > 64 && scatter_lds_bytes<Pay, KT, NT>(g, tile_full) > kScatterLdsBudget) tile_full -= 64;
-    if (scatter_lds_bytes<Pay, KT, NT>(g, tile_full) > kScatterLdsBudget) return fail(PSK_EINVAL, "pass 1: %u slices do not fit the LDS stage", g->nbuckets);
+    while (tile_full > 64 && scatter_lds_bytes<Pay, KT, NT>(g, tile_full, kSorted) > kScatterLdsBudget) tile_full -= 64;
+    if (scatter_lds_bytes<Pay, KT, NT>(g, tile_full, kSorted) > kScatterLdsBudget) return fail(PSK_EINVAL, "pass 1: %u slices do not fit the LDS stage", g->nbuckets);
     const uint64_t ntiles = (n + tile_full - 1) / tile_full;
     if (fixed) {  // append behind what the segments already hold: the first min(nwg, tiles) workgroups each take their share of tiles
         if (Pay::mode != kModePlain) return fail(PSK_EINVAL, "persistent segments carry payload-free probes");
@@ -371,14 +375,14 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
             if (tk > tile_full) tk = tile_full;
         }
         g->tile = (uint32_t)tk;
-        const size_t lds = scatter_lds_bytes<Pay, KT, NT>(g, tk);
+        const size_t lds = scatter_lds_bytes<Pay, KT, NT>(g, tk, kSorted);
         auto kern = k_part_scatter<Src, IdxFn, Pay, Spill, KT, NT>;
         PSK_TRY(set_dyn_lds(kern, lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, src, idxfn, pay, spill, *g, n, fixed->cnt, fixed->part);
         HIP_TRY(hipGetLastError());
         return PSK_OK;
     }
-    uint64_t per_cu = NT > 512 ? 1 : (scatter_lds_bytes<Pay, KT, NT>(g, tile_full) > kScatterLdsTwoPerCu ? 1 : 2);
+    uint64_t per_cu = NT > 512 ? 1 : (scatter_lds_bytes<Pay, KT, NT>(g, tile_full, kSorted) > kScatterLdsTwoPerCu ? 1 : 2);
     if (kBenchKnobs && (g->dbg & 8)) per_cu = 1;  // ablation: one workgroup per CU
     uint64_t nwg = 256 * per_cu;
     if (want_wgs) nwg = want_wgs;  // caller's choice (keyed lookups into big tables: twice the keys per round)
@@ -394,7 +398,7 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
         tk = ((n + nwg * tiles_per_wg - 1) / (nwg * tiles_per_wg) + 63) & ~63ULL;
         if (tk > tile_full) tk = tile_full;
     }
-    const size_t lds = scatter_lds_bytes<Pay, KT, NT>(g, tk);
+    const size_t lds = scatter_lds_bytes<Pay, KT, NT>(g, tk, kSorted);
     const double mean = (double)tiles_per_wg * (double)tk * kk / (double)g->nbuckets;  // probes per segment
     // 16-byte groups per segment: mean/GS, + ~half a group of padding per (tile, slice) run, + 8 sigma
     uint64_t segcap = (uint64_t)(mean / Tile::GS + 0.5 * (double)tiles_per_wg + 8.0 * __builtin_sqrt(mean) / Tile::GS + 16.0);
@@ -422,13 +426,19 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
 
 // The workgroup shape launch_scatter picks for (Pay, KT) on geometry g: threads per workgroup, and the pass-1 workgroups
 // launch_scatter_nt starts by default (before it clamps them to the number of tiles)
-template <class Pay, int KT>
+// the two-per-CU twin (Pay::fat512) exists for the 16-byte fast layouts only: the other layouts take the one 1024-thread shape (keys of
+// different lengths hold a descriptor and a window per key in registers -- four keys per thread spill --, and the rare layouts are not worth
+// a second copy of every kernel)
+template <class Src>
+struct src_fat512 { static constexpr bool value = std::is_same<Src, KeysFixed16>::value || std::is_same<Src, KeysFixed16Multi>::value; };
+
+template <class Pay, int KT, bool FAT = true>
 static int scatter_threads(const PartGeom *g)
 {
     // k <= 8 without the two-per-CU shape (every payload but the Bloom insert's / the tile-flag lookup's): 1024 threads, always -- its stage fits the
     // LDS for every geometry the single-level path takes (at most 2048 slices, at most 16 K probes per tile: <= 154 KB), so the 512-thread
     // form of these kernels is not even instantiated (round 5: it was a third of the library's device code and never selected)
-    if constexpr (KT <= 8 && !pay_fat512<Pay>::value) return 1024;
+    if constexpr (KT <= 8 && !(pay_fat512<Pay>::value && FAT)) return 1024;
     if constexpr (KT <= 8) {
         const bool fits1024 = scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget;
         const bool two_per_cu = pay_fat512<Pay>::value && scatter_lds_bytes<Pay, KT, kPartThreads>(g) <= kScatterLdsTwoPerCu;
@@ -440,10 +450,10 @@ static int scatter_threads(const PartGeom *g)
     return kPartThreads;
 }
 // largest round (keys) whose tiles number at most `max_tiles` per pass-1 workgroup (probes that spell the tile's ordinal in 4 bits)
-template <class Pay, int KT>
+template <class Pay, int KT, bool FAT = true>
 static uint64_t scatter_round_cap(const PartGeom *g, uint32_t want_wgs, uint32_t max_tiles)
 {
-    const bool big = scatter_threads<Pay, KT>(g) == 1024;
+    const bool big = scatter_threads<Pay, KT, FAT>(g) == 1024;
     const size_t lds = big ? scatter_lds_bytes<Pay, KT, 1024>(g) : scatter_lds_bytes<Pay, KT, kPartThreads>(g);
     const uint64_t tile = big ? (uint64_t)PartTile<Pay, KT, 1024>::TILE : (uint64_t)PartTile<Pay, KT, kPartThreads>::TILE;
     uint64_t nwg = 256 * (uint64_t)(big ? 1 : (lds > kScatterLdsTwoPerCu ? 1 : 2));
@@ -470,10 +480,10 @@ static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, con
         // tile must stay within 2^(31 - shift) keys (PayKeyId::max_tile caps it at 2048 keys)
         if constexpr (Pay::mode == kModeKeyed)
             static_assert(((uint64_t)PartTile<Pay, KT, 1024>::TILE << Pay::slice_shift) <= (1ULL << 31), "keyed tile too large");
-        if constexpr (!pay_fat512<Pay>::value) {  // one shape only (scatter_threads; launch_scatter_nt cuts the tile where the stage would not fit)
+        if constexpr (!(pay_fat512<Pay>::value && src_fat512<Src>::value)) {  // one shape only (scatter_threads; launch_scatter_nt cuts the tile where the stage would not fit)
             return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st, want_wgs, fixed);
         } else {
-            if (scatter_threads<Pay, KT>(g) == 1024) return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st, want_wgs, fixed);
+            if (scatter_threads<Pay, KT, true>(g) == 1024) return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, 1024>(s, src, idxfn, pay, spill, g, n, st, want_wgs, fixed);
             return launch_scatter_nt<Src, IdxFn, Pay, Spill, KT, kPartThreads>(s, src, idxfn, pay, spill, g, n, st, want_wgs, fixed);
         }
     } else {
@@ -485,8 +495,11 @@ static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, con
 template <class Src, class F>
 static int with_kt(uint32_t k, F &&f)
 {
-    constexpr bool fast = std::is_same<Src, KeysFixed16>::value || std::is_same<Src, KeysFixed16Multi>::value;
-    if (fast) {
+    // (`if constexpr`: a plain `if` instantiated -- and emitted -- the exact-k kernels of EVERY layout, though the rare ones could never be
+    // selected: 6 dead kernels per layout, payload and launcher.  Ragged byte keys -- the reference's native key type -- get the exact sizes too.)
+    constexpr bool fast16 = std::is_same<Src, KeysFixed16>::value || std::is_same<Src, KeysFixed16Multi>::value;
+    constexpr bool fast = fast16 || std::is_same<Src, KeysVarlen<uint8_t>>::value;
+    if constexpr (fast) {
         switch (k) {
             case 3: return f(std::integral_constant<int, 3>{});
             case 4: return f(std::integral_constant<int, 4>{});
@@ -500,7 +513,9 @@ static int with_kt(uint32_t k, F &&f)
     if (k <= 8) return f(std::integral_constant<int, 8>{});
     // (k = 9 .. 16 on the other layouts runs the 32-chain instantiation, whose chains go four at a time and stop at k: both forms hash one key
     // per thread and tile, so a separate 16-chain kernel per layout and payload bought nothing but device code)
-    if (fast && k <= 16) return f(std::integral_constant<int, 16>{});
+    if constexpr (fast16) {
+        if (k <= 16) return f(std::integral_constant<int, 16>{});
+    }
     return f(std::integral_constant<int, 32>{});
 }
 
@@ -512,10 +527,10 @@ static int with_part_source(const Batch &b, bool *handled, F &&f)
     switch (b.layout) {
         case PSK_KEYS_FIXED:
             if (b.key_len == 16 && ((uintptr_t)b.data & 15) == 0) return f(KeysFixed16{(const uint4 *)b.data});
-            if (b.key_len % 4 == 0 && ((uintptr_t)b.data & 3) == 0) return f(KeysFixed<true>{(const uint8_t *)b.data, b.key_len});
-            return f(KeysFixed<false>{(const uint8_t *)b.data, b.key_len});
-        case PSK_KEYS_VARLEN8: return f(KeysVarlen<uint8_t>{(const uint8_t *)b.data, b.offs});
-        case PSK_KEYS_VARLEN32: return f(KeysVarlen<uint32_t>{(const uint32_t *)b.data, b.offs});
+            if (b.key_len % 4 == 0 && ((uintptr_t)b.data & 3) == 0) return f(KeysFixed<true>{(const uint8_t *)b.data, b.key_len, b.n});
+            return f(KeysFixed<false>{(const uint8_t *)b.data, b.key_len, b.n});
+        case PSK_KEYS_VARLEN8: return f(KeysVarlen<uint8_t>{(const uint8_t *)b.data, b.offs, b.n});
+        case PSK_KEYS_VARLEN32: return f(KeysVarlen<uint32_t>{(const uint32_t *)b.data, b.offs, b.n});
         case PSK_KEYS_HASHES: return f(KeysHashes{(const uint64_t *)b.data, b.key_len});
         default: break;
     }
@@ -674,11 +689,12 @@ PSK_DECLARE_VARIANTS(int, cbf_remove_fast_begin, (psk_sketch *s, const Batch &b,
 PSK_DECLARE_VARIANTS(int, cbf_remove_fast_undo, (psk_sketch *s, hipStream_t st))
 // The fold of an update window (psk_window.hpp): phase-aware pass 1 over the window's key list + k_win_fold; *launched = false: table /
 // window not eligible (nothing changed); *ok = false: the proof failed -- the fold has been undone, the caller replays batch by batch.
-struct WinPhaseHost {
-    uint64_t start, n;
+struct WinBatchHost {   // one waiting batch, in arrival order: n 16-byte keys at `keys` (the window's list, or the caller's own buffer)
+    const void *keys;
+    uint64_t n;
     uint32_t remove;
 };
-PSK_DECLARE_VARIANTS(int, cbf_window_fold, (psk_sketch *s, const WinPhaseHost *ph, uint32_t nph, const void *keys_dev, uint64_t nlist, hipStream_t st, bool *launched, bool *ok))
+PSK_DECLARE_VARIANTS(int, cbf_window_fold, (psk_sketch *s, const WinBatchHost *wb, uint32_t nb, hipStream_t st, bool *launched, bool *ok))
 extern PSK_HIDDEN __thread int64_t g_remove_exact, g_window, g_window_keys;
 extern PSK_HIDDEN int64_t g_cbf_ordered_replays;
 extern PSK_HIDDEN int64_t g_window_folds, g_window_replays, g_window_force_fail;

@@ -131,7 +131,7 @@ static bool tile_flag_geometry(psk_sketch *s, const Batch &b, PartGeom *g, uint6
             using Src = decltype(src);
             return with_kt<Src>(s->k, [&](auto kt) {
                 constexpr int KT = decltype(kt)::value;
-                cap = scatter_round_cap<PayTileTag, KT>(g, 0, PayTileTag::max_tiles_per_wg);
+                cap = scatter_round_cap<PayTileTag, KT, src_fat512<Src>::value>(g, 0, PayTileTag::max_tiles_per_wg);
                 return (int)PSK_OK;
             });
         }) != PSK_OK || !handled || cap == 0) return false;

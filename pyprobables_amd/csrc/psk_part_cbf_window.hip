@@ -7,40 +7,66 @@ extern PSK_HIDDEN int64_t g_window_image;  // psk_capi.hip: option "update_windo
 extern PSK_HIDDEN int64_t g_window_wide;   // option "update_window_wide"
 extern PSK_HIDDEN int64_t g_window_shadow, g_window_shadow_writes;  // options "update_window_shadow" / "update_window_shadow_writes" (read-only tally)
 
+// Tables of the window's pass 1 and fold (pinned staging + device copy, one contiguous upload): [0 .. kWinMaxPhases] the fold's phases,
+// behind them the pieces of pass 1 (PhaseDesc in psk_partition.hpp).
+constexpr size_t kWinMaxPieces = 4096 + 2 * kWinMaxPhases;   // (kWinMaxBatches waiting batches, each cut at most once more per phase end)
+constexpr size_t kWinTableEntries = (kWinMaxPhases + 1) + (kWinMaxPieces + 1);
+
 template <int KT, int NT>
-static int window_scatter(psk_sketch *s, const WinPhaseHost *ph, uint32_t nph_host, const void *keys_dev, uint64_t nlist, PartGeom *g, uint32_t *flag,
-                          hipStream_t st, uint32_t *nph_out)
+static int window_scatter(psk_sketch *s, const WinBatchHost *wb, uint32_t nb, PartGeom *g, uint32_t *flag, hipStream_t st, uint32_t *nph_out)
 {
     using Tile = PartTile<PayNonePhased, KT, NT>;
     const uint64_t tk = Tile::TILE;
-    // phases start on tile boundaries: phase p owns ceil(n_p / tile) tiles, the last one short
-    if (!s->win.pin) HIP_TRY(hipHostMalloc(&s->win.pin, (kWinMaxPhases + 1) * sizeof(PhaseDesc), hipHostMallocDefault));
-    PhaseDesc *hd = (PhaseDesc *)s->win.pin;
+    if (!s->win.pin) HIP_TRY(hipHostMalloc(&s->win.pin, kWinTableEntries * sizeof(PhaseDesc), hipHostMallocDefault));
+    PhaseDesc *fold = (PhaseDesc *)s->win.pin;            // [nph + 1]
+    PhaseDesc *piece = fold + (kWinMaxPhases + 1);         // [npc + 1]
     const uint32_t nwg = 256;  // one 1024-thread workgroup per CU (k <= 8), every one of them writes its snapshots
     // A phase of the fold is at most two tiles per pass-1 workgroup (longer runs of same-type batches are cut: k_win_fold holds a
     // phase's probe groups of a segment in a fixed number of registers).
     // (tables of few slices bring long runs per tile -- 2048 keys x k / B probes: 6.5 groups at 366 slices -- so there one tile per workgroup
     // and phase: with two, nearly every slice of a 9.6e7-counter table overflowed the fold's 12 groups per segment and phase and took the atomics)
     const double groups_per_tile = (double)tk * (g->k < (uint32_t)KT ? g->k : (uint32_t)KT) / (double)g->nbuckets / 6.0 + 0.5;
-    const uint64_t cut = (groups_per_tile > 4.0 ? 1ULL : 2ULL) * nwg * tk;
-    uint64_t tiles = 0;
-    uint32_t nph = 0;
-    for (uint32_t p = 0; p < nph_host; ++p) {
-        for (uint64_t off = 0; off < ph[p].n; off += cut) {
-            const uint64_t cnt = ph[p].n - off < cut ? ph[p].n - off : cut;
-            if (nph >= (uint32_t)kWinMaxPhases) {  // (the caller replays such a window batch by batch)
-                *nph_out = 0;
-                return PSK_OK;
+    const uint64_t max_tiles = (groups_per_tile > 4.0 ? 1ULL : 2ULL) * nwg;  // tiles per phase
+    // Every piece -- a stretch of keys contiguous in memory -- starts on a tile boundary and its last tile is short; a batch that follows its
+    // predecessor in memory (copies in the window's list) continues that piece when the piece ends on a whole tile.
+    uint64_t tiles = 0, phase_tiles = 0;
+    uint32_t nph = 0, npc = 0;
+    *nph_out = 0;
+    for (uint32_t bi = 0; bi < nb; ++bi) {
+        if (((uintptr_t)wb[bi].keys & 15) != 0) return fail(PSK_EINVAL, "update window: key batches must be 16-byte aligned");
+        for (uint64_t off = 0; off < wb[bi].n;) {
+            if (nph == 0 || (fold[nph - 1].remove != wb[bi].remove) || phase_tiles == max_tiles) {
+                if (nph >= (uint32_t)kWinMaxPhases) return PSK_OK;  // (the caller replays such a window batch by batch)
+                if (npc) piece[npc - 1].remove |= kPieceEndsPhase;
+                fold[nph++] = PhaseDesc{(uint32_t)tiles, wb[bi].remove, 0LL, 0ULL};
+                phase_tiles = 0;
             }
-            hd[nph++] = PhaseDesc{(uint32_t)tiles, ph[p].remove, (long long)(ph[p].start + off) - (long long)(tiles * tk), cnt};
-            tiles += (cnt + tk - 1) / tk;
+            const uint64_t room = (max_tiles - phase_tiles) * tk;
+            const uint64_t cnt = wb[bi].n - off < room ? wb[bi].n - off : room;
+            const uint64_t first = (uint64_t)((uintptr_t)wb[bi].keys >> 4) + off;  // in 16-byte units from address 0
+            PhaseDesc *pv = npc ? &piece[npc - 1] : nullptr;
+            const bool joins = pv && !(pv->remove & kPieceEndsPhase) && (pv->remove >> 8) == nph - 1 && pv->nkeys % tk == 0 &&
+                               (uint64_t)(pv->key_off + (long long)((uint64_t)pv->tile0 * tk)) + pv->nkeys == first;
+            if (joins) {
+                pv->nkeys += cnt;
+            } else {
+                if (npc >= kWinMaxPieces) return PSK_OK;
+                piece[npc++] = PhaseDesc{(uint32_t)tiles, (wb[bi].remove & 1u) | ((nph - 1) << 8), (long long)first - (long long)(tiles * tk), cnt};
+            }
+            const uint64_t t = (cnt + tk - 1) / tk;
+            tiles += t;
+            phase_tiles += t;
+            off += cnt;
         }
     }
-    *nph_out = nph;
+    if (npc == 0) return PSK_OK;
+    piece[npc - 1].remove |= kPieceEndsPhase;
     if (tiles >= (1ULL << 31)) return fail(PSK_EINVAL, "update window of %llu tiles", (unsigned long long)tiles);
-    hd[nph] = PhaseDesc{(uint32_t)tiles, 0u, 0LL, 0ULL};
-    PSK_TRY(ensure(s->s_phase, (kWinMaxPhases + 1) * sizeof(PhaseDesc)));
-    HIP_TRY(hipMemcpyAsync(s->s_phase.p, hd, (nph + 1) * sizeof(PhaseDesc), hipMemcpyHostToDevice, st));  // (pinned: consumed before the flush's sync)
+    fold[nph] = PhaseDesc{(uint32_t)tiles, 0u, 0LL, 0ULL};
+    piece[npc] = PhaseDesc{(uint32_t)tiles, 0u, 0LL, 0ULL};
+    PSK_TRY(ensure(s->s_phase, kWinTableEntries * sizeof(PhaseDesc)));
+    // (pinned: consumed before the flush's sync; the unused tail of the fold's table travels along -- one copy)
+    HIP_TRY(hipMemcpyAsync(s->s_phase.p, fold, ((kWinMaxPhases + 1) + npc + 1) * sizeof(PhaseDesc), hipMemcpyHostToDevice, st));
     const uint64_t tiles_per_wg = (tiles + nwg - 1) / nwg;
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
     const double mean = (double)tiles_per_wg * (double)tk * kk / (double)g->nbuckets;
@@ -54,25 +80,27 @@ static int window_scatter(psk_sketch *s, const WinPhaseHost *ph, uint32_t nph_ho
     PSK_TRY(ensure(s->s_part, (uint64_t)g->nbuckets * nwg * segcap * 16 + 256));
     PSK_TRY(ensure(s->s_cnt, (uint64_t)g->nbuckets * nwg * 4 + 128));
     PSK_TRY(ensure(s->s_snap, (uint64_t)nph * g->nbuckets * nwg * 4));
-    const PayNonePhased pay{(const PhaseDesc *)s->s_phase.p, nph, (uint32_t *)s->s_snap.p, nlist};
+    const PhaseDesc *piece_dev = (const PhaseDesc *)s->s_phase.p + (kWinMaxPhases + 1);
+    const PayNonePhased pay{piece_dev, npc, (uint32_t *)s->s_snap.p, (uint64_t)(piece[0].key_off + (long long)((uint64_t)piece[0].tile0 * tk))};
     // (an overflowing segment would need the reference's clamp, which the undo could not invert: it raises the flag instead)
     const SpillRaiseFlagCounter spill{flag};
     const size_t lds = scatter_lds_bytes<PayNonePhased, KT, NT>(g);
     auto kern = k_part_scatter<KeysFixed16, IdxBloom<kTuPow2>, PayNonePhased, SpillRaiseFlagCounter, KT, NT>;
     PSK_TRY(set_dyn_lds(kern, lds));
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, st, KeysFixed16{(const uint4 *)keys_dev}, IdxBloom<kTuPow2>{s->md}, pay, spill, *g, tiles * tk,
+    // (the keys are addressed from 0 in 16-byte units: a piece's key_off is where its memory is)
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, st, KeysFixed16{(const uint4 *)nullptr}, IdxBloom<kTuPow2>{s->md}, pay, spill, *g, tiles * tk,
                        (uint32_t *)s->s_cnt.p, (uint4 *)s->s_part.p);
     HIP_TRY(hipGetLastError());
+    *nph_out = nph;
     return PSK_OK;
 }
 
-int PSK_VARIANT(cbf_window_fold)(psk_sketch *s, const WinPhaseHost *ph, uint32_t nph, const void *keys_dev, uint64_t nlist, hipStream_t st, bool *launched,
-                                 bool *ok)
+int PSK_VARIANT(cbf_window_fold)(psk_sketch *s, const WinBatchHost *wb, uint32_t nb, hipStream_t st, bool *launched, bool *ok)
 {
     *launched = false;
     *ok = false;
     PartGeom g;
-    if (g_update_nibble == 0 || nph == 0 || nlist == 0 || s->k > 32 || !nib_geometry(s->m, true, &g)) return PSK_OK;
+    if (g_update_nibble == 0 || nb == 0 || s->k > 32 || !nib_geometry(s->m, true, &g)) return PSK_OK;
     g.k = s->k;
     PSK_TRY(ensure(s->s_flag, 8));
     uint32_t *flag = (uint32_t *)s->s_flag.p;  // [0] a remove met a zero (undo + replay), [1] a slice took the atomics (its 4-bit image is void)
@@ -81,9 +109,9 @@ int PSK_VARIANT(cbf_window_fold)(psk_sketch *s, const WinPhaseHost *ph, uint32_t
     PSK_TRY(with_kt<KeysFixed16>(s->k, [&](auto kt) {
         constexpr int KT = decltype(kt)::value;
         if constexpr (KT <= 8) {
-            if (scatter_lds_bytes<PayNonePhased, KT, 1024>(&g) <= kScatterLdsBudget) return window_scatter<KT, 1024>(s, ph, nph, keys_dev, nlist, &g, flag, st, &nph_dev);
+            if (scatter_lds_bytes<PayNonePhased, KT, 1024>(&g) <= kScatterLdsBudget) return window_scatter<KT, 1024>(s, wb, nb, &g, flag, st, &nph_dev);
         }
-        if (scatter_lds_bytes<PayNonePhased, KT, kPartThreads>(&g) <= kScatterLdsBudget) return window_scatter<KT, kPartThreads>(s, ph, nph, keys_dev, nlist, &g, flag, st, &nph_dev);
+        if (scatter_lds_bytes<PayNonePhased, KT, kPartThreads>(&g) <= kScatterLdsBudget) return window_scatter<KT, kPartThreads>(s, wb, nb, &g, flag, st, &nph_dev);
         return (int)PSK_OK;
     }));
     if (nph_dev == 0) return PSK_OK;

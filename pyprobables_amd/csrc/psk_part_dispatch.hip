@@ -24,6 +24,5 @@ PSK_DISPATCH(cbf_remove_fast_begin, (psk_sketch *s, const Batch &b, hipStream_t 
 PSK_DISPATCH(cbf_remove_fast_undo, (psk_sketch *s, hipStream_t st), (s, st))
 PSK_DISPATCH(cbf_unit_multi_partitioned, (psk_sketch *s, const void *const *base, const uint64_t *start, uint32_t nb, uint64_t n, int neg, hipStream_t st, bool *done),
              (s, base, start, nb, n, neg, st, done))
-PSK_DISPATCH(cbf_window_fold, (psk_sketch *s, const WinPhaseHost *ph, uint32_t nph, const void *keys, uint64_t nlist, hipStream_t st, bool *launched, bool *ok),
-             (s, ph, nph, keys, nlist, st, launched, ok))
+PSK_DISPATCH(cbf_window_fold, (psk_sketch *s, const WinBatchHost *wb, uint32_t nb, hipStream_t st, bool *launched, bool *ok), (s, wb, nb, st, launched, ok))
 PSK_DISPATCH(cbf_nib_scatter, (psk_sketch *s, const Batch &b, int neg, int second, PartGeom *g_out, hipStream_t st, bool *done), (s, b, neg, second, g_out, st, done))

@@ -24,6 +24,7 @@
 // Anything that does not fit (segment overflow on adversarial / duplicate-heavy batches, weights too
 // large to inline) falls back to an exact direct atomic on the table, so the result is always exact.
 #pragma once
+#include <type_traits>
 #include "psk_device.hpp"
 
 // Bench-only ablation / phase-profile knobs (PartGeom::dbg) exist only in a -DPSK_BENCH_KNOBS=1 build
@@ -120,6 +121,11 @@ template <class Pay, class = void>
 struct pay_has_keep { static constexpr bool value = false; };
 template <class Pay>
 struct pay_has_keep<Pay, decltype((void)&Pay::keep)> { static constexpr bool value = true; };
+// key sources whose keys differ in length (KeysVarlen): pass 1 hands the keys of a tile to its lanes in order of length (below)
+template <class Src, class = void>
+struct src_sorted { static constexpr bool value = false; };
+template <class Src>
+struct src_sorted<Src, decltype((void)Src::sorted)> { static constexpr bool value = Src::sorted; };
 template <class Pay, class = void>
 struct pay_weighted_plain { static constexpr bool value = false; };
 template <class Pay>
@@ -212,15 +218,19 @@ struct PayUnitMasked {  // PayNone's probes, for the keys with amount[i] != 0 on
     __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
     __device__ __forceinline__ uint32_t keep(uint64_t i) const { return amount[i]; }
 };
-// One PHASE of a CountingBloomFilter update window (psk_window.hpp): a run of same-type batches (all adds, or all removes) of the
-// window's key list.  Pass 1 runs ONCE over the whole list, but a tile never straddles two phases: phase p owns the tiles
-// [tile0, next phase's tile0), key j of tile t is list entry key_off + t * tile + j, and the phase's last tile is short.
+// One PHASE of a CountingBloomFilter update window (psk_window.hpp): a run of same-type batches (all adds, or all removes).
+// Pass 1 runs ONCE over all waiting keys, but a tile never straddles two phases: phase p owns the tiles [tile0, next phase's tile0).
+// The fold reads a table of its phases (`remove` = 0 / 1); pass 1 reads a table of PIECES of them -- one per stretch of keys that is
+// contiguous in memory (a batch, or part of one: batches wait where the caller left them, or as copies in the window's list) -- whose
+// `remove` also says whether the piece ends its phase (kPieceEndsPhase: the workgroups leave their segment counts) and which one (bits 8..).
+// Key j of tile t of a piece is key_off + t * tile + j in units of 16 bytes from address 0: the piece's last tile is short.
 struct PhaseDesc {
-    uint32_t tile0;            // first pass-1 tile of the phase (entry [nph] closes the table: tile0 = number of tiles)
-    uint32_t remove;           // 0 adds, 1 removes (countingbloom.py:135-155 / :186-208)
+    uint32_t tile0;            // first pass-1 tile of the phase / piece (entry [n] closes the table: tile0 = number of tiles)
+    uint32_t remove;           // bit 0: 0 adds, 1 removes (countingbloom.py:135-155 / :186-208)
     long long key_off;
     unsigned long long nkeys;
 };
+constexpr uint32_t kPieceEndsPhase = 2u;
 // PayNone's probes for such a list.  A (slice, workgroup) segment receives its tiles in tile order, i.e. in phase order, so the
 // segment's fill count at the END of every phase cuts it into per-phase pieces: the workgroup leaves these counts in
 // snap[phase][slice][workgroup] (the fold walks a slice phase by phase: adds, barrier, removes that must not meet a zero, ...).
@@ -228,10 +238,10 @@ struct PayNonePhased {
     static constexpr int mode = kModePlain;
     static constexpr int group = 6;
     static constexpr bool phased = true;
-    const PhaseDesc *ph;       // device array [nph + 1]
+    const PhaseDesc *ph;       // device array [nph + 1]: the PIECES
     uint32_t nph;
-    uint32_t *snap;            // [nph][nbuckets][nwg]
-    uint64_t nlist;            // keys in the list (prefetches are clamped to it)
+    uint32_t *snap;            // [phases][nbuckets][nwg]
+    uint64_t first;            // the first piece's first key (what the prefetches of a workgroup without tiles fall back to)
     __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
 };
 struct PayUnit {   // unit-weight counter adds: 8 probes per group, 16-bit slice-local cell indices (slices <= 2^15 cells)
@@ -513,8 +523,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     const uint32_t dbg = kBenchKnobs ? g.dbg : 0u;  // folds to 0 in the shipped build
     const uint32_t B = g.nbuckets;
     constexpr bool PHASED = pay_is_phased<Pay>::value;  // n = tiles x tile size (virtual: every phase is padded to whole tiles)
-    uint64_t nlim = n;                         // keys the source holds
-    if constexpr (PHASED) nlim = pay.nlist;
+    const uint64_t nlim = n;                   // keys the source holds (phased lists: tiles x tile size, see tile_base)
     const uint64_t last = nlim ? nlim - 1 : 0; // index the clamped prefetches fall back to (the key buffer holds at least one key)
     uint32_t *hist0 = smem;  // two copies: tile t counts in one while the scan phase of tile t zeroes the other
     uint32_t *off = hist0 + 2 * B;
@@ -527,6 +536,12 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     // (sized by the tile the host chose -- g.tile <= TILE: evened tiles, or tiles cut down so that the stage fits the LDS at 2048 slices)
     const uint32_t stage_cap = (g.tile * (g.k < (uint32_t)KT ? g.k : (uint32_t)KT) + (uint32_t)(GS - 1) * B + 3u) & ~3u;
     uint32_t *gb = stage + stage_cap;
+    // keys of different lengths (src_sorted): class counts, class offsets and the slot order of the tile's length sort, behind everything else
+    // (+ the keys' descriptors in slot order, 16 bytes each, 16-byte aligned)
+    uint32_t *sort_hist = reinterpret_cast<uint32_t *>(((uintptr_t)(gb + (PAIR ? stage_cap / GS + 4 : 0)) + 15) & ~(uintptr_t)15);
+    uint32_t *sort_off = sort_hist + 64;
+    uint4 *sort_keys = reinterpret_cast<uint4 *>(sort_off + 64);
+    uint16_t *sort_order = reinterpret_cast<uint16_t *>(sort_keys + T::TILE);
     // KT other than the round-up sizes 8 / 16 / 32 is an exact instantiation (with_kt): k == KT, and every per-probe
     // "j < k" test below folds away (28 exec-mask branch sequences per tile for k = 7)
     constexpr bool kExactK = KT != 8 && KT != 16 && KT != 32;
@@ -539,19 +554,30 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
 
     for (uint32_t b = threadIdx.x; b < B; b += NT) cur[b] = g.append ? segcnt[(uint64_t)b * g.nwg + blockIdx.x] : 0u;
     for (uint32_t b = threadIdx.x; b < 2 * B; b += NT) hist0[b] = 0;
+    if constexpr (src_sorted<Src>::value) {
+        if (threadIdx.x < 64) sort_hist[threadIdx.x] = 0;
+    }
     uint32_t parity = 0;
     lds_barrier();
 
     // Software pipeline over tiles: the NEXT tile's keys are loaded right after this tile's hash phase and
     // pinned before this tile's write-out stores are issued (vmcnt counts loads and stores in order on CDNA4:
     // a key load waited for AFTER the stores would also wait for ~300 KB of stores to drain).
-    // list index of tile t's first key; phased lists: p (a phase at or before t's) moves on to t's phase -- uniform, scalar loads
-    auto tile_base = [&](uint64_t t, uint32_t &p) -> uint64_t {
+    // list index of tile t's first key and of its last one (`lastk`: what the tile's loads are clamped to); phased lists: p (a piece at
+    // or before t's) moves on to t's piece -- uniform, scalar loads
+    auto tile_base = [&](uint64_t t, uint32_t &p, uint64_t &lastk) -> uint64_t {
         if constexpr (PHASED) {
-            if (t >= ntiles) return nlim;  // (past the end: every lane clamps)
+            if (t >= ntiles) {  // (past the end: every lane clamps to a key that exists)
+                lastk = pay.first;
+                return pay.first;
+            }
             while (p + 1 < pay.nph && t >= (uint64_t)pay.ph[p + 1].tile0) ++p;
-            return (uint64_t)(pay.ph[p].key_off + (long long)(t * tk));
+            const uint64_t b = (uint64_t)(pay.ph[p].key_off + (long long)(t * tk));
+            const uint64_t left = pay.ph[p].nkeys - (t - pay.ph[p].tile0) * tk;  // keys of the piece from this tile on
+            lastk = b + (left < tk ? left : tk) - 1;
+            return b;
         } else {
+            lastk = last;
             return t * tk;
         }
     };
@@ -559,19 +585,81 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     auto write_snapshot = [&](uint32_t p) {
         if constexpr (PHASED) {
             // (bit 31: the phase removes -- the fold reads the phase's type off the counts it loads anyway, phases ahead of their use)
-            const uint32_t type_bit = pay.ph[p].remove ? 0x80000000u : 0u;
-            for (uint32_t b = threadIdx.x; b < B; b += NT) pay.snap[((uint64_t)p * B + b) * g.nwg + blockIdx.x] = cur[b] | type_bit;
+            const uint32_t f = pay.ph[p].remove;
+            if (!(f & kPieceEndsPhase)) return;  // (uniform)
+            const uint32_t type_bit = (f & 1u) ? 0x80000000u : 0u;
+            for (uint32_t b = threadIdx.x; b < B; b += NT) pay.snap[((uint64_t)(f >> 8) * B + b) * g.nwg + blockIdx.x] = cur[b] | type_bit;
         }
     };
     typename Src::Key kcur[KPT];
+    uint64_t b0 = 0;
     if (kPartPipeline) {
         uint32_t p0 = 0;
-        const uint64_t b0 = tile_base(blockIdx.x, p0);
+        uint64_t l0;
+        b0 = tile_base(blockIdx.x, p0, l0);
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
             const uint64_t i = b0 + (uint64_t)q * NT + threadIdx.x;
-            kcur[q] = src.load(i < nlim ? i : last);  // coalesced; clamped, never branched around (a conditional load
+            kcur[q] = src.load(i < l0 ? i : l0);  // coalesced; clamped, never branched around (a conditional load
         }                                              // makes hipcc wait vmcnt(0) per element: serial round trips)
+    }
+    // Keys of different lengths (KeysVarlen): a wave hashes for as long as its LONGEST key lasts, every shorter key's lane idling -- with
+    // lengths 4 .. 40 (mean 16) the hash phase took 4 x the time of 16-byte keys.  So a tile's keys are handed to the lanes in order of
+    // length: a counting sort of the prefetched lengths (64 classes: exact up to 47 elements; LDS atomics, one wave scans) gives every key a
+    // slot, the keys' descriptors go through LDS into slot order, and lane (q, thread) takes the key of slot q * NT + thread -- for odd q
+    // with the waves in reverse order, so that every wave gets short AND long keys.  Everything behind the hash phase names a key by its
+    // index i.  The sort of tile t + 1 runs in front of tile t's write-out, on the prefetched descriptors, and ends with the requests for
+    // the keys' first windows: they land under the write-out (as dependent loads in front of every key's chains -- offsets, then windows,
+    // key after key -- they cost a tile ~10 us, as much as the rest of it).
+    constexpr bool SORTED = src_sorted<Src>::value;
+    static_assert(!(SORTED && PHASED), "phased lists hold 16-byte keys");
+    static_assert(!SORTED || sizeof(typename Src::Key) == 16, "the length sort moves 16-byte key descriptors");
+    uint32_t slot[KPT], slot_n[SORTED ? KPT : 1];  // of this tile / of the next one (sorted in the middle of this tile)
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) slot[q] = (uint32_t)q * NT + threadIdx.x;
+    typename Src::Key ks[SORTED ? KPT : 1];
+    uint4 kfirst[SORTED ? KPT : 1];
+    auto sort_tile = [&](uint64_t nb, uint64_t ne) {  // keys [nb, ne) in kcur (natural order) -> slot_n / ks / kfirst
+        if constexpr (SORTED) {
+            uint32_t cls[KPT], crank[KPT];
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                const uint64_t i = nb + (uint32_t)q * NT + threadIdx.x;
+                cls[q] = i < ne ? Src::len_class(kcur[q]) : 63u;  // keys past the tile's end: behind all others
+                crank[q] = atomicAdd(&sort_hist[cls[q]], 1u);
+            }
+            lds_barrier();
+            if (threadIdx.x < 64) {
+                const uint32_t v = sort_hist[threadIdx.x];
+                sort_off[threadIdx.x] = wave_inclusive_scan(v) - v;
+                sort_hist[threadIdx.x] = 0;  // (the next tile counts behind two more barriers)
+            }
+            lds_barrier();
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                const uint32_t pos = sort_off[cls[q]] + crank[q];
+                uint4 d;
+                __builtin_memcpy(&d, &kcur[q], 16);
+                sort_keys[pos] = d;
+                sort_order[pos] = (uint16_t)((uint32_t)q * NT + threadIdx.x);
+            }
+            lds_barrier();
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                const uint32_t pos = (uint32_t)q * NT + ((q & 1) ? (uint32_t)(NT - 64) - (threadIdx.x & ~63u) + (threadIdx.x & 63u) : threadIdx.x);
+                const uint4 d = sort_keys[pos];
+                __builtin_memcpy(&ks[q], &d, 16);
+                slot_n[q] = sort_order[pos];
+            }
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) kfirst[q] = src.first(ks[q]);
+        }
+    };
+    if constexpr (SORTED) {
+        const uint64_t e0 = blockIdx.x < ntiles ? (b0 + tk < nlim ? b0 + tk : nlim) : b0;
+        sort_tile(b0, e0);
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) slot[q] = slot_n[q];
     }
 
     // phase profile (dbg & 32): lane 0 of wave 0 accumulates s_memtime deltas per phase; bench-only
@@ -600,13 +688,13 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         uint32_t idx[KPT][KT], rank[KPT][KT], payload[KPT];
         uint32_t fold = 0;
         uint32_t ph_tile = ph_cur;
-        const uint64_t base = tile_base(tile, ph_tile);
+        uint64_t tile_last;
+        const uint64_t base = tile_base(tile, ph_tile, tile_last);
         uint64_t tile_end = base + tk < nlim ? base + tk : nlim;
         if constexpr (PHASED) {
-            // cur[] is what my segments held after my last tile, i.e. at the end of every phase before this tile's
+            // cur[] is what my segments held after my last tile, i.e. at the end of every piece before this tile's
             for (; ph_cur < ph_tile; ++ph_cur) write_snapshot(ph_cur);
-            const uint64_t left = pay.ph[ph_tile].nkeys - (tile - pay.ph[ph_tile].tile0) * tk;  // keys of the phase from this tile on
-            tile_end = base + (left < tk ? left : tk);
+            tile_end = tile_last + 1;
         }
         // Pay::keep (masked batches): a key whose flag is 0 sends no probes.  The flags are requested up front and first consumed
         // behind the key's hash chains, which hides the load.
@@ -615,28 +703,39 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         if constexpr (KEEP) {
 #pragma unroll
             for (int q = 0; q < KPT; ++q) {
-                const uint64_t i = base + (uint64_t)q * NT + threadIdx.x;
+                const uint64_t i = base + slot[q];
                 kw[q] = pay.keep(i < nlim ? i : last);
             }
         }
         auto kept = [&](int q) -> bool { if constexpr (KEEP) return kw[q] != 0; else return true; };
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
-            const uint64_t i = base + (uint64_t)q * NT + threadIdx.x;
+            const uint64_t i = base + slot[q];
             if (i < tile_end) {
-                const typename Src::Key key = kPartPipeline ? kcur[q] : src.load(i);
+                typename Src::Key key;
+                if constexpr (SORTED) key = ks[q];
+                else key = kPartPipeline ? kcur[q] : src.load(i);
+                // hash<G> / hash32<G> of the key; sources with a first window (SORTED) take it along
+                auto hash32_of = [&](auto gtag, uint32_t s0, uint32_t (&hh)[decltype(gtag)::value]) {
+                    if constexpr (SORTED) src.template hash32_first<decltype(gtag)::value>(key, kfirst[q], i, s0, hh);
+                    else src.template hash32<decltype(gtag)::value>(key, i, s0, hh);
+                };
+                auto hash64_of = [&](auto gtag, uint32_t s0, uint64_t (&hh)[decltype(gtag)::value]) {
+                    if constexpr (SORTED) src.template hash_first<decltype(gtag)::value>(key, kfirst[q], i, s0, hh);
+                    else src.template hash<decltype(gtag)::value>(key, i, s0, hh);
+                };
                 if (PAIR || pay_weighted_plain<Pay>::value) payload[q] = pay(i, base);
                 if constexpr (IdxFn::lo32) {  // 32-bit chains (power-of-two table: the upper hash halves are dead)
                     uint32_t h[KT];
                     if (dbg & 4) {
                         for (int j = 0; j < KT; ++j) h[j] = (uint32_t)(((uint64_t)(i * 2654435761u + j * 40503u) * 0x9E3779B97F4A7C15ULL) >> 13);
                     } else if constexpr (KT <= 8 || KT % 4 != 0) {  // exact k: every chain is live
-                        src.template hash32<KT>(key, i, 0, h);
+                        hash32_of(std::integral_constant<int, KT>{}, 0u, h);
                     } else {  // KT is k rounded up: run the chains four at a time and skip the groups past k
 #pragma unroll
                         for (int s0 = 0; s0 < KT; s0 += 4) {
                             uint32_t hh[4] = {0, 0, 0, 0};
-                            if ((uint32_t)s0 < k) src.template hash32<4>(key, i, (uint32_t)s0, hh);
+                            if ((uint32_t)s0 < k) hash32_of(std::integral_constant<int, 4>{}, (uint32_t)s0, hh);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) h[s0 + e] = hh[e];
                         }
@@ -654,12 +753,12 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
                     if (dbg & 4) {
                         for (int j = 0; j < KT; ++j) h[j] = ((uint64_t)(i * 2654435761u + j * 40503u) * 0x9E3779B97F4A7C15ULL) >> 13;
                     } else if constexpr (KT <= 8 || KT % 4 != 0) {  // exact k: every chain is live
-                        src.template hash<KT>(key, i, 0, h);
+                        hash64_of(std::integral_constant<int, KT>{}, 0u, h);
                     } else {
 #pragma unroll
                         for (int s0 = 0; s0 < KT; s0 += 4) {
                             uint64_t hh[4] = {0, 0, 0, 0};
-                            if ((uint32_t)s0 < k) src.template hash<4>(key, i, (uint32_t)s0, hh);
+                            if ((uint32_t)s0 < k) hash64_of(std::integral_constant<int, 4>{}, (uint32_t)s0, hh);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) h[s0 + e] = hh[e];
                         }
@@ -678,11 +777,18 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
             if (fold == 0x12345u) segcnt[0] = fold;
             if (kPartPipeline) {
                 uint32_t pn = ph_tile;
-                const uint64_t nbase = tile_base(tile + gridDim.x, pn);
+                uint64_t ln;
+                const uint64_t nbase = tile_base(tile + gridDim.x, pn, ln);
 #pragma unroll
                 for (int q = 0; q < KPT; ++q) {
                     const uint64_t i = nbase + (uint64_t)q * NT + threadIdx.x;
-                    kcur[q] = src.load(i < nlim ? i : last);
+                    kcur[q] = src.load(i < ln ? i : ln);
+                }
+                if constexpr (SORTED) {
+                    const uint64_t tn = tile + gridDim.x;
+                    sort_tile(nbase, tn < ntiles ? (nbase + tk < nlim ? nbase + tk : nlim) : nbase);
+#pragma unroll
+                    for (int q = 0; q < KPT; ++q) slot[q] = slot_n[q];
                 }
             }
             continue;
@@ -692,13 +798,15 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         PSK_TICK(2);
 
         // ---- prefetch the next tile's keys (consumed -- pinned -- before the write-out below)
+        uint64_t nbase = 0;
         if (kPartPipeline) {
             uint32_t pn = ph_tile;
-            const uint64_t nbase = tile_base(tile + gridDim.x, pn);
+            uint64_t ln;
+            nbase = tile_base(tile + gridDim.x, pn, ln);
 #pragma unroll
             for (int q = 0; q < KPT; ++q) {
                 const uint64_t i = nbase + (uint64_t)q * NT + threadIdx.x;
-                kcur[q] = src.load(i < nlim ? i : last);  // unconditional (clamped) on purpose, see above
+                kcur[q] = src.load(i < ln ? i : ln);  // unconditional (clamped) on purpose, see above
             }
         }
 
@@ -745,13 +853,18 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         lds_barrier();
         if (B <= 64 * kPartScanPerThread) tile_probes = wave_tot[0];
         PSK_TICK(3);
+        if constexpr (SORTED) {  // the NEXT tile's length sort: its descriptors have been on their way since the barrier before the scan, and the
+            const uint64_t tn = tile + gridDim.x;  // first windows it requests land under the stage sort below
+            sort_tile(nbase, tn < ntiles ? (nbase + tk < nlim ? nbase + tk : nlim) : nbase);
+            PSK_TICK(10);
+        }
 
         // ---- counting-sort the probes into the LDS stage; one thread per slice also fills its run's trailing pads
         // (in the scan phase that was 4 slices x up to GS-1 serial stores on the single scanning wave: 18 % of pass 1)
         constexpr bool LOOKUP = pay_is_lookup<Pay>::value;
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
-            const uint64_t i = base + (uint64_t)q * NT + threadIdx.x;
+            const uint64_t i = base + slot[q];
             if (i < tile_end && kept(q)) {
                 uint32_t pos[LOOKUP ? 2 * ((KT + 1) / 2) : 1] = {};  // lookups: where each of my probes sits in the sorted stage
                 if constexpr (pay_has_tally<Pay>::value) {
@@ -822,6 +935,13 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
 #pragma unroll
         for (int q = 0; q < KPT; ++q)
             if (kPartPipeline) Src::pin(kcur[q]);  // next tile's keys have landed: nothing to wait for later
+        if constexpr (SORTED) {  // the next tile's first windows as well; its slots take over (this tile's were last used by the stage sort)
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                asm volatile("" : "+v"(kfirst[q].x), "+v"(kfirst[q].y), "+v"(kfirst[q].z), "+v"(kfirst[q].w));
+                slot[q] = slot_n[q];
+            }
+        }
         if (!(dbg & 1)) {
             const uint32_t ngroups = tile_probes / GS;
             for (uint32_t gi = threadIdx.x; gi < ngroups; gi += NT) {

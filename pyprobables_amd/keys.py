@@ -72,8 +72,9 @@ def _pack_homogeneous(keys: list, n: int):
         try:
             blob8 = joined.encode("latin-1")  # code points <= 255 == byte values
         except UnicodeEncodeError:
-            offs = np.zeros(n + 1, dtype=np.uint64)
+            offs = np.zeros(n + 1, dtype=np.int64)  # (same dtype as `lens`: a uint64 `out` sends cumsum down its casting path, 10 x slower)
             np.cumsum(lens, out=offs[1:])
+            offs = offs.view(np.uint64)
             blob = np.frombuffer(joined.encode("utf-32-le", "surrogatepass"), dtype=np.uint32)
             if blob.size != int(offs[-1]):
                 return None  # (lone surrogates / odd encodings: let the careful path decide)
@@ -87,8 +88,9 @@ def _pack_homogeneous(keys: list, n: int):
     if int(lens.min()) == first == int(lens.max()):
         a = np.frombuffer(blob8, dtype=np.uint8).reshape(n, first) if first else np.zeros((n, 0), dtype=np.uint8)
         return KeyBatch(N.KEYS_FIXED, _np_ptr(a) if a.size else 0, 0, n, first, N.HOST, None, [a, blob8])
-    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(lens, out=offs[1:])
+    offs = offs.view(np.uint64)
     blob = np.frombuffer(blob8, dtype=np.uint8)
     return KeyBatch(N.KEYS_VARLEN8, _np_ptr(blob), _np_ptr(offs), n, 0, N.HOST, None, [blob, offs, blob8])
 
@@ -140,6 +142,9 @@ def _pack_ragged(blob, offsets) -> KeyBatch:
         raise ValueError("(blob, offsets): offsets must ascend")
     if int(o[-1]) > b.size:
         raise ValueError("(blob, offsets): offsets reach past the blob")
+    if o[0] != 0:  # (the engine stages host blobs from their first byte: offsets relative to the first key)
+        b = b[int(o[0]):]
+        o = o - o[0]
     b = np.ascontiguousarray(b)
     if b.size == 0:
         b = np.zeros(1, dtype=b.dtype)

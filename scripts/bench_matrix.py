@@ -39,7 +39,13 @@ def bloom_case(label, est, fpr, keys):
     del f
 
 
+import os
+
+ONLY = os.environ.get("PSK_MATRIX_ONLY", "")  # "varlen": the headline row + the variable-length rows (development)
 bloom_case("bloom pow2 2^28 (headline)", 28005615, 0.01, keys16)
+if ONLY == "varlen":
+    _real_bloom_case = bloom_case
+    bloom_case = lambda *a, **k: None  # noqa: E731
 bloom_case("bloom non-pow2 ~96 Mbit", 10_000_000, 0.01, keys16)
 bloom_case("bloom non-pow2 ~1.9 Gbit", 200_000_000, 0.01, keys16)
 bloom_case("bloom pow2 2^31", 224044920, 0.01, keys16)
@@ -52,6 +58,8 @@ k13 = torch.randint(0, 256, (n, 13), dtype=torch.uint8, device="cuda")
 bloom_case("bloom 8-byte keys", 28005615, 0.01, k8)
 bloom_case("bloom 32-byte keys", 28005615, 0.01, k32)
 bloom_case("bloom 13-byte keys (unaligned)", 28005615, 0.01, k13)
+if ONLY == "varlen":
+    bloom_case = _real_bloom_case
 # ---- the reference's native key type: variable-length byte / str keys (hashes.py:98 walks code points) ----
 def ragged(kind, nn, seed=7):
     """(blob, offsets) on the device.  wide: 4 + min(36, floor(Exp(12.6))) bytes, mean ~16; narrow: 4 + min(36, Poisson(12));
@@ -85,6 +93,11 @@ for kind, label in [("wide", "bloom ragged bytes 4-40 (exp, device)"), ("narrow"
     c = t(lambda: f.check_many(dk))
     rows.append((label, f"mean {mean:.1f} max {mx}", n / a / 1e3, n / c / 1e3))
     del f, dk
+if ONLY == "varlen":
+    print(f"{'case':48s} {'geometry':22s} {'update Mkeys/s':>15s} {'lookup Mkeys/s':>15s}")
+    for r in rows:
+        print(f"{r[0]:48s} {r[1]:22s} {r[2]:15.0f} {r[3]:15.0f}")
+    sys.exit(0)
 # host lists of bytes / str (packing + PCIe inclusive), 1 M keys
 nh = 1_000_000
 blob, offs, mean, mx = ragged("wide", nh)

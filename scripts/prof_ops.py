@@ -58,7 +58,24 @@ if op == "cfg4_stream":
 keys = gen(n, 0)
 w = torch.empty(n, dtype=torch.int32, device="cuda")
 N.check(N.lib().psk_gen_weights(w.data_ptr(), 0, n, 0x5EED, 0, st()))
-if op.startswith("bloom"):
+if op.startswith("bloomvar"):  # ragged byte keys (the reference's native key type): PSK_VARLEN_KIND = wide (4 + Exp(12.6), default) | narrow | words
+    import numpy as np
+
+    kind = os.environ.get("PSK_VARLEN_KIND", "wide")
+    rng = np.random.default_rng(7)
+    if kind == "wide":
+        lens = 4 + np.minimum(36, np.floor(rng.exponential(12.6, n))).astype(np.int64)
+    elif kind == "narrow":
+        lens = 4 + np.minimum(36, rng.poisson(12, n)).astype(np.int64)
+    else:
+        lens = np.clip(np.round(rng.normal(8, 2.5, n)), 2, 15).astype(np.int64)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    pair = (torch.from_numpy(rng.integers(0, 256, int(offs[-1]), dtype=np.uint8)).cuda(), torch.from_numpy(offs).cuda())
+    s = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01)
+    s.add_many(pair)
+    fn = {"bloomvar_add": lambda: s.add_many(pair), "bloomvar_check": lambda: s.check_many(pair)}[op]
+elif op.startswith("bloom"):
     s = pa.BloomFilter(est_elements=224044920 if op.startswith("bloom31") else 28005615, false_positive_rate=0.01)  # 2^31 / 2^28 bits
     s.add_many(keys)
     fresh = gen(n, 7 * n)
@@ -77,7 +94,7 @@ else:
         N.set_option("cbf_lookup_shadow", 0)
     fn = {"add": lambda: s.add_many(keys), "check": lambda: s.check_many(keys), "check_kept": lambda: s.check_many(keys),
           "remove": lambda: (s.add_many(keys), s.remove_many(keys))}[op.split("_", 1)[1]]  # (remove: the keys go back in first, so that every remove finds its key)
-launches = 2 + iters + (1 if op in ("bloom_add", "bloom31_add", "cms_add", "cbf_add", "cbf25_add") else 0)  # the set-up insert runs the same kernels
+launches = 2 + iters + (1 if op in ("bloomvar_add", "bloom_add", "bloom31_add", "cms_add", "cbf_add", "cbf25_add") else 0)  # the set-up insert runs the same kernels
 for _ in range(2):
     fn()
 torch.cuda.synchronize()

@@ -291,3 +291,106 @@ def test_combined_update_after_window_batches_keeps_the_order(pa, oracle, N):
     cbf._dirty = True
     assert np.array_equal(_table(cbf), oc.bloom)
     assert np.array_equal(cbf.check_many(dk).cpu().numpy().astype(np.uint32), oc.check_keys(keys))
+
+
+# ----------------------------------------------------------------------------------- borrowed batches (round 5)
+def _run_lent(cbf, oc, ops, hold):
+    """every batch in its OWN device tensor (the window's pieces are not contiguous), kept alive by the sketch, not by the test"""
+    for rem, kk in ops:
+        t = _dev(kk)
+        if hold is not None:
+            hold.append(t.data_ptr())
+        if rem:
+            cbf.remove_many(t)
+            oc.update_keys(kk, -np.ones(len(kk), dtype=np.int64))
+        else:
+            cbf.add_many(t)
+            oc.update_keys(kk)
+        del t
+
+
+@pytest.mark.parametrize("est", [3_600_000, 10_000_000])
+def test_borrowed_batches_are_hashed_where_they_lie(pa, oracle, N, est):
+    """CountingBloomFilter(borrow_keys=True): the window keeps pointers to the caller's tensors (PSK_DEVICE_BORROWED) -- same table, same
+    counts, one fold, and no key list is ever allocated"""
+    cbf = pa.CountingBloomFilter(est_elements=est, false_positive_rate=0.01, borrow_keys=True)
+    m, k = cbf.number_bits, cbf.number_hashes
+    B = 200_000 if est < 5_000_000 else 400_000
+    ops = _stream(oracle, 12, B)
+    ops[3] = (ops[3][0], ops[3][1][:-777])     # batches that do not end on a tile boundary
+    ops[6] = (ops[6][0], ops[6][1][:70_001])
+    oc = oracle.OracleCBF(m, k)
+    folds, replays = N.get_option("update_window_folds"), N.get_option("update_window_replays")
+    _run_lent(cbf, oc, ops, None)
+    assert cbf._tab.get_option("window_pending_batches") == len(ops)
+    assert len(cbf._borrowed) == len(ops)
+    _same(cbf, oc)
+    assert cbf._tab.get_option("window_pending_batches") == 0
+    assert N.get_option("update_window_folds") == folds + 1 and N.get_option("update_window_replays") == replays
+    assert cbf.batch_diagnostics() == {"violations": 0, "saturated": 0}
+    probe = np.concatenate([ops[0][1][:5000], ops[-2][1][:5000], oracle.gen_keys16(777, 5000)])
+    assert np.array_equal(cbf.check_many(_dev(probe)).cpu().numpy().view(np.uint32), oc.check_keys(probe))
+    assert not cbf._borrowed  # (the references went with the flush)
+
+
+def test_borrowed_window_replays_ill_formed_streams_from_the_callers_tensors(pa, oracle, N):
+    cbf = pa.CountingBloomFilter(est_elements=3_600_000, false_positive_rate=0.01, borrow_keys=True)
+    m, k = cbf.number_bits, cbf.number_hashes
+    B = 200_000
+    ops = _stream(oracle, 12, B)
+    absent = oracle.gen_keys16(999, B // 2)
+    ops.insert(7, (True, np.concatenate([absent, ops[4][1][B // 2:B // 2 + 1000]])))
+    oc = oracle.OracleCBF(m, k)
+    replays = N.get_option("update_window_replays")
+    _run_lent(cbf, oc, ops, None)
+    _same(cbf, oc)
+    assert N.get_option("update_window_replays") == replays + 1
+
+
+def test_borrowed_copied_and_host_batches_mix_in_one_window(pa, oracle, N):
+    """a lent tensor, a host array (copied into the list), a misaligned device view (copied), an adds-only run of several lent batches"""
+    cbf = pa.CountingBloomFilter(est_elements=3_600_000, false_positive_rate=0.01, borrow_keys=True)
+    m, k = cbf.number_bits, cbf.number_hashes
+    oc = oracle.OracleCBF(m, k)
+    B = 150_000
+    keys = oracle.gen_keys16(21, 8 * B)
+    flat = torch.zeros(B * 16 + 8, dtype=torch.uint8, device="cuda")
+    folds = N.get_option("update_window_folds")
+    for b in range(8):
+        kk = keys[b * B:(b + 1) * B]
+        if b % 3 == 0:
+            cbf.add_many(_dev(kk))                       # lent
+        elif b % 3 == 1:
+            cbf.add_many(kk)                             # host: copied
+        else:
+            flat[8:].copy_(_dev(kk).reshape(-1))
+            cbf.add_many(flat[8:].view(B, 16))           # 8 bytes off a 16-byte boundary: copied -- and `flat` may be overwritten right away
+            flat.zero_()
+        oc.update_keys(kk)
+        if b >= 1:
+            d = keys[(b - 1) * B:(b - 1) * B + B // 2]
+            cbf.remove_many(_dev(d))
+            oc.update_keys(d, -np.ones(len(d), dtype=np.int64))
+    _same(cbf, oc)
+    assert N.get_option("update_window_folds") == folds + 1
+    # adds only, several lent batches: one phase whose keys do not lie end to end
+    more = oracle.gen_keys16(22, 6 * B)
+    for b in range(6):
+        cbf.add_many(_dev(more[b * B:(b + 1) * B]))
+        oc.update_keys(more[b * B:(b + 1) * B])
+    _same(cbf, oc)
+
+
+def test_c_abi_borrowed_add_remove(pa, oracle, N):
+    """psk_cbf_add / psk_cbf_remove with PSK_DEVICE_BORROWED on a table too small for windows: applied at once, nothing kept"""
+    cbf = pa.CountingBloomFilter(est_elements=100_000, false_positive_rate=0.01, borrow_keys=True)
+    oc = oracle.OracleCBF(cbf.number_bits, cbf.number_hashes)
+    kk = oracle.gen_keys16(5, 120_000)
+    t = _dev(kk)
+    cbf.add_many(t)
+    assert cbf._tab.get_option("window_pending_batches") == 0
+    t.zero_()  # (not waiting: free to go)
+    oc.update_keys(kk)
+    cbf.remove_many(_dev(kk[:50_000]))
+    oc.update_keys(kk[:50_000], -np.ones(50_000, dtype=np.int64))
+    _same(cbf, oc)
