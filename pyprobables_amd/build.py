@@ -69,7 +69,14 @@ def needs_build() -> bool:
     if not OUT.exists():
         return True
     t = OUT.stat().st_mtime
-    return _newest_header() > t or any((CSRC / f).stat().st_mtime > t for f, _, _ in SOURCES)
+    if _newest_header() > t or any((CSRC / f).stat().st_mtime > t for f, _, _ in SOURCES):
+        return True
+    # (a PSK_BUILD_ONLY build links a library that is newer than every header while the objects it skipped are stale)
+    for src, stem, _ in SOURCES:
+        obj = OBJ / (stem + ".o")
+        if not obj.exists() or obj.stat().st_mtime < max([(CSRC / src).stat().st_mtime] + [f.stat().st_mtime for f in _deps(CSRC / src)]):
+            return True
+    return False
 
 
 def _compile(item, force: bool, verbose: bool, objdir: Path, extra: list) -> Path:

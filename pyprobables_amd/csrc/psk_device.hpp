@@ -159,48 +159,49 @@ struct KeysFixed16Multi {
 // windows cover one contiguous stretch of the blob just as the fixed-16 layout's loads do), the next window requested before the current
 // one is hashed, and the key's words are cut out of neighbouring dwords with v_alignbyte_b32 -- instead of one dependent
 // global_load_ubyte in front of every step of the k chains (rounds 1-4).
-// `room`: bytes from the key's first byte to the end of the whole blob.  A dword is only ever requested if it holds a byte of the
-// blob (it then lies in a mapped page); the last windows of the batch fall back to dword loads clamped to the blob's last dword.
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
-struct ByteWindows {
-    const uint32_t *w;  // the dword that holds the key's first byte
-    uint32_t a;         // that byte's position in it
-    uint32_t safe;      // dwords from w on that may be loaded
-    __device__ __forceinline__ ByteWindows(const uint8_t *q, uint32_t room)
-    {
-        const uintptr_t addr = (uintptr_t)q;
-        a = (uint32_t)addr & 3u;
-        w = reinterpret_cast<const uint32_t *>(addr - a);
-        safe = (a + room + 3u) >> 2;
-    }
-    __device__ __forceinline__ uint4 load(uint32_t t) const
-    {
-        const uint32_t d0 = 4u * t;
-        if (d0 + 4u <= safe) {
-            const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(w + d0);
-            return make_uint4(v.x, v.y, v.z, v.w);
-        }
-        const uint32_t last = safe - 1u;  // (safe >= 1: the caller holds at least one byte)
-        return make_uint4(w[d0 < last ? d0 : last], w[d0 + 1 < last ? d0 + 1 : last], w[d0 + 2 < last ? d0 + 2 : last], w[d0 + 3 < last ? d0 + 3 : last]);
-    }
-};
-
-// word(w): four key bytes (little endian); byte(e): one.  len < 2^31.  `cur`: the key's first window (bw.load(0); a caller that hashes
-// several keys requests all their first windows before it walks the first key)
-template <class WordFn, class ByteFn>
-__device__ __forceinline__ void walk_key_bytes(const ByteWindows &bw, uint4 cur, uint32_t len, WordFn &&word, ByteFn &&byte)
+// The window [p, p + 16), p 4-byte aligned and inside a mapped page (its first dword holds a byte the caller owns), of which the caller
+// uses the first `need` bytes.  ONE load, NO branch: a window that would reach into the next 4 KiB page although the caller needs nothing
+// there -- the page may not exist -- is requested `sh` dwords further down, where it ends at the page boundary, and a two-stage select moves
+// its dwords back into place.  (Round 5's first form chose between the dwordx4 and four clamped dword loads with an if: the two paths
+// delivered the window in different registers, hipcc joined them with moves -- and therefore waited vmcnt(0) right behind every load; the
+// windows of a 2048-key tile cost ~10 us of exposed latency, as much as everything else in the tile.)
+__device__ __forceinline__ uint4 load_window16(const uint32_t *p, uint32_t need)
 {
-    if (len == 0) return;
-    const uint32_t nwin = (bw.a + len + 15u) >> 4;
+    const uint32_t in_page = (uint32_t)(uintptr_t)p & 0xFFFu;
+    const uint32_t over = in_page > 0xFF0u ? in_page - 0xFF0u : 0u;          // bytes of the window beyond the page: 0, 4, 8, 12
+    const uint32_t sh = (need + over <= 16u) ? over >> 2 : 0u;                // (need beyond the boundary: the next page holds key bytes, it exists)
+    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(p - sh);
+    const bool s1 = (sh & 1u) != 0, s2 = (sh & 2u) != 0;
+    const uint32_t x1 = s1 ? v.y : v.x, y1 = s1 ? v.z : v.y, z1 = s1 ? v.w : v.z, w1 = v.w;
+    return make_uint4(s2 ? z1 : x1, s2 ? w1 : y1, z1, w1);
+}
+
+// word(w): four key bytes (little endian); byte(e): one.  len < 2^31.  `cur`: the key's first window (first_window16; a caller that
+// hashes several keys requests all their first windows before it walks the first key)
+__device__ __forceinline__ uint4 first_window16(const uint8_t *q, uint32_t len)
+{
+    const uint32_t a = (uint32_t)(uintptr_t)q & 3u;
+    // (pointer arithmetic, no round trip through an integer: that would turn the window loads into FLAT instructions -- which also count
+    // against lgkmcnt, so that every LDS barrier of pass 1 waited for the windows in flight)
+    return load_window16(reinterpret_cast<const uint32_t *>(q - a), a + len);
+}
+template <class WordFn, class ByteFn>
+__device__ __forceinline__ void walk_key_bytes(const uint8_t *q, uint4 cur, uint32_t len, WordFn &&word, ByteFn &&byte)
+{
+    const uint32_t a = (uint32_t)(uintptr_t)q & 3u;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(q - a);
+    const uint32_t span = a + len;
+    const uint32_t nwin = len ? (span + 15u) >> 4 : 0u;
     uint32_t left = len;
     for (uint32_t t = 0; t < nwin; ++t) {
-        uint4 nxt = cur;
-        if (t + 1 < nwin) nxt = bw.load(t + 1);
+        const uint32_t tn = t + 1 < nwin ? t + 1 : t;  // (the last window once more rather than a branch around the load)
+        const uint4 nxt = load_window16(w + 4u * tn, span - 16u * tn);
         const uint32_t d[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint32_t kw = __builtin_amdgcn_alignbyte(d[e + 1], d[e], bw.a);
+            const uint32_t kw = __builtin_amdgcn_alignbyte(d[e + 1], d[e], a);
             if (left >= 4) {
                 word(kw);
                 left -= 4;
@@ -214,35 +215,21 @@ __device__ __forceinline__ void walk_key_bytes(const ByteWindows &bw, uint4 cur,
         cur = nxt;
     }
 }
-
 template <class WordFn, class ByteFn>
-__device__ __forceinline__ void walk_key_bytes(const uint8_t *q, uint32_t len, uint32_t room, WordFn &&word, ByteFn &&byte)
+__device__ __forceinline__ void walk_key_bytes(const uint8_t *q, uint32_t len, WordFn &&word, ByteFn &&byte)
 {
     if (len == 0) return;
-    const ByteWindows bw(q, room);
-    walk_key_bytes(bw, bw.load(0), len, word, byte);
+    walk_key_bytes(q, first_window16(q, len), len, word, byte);
 }
 
-// 4-byte elements (code points of str keys): windows of four elements, `room` in elements (>= 1)
-__device__ __forceinline__ uint4 elem_window(const uint32_t *q, uint32_t room, uint32_t t)
-{
-    const uint32_t d0 = 4u * t;
-    if (d0 + 4u <= room) {
-        const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(q + d0);
-        return make_uint4(v.x, v.y, v.z, v.w);
-    }
-    const uint32_t last = room - 1u;
-    return make_uint4(q[d0 < last ? d0 : last], q[d0 + 1 < last ? d0 + 1 : last], q[d0 + 2 < last ? d0 + 2 : last], q[d0 + 3 < last ? d0 + 3 : last]);
-}
+// 4-byte elements (code points of str keys): windows of four elements
 template <class ElemFn>
-__device__ __forceinline__ void walk_key_elems(const uint32_t *q, uint4 cur, uint32_t len, uint32_t room, ElemFn &&elem)
+__device__ __forceinline__ void walk_key_elems(const uint32_t *q, uint4 cur, uint32_t len, ElemFn &&elem)
 {
-    if (len == 0) return;
-    auto loadwin = [&](uint32_t t) -> uint4 { return elem_window(q, room, t); };
     const uint32_t nwin = (len + 3u) >> 2;
     for (uint32_t t = 0; t < nwin; ++t) {
-        uint4 nxt = cur;
-        if (t + 1 < nwin) nxt = loadwin(t + 1);
+        const uint32_t tn = t + 1 < nwin ? t + 1 : t;
+        const uint4 nxt = load_window16(q + 4u * tn, 4u * (len - 4u * tn));
         const uint32_t d[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -250,27 +237,16 @@ __device__ __forceinline__ void walk_key_elems(const uint32_t *q, uint4 cur, uin
         cur = nxt;
     }
 }
-template <class ElemFn>
-__device__ __forceinline__ void walk_key_elems(const uint32_t *q, uint32_t len, uint32_t room, ElemFn &&elem)
-{
-    if (len == 0) return;
-    walk_key_elems(q, elem_window(q, room, 0), len, room, elem);
-}
 
 constexpr uint32_t kKeyLenBig = 0xFFFFFFFFu;  // Key::len of a key of 2^31 elements or more: walked element by element from off[]
-constexpr uint64_t kKeyRoomMax = 0x7FFFFFF0ull;
 
 template <bool DWORDS>
 struct KeysFixed {  // uint8[n][L]; DWORDS: L % 4 == 0 and base 4-byte aligned
     const uint8_t *p;
     uint32_t L;
-    uint64_t n;  // keys the matrix holds (bounds the windows of the last keys)
-    struct Key { const uint8_t *q; uint32_t room; };
-    __device__ __forceinline__ Key load(uint64_t i) const
-    {
-        const uint64_t room = (n - i) * (uint64_t)L;
-        return Key{p + i * (uint64_t)L, (uint32_t)(room < kKeyRoomMax ? room : kKeyRoomMax)};
-    }
+    uint64_t n;  // keys the matrix holds
+    struct Key { const uint8_t *q; };
+    __device__ __forceinline__ Key load(uint64_t i) const { return Key{p + i * (uint64_t)L}; }
     static __device__ __forceinline__ void pin(Key &) {}
     template <int G>
     __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
@@ -281,7 +257,7 @@ struct KeysFixed {  // uint8[n][L]; DWORDS: L % 4 == 0 and base 4-byte aligned
             const uint32_t *q = reinterpret_cast<const uint32_t *>(k.q);
             for (uint32_t j = 0; j < L / 4; ++j) fnv_word<G>(h, pr, q[j]);
         } else {
-            walk_key_bytes(k.q, L, k.room, [&](uint32_t w) { fnv_word<G>(h, pr, w); },
+            walk_key_bytes(k.q, L, [&](uint32_t w) { fnv_word<G>(h, pr, w); },
                            [&](uint32_t e) {
 #pragma unroll
                                for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e, pr.p[g]);
@@ -296,7 +272,7 @@ struct KeysFixed {  // uint8[n][L]; DWORDS: L % 4 == 0 and base 4-byte aligned
             const uint32_t *q = reinterpret_cast<const uint32_t *>(k.q);
             for (uint32_t j = 0; j < L / 4; ++j) fnv_word32<G>(h, q[j]);
         } else {
-            walk_key_bytes(k.q, L, k.room, [&](uint32_t w) { fnv_word32<G>(h, w); },
+            walk_key_bytes(k.q, L, [&](uint32_t w) { fnv_word32<G>(h, w); },
                            [&](uint32_t e) {
 #pragma unroll
                                for (int g = 0; g < G; ++g) h[g] = fnv_step32(h[g], e);
@@ -309,8 +285,12 @@ template <class T>
 struct KeysVarlen {  // elements T (uint8 bytes, or uint32 code points for str keys: hashes.py:98)
     const T *p;
     const uint64_t *off;
-    uint64_t n;  // keys of the batch: off[n] is the end of the blob
-    struct Key { const T *q; uint32_t len; uint32_t room; };
+    uint64_t n;  // keys of the batch
+    // (the key's POSITION in the blob, not its address: descriptors travel through LDS in pass 1's length sort, and a pointer read back
+    // from there has no address space -- its loads would be FLAT instructions, which count against lgkmcnt as well and make every LDS
+    // barrier wait for the windows in flight)
+    struct Key { uint64_t at; uint32_t len; uint32_t pad; };
+    __device__ __forceinline__ const T *ptr(const Key &k) const { return p + k.at; }
     static constexpr bool sorted = true;  // pass 1 hands a tile's keys to its lanes in order of length (psk_partition.hpp, src_sorted)
     // length class of the sort (0 .. 62): the exact length below 48 elements -- the lanes of a wave then agree on every step of the walk --,
     // steps of 16 up to 272, one class for the rest
@@ -318,20 +298,20 @@ struct KeysVarlen {  // elements T (uint8 bytes, or uint32 code points for str k
     {
         return k.len < 48u ? k.len : (k.len < 48u + 14u * 16u ? 48u + ((k.len - 48u) >> 4) : 62u);
     }
-    // the key's first window (requested for all keys of a thread before the first one is walked)
-    __device__ __forceinline__ uint4 first(const Key &k) const
-    {
-        if (k.len == 0) return make_uint4(0, 0, 0, 0);
-        if constexpr (sizeof(T) == 1) return ByteWindows(reinterpret_cast<const uint8_t *>(k.q), k.room).load(0);
-        else return elem_window(reinterpret_cast<const uint32_t *>(k.q), k.room, 0);
-    }
     __device__ __forceinline__ Key load(uint64_t i) const
     {
-        const uint64_t a = off[i], b = off[i + 1], e = off[n];  // (off[n]: one address for the whole wave, a scalar load)
-        const uint64_t len = b - a, room = e - a;
-        return Key{p + a, len < 0x80000000ull ? (uint32_t)len : kKeyLenBig, (uint32_t)(room < kKeyRoomMax ? room : kKeyRoomMax)};
+        const uint64_t a = off[i], len = off[i + 1] - a;
+        return Key{a, len < 0x80000000ull ? (uint32_t)len : kKeyLenBig, 0u};
     }
     static __device__ __forceinline__ void pin(Key &) {}
+    // the key's first window (requested for all keys of a thread before the first one is walked).  An EMPTY key owns no byte -- it may sit
+    // at the very end of the blob, past the last mapped page: its window (never looked at) is taken at the blob's first element instead.
+    __device__ __forceinline__ uint4 first(const Key &k) const
+    {
+        const T *q = k.len ? p + k.at : p;
+        if constexpr (sizeof(T) == 1) return first_window16(reinterpret_cast<const uint8_t *>(q), k.len);
+        else return load_window16(reinterpret_cast<const uint32_t *>(q), 4u * (k.len < 4u ? k.len : 4u));
+    }
     template <int G>
     __device__ __forceinline__ void hash_first(const Key &k, const uint4 &w0, uint64_t i, uint32_t s0, uint64_t (&h)[G]) const
     {
@@ -343,14 +323,11 @@ struct KeysVarlen {  // elements T (uint8 bytes, or uint32 code points for str k
         };
         if (k.len == kKeyLenBig) {  // 2 G elements in one key: the plain walk
             const uint64_t len = off[i + 1] - off[i];
-            for (uint64_t j = 0; j < len; ++j) step((uint32_t)k.q[j]);
+            for (uint64_t j = 0; j < len; ++j) step((uint32_t)ptr(k)[j]);
             return;
         }
-        if constexpr (sizeof(T) == 1) {
-            if (k.len) walk_key_bytes(ByteWindows(reinterpret_cast<const uint8_t *>(k.q), k.room), w0, k.len, [&](uint32_t w) { fnv_word<G>(h, pr, w); }, step);
-        } else {
-            walk_key_elems(reinterpret_cast<const uint32_t *>(k.q), w0, k.len, k.room, step);
-        }
+        if constexpr (sizeof(T) == 1) walk_key_bytes(reinterpret_cast<const uint8_t *>(ptr(k)), w0, k.len, [&](uint32_t w) { fnv_word<G>(h, pr, w); }, step);
+        else walk_key_elems(reinterpret_cast<const uint32_t *>(ptr(k)), w0, k.len, step);
     }
     template <int G>
     __device__ __forceinline__ void hash32_first(const Key &k, const uint4 &w0, uint64_t i, uint32_t s0, uint32_t (&h)[G]) const
@@ -362,14 +339,11 @@ struct KeysVarlen {  // elements T (uint8 bytes, or uint32 code points for str k
         };
         if (k.len == kKeyLenBig) {
             const uint64_t len = off[i + 1] - off[i];
-            for (uint64_t j = 0; j < len; ++j) step((uint32_t)k.q[j]);
+            for (uint64_t j = 0; j < len; ++j) step((uint32_t)ptr(k)[j]);
             return;
         }
-        if constexpr (sizeof(T) == 1) {
-            if (k.len) walk_key_bytes(ByteWindows(reinterpret_cast<const uint8_t *>(k.q), k.room), w0, k.len, [&](uint32_t w) { fnv_word32<G>(h, w); }, step);
-        } else {
-            walk_key_elems(reinterpret_cast<const uint32_t *>(k.q), w0, k.len, k.room, step);
-        }
+        if constexpr (sizeof(T) == 1) walk_key_bytes(reinterpret_cast<const uint8_t *>(ptr(k)), w0, k.len, [&](uint32_t w) { fnv_word32<G>(h, w); }, step);
+        else walk_key_elems(reinterpret_cast<const uint32_t *>(ptr(k)), w0, k.len, step);
     }
     template <int G>
     __device__ __forceinline__ void hash(const Key &k, uint64_t i, uint32_t s0, uint64_t (&h)[G]) const { hash_first<G>(k, first(k), i, s0, h); }

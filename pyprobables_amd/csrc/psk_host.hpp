@@ -333,7 +333,7 @@ static int set_dyn_lds(K kernel, size_t bytes)
 template <class Pay, int KT, int NT>
 static size_t scatter_lds_bytes(const PartGeom *g, uint64_t tile = 0, bool sorted = false)  // tile: keys per tile (0 = the shape's full tile)
 {
-    if (sorted) return scatter_lds_bytes<Pay, KT, NT>(g, tile, false) + 16 + 512 + 18 * (size_t)PartTile<Pay, KT, NT>::TILE;  // length sort (src_sorted): counts, descriptors, slots
+    if (sorted) return scatter_lds_bytes<Pay, KT, NT>(g, tile, false) + 16 + 8 * (size_t)kSortBins + 18 * (size_t)PartTile<Pay, KT, NT>::TILE;  // length sort (src_sorted): counts, descriptors, slots
     using Tile = PartTile<Pay, KT, NT>;
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
     const size_t tk = tile ? (size_t)tile : (size_t)Tile::TILE;

@@ -44,6 +44,8 @@ constexpr int kPartScanPerThread = 4;   // slices per lane of a scanning thread:
 constexpr bool kPartPipeline = true;   // prefetch the next tile's keys under the current tile (see k_part_scatter)
 constexpr bool kPartHash32 = true;     // explicit 32-bit FNV chains for power-of-two tables
 constexpr uint32_t kNibShift = 18;           // log2(counters per 4-bit slice image): psk_nibble.hpp (CountingBloomFilter tables beyond 2^26 cells)
+constexpr int kSortSub = 16;                 // pass 1's length sort of ragged keys: counters per length class (one per lane mod 16)
+constexpr int kSortBins = 64 * kSortSub;
 constexpr uint32_t kPadProbe = 0xFFFFFFFFu;  // filler that pads every run to whole groups; pass 2 skips it
 
 enum PartMode { kModePlain = 0, kModeInline = 1, kModeKeyed = 2 };
@@ -538,9 +540,10 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     uint32_t *gb = stage + stage_cap;
     // keys of different lengths (src_sorted): class counts, class offsets and the slot order of the tile's length sort, behind everything else
     // (+ the keys' descriptors in slot order, 16 bytes each, 16-byte aligned)
-    uint32_t *sort_hist = reinterpret_cast<uint32_t *>(((uintptr_t)(gb + (PAIR ? stage_cap / GS + 4 : 0)) + 15) & ~(uintptr_t)15);
-    uint32_t *sort_off = sort_hist + 64;
-    uint4 *sort_keys = reinterpret_cast<uint4 *>(sort_off + 64);
+    // (aligned by index arithmetic on the LDS base: an integer round trip would make these FLAT accesses)
+    uint32_t *sort_hist = smem + ((uint32_t)((gb + (PAIR ? stage_cap / GS + 4 : 0)) - smem) + 3u & ~3u);
+    uint32_t *sort_off = sort_hist + kSortBins;
+    uint4 *sort_keys = reinterpret_cast<uint4 *>(sort_off + kSortBins);
     uint16_t *sort_order = reinterpret_cast<uint16_t *>(sort_keys + T::TILE);
     // KT other than the round-up sizes 8 / 16 / 32 is an exact instantiation (with_kt): k == KT, and every per-probe
     // "j < k" test below folds away (28 exec-mask branch sequences per tile for k = 7)
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     for (uint32_t b = threadIdx.x; b < B; b += NT) cur[b] = g.append ? segcnt[(uint64_t)b * g.nwg + blockIdx.x] : 0u;
     for (uint32_t b = threadIdx.x; b < 2 * B; b += NT) hist0[b] = 0;
     if constexpr (src_sorted<Src>::value) {
-        if (threadIdx.x < 64) sort_hist[threadIdx.x] = 0;
+        for (uint32_t b = threadIdx.x; b < (uint32_t)kSortBins; b += NT) sort_hist[b] = 0;
     }
     uint32_t parity = 0;
     lds_barrier();
@@ -621,18 +624,37 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
     uint4 kfirst[SORTED ? KPT : 1];
     auto sort_tile = [&](uint64_t nb, uint64_t ne) {  // keys [nb, ne) in kcur (natural order) -> slot_n / ks / kfirst
         if constexpr (SORTED) {
+            // (every class has kSortSub counters, one per lane mod kSortSub: the lanes of a wave -- neighbours in the batch, often of ONE length --
+            // would otherwise queue at one LDS address, and a returning atomic there takes its ~16 cycles per lane, one after the other:
+            // 64 classes x 1 counter cost a 2048-key tile ~12 us, as much as everything else in it)
             uint32_t cls[KPT], crank[KPT];
 #pragma unroll
             for (int q = 0; q < KPT; ++q) {
                 const uint64_t i = nb + (uint32_t)q * NT + threadIdx.x;
-                cls[q] = i < ne ? Src::len_class(kcur[q]) : 63u;  // keys past the tile's end: behind all others
+                cls[q] = (i < ne ? Src::len_class(kcur[q]) : 63u) * (uint32_t)kSortSub + (threadIdx.x & (uint32_t)(kSortSub - 1));  // past the tile's end: behind all others
                 crank[q] = atomicAdd(&sort_hist[cls[q]], 1u);
             }
             lds_barrier();
-            if (threadIdx.x < 64) {
-                const uint32_t v = sort_hist[threadIdx.x];
-                sort_off[threadIdx.x] = wave_inclusive_scan(v) - v;
-                sort_hist[threadIdx.x] = 0;  // (the next tile counts behind two more barriers)
+            {   // exclusive scan over the counters in class order (a thread takes kSortBins / NT neighbours)
+                constexpr int BPT = kSortBins / NT > 0 ? kSortBins / NT : 1;
+                uint32_t v[BPT], sum = 0;
+#pragma unroll
+                for (int c = 0; c < BPT; ++c) {
+                    const uint32_t b = threadIdx.x * BPT + c;
+                    v[c] = b < (uint32_t)kSortBins ? sort_hist[b] : 0u;
+                    sum += v[c];
+                }
+                uint32_t total;
+                uint32_t run = block_exclusive_scan<NT>(sum, wave_tot, &total);
+#pragma unroll
+                for (int c = 0; c < BPT; ++c) {
+                    const uint32_t b = threadIdx.x * BPT + c;
+                    if (b < (uint32_t)kSortBins) {
+                        sort_off[b] = run;
+                        sort_hist[b] = 0;  // (the next tile counts behind more barriers)
+                    }
+                    run += v[c];
+                }
             }
             lds_barrier();
 #pragma unroll
@@ -1546,10 +1568,11 @@ static __global__ __launch_bounds__(kApplyThreads) void k_bloom_test_flag(const 
             const uint64_t pieces = (m1 - m0) >> 4, per = (pieces + gridDim.x - 1) / gridDim.x;
             const uint64_t lo = (uint64_t)b * per, hi = lo + per < pieces ? lo + per : pieces;
             const uint4 ones = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
-            for (uint64_t i = lo + threadIdx.x; i < hi; i += kApplyThreads) reinterpret_cast<uint4 *>(m0)[i] = ones;
+            uint4 *mid = reinterpret_cast<uint4 *>(out + (m0 - a0));  // (pointer arithmetic: through the integer these were FLAT stores)
+            for (uint64_t i = lo + threadIdx.x; i < hi; i += kApplyThreads) mid[i] = ones;
             if (b == 0) {
                 if (threadIdx.x < (uint32_t)(m0 - a0)) out[threadIdx.x] = 1;
-                if (threadIdx.x < (uint32_t)(a1 - m1)) reinterpret_cast<uint8_t *>(m1)[threadIdx.x] = 1;
+                if (threadIdx.x < (uint32_t)(a1 - m1)) out[(m1 - a0) + threadIdx.x] = 1;
             }
         } else if (b == 0) {
             for (uint64_t i = threadIdx.x; i < n; i += kApplyThreads) out[i] = 1;

@@ -49,7 +49,8 @@ torch.cuda.synchronize()
 N.check(N.lib().psk_debug_phase_profile(blm._tab.handle, 256, 256, buf))
 names = {1: "top of tile", 9: "hash + hist (own work)", 2: "wait at barrier 1", 6: "scan: read hist + zero", 7: "scan: wave scan", 8: "scan: cursors",
          3: "wait at barrier 2", 10: "length sort of the next tile", 4: "stage sort + barrier", 5: "write-out"}
-tot = sum(buf[1:12])
+print("raw", list(buf))
+tot = max(1, sum(buf[1:12]))
 for i in [1, 9, 2, 6, 7, 8, 3, 10, 4, 5]:
     print(f"{kind} phase {names[i]:30s} {buf[i]/max(1, buf[0])/3:10.0f} ticks per WG per launch  ({100.0*buf[i]/tot:5.1f} %)")
 N.set_option("part_debug", 0)
