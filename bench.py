@@ -289,7 +289,7 @@ def timed_loop(torch, fn, iters, warm=2):
 
 def pmc_traffic(op: str, n: int):
     """HBM-side bytes per launch of `op` from the committed PMC profile of the same workload and kernels
-    (scripts/profile_r04.sh -> profiles/r04_pmc_traffic.json); None when there is no matching record.  A record measured
+    (scripts/profile_r05.sh -> profiles/r05_pmc_traffic.json); None when there is no matching record.  A record measured
     on chunks of the same kernels (`per_key_scalable`: cfg 5 inserts its shard in 2^25-key calls) is scaled by the key count."""
     try:
         pmc = json.loads(PMC_FILE.read_text())
@@ -304,8 +304,8 @@ def pmc_traffic(op: str, n: int):
 
 
 def l2_hit(op: str):
-    """L2 hit rate TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum) of the launch's kernels (profiles/r04_l2_hit.json,
-    scripts/profile_r04.sh: its own rocprofv3 --pmc pass); None when there is no record"""
+    """L2 hit rate TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum) of the launch's kernels (profiles/r05_l2_hit.json,
+    scripts/profile_r05.sh: its own rocprofv3 --pmc pass); None when there is no record"""
     try:
         return json.loads(L2_FILE.read_text())[op]["l2_hit"]
     except Exception:
@@ -649,6 +649,23 @@ def side_measurements(ctx: Ctx, n, blm, keys):
     out["check_half_fresh_hits"] = int(res.sum().item())          # n/2 true members + the false positives among the fresh half
     out["check_half_fresh_members_found"] = bool(res[: n // 2].all().item())
     del fresh, mixed, res
+    # The reference's NATIVE key type: variable-length byte / str keys (hashes.py:98 walks the key element by element).  A ragged batch
+    # handed over as (blob, offsets) on the device: lengths 4 + min(36, floor(Exp(12.6))) bytes (4 .. 40, mean ~15.4).
+    import numpy as np
+
+    rng = np.random.default_rng(7)
+    lens = 4 + np.minimum(36, np.floor(rng.exponential(12.6, n))).astype(np.int64)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    pair = (torch.from_numpy(rng.integers(0, 256, int(offs[-1]), dtype=np.uint8)).to(f"cuda:{dev}"), torch.from_numpy(offs).to(f"cuda:{dev}"))
+    rb = pa.BloomFilter(est_elements=28005615, false_positive_rate=0.01, device=dev)
+    ms_a = timed_loop(torch, lambda: rb.add_many(pair), 5)
+    ms_c = timed_loop(torch, lambda: rb.check_many(pair), 5)
+    out["bloom_ragged_keys_Mkeys_s"] = {"insert": n / ms_a / 1e3, "check": n / ms_c / 1e3, "all_found": bool(rb.check_many(pair).all().item()),
+                                        "mean_key_bytes": float(lens.mean()), "max_key_bytes": int(lens.max()),
+                                        "note": "ragged byte keys (the reference's native key type) as a device (blob, offsets) pair into the cfg-2 "
+                                                "filter: 16-byte windows per lane + a per-tile length sort in pass 1; not part of `value`"}
+    del rb, pair, lens, offs
     w = ctx.gen_weights(n, 0)
     cms = pa.CountMinSketch(width=2**20, depth=5, device=dev)
     ms = timed_loop(torch, lambda: cms.add_many(keys, w), 5)
@@ -1177,6 +1194,16 @@ def run(args):
             obj, f2 = extra_config(ctx, args, name)
             line["configs"][name] = obj
             fails += [f"{name}: {x}" for x in f2]
+        # cfg 4 once more with CountingBloomFilter(borrow_keys=True): same API calls, same exactness; the update window hashes the caller's
+        # (resident, never overwritten) key tensors where they lie instead of copying every batch into its key list
+        import copy
+
+        a2 = copy.copy(args)
+        a2.borrow_window = True
+        ob, f2 = extra_config(ctx, a2, "cfg4")
+        line["configs"]["cfg4"]["with_borrow_keys"] = {"value": ob["value"], "unit": ob["unit"], "ms_per_step": ob["ms_per_step"], "parity_ok": ob["parity_ok"],
+                                                       "api": ob["config"]["api"], "roofline_frac": ob["roofline"]["frac"]}
+        fails += [f"cfg4 (borrow_keys): {x}" for x in f2]
         c3 = line["configs"]["cfg3"]
         line["cms"] = {"insert_Mupdates_s": c3["value"], "lookup_Mkeys_s": c3["detail"]["check_Mkeys_s"], "source": "configs.cfg3 (100M weighted updates in 10 passes; lookups of the 10M keys)"}
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:

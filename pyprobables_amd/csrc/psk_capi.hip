@@ -528,6 +528,7 @@ int64_t g_nib_nt = 1;   // nontemporal table loads in k_nib_gather (1 GiB lookup
 int64_t g_nib_min_lg_lookup = 23, g_nib_min_lg_update = 24;  // see nib_geometry (psk_host.hpp); measured crossovers: scripts/ab_nib_threshold.py
 int64_t g_nib_update_parts = 1;   // 1 = one workgroup per slice (default: two measured the same, 0.78-0.82 ms per 10 M adds either way), 2 = two, 0 = by slice size; see nib_update_lgparts
 int64_t g_nib_update_layout = 1;   // see psk_nibble.hpp (bench A/B)
+int64_t g_ragged_sort = 1;    // pass 1's per-tile length sort of ragged keys (A/B: 0 = batch order); option "ragged_sort"
 int64_t g_big_table_nt = 1;   // nontemporal table sweeps in the Bloom pass-2 kernels for tables of 128 MiB and more (BASELINE cfg 5); option "big_table_nt"
 int64_t g_window_shadow = 0;   // 1 = a successful window fold leaves the lookups' kept 4-bit images up to date (when they exist) instead of stale.  Measured on the
                                // 1 GiB table (scripts/ab_window_shadow.py: rounds of 15 M window updates + a 10 M-key lookup): 2.99 vs 3.00 ms per round -- the
@@ -589,6 +590,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "update_window_wide")) g_window_wide = value;
     else if (!strcmp(name, "update_window_shadow")) g_window_shadow = value;
     else if (!strcmp(name, "big_table_nt")) g_big_table_nt = value;
+    else if (!strcmp(name, "ragged_sort")) g_ragged_sort = value;
     else if (!strcmp(name, "nibble_min_lg_lookup")) g_nib_min_lg_lookup = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_min_lg_update")) g_nib_min_lg_update = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_nt_loads")) g_nib_nt = value;
@@ -687,6 +689,7 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "update_window_shadow")) *value = g_window_shadow;
     else if (!strcmp(name, "update_window_shadow_writes")) *value = g_window_shadow_writes;
     else if (!strcmp(name, "big_table_nt")) *value = g_big_table_nt;
+    else if (!strcmp(name, "ragged_sort")) *value = g_ragged_sort;
     else if (!strcmp(name, "nibble_min_lg_lookup")) *value = g_nib_min_lg_lookup;
     else if (!strcmp(name, "nibble_min_lg_update")) *value = g_nib_min_lg_update;
     else if (!strcmp(name, "nibble_nt_loads")) *value = g_nib_nt;

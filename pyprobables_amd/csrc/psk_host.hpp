@@ -247,6 +247,7 @@ extern PSK_HIDDEN int64_t g_nib_nt;             // nontemporal table loads in th
 extern PSK_HIDDEN int64_t g_nib_update_layout;  // delta-image layout of k_nib_apply: 0 pieces, 1 blocks (psk_nibble.hpp)
 extern PSK_HIDDEN int64_t g_lookup_nibble, g_update_nibble;  // CBF tables beyond one level of 32-bit slices: 4-bit slice images (psk_nibble.hpp)
 extern PSK_HIDDEN int64_t g_part_dense_groups;   // pass 2 walks a wave's segments end to end when a segment holds fewer groups than this on average (0 = never)
+extern PSK_HIDDEN int64_t g_ragged_sort;         // option "ragged_sort": pass 1 hands keys of different lengths to its lanes in order of length (psk_partition.hpp sort_tile)
 extern PSK_HIDDEN int64_t g_big_table_nt;        // option "big_table_nt": nontemporal sweeps of Bloom tables of 128 MiB and more (psk_partition.hpp slice_piece)
 extern PSK_HIDDEN int64_t g_part_wgs;            // bench knob: pass 1 workgroups (0 = auto: one or two per CU)
 extern PSK_HIDDEN int64_t g_lookup_split;        // bench knob: 0 = never share a slice between two pass-2 workgroups
@@ -270,7 +271,7 @@ static inline bool part_slices(uint64_t cells, uint32_t max_shift, uint32_t min_
     if (B > max_buckets) return false;
     g->nbuckets = (uint32_t)B;
     g->shift = (uint32_t)shift;
-    g->dbg = (uint32_t)g_part_debug | (g_big_table_nt != 0 ? kGeomNtBit : 0u);
+    g->dbg = (uint32_t)g_part_debug | (g_big_table_nt != 0 ? kGeomNtBit : 0u) | (g_ragged_sort == 0 ? kGeomNoSortBit : 0u);
     g->split = g->split_idx = 0;
     g->dense = 0;
     g->append = 0;

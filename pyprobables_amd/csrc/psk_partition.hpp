@@ -44,6 +44,7 @@ constexpr int kPartScanPerThread = 4;   // slices per lane of a scanning thread:
 constexpr bool kPartPipeline = true;   // prefetch the next tile's keys under the current tile (see k_part_scatter)
 constexpr bool kPartHash32 = true;     // explicit 32-bit FNV chains for power-of-two tables
 constexpr uint32_t kNibShift = 18;           // log2(counters per 4-bit slice image): psk_nibble.hpp (CountingBloomFilter tables beyond 2^26 cells)
+constexpr uint32_t kGeomNoSortBit = 0x40000000u;  // PartGeom::dbg bit 30 (a production bit): option "ragged_sort" is off -- ragged keys go to the lanes in batch order
 constexpr int kSortSub = 16;                 // pass 1's length sort of ragged keys: counters per length class (one per lane mod 16)
 constexpr int kSortBins = 64 * kSortSub;
 constexpr uint32_t kPadProbe = 0xFFFFFFFFu;  // filler that pads every run to whole groups; pass 2 skips it
@@ -628,12 +629,14 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
             // would otherwise queue at one LDS address, and a returning atomic there takes its ~16 cycles per lane, one after the other:
             // 64 classes x 1 counter cost a 2048-key tile ~12 us, as much as everything else in it)
             uint32_t cls[KPT], crank[KPT];
+            const bool nosort = (g.dbg & kGeomNoSortBit) != 0;  // (uniform; option "ragged_sort" = 0: batch order -- the descriptors still travel)
 #pragma unroll
             for (int q = 0; q < KPT; ++q) {
                 const uint64_t i = nb + (uint32_t)q * NT + threadIdx.x;
                 cls[q] = (i < ne ? Src::len_class(kcur[q]) : 63u) * (uint32_t)kSortSub + (threadIdx.x & (uint32_t)(kSortSub - 1));  // past the tile's end: behind all others
-                crank[q] = atomicAdd(&sort_hist[cls[q]], 1u);
+                if (!nosort) crank[q] = atomicAdd(&sort_hist[cls[q]], 1u);
             }
+            if (!nosort) {
             lds_barrier();
             {   // exclusive scan over the counters in class order (a thread takes kSortBins / NT neighbours)
                 constexpr int BPT = kSortBins / NT > 0 ? kSortBins / NT : 1;
@@ -657,9 +660,10 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
                 }
             }
             lds_barrier();
+            }
 #pragma unroll
             for (int q = 0; q < KPT; ++q) {
-                const uint32_t pos = sort_off[cls[q]] + crank[q];
+                const uint32_t pos = nosort ? (uint32_t)q * NT + threadIdx.x : sort_off[cls[q]] + crank[q];
                 uint4 d;
                 __builtin_memcpy(&d, &kcur[q], 16);
                 sort_keys[pos] = d;

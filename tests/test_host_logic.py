@@ -220,3 +220,24 @@ def test_homogeneous_packing_rejects_non_key_elements():
     with pytest.raises(TypeError):
         pack_keys([b"abc", _array.array("B", [1, 2, 3]), b"hi"])
     assert pack_keys([b"abc", bytearray(b"xy"), memoryview(b"z")]).n == 3
+
+
+def test_pack_keys_ragged_pairs_on_the_host():
+    """(blob, offsets) pairs: layout by element width, offsets rebased to the first key, validation of shapes / dtypes / order"""
+    blob = np.arange(20, dtype=np.uint8)
+    b = pack_keys((blob, np.array([3, 5, 5, 12], dtype=np.int64)))
+    assert (b.layout, b.n, b.where) == (N.KEYS_VARLEN8, 3, N.HOST)
+    assert b.keep[1].tolist() == [0, 2, 2, 9] and bytes(b.keep[0][:9]) == bytes(range(3, 12))
+    cps = np.array([0x20AC, 65, 66, 0x1F600], dtype=np.uint32)
+    b = pack_keys((cps, np.array([0, 1, 4], dtype=np.uint64)))
+    assert (b.layout, b.n) == (N.KEYS_VARLEN32, 2)
+    b = pack_keys((np.zeros(0, dtype=np.uint8), np.zeros(3, dtype=np.int64)))  # all keys empty
+    assert (b.layout, b.n) == (N.KEYS_VARLEN8, 2) and b.data != 0
+    with pytest.raises(TypeError):
+        pack_keys((blob, np.array([0, 3], dtype=np.int32)))
+    with pytest.raises(TypeError):
+        pack_keys((blob.astype(np.float32), np.array([0, 3], dtype=np.int64)))
+    with pytest.raises(ValueError):
+        pack_keys((blob, np.array([0, 30], dtype=np.int64)))
+    with pytest.raises(ValueError):
+        pack_keys((blob, np.array([0, 5, 4], dtype=np.int64)))
