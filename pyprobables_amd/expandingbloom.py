@@ -164,7 +164,10 @@ class ExpandingBloomFilter:
         m = 2^28)."""
         k = self._k
         lg = max(12, (2 * min(count, self._SUB) * k - 1).bit_length())
-        slots = self._buf(f"slots{lg}", 2 << lg, torch.int32, fill=-1)
+        # ONE map, sized for a full step (the kernel takes lg as a parameter and leaves the slots it used reset): chunk sizes that vary
+        # used to leave a map per size alive
+        lg_max = max(12, (2 * self._SUB * k - 1).bit_length())
+        slots = self._buf("slots", 2 << lg_max, torch.int32, fill=-1)
         flag = self._buf("flag", min(count, self._SUB), torch.uint8)
         cnt = self._buf("count", 2, torch.int64)
         cnt.zero_()
@@ -175,7 +178,7 @@ class ExpandingBloomFilter:
                                                     n, k, slots.data_ptr(), lg, flag.data_ptr(), cnt.data_ptr(), self._dev(), self._stream()))
             N.check(L.psk_idx_insert(tab, idx.data_ptr() + 4 * (start + s) * k, flag.data_ptr(), n, k, self._dev(), self._stream()))
         inserted, full = (int(x) for x in cnt.tolist())
-        if full:
+        if full:  # (a map of twice the step's probes cannot fill: a guard, not a path)
             raise RuntimeError("stacked filter: the resolution map overflowed")
         return inserted
 
