@@ -129,6 +129,31 @@ struct KeysFixed16 {  // uint8[n][16], 16-byte aligned: one global_load_dwordx4 
     }
 };
 
+// uint8[n][8], 8-byte aligned (64-bit integer ids, the other common fixed layout; round 5): one global_load_dwordx2 per lane, prefetched and
+// hashed from registers like the 16-byte layout -- through the generic dword loop (loads in front of the chains, k rounded up to 8) 8-byte
+// keys ran SLOWER than 16-byte ones (48.6 against 55.7 G inserts/s)
+struct KeysFixed8 {
+    const uint2 *p;
+    struct Key { uint2 w; };
+    __device__ __forceinline__ Key load(uint64_t i) const { return Key{p[i]}; }
+    static __device__ __forceinline__ void pin(Key &k) { asm volatile("" : "+v"(k.w.x), "+v"(k.w.y)); }
+    template <int G>
+    __device__ __forceinline__ void hash(const Key &k, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
+    {
+        fnv_init<G>(h, s0);
+        FnvPairs<G> pr;
+        fnv_word<G>(h, pr, k.w.x);
+        fnv_word<G>(h, pr, k.w.y);
+    }
+    template <int G>
+    __device__ __forceinline__ void hash32(const Key &k, uint64_t, uint32_t s0, uint32_t (&h)[G]) const
+    {
+        fnv_init32<G>(h, s0);
+        fnv_word32<G>(h, k.w.x);
+        fnv_word32<G>(h, k.w.y);
+    }
+};
+
 // Several 16-byte-key batches laid end to end WITHOUT being copied together (borrowed batches of the write-combined CBF updates):
 // key i lives in batch j with start[j] <= i < start[j + 1].  j is guessed as floor(i * nb / n) -- exact for equal-sized batches, the
 // usual stream -- and corrected by walking start[] (a few hundred bytes, cached); a binary search per key (7 dependent loads for 50

@@ -431,7 +431,7 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
 // different lengths hold a descriptor and a window per key in registers -- four keys per thread spill --, and the rare layouts are not worth
 // a second copy of every kernel)
 template <class Src>
-struct src_fat512 { static constexpr bool value = std::is_same<Src, KeysFixed16>::value || std::is_same<Src, KeysFixed16Multi>::value; };
+struct src_fat512 { static constexpr bool value = std::is_same<Src, KeysFixed16>::value || std::is_same<Src, KeysFixed16Multi>::value || std::is_same<Src, KeysFixed8>::value; };
 
 template <class Pay, int KT, bool FAT = true>
 static int scatter_threads(const PartGeom *g)
@@ -498,7 +498,7 @@ static int with_kt(uint32_t k, F &&f)
 {
     // (`if constexpr`: a plain `if` instantiated -- and emitted -- the exact-k kernels of EVERY layout, though the rare ones could never be
     // selected: 6 dead kernels per layout, payload and launcher.  Ragged byte keys -- the reference's native key type -- get the exact sizes too.)
-    constexpr bool fast16 = std::is_same<Src, KeysFixed16>::value || std::is_same<Src, KeysFixed16Multi>::value;
+    constexpr bool fast16 = std::is_same<Src, KeysFixed16>::value || std::is_same<Src, KeysFixed16Multi>::value || std::is_same<Src, KeysFixed8>::value;
     constexpr bool fast = fast16 || std::is_same<Src, KeysVarlen<uint8_t>>::value;
     if constexpr (fast) {
         switch (k) {
@@ -528,6 +528,7 @@ static int with_part_source(const Batch &b, bool *handled, F &&f)
     switch (b.layout) {
         case PSK_KEYS_FIXED:
             if (b.key_len == 16 && ((uintptr_t)b.data & 15) == 0) return f(KeysFixed16{(const uint4 *)b.data});
+            if (b.key_len == 8 && ((uintptr_t)b.data & 7) == 0) return f(KeysFixed8{(const uint2 *)b.data});
             if (b.key_len % 4 == 0 && ((uintptr_t)b.data & 3) == 0) return f(KeysFixed<true>{(const uint8_t *)b.data, b.key_len, b.n});
             return f(KeysFixed<false>{(const uint8_t *)b.data, b.key_len, b.n});
         case PSK_KEYS_VARLEN8: return f(KeysVarlen<uint8_t>{(const uint8_t *)b.data, b.offs, b.n});

@@ -165,3 +165,33 @@ def test_pair_validation(pa):
         pa.BloomFilter(est_elements=100, false_positive_rate=0.1).add_many((np.zeros(4, dtype=np.uint8), np.array([0, 3, 9], dtype=np.int64)))
     with pytest.raises(ValueError):
         pa.BloomFilter(est_elements=100, false_positive_rate=0.1).add_many((np.zeros(4, dtype=np.uint8), np.array([0, 3, 2], dtype=np.int64)))
+
+
+@pytest.mark.parametrize("part", [False, True], indirect=True)
+@pytest.mark.parametrize("est,fpr", [(300_000, 0.01), (28005615 // 16, 0.01), (200_000, 0.00001)])  # Barrett / power of two / k = 17
+def test_eight_byte_keys_fast_layout_vs_oracle(pa, oracle, part, est, fpr):
+    """64-bit ids: the 8-byte fast layout (KeysFixed8: one dwordx2 per lane, exact k) when the batch is 8-byte aligned, the generic dword
+    walk when it is not -- same tables, same answers"""
+    rng = np.random.default_rng(8)
+    n = 80_000
+    keys = rng.integers(0, 256, size=(n, 8), dtype=np.uint8)
+    flat = torch.zeros(n * 8 + 4, dtype=torch.uint8, device="cuda")
+    flat[4:].copy_(torch.from_numpy(keys).cuda().reshape(-1))
+    off4 = flat[4:].view(n, 8)  # 4 bytes off an 8-byte boundary
+    for dk in (torch.from_numpy(keys).cuda(), off4):
+        blm = pa.BloomFilter(est_elements=est, false_positive_rate=fpr)
+        ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+        blm.add_many(dk[: n // 2])
+        ob.add_keys(keys[: n // 2])
+        assert np.array_equal(_table(blm), ob.bloom)
+        assert np.array_equal(blm.check_many(dk).cpu().numpy().astype(np.uint8), ob.check_keys(keys))
+    cms = pa.CountMinSketch(width=2**16, depth=5)
+    ref = pa.CountMinSketch(width=2**16, depth=5)
+    w = rng.integers(1, 9, size=n).astype(np.int32)
+    cms.add_many(torch.from_numpy(keys).cuda(), torch.from_numpy(w).cuda())
+    ref.add_many(off4, torch.from_numpy(w).cuda())
+    assert torch.equal(cms.table_tensor, ref.table_tensor)
+    oc = oracle.OracleCMS(2**16, 5)
+    oc.add_keys(keys, w)
+    assert np.array_equal(np.frombuffer(bytes(cms._bins), dtype=np.int32), oc.bins)
+    assert np.array_equal(cms.check_many(torch.from_numpy(keys).cuda()).cpu().numpy(), oc.check_keys(keys).astype(np.int32))
