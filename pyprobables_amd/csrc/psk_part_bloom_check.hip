@@ -131,7 +131,9 @@ static bool tile_flag_geometry(psk_sketch *s, const Batch &b, PartGeom *g, uint6
             using Src = decltype(src);
             return with_kt<Src>(s->k, [&](auto kt) {
                 constexpr int KT = decltype(kt)::value;
-                cap = scatter_round_cap<PayTileTag, KT, src_fat512<Src>::value>(g, 0, PayTileTag::max_tiles_per_wg);
+                // (layouts without the two-per-CU shape: 512 of the 1024-thread workgroups, two per CU one after the other, so that a 10 M-key
+                // batch stays ONE round as it is for the 16-byte layout -- two rounds of 5 M cost ragged keys 30 us per lookup)
+                cap = scatter_round_cap<PayTileTag, KT, src_fat512<Src>::value>(g, src_fat512<Src>::value ? 0u : 512u, PayTileTag::max_tiles_per_wg);
                 return (int)PSK_OK;
             });
         }) != PSK_OK || !handled || cap == 0) return false;
@@ -161,7 +163,8 @@ static int tile_flag_scatter(psk_sketch *s, const Batch &sub, uint64_t cnt, bool
             const uint32_t gen = ++s->tflag_gen;
             *gen_out = gen;
             SpillBloomFlag spill{(const uint32_t *)s->table, (uint32_t *)s->s_tflag.p, gen, defer ? 1u : 0u};
-            return launch_scatter<Src, IdxBloom<kTuPow2>, PayTileTag, SpillBloomFlag, KT>(s, src, IdxBloom<kTuPow2>{s->md}, PayTileTag{}, spill, g, cnt, st);
+            return launch_scatter<Src, IdxBloom<kTuPow2>, PayTileTag, SpillBloomFlag, KT>(s, src, IdxBloom<kTuPow2>{s->md}, PayTileTag{}, spill, g, cnt, st,
+                                                                                          src_fat512<Src>::value ? 0u : 512u);
         });
     });
 }
