@@ -105,6 +105,7 @@ struct psk_sketch {
     DevBuf s_flag;                             // split lookup: "a segment overflowed" flag
     DevBuf s_tflag;                            // tile-flag Bloom lookups: one uint32 per pass-1 tile of a round; "flagged" = holds the round's
     uint32_t tflag_gen = 0;                    // generation number (never 0), so the flags are never reset
+    uint32_t tflag_wgs = 0;  // pass-1 workgroups of the tile-flag lookup in progress (0: the shape's own count; tile_flag_geometry)
     DevBuf s_part2, s_cnt2;                    // two-level path: bucket buffer + fill counts after the second split
     DevBuf s_merge;                            // multi-GPU merge (psk_merge_or / _sum): exchange buffers
     DevBuf s_tally;                            // weighted pass 1: (sum w, sum |w|) per workgroup, folded by k_tally_fold

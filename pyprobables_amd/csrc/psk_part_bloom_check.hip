@@ -131,9 +131,21 @@ static bool tile_flag_geometry(psk_sketch *s, const Batch &b, PartGeom *g, uint6
             using Src = decltype(src);
             return with_kt<Src>(s->k, [&](auto kt) {
                 constexpr int KT = decltype(kt)::value;
-                // (layouts without the two-per-CU shape: 512 of the 1024-thread workgroups, two per CU one after the other, so that a 10 M-key
-                // batch stays ONE round as it is for the 16-byte layout -- two rounds of 5 M cost ragged keys 30 us per lookup)
-                cap = scatter_round_cap<PayTileTag, KT, src_fat512<Src>::value>(g, src_fat512<Src>::value ? 0u : 512u, PayTileTag::max_tiles_per_wg);
+                // More pass-1 workgroups than the chip runs at once (they follow one another) where 16 tiles each would cut the batch into
+                // more rounds: layouts without the two-per-CU shape get 512 (a 10 M-key batch stays ONE round as it is for the 16-byte
+                // layout -- two rounds of 5 M cost ragged keys 30 us per lookup), and big tables, whose every round sweeps the WHOLE table in
+                // pass 2, up to 1024 (m = 2^31: a 2^25-key lookup was four rounds, four 256 MiB sweeps of 127 us)
+                uint32_t want = src_fat512<Src>::value ? 0u : 512u;
+                cap = scatter_round_cap<PayTileTag, KT, src_fat512<Src>::value>(g, want, PayTileTag::max_tiles_per_wg);
+                if (s->padded_bytes >= (64ULL << 20) && g_part_wgs <= 0) {
+                    while (round_keys > cap && want < 1024u) {
+                        want = want ? want * 2 : 512u;
+                        const uint64_t c2 = scatter_round_cap<PayTileTag, KT, src_fat512<Src>::value>(g, want, PayTileTag::max_tiles_per_wg);
+                        if (c2 <= cap) break;
+                        cap = c2;
+                    }
+                }
+                s->tflag_wgs = want;
                 return (int)PSK_OK;
             });
         }) != PSK_OK || !handled || cap == 0) return false;
@@ -164,7 +176,7 @@ static int tile_flag_scatter(psk_sketch *s, const Batch &sub, uint64_t cnt, bool
             *gen_out = gen;
             SpillBloomFlag spill{(const uint32_t *)s->table, (uint32_t *)s->s_tflag.p, gen, defer ? 1u : 0u};
             return launch_scatter<Src, IdxBloom<kTuPow2>, PayTileTag, SpillBloomFlag, KT>(s, src, IdxBloom<kTuPow2>{s->md}, PayTileTag{}, spill, g, cnt, st,
-                                                                                          src_fat512<Src>::value ? 0u : 512u);
+                                                                                          s->tflag_wgs);
         });
     });
 }
