@@ -536,6 +536,7 @@ int64_t g_window_shadow = 0;   // 1 = a successful window fold leaves the lookup
                                // 0.1 ms the lookup saves is within the noise of the round and is partly paid by the fold's 128 MiB of image stores: off
 int64_t g_window_shadow_writes = 0;  // folds that did (tests)
 int64_t g_window_wide = 1;    // update windows on tables of few slices: the fold with five probe groups per lane and phase and byte-wide group counts (0: three, nibbles)
+int64_t g_window_tile = 0;    // keys per pass-1 tile of an update window: 0 = rule (4096 for tables of many slices), 2048 / 4096 forced; option "update_window_tile"
 int64_t g_window_image = 4;   // update windows' fold: 4 = nibble images, one workgroup per 2^18-counter slice; 8 = byte images, two per slice (round 4 A/B)
 int64_t g_window_nt = 1;   // nontemporal table loads / stores in the update windows' fold (k_win_fold); option "update_window_nt"
 int64_t g_nib_gather_pipe = 0;   // 1 = k_nib_gather_pipe (psk_nibble_pipe.hpp: the next slice's table load under this slice's probe walk) when no kept images exist.
@@ -592,6 +593,7 @@ extern "C" int psk_set_option(const char *name, int64_t value)
     else if (!strcmp(name, "update_window_shadow")) g_window_shadow = value;
     else if (!strcmp(name, "big_table_nt")) g_big_table_nt = value;
     else if (!strcmp(name, "ragged_sort")) g_ragged_sort = value;
+    else if (!strcmp(name, "update_window_tile")) g_window_tile = value;
     else if (!strcmp(name, "nibble_min_lg_lookup")) g_nib_min_lg_lookup = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_min_lg_update")) g_nib_min_lg_update = value < 20 ? 20 : value;
     else if (!strcmp(name, "nibble_nt_loads")) g_nib_nt = value;
@@ -691,6 +693,7 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
     else if (!strcmp(name, "update_window_shadow_writes")) *value = g_window_shadow_writes;
     else if (!strcmp(name, "big_table_nt")) *value = g_big_table_nt;
     else if (!strcmp(name, "ragged_sort")) *value = g_ragged_sort;
+    else if (!strcmp(name, "update_window_tile")) *value = g_window_tile;
     else if (!strcmp(name, "nibble_min_lg_lookup")) *value = g_nib_min_lg_lookup;
     else if (!strcmp(name, "nibble_min_lg_update")) *value = g_nib_min_lg_update;
     else if (!strcmp(name, "nibble_nt_loads")) *value = g_nib_nt;

@@ -5,6 +5,7 @@
 extern PSK_HIDDEN int64_t g_window_nt;     // psk_capi.hip: option "update_window_nt"
 extern PSK_HIDDEN int64_t g_window_image;  // psk_capi.hip: option "update_window_image"
 extern PSK_HIDDEN int64_t g_window_wide;   // option "update_window_wide"
+extern PSK_HIDDEN int64_t g_window_tile;   // option "update_window_tile": 0 = by the rule in window_scatter, 2048 / 4096 = forced (A/B)
 extern PSK_HIDDEN int64_t g_window_shadow, g_window_shadow_writes;  // options "update_window_shadow" / "update_window_shadow_writes" (read-only tally)
 
 // Tables of the window's pass 1 and fold (pinned staging + device copy, one contiguous upload): [0 .. kWinMaxPhases] the fold's phases,
@@ -16,7 +17,15 @@ template <int KT, int NT>
 static int window_scatter(psk_sketch *s, const WinBatchHost *wb, uint32_t nb, PartGeom *g, uint32_t *flag, hipStream_t st, uint32_t *nph_out)
 {
     using Tile = PartTile<PayNonePhased, KT, NT>;
-    const uint64_t tk = Tile::TILE;
+    // keys per tile: the shape's full tile (4096 keys for k <= 8) where it brings at most ~6 probe groups per slice and its stage fits the
+    // LDS -- tables of ~900 slices and more, BASELINE cfg 4's 1024 --, half of it otherwise (the fold holds 12 groups per segment and phase)
+    uint64_t tk = Tile::TILE;
+    {
+        const uint32_t kk0 = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
+        const bool roomy = (double)tk * kk0 / (double)g->nbuckets / 6.0 + 0.5 <= 6.0 && scatter_lds_bytes<PayNonePhased, KT, NT>(g, tk) <= kScatterLdsBudget;
+        if (!roomy && tk >= 2048 && g_window_tile != 4096) tk /= 2;
+        if (g_window_tile == 2048 && tk > 2048) tk = 2048;  // option "update_window_tile" (A/B)
+    }
     if (!s->win.pin) HIP_TRY(hipHostMalloc(&s->win.pin, kWinTableEntries * sizeof(PhaseDesc), hipHostMallocDefault));
     PhaseDesc *fold = (PhaseDesc *)s->win.pin;            // [nph + 1]
     PhaseDesc *piece = fold + (kWinMaxPhases + 1);         // [npc + 1]
@@ -84,7 +93,7 @@ static int window_scatter(psk_sketch *s, const WinBatchHost *wb, uint32_t nb, Pa
     const PayNonePhased pay{piece_dev, npc, (uint32_t *)s->s_snap.p, (uint64_t)(piece[0].key_off + (long long)((uint64_t)piece[0].tile0 * tk))};
     // (an overflowing segment would need the reference's clamp, which the undo could not invert: it raises the flag instead)
     const SpillRaiseFlagCounter spill{flag};
-    const size_t lds = scatter_lds_bytes<PayNonePhased, KT, NT>(g);
+    const size_t lds = scatter_lds_bytes<PayNonePhased, KT, NT>(g, tk);
     auto kern = k_part_scatter<KeysFixed16, IdxBloom<kTuPow2>, PayNonePhased, SpillRaiseFlagCounter, KT, NT>;
     PSK_TRY(set_dyn_lds(kern, lds));
     // (the keys are addressed from 0 in 16-byte units: a piece's key_off is where its memory is)
@@ -109,7 +118,7 @@ int PSK_VARIANT(cbf_window_fold)(psk_sketch *s, const WinBatchHost *wb, uint32_t
     PSK_TRY(with_kt<KeysFixed16>(s->k, [&](auto kt) {
         constexpr int KT = decltype(kt)::value;
         if constexpr (KT <= 8) {
-            if (scatter_lds_bytes<PayNonePhased, KT, 1024>(&g) <= kScatterLdsBudget) return window_scatter<KT, 1024>(s, wb, nb, &g, flag, st, &nph_dev);
+            if (scatter_lds_bytes<PayNonePhased, KT, 1024>(&g, PartTile<PayNonePhased, KT, 1024>::TILE / 2) <= kScatterLdsBudget) return window_scatter<KT, 1024>(s, wb, nb, &g, flag, st, &nph_dev);
         }
         if (scatter_lds_bytes<PayNonePhased, KT, kPartThreads>(&g) <= kScatterLdsBudget) return window_scatter<KT, kPartThreads>(s, wb, nb, &g, flag, st, &nph_dev);
         return (int)PSK_OK;

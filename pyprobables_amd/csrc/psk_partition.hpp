@@ -116,6 +116,12 @@ template <class Pay, class = void>
 struct pay_fat512 { static constexpr bool value = false; };
 template <class Pay>
 struct pay_fat512<Pay, decltype((void)Pay::fat512)> { static constexpr bool value = Pay::fat512; };
+// 32 probes per thread in the 1024-thread shape as well: 4096-key tiles for tables of ~900 slices and more, where a 2048-key tile brings
+// only 2-3 probe groups per slice and the per-tile, per-slice work (scan, pads, separately addressed group stores) dominates pass 1
+template <class Pay, class = void>
+struct pay_fat1024 { static constexpr bool value = false; };
+template <class Pay>
+struct pay_fat1024<Pay, decltype((void)Pay::fat1024)> { static constexpr bool value = Pay::fat1024; };
 template <class Pay, class = void>
 struct pay_has_tally { static constexpr bool value = false; };
 template <class Pay>
@@ -241,6 +247,7 @@ struct PayNonePhased {
     static constexpr int mode = kModePlain;
     static constexpr int group = 6;
     static constexpr bool phased = true;
+    static constexpr bool fat1024 = true;  // (update windows exist for big tables: 4096-key tiles where the slices are many, window_scatter)
     const PhaseDesc *ph;       // device array [nph + 1]: the PIECES
     uint32_t nph;
     uint32_t *snap;            // [phases][nbuckets][nwg]
@@ -414,7 +421,7 @@ struct PartTile {
     // (Pay::fat512: the Bloom insert only.  Keyed lookups and weighted adds measured the same either way, unit counter adds
     // 2 % and the counter lookups -- more registers per key: perm[] positions -- 5 % worse: they keep 16 probes per thread;
     // scripts/ab_shape.py.)
-    static constexpr int PP = (NT_ == 512 && KT <= 8 && pay_fat512<Pay>::value) ? kPartProbes : kPartProbes / 2;
+    static constexpr int PP = (KT <= 8 && ((NT_ == 512 && pay_fat512<Pay>::value) || (NT_ == 1024 && pay_fat1024<Pay>::value))) ? kPartProbes : kPartProbes / 2;
     static constexpr int KPT_CAP = NT_ == 512 ? 6 : 1 << 20;        // registers: 2 words per probe + 4 per prefetched key
     static constexpr int KPT1 = PP / KT >= 1 ? PP / KT : 1;
     static constexpr int KPT0 = KPT1 < KPT_CAP ? KPT1 : KPT_CAP;
