@@ -437,12 +437,14 @@ struct src_fat512 { static constexpr bool value = std::is_same<Src, KeysFixed16>
 template <class Pay, int KT, bool FAT = true>
 static int scatter_threads(const PartGeom *g)
 {
+    if constexpr (!FAT && (pay_fat512<Pay>::value || pay_fat1024<Pay>::value)) return scatter_threads<PaySlim<Pay>, KT, false>(g);
     // k <= 8 without the two-per-CU shape (every payload but the Bloom insert's / the tile-flag lookup's): 1024 threads, always -- its stage fits the
     // LDS for every geometry the single-level path takes (at most 2048 slices, at most 16 K probes per tile: <= 154 KB), so the 512-thread
     // form of these kernels is not even instantiated (round 5: it was a third of the library's device code and never selected)
     if constexpr (KT <= 8 && !(pay_fat512<Pay>::value && FAT)) return 1024;
     if constexpr (KT <= 8) {
-        const bool fits1024 = scatter_lds_bytes<Pay, KT, 1024>(g) <= kScatterLdsBudget;
+        // (a 4096-key tile is cut to what fits -- launch_scatter_nt --: the shape is taken as long as 2048 keys do)
+        const bool fits1024 = scatter_lds_bytes<Pay, KT, 1024>(g, PartTile<Pay, KT, 1024>::TILE > 2048 ? 2048 : 0) <= kScatterLdsBudget;
         const bool two_per_cu = pay_fat512<Pay>::value && scatter_lds_bytes<Pay, KT, kPartThreads>(g) <= kScatterLdsTwoPerCu;
         bool use1024 = fits1024 && !two_per_cu;
         if (g_part_tile_threads == 1024) use1024 = fits1024;
@@ -452,12 +454,16 @@ static int scatter_threads(const PartGeom *g)
     return kPartThreads;
 }
 // largest round (keys) whose tiles number at most `max_tiles` per pass-1 workgroup (probes that spell the tile's ordinal in 4 bits)
-template <class Pay, int KT, bool FAT = true>
+template <class Pay, int KT, bool FAT = true, bool SORTED = false>
 static uint64_t scatter_round_cap(const PartGeom *g, uint32_t want_wgs, uint32_t max_tiles)
 {
+    if constexpr (!FAT && (pay_fat512<Pay>::value || pay_fat1024<Pay>::value)) return scatter_round_cap<PaySlim<Pay>, KT, false, SORTED>(g, want_wgs, max_tiles);
     const bool big = scatter_threads<Pay, KT, FAT>(g) == 1024;
     const size_t lds = big ? scatter_lds_bytes<Pay, KT, 1024>(g) : scatter_lds_bytes<Pay, KT, kPartThreads>(g);
-    const uint64_t tile = big ? (uint64_t)PartTile<Pay, KT, 1024>::TILE : (uint64_t)PartTile<Pay, KT, kPartThreads>::TILE;
+    uint64_t tile = big ? (uint64_t)PartTile<Pay, KT, 1024>::TILE : (uint64_t)PartTile<Pay, KT, kPartThreads>::TILE;
+    // (the tile launch_scatter_nt will really use: cut where the LDS stage -- with the length sort's share for ragged keys -- would not fit)
+    if (big) while (tile > 64 && scatter_lds_bytes<Pay, KT, 1024>(g, tile, SORTED) > kScatterLdsBudget) tile -= 64;
+    else while (tile > 64 && scatter_lds_bytes<Pay, KT, kPartThreads>(g, tile, SORTED) > kScatterLdsBudget) tile -= 64;
     uint64_t nwg = 256 * (uint64_t)(big ? 1 : (lds > kScatterLdsTwoPerCu ? 1 : 2));
     if (kBenchKnobs && (g->dbg & 8)) nwg = 256;
     if (want_wgs) nwg = want_wgs;
@@ -474,6 +480,9 @@ template <class Src, class IdxFn, class Pay, class Spill, int KT>
 static int launch_scatter(psk_sketch *s, const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, PartGeom *g,
                           uint64_t n, hipStream_t st, uint32_t want_wgs = 0, const ScatterTarget *fixed = nullptr)
 {
+    // (the fat shapes -- 32 probes per thread -- are for the 16- and 8-byte layouts: every other layout runs the payload's plain twin)
+    if constexpr (!src_fat512<Src>::value && (pay_fat512<Pay>::value || pay_fat1024<Pay>::value))
+        return launch_scatter<Src, IdxFn, PaySlim<Pay>, Spill, KT>(s, src, idxfn, PaySlim<Pay>(pay), spill, g, n, st, want_wgs, fixed);
     if constexpr (Pay::mode == kModeKeyed)
         static_assert(((uint64_t)PartTile<Pay, KT, kPartThreads>::TILE << Pay::slice_shift) <= (1ULL << 31),
                       "512-thread tiles must keep keyed probes inside 31 bits for the largest slice");

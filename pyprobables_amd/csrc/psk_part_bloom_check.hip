@@ -136,11 +136,11 @@ static bool tile_flag_geometry(psk_sketch *s, const Batch &b, PartGeom *g, uint6
                 // layout -- two rounds of 5 M cost ragged keys 30 us per lookup), and big tables, whose every round sweeps the WHOLE table in
                 // pass 2, up to 1024 (m = 2^31: a 2^25-key lookup was four rounds, four 256 MiB sweeps of 127 us)
                 uint32_t want = src_fat512<Src>::value ? 0u : 512u;
-                cap = scatter_round_cap<PayTileTag, KT, src_fat512<Src>::value>(g, want, PayTileTag::max_tiles_per_wg);
+                cap = scatter_round_cap<PayTileTag, KT, src_fat512<Src>::value, src_sorted<Src>::value>(g, want, PayTileTag::max_tiles_per_wg);
                 if (s->padded_bytes >= (64ULL << 20) && g_part_wgs <= 0) {
                     while (round_keys > cap && want < 1024u) {
                         want = want ? want * 2 : 512u;
-                        const uint64_t c2 = scatter_round_cap<PayTileTag, KT, src_fat512<Src>::value>(g, want, PayTileTag::max_tiles_per_wg);
+                        const uint64_t c2 = scatter_round_cap<PayTileTag, KT, src_fat512<Src>::value, src_sorted<Src>::value>(g, want, PayTileTag::max_tiles_per_wg);
                         if (c2 <= cap) break;
                         cap = c2;
                     }

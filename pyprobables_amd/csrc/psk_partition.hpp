@@ -122,6 +122,14 @@ template <class Pay, class = void>
 struct pay_fat1024 { static constexpr bool value = false; };
 template <class Pay>
 struct pay_fat1024<Pay, decltype((void)Pay::fat1024)> { static constexpr bool value = Pay::fat1024; };
+// the same payload in the plain shapes (16 probes per thread): for the key layouts that hold more per key in registers than the 16-byte
+// ones (launch_scatter; the probe format, and with it pass 2, is the payload's)
+template <class Pay>
+struct PaySlim : Pay {
+    static constexpr bool fat512 = false;
+    static constexpr bool fat1024 = false;
+    __host__ __device__ PaySlim(const Pay &p) : Pay(p) {}
+};
 template <class Pay, class = void>
 struct pay_has_tally { static constexpr bool value = false; };
 template <class Pay>
@@ -205,6 +213,7 @@ struct PayNone {   // Bloom insert: 6 probes per group, 20-bit slice-local bit i
     static constexpr int mode = kModePlain;
     static constexpr int group = 6;
     static constexpr bool fat512 = true;  // PartTile: two 512-thread workgroups per CU with 32 probes per thread (measured: -3.5 %)
+    static constexpr bool fat1024 = true; // ... and 32 per thread in the 1024-thread shape too (tables of more than ~512 slices: 4096-key tiles)
     __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
 };
 // Bloom lookups of batches whose keys are (nearly) all present (round 5): PayNone's 2.67-byte probes -- the lookup's pass 1 is then the
@@ -216,6 +225,7 @@ struct PayTileTag {
     static constexpr int mode = kModePlain;
     static constexpr int group = 6;
     static constexpr bool fat512 = true;
+    static constexpr bool fat1024 = true;
     static constexpr bool tile_tag = true;
     static constexpr uint32_t max_tiles_per_wg = 16;
     __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }
@@ -422,7 +432,7 @@ struct PartTile {
     // 2 % and the counter lookups -- more registers per key: perm[] positions -- 5 % worse: they keep 16 probes per thread;
     // scripts/ab_shape.py.)
     static constexpr int PP = (KT <= 8 && ((NT_ == 512 && pay_fat512<Pay>::value) || (NT_ == 1024 && pay_fat1024<Pay>::value))) ? kPartProbes : kPartProbes / 2;
-    static constexpr int KPT_CAP = NT_ == 512 ? 6 : 1 << 20;        // registers: 2 words per probe + 4 per prefetched key
+    static constexpr int KPT_CAP = (NT_ == 512 || PP == kPartProbes) ? 6 : 1 << 20;  // registers: 2 words per probe + 4 per prefetched key
     static constexpr int KPT1 = PP / KT >= 1 ? PP / KT : 1;
     static constexpr int KPT0 = KPT1 < KPT_CAP ? KPT1 : KPT_CAP;
     static constexpr int KPT_PAY = pay_max_tile<Pay>::value / NT_;  // (keyed probes: the key index inside the tile has 11 bits)
