@@ -772,8 +772,10 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
                     uint32_t h[KT];
                     if (dbg & 4) {
                         for (int j = 0; j < KT; ++j) h[j] = (uint32_t)(((uint64_t)(i * 2654435761u + j * 40503u) * 0x9E3779B97F4A7C15ULL) >> 13);
-                    } else if constexpr (KT <= 8 || KT % 4 != 0) {  // exact k: every chain is live
+                    } else if constexpr (KT != 8 && (KT <= 8 || KT % 4 != 0)) {  // exact k: every chain is live
                         hash32_of(std::integral_constant<int, KT>{}, 0u, h);
+                    } else if (KT == 8 && k > 4) {  // (k = 5 .. 8 through the round-up kernel: ONE walk of the key -- two walks of four chains cost the
+                        hash32_of(std::integral_constant<int, KT>{}, 0u, h);  // layouts that re-read their windows 20 %)
                     } else {  // KT is k rounded up: run the chains four at a time and skip the groups past k
 #pragma unroll
                         for (int s0 = 0; s0 < KT; s0 += 4) {
@@ -795,7 +797,9 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
                     uint64_t h[KT];
                     if (dbg & 4) {
                         for (int j = 0; j < KT; ++j) h[j] = ((uint64_t)(i * 2654435761u + j * 40503u) * 0x9E3779B97F4A7C15ULL) >> 13;
-                    } else if constexpr (KT <= 8 || KT % 4 != 0) {  // exact k: every chain is live
+                    } else if constexpr (KT != 8 && (KT <= 8 || KT % 4 != 0)) {  // exact k: every chain is live
+                        hash64_of(std::integral_constant<int, KT>{}, 0u, h);
+                    } else if (KT == 8 && k > 4) {
                         hash64_of(std::integral_constant<int, KT>{}, 0u, h);
                     } else {
 #pragma unroll

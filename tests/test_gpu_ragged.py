@@ -51,7 +51,7 @@ def _table(f, dtype=np.uint8):
 
 
 @pytest.mark.parametrize("part", [False, True], indirect=True)
-@pytest.mark.parametrize("est,fpr", [(400_000, 0.01), (28005615 // 16, 0.01)])  # Barrett chains / power-of-two table (32-bit chains)
+@pytest.mark.parametrize("est,fpr", [(400_000, 0.01), (28005615 // 16, 0.01), (400_000, 0.1), (2**22 // 8, 0.02)])  # Barrett / power of two (32-bit chains); k = 3 / 6: the round-up kernel
 @pytest.mark.parametrize("lead", [0, 1, 2, 3])
 def test_bloom_device_ragged_pairs_vs_oracle(pa, oracle, part, est, fpr, lead):
     rng = np.random.default_rng(100 + lead)
@@ -168,7 +168,7 @@ def test_pair_validation(pa):
 
 
 @pytest.mark.parametrize("part", [False, True], indirect=True)
-@pytest.mark.parametrize("est,fpr", [(300_000, 0.01), (28005615 // 16, 0.01), (200_000, 0.00001)])  # Barrett / power of two / k = 17
+@pytest.mark.parametrize("est,fpr", [(300_000, 0.01), (28005615 // 16, 0.01), (200_000, 0.00001), (300_000, 0.1), (300_000, 0.02)])  # Barrett / power of two / k = 17 / k = 3, 6: the round-up kernel
 def test_eight_byte_keys_fast_layout_vs_oracle(pa, oracle, part, est, fpr):
     """64-bit ids: the 8-byte fast layout (KeysFixed8: one dwordx2 per lane, exact k) when the batch is 8-byte aligned, the generic dword
     walk when it is not -- same tables, same answers"""
