@@ -113,6 +113,10 @@ int psk_device_count(int *count);
  * over the table -- persistent workgroups, the fold of one slice under the probe groups of the next, nontemporal table accesses; 3 = the same
  * with plain accesses; 0 = the two-phase kernel of round 3), "nibble_lookup_pipe" (default 0: 1 = the pipelined form of the lookups' table pass,
  * measured without gain), "remove_exact" (0: remove_many may tally violations instead of replaying order-dependent batches);
+ * round 5: "ragged_sort" (default 1: pass 1 hands keys of different lengths to its lanes in order of length -- a counting sort per tile; 0 = batch
+ * order, A/B), "update_window_tile" (keys per pass-1 tile of an update window: 0 (default) = 4096 where the table has ~900 slices and more,
+ * 2048 otherwise; 2048 / 4096 = forced), "bloom_lookup" 3 = the tile-flag scheme for batches of present keys (2, the default, picks per call);
+ * per sketch, read-only: "window_pending_batches" (batches the update window still holds: PSK_DEVICE_BORROWED buffers among them must stay);
  * bench knobs: "lookup_split", "lookup_run_lanes", "tile_threads", "scatter_workgroups", "slice_bias" */
 int psk_set_option(const char *name, int64_t value);
 int psk_get_option(const char *name, int64_t *value);

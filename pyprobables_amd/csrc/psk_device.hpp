@@ -254,7 +254,8 @@ __device__ __forceinline__ void walk_key_elems(const uint32_t *q, uint4 cur, uin
     const uint32_t nwin = (len + 3u) >> 2;
     for (uint32_t t = 0; t < nwin; ++t) {
         const uint32_t tn = t + 1 < nwin ? t + 1 : t;
-        const uint4 nxt = load_window16(q + 4u * tn, 4u * (len - 4u * tn));
+        const uint32_t left_n = len - 4u * tn;  // (>= 1; capped before the multiply: a key of 2^30 code points and more must not wrap)
+        const uint4 nxt = load_window16(q + 4u * tn, 4u * (left_n < 4u ? left_n : 4u));
         const uint32_t d[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
