@@ -195,3 +195,31 @@ def test_eight_byte_keys_fast_layout_vs_oracle(pa, oracle, part, est, fpr):
     oc.add_keys(keys, w)
     assert np.array_equal(np.frombuffer(bytes(cms._bins), dtype=np.int32), oc.bins)
     assert np.array_equal(cms.check_many(torch.from_numpy(keys).cuda()).cpu().numpy(), oc.check_keys(keys).astype(np.int32))
+
+
+def test_batch_order_option_gives_the_same_table(pa, oracle):
+    """option ragged_sort = 0 (pass 1 takes ragged keys in batch order instead of sorting each tile by length): same table, same answers"""
+    from pyprobables_amd import _native as N
+
+    rng = np.random.default_rng(77)
+    n = 300_000
+    blob, offs = _ragged(rng, n, 0, 60)
+    keys = _keys(blob, offs)
+    pair = (torch.from_numpy(blob).cuda(), torch.from_numpy(offs).cuda())
+    old = [N.get_option(k) for k in ("ragged_sort", "partition_min_keys")]
+    try:
+        N.set_option("partition_min_keys", 1)
+        tables = []
+        for srt in (1, 0):
+            N.set_option("ragged_sort", srt)
+            blm = pa.BloomFilter(est_elements=2_000_000, false_positive_rate=0.01)
+            blm.add_many((pair[0], pair[1][: n // 2 + 1]))
+            tables.append((_table(blm).copy(), blm.check_many(pair).cpu().numpy()))
+        ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+        ob.add_varlen(keys[: n // 2])
+        for tab, got in tables:
+            assert np.array_equal(tab, ob.bloom)
+            assert np.array_equal(got.astype(np.uint8), ob.check_varlen(keys))
+    finally:
+        N.set_option("ragged_sort", old[0])
+        N.set_option("partition_min_keys", old[1])

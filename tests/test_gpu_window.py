@@ -394,3 +394,18 @@ def test_c_abi_borrowed_add_remove(pa, oracle, N):
     cbf.remove_many(_dev(kk[:50_000]))
     oc.update_keys(kk[:50_000], -np.ones(50_000, dtype=np.int64))
     _same(cbf, oc)
+
+
+@pytest.mark.parametrize("tile", [2048, 4096])
+def test_window_tile_sizes_agree(pa, oracle, N, tile):
+    """option update_window_tile: 2048- and 4096-key pass-1 tiles forced on a table of few slices (4096 there overflows the fold's registers for
+    some slices: they take the atomics) -- the oracle's table either way"""
+    old = N.get_option("update_window_tile")
+    try:
+        N.set_option("update_window_tile", tile)
+        cbf = pa.CountingBloomFilter(est_elements=3_600_000, false_positive_rate=0.01)
+        oc = oracle.OracleCBF(cbf.number_bits, cbf.number_hashes)
+        _run(cbf, oc, _stream(oracle, 10, 200_000, seed=31))
+        _same(cbf, oc)
+    finally:
+        N.set_option("update_window_tile", old)
