@@ -892,8 +892,9 @@ class Cfg5:
         self.ctx, self.args, self.pa, self.parallel = ctx, args, pa, parallel
         self.lo, self.hi = parallel.shard_range(args.n_total, ctx.rank, ctx.world)
         self.n = self.hi - self.lo
-        # the shard's keys, generated on the device in rounds of 32M keys (512 MB) and kept resident
-        self.chunks, R = [], 1 << 25
+        # the shard's keys, generated on the device in rounds of 64M keys (1 GiB: one call = one partition round, option partition_max_keys)
+        # and kept resident -- every call sweeps the whole 256 MiB table once per round, so the calls are as large as a round
+        self.chunks, R = [], 1 << 26
         for s in range(self.lo, self.hi, R):
             self.chunks.append(ctx.gen_keys(min(R, self.hi - s), s))
         self.blm = pa.BloomFilter(est_elements=224044920, false_positive_rate=0.01, device=ctx.dev)
