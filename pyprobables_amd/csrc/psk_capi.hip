@@ -424,6 +424,7 @@ static int with_source(const Batch &b, F &&f)
         case PSK_KEYS_FIXED:
             if (b.key_len == 16 && ((uintptr_t)b.data & 15) == 0) return f(KeysFixed16{(const uint4 *)b.data});
             if (b.key_len == 8 && ((uintptr_t)b.data & 7) == 0) return f(KeysFixed8{(const uint2 *)b.data});
+            if (b.key_len == 32 && ((uintptr_t)b.data & 15) == 0) return f(KeysFixed32{(const uint4 *)b.data});
             if (b.key_len % 4 == 0 && ((uintptr_t)b.data & 3) == 0) return f(KeysFixed<true>{(const uint8_t *)b.data, b.key_len, b.n});
             return f(KeysFixed<false>{(const uint8_t *)b.data, b.key_len, b.n});
         case PSK_KEYS_VARLEN8: return f(KeysVarlen<uint8_t>{(const uint8_t *)b.data, b.offs, b.n});

@@ -512,7 +512,7 @@ static int with_kt(uint32_t k, F &&f)
     // matter most -- 7 (fpr 0.01) and 5 (the CountMinSketch's default depth) --; everything else the round-ups, whose chains go four at a
     // time and stop at k.  (Exact sizes for all three layouts were 60 % of the library's device code and of its build time.)
     constexpr bool fast16 = std::is_same<Src, KeysFixed16>::value || std::is_same<Src, KeysFixed16Multi>::value;
-    constexpr bool fast2 = std::is_same<Src, KeysFixed8>::value || std::is_same<Src, KeysVarlen<uint8_t>>::value;
+    constexpr bool fast2 = std::is_same<Src, KeysFixed8>::value || std::is_same<Src, KeysFixed32>::value || std::is_same<Src, KeysVarlen<uint8_t>>::value;
     if constexpr (fast16) {
         switch (k) {
             case 3: return f(std::integral_constant<int, 3>{});
@@ -548,6 +548,7 @@ static int with_part_source(const Batch &b, bool *handled, F &&f)
         case PSK_KEYS_FIXED:
             if (b.key_len == 16 && ((uintptr_t)b.data & 15) == 0) return f(KeysFixed16{(const uint4 *)b.data});
             if (b.key_len == 8 && ((uintptr_t)b.data & 7) == 0) return f(KeysFixed8{(const uint2 *)b.data});
+            if (b.key_len == 32 && ((uintptr_t)b.data & 15) == 0) return f(KeysFixed32{(const uint4 *)b.data});
             if (b.key_len % 4 == 0 && ((uintptr_t)b.data & 3) == 0) return f(KeysFixed<true>{(const uint8_t *)b.data, b.key_len, b.n});
             return f(KeysFixed<false>{(const uint8_t *)b.data, b.key_len, b.n});
         case PSK_KEYS_VARLEN8: return f(KeysVarlen<uint8_t>{(const uint8_t *)b.data, b.offs, b.n});

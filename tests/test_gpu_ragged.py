@@ -223,3 +223,22 @@ def test_batch_order_option_gives_the_same_table(pa, oracle):
     finally:
         N.set_option("ragged_sort", old[0])
         N.set_option("partition_min_keys", old[1])
+
+
+@pytest.mark.parametrize("part", [False, True], indirect=True)
+@pytest.mark.parametrize("est,fpr", [(300_000, 0.01), (28005615 // 16, 0.01), (300_000, 0.1)])
+def test_thirty_two_byte_keys_fast_layout_vs_oracle(pa, oracle, part, est, fpr):
+    """digest-sized keys: the 32-byte fast layout (KeysFixed32: two dwordx4 per lane) when the batch is 16-byte aligned, the generic dword walk
+    when it is not"""
+    rng = np.random.default_rng(32)
+    n = 70_000
+    keys = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    flat = torch.zeros(n * 32 + 4, dtype=torch.uint8, device="cuda")
+    flat[4:].copy_(torch.from_numpy(keys).cuda().reshape(-1))
+    for dk in (torch.from_numpy(keys).cuda(), flat[4:].view(n, 32)):
+        blm = pa.BloomFilter(est_elements=est, false_positive_rate=fpr)
+        ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+        blm.add_many(dk[: n // 2])
+        ob.add_keys(keys[: n // 2])
+        assert np.array_equal(_table(blm), ob.bloom)
+        assert np.array_equal(blm.check_many(dk).cpu().numpy().astype(np.uint8), ob.check_keys(keys))
