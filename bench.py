@@ -641,9 +641,10 @@ def side_measurements(ctx: Ctx, n, blm, keys):
     # Bloom lookups that MISS (the timed step only looks up inserted keys: every probe hits).  blm holds keys [0, n).
     fresh = ctx.gen_keys(n, 10 * n)
     mixed = torch.cat([keys[: n // 2], fresh[: n - n // 2]])
-    ms = timed_loop(torch, lambda: blm.check_many(fresh), 5)
+    # (all absent: the automatic choice goes tile flags -> return trip -> lazy gathers within three calls; half absent: the return trip)
+    ms = timed_loop(torch, lambda: blm.check_many(fresh), 5, warm=4)
     out["check_all_fresh_Mkeys_s"] = n / ms / 1e3
-    ms = timed_loop(torch, lambda: blm.check_many(mixed), 5)
+    ms = timed_loop(torch, lambda: blm.check_many(mixed), 5, warm=4)
     out["check_half_fresh_Mkeys_s"] = n / ms / 1e3
     res = blm.check_many(mixed)
     out["check_half_fresh_hits"] = int(res.sum().item())          # n/2 true members + the false positives among the fresh half

@@ -228,19 +228,100 @@ static int bloom_check_tile_flags(psk_sketch *s, const Batch &b, uint8_t *out_de
     return PSK_OK;
 }
 
+// Lazy gathers (scheme 4, round 5): lookups of keys that are (nearly) all ABSENT -- what a Bloom filter is asked most often (a deduplicating
+// caller, a cache in front of a store).  bloom.py:261-272 stops at the first clear bit, and so does a lane here: one key per lane, the word of
+// probe j is requested only by the lanes still undecided, chain j + 1 is hashed while that gather is in flight, and a wave leaves the key
+// when none of its lanes is left.  A key absent from a table with a share f of its bits set costs 1 / (1 - f) gathers (1.3 at cfg 2's 23 %)
+// instead of the k probes + the way back of the partitioned schemes; every gather is a 64-byte line across the fabric (~63 G/s), so the
+// scheme only pays while the gathers per key stay below ~1.7 -- the kernel tallies the gathers it issued and choose_scheme goes by them.
+// H32: power-of-two tables up to 2^32 bits, the 32-bit chains.
+template <class Src, bool POW2, bool H32>
+__global__ __launch_bounds__(kBlock) void k_bloom_check_lazy(Src src, const uint32_t *tab, Mod md, uint32_t k, uint64_t n, uint8_t *out,
+                                                             unsigned long long *gather_ctr)
+{
+    auto bit_of = [&](const typename Src::Key &key, uint64_t i, uint32_t j) -> uint64_t {
+        if constexpr (H32) {
+            uint32_t h[1];
+            src.template hash32<1>(key, i, j, h);
+            return (uint64_t)(h[0] & (uint32_t)md.mask);
+        } else {
+            uint64_t h[1];
+            src.template hash<1>(key, i, j, h);
+            return reduce<POW2>(md, h[0]);
+        }
+    };
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t nround = (n + 63) & ~63ULL;  // wave-uniform trip count
+    uint32_t ngather = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nround; i += stride) {
+        const bool mine = i < n;
+        const uint64_t ii = mine ? i : n - 1;
+        const typename Src::Key key = src.load(ii);
+        bool alive = mine;
+        uint64_t bit = bit_of(key, ii, 0);
+        for (uint32_t j = 0; j < k; ++j) {
+            uint32_t word = 0;
+            if (alive) {
+                word = tab[bit >> 5];
+                ++ngather;
+            }
+            const uint32_t sh = (uint32_t)bit & 31u;
+            if (j + 1 < k) bit = bit_of(key, ii, j + 1);  // (under the gather)
+            alive = alive && ((word >> sh) & 1u) != 0;
+            if (__ballot(alive) == 0) break;               // (uniform)
+        }
+        if (mine) out[i] = alive ? 1 : 0;
+    }
+    if (gather_ctr) {  // one atomic per workgroup
+        __shared__ uint32_t wsum[kBlock / 64];
+        for (int o = 32; o > 0; o >>= 1) ngather += __shfl_down(ngather, o);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ngather;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (int w = 0; w < kBlock / 64; ++w) t += wsum[w];
+            if (t) atomicAdd(gather_ctr, t);
+        }
+    }
+}
+
+static int bloom_check_lazy(psk_sketch *s, const Batch &b, uint8_t *out_dev, hipStream_t st, bool *done)
+{
+    *done = false;
+    if (b.n == 0) return PSK_OK;
+    bool handled = false;
+    PSK_TRY(with_part_source(b, &handled, [&](auto src) {
+        using Src = decltype(src);
+        const dim3 grid((unsigned)grid_for_keys(b.n)), block(kBlock);
+        unsigned long long *ctr = g_bloom_lookup == 2 ? s->lk.dev : nullptr;
+        if constexpr (kTuPow2) {
+            if (s->m <= (1ULL << 32))
+                hipLaunchKernelGGL((k_bloom_check_lazy<Src, true, true>), grid, block, 0, st, src, (const uint32_t *)s->table, s->md, s->k, b.n, out_dev, ctr);
+            else
+                hipLaunchKernelGGL((k_bloom_check_lazy<Src, true, false>), grid, block, 0, st, src, (const uint32_t *)s->table, s->md, s->k, b.n, out_dev, ctr);
+        } else {
+            hipLaunchKernelGGL((k_bloom_check_lazy<Src, false, false>), grid, block, 0, st, src, (const uint32_t *)s->table, s->md, s->k, b.n, out_dev, ctr);
+        }
+        HIP_TRY(hipGetLastError());
+        return (int)PSK_OK;
+    }));
+    *done = handled;
+    return PSK_OK;
+}
+
 // Which scheme?  Keyed probes cost ~240 us per 10 M all-hit keys but one scattered byte store per probe that misses (~450 us
 // when every key is absent); the return trip costs ~300 us whatever the answers.  Mode 2 follows what the previous large
 // lookups on this handle saw: the tally of the last finished call sits in a pinned page (no synchronisation: it may be one
 // call late, and the very first call is keyed).
 static int choose_scheme(psk_sketch *s, hipStream_t st)
 {
-    if (g_bloom_lookup != 2) return (int)g_bloom_lookup;   // forced: 0 keyed, 1 return trip, 3 tile flags
+    if (g_bloom_lookup != 2) return (int)g_bloom_lookup;   // forced: 0 keyed, 1 return trip, 3 tile flags, 4 lazy gathers
     if (!s->lk.dev) {
         HIP_TRY(hipMalloc((void **)&s->lk.dev, 8));
         void *pin = nullptr;
-        HIP_TRY(hipHostMalloc(&pin, 32, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&pin, 64, hipHostMallocDefault));  // [0..3] written by the device (psk_sketch::lk), [4] [5] host-only (lazy gathers, below)
         s->lk.pin = (volatile unsigned long long *)pin;
-        s->lk.pin[0] = s->lk.pin[1] = s->lk.pin[2] = s->lk.pin[3] = 0;
+        for (int e = 0; e < 8; ++e) s->lk.pin[e] = 0;
         HIP_TRY(hipMemsetAsync(s->lk.dev, 0, 8, st));  // once: k_lookup_publish re-zeroes the tally at the end of every call
     }
     const unsigned long long miss = s->lk.pin[0], units = s->lk.pin[1], by = s->lk.pin[2], seq = s->lk.pin[3];
@@ -257,7 +338,23 @@ static int choose_scheme(psk_sketch *s, hipStream_t st)
         // Tile flags pay a direct re-check of every ~2000-key tile that holds one miss: only while (almost) nothing misses -- one probe
         // in a million flags ~1 % of the tiles.  Keyed probes pay a scattered byte store per miss: beyond ~1/4 of the probes the return
         // trip, whose cost does not depend on the answers, is cheaper.
-        if (by == 1) s->lk.mode = flags_ok ? 3 : (f < 0.12 ? 0 : 1);
+        // Lazy gathers (4) tally the GATHERS they issued (per key: 1 / (1 - fill) for an absent key, k for a present one): they stay while a
+        // key costs at most kLazyStay gathers (what the return trip costs at this table's slice count) and are entered
+        // from the return trip, the one scheme that counts absent KEYS, when (nearly) every key was absent; a handle whose table is too full
+        // for them (gathers per key above the bound although every key is absent) is not tried again for kLazyBackoff calls.
+        // (scripts/ab_bloom_lookup_r05.py, profiles/r05_ab_bloom_lookup_lazy.txt: a gather costs ~17.4 ns of kernel time at any table
+        // size, the return trip 28.5 ns per key at 256 slices and 54.7 at 2048 -- the bound is their ratio)
+        const double kLazyStay = s->m <= (1ULL << 29) ? 1.6 : (s->m <= (1ULL << 30) ? 2.2 : 3.0);
+        const double kLazyEnter = s->m <= (1ULL << 29) ? 0.93 : (s->m <= (1ULL << 30) ? 0.88 : 0.80);
+        constexpr uint32_t kLazyBackoff = 32;
+        volatile unsigned long long &lazy_seq = s->lk.pin[4], &lazy_wait = s->lk.pin[5];  // (host-only words of the pinned page)
+        if (seq != lazy_seq) {
+            lazy_seq = seq;
+            if (lazy_wait) lazy_wait = lazy_wait - 1;
+            if (by == 4 && f > kLazyStay) lazy_wait = kLazyBackoff;
+        }
+        if (by == 4) s->lk.mode = f <= kLazyStay ? 4 : 1;
+        else if (by == 1) s->lk.mode = flags_ok ? 3 : (f >= kLazyEnter && !lazy_wait ? 4 : (f < 0.12 ? 0 : 1));
         else s->lk.mode = flags_ok ? 3 : (f > 0.22 ? 1 : 0);
     }
     return s->lk.mode;
@@ -288,6 +385,10 @@ int PSK_VARIANT(bloom_check_partitioned)(psk_sketch *s, const Batch &b, uint8_t 
     if (scheme == 3) {
         PSK_TRY(bloom_check_tile_flags(s, b, out_dev, st, done));
         if (*done) return PSK_OK;  // (the finishing kernel of the last round has published the tally)
+    }
+    if (scheme == 4) {
+        PSK_TRY(bloom_check_lazy(s, b, out_dev, st, done));
+        if (*done) return publish_tally(s, b.n, 4, st);
     }
     *done = false;
     PartGeom g;

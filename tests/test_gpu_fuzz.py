@@ -66,7 +66,7 @@ def test_fuzz_bloom(pa, oracle, engine_options, seed):
     engine_options.set_option("partition_max_keys", int(rng.choice([2048, 1 << 25])))
     engine_options.set_option("partition_cache_bytes", int(rng.choice([0, 1 << 16, 240 << 20])))
     engine_options.set_option("partition_two_level_slices", int(rng.choice([0, 2, 512])))
-    engine_options.set_option("bloom_lookup", int(seed % 4))   # keyed probes / return trip / chosen per call / tile flags
+    engine_options.set_option("bloom_lookup", int(seed % 5))   # keyed probes / return trip / chosen per call / tile flags / lazy gathers
     engine_options.set_option("even_tiles", int(seed // 3 % 2))
     engine_options.set_option("dense_walk_groups", (0, 40, 1 << 30)[seed // 2 % 3])  # pass 2: chunked walk / by segment length / end-to-end walk
     est = int(rng.choice([50, 3000, 40_000, 200_000, 1_000_000]))

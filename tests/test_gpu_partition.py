@@ -613,10 +613,11 @@ def test_cbf_unchecked_remove_direct_and_partitioned_agree(pa, oracle, force_par
 
 
 # ------------------------------------------------------------------ Bloom lookups: return trip vs keyed probes
-@pytest.mark.parametrize("mode", [1, 0, 3])
+@pytest.mark.parametrize("mode", [1, 0, 3, 4])
 def test_bloom_lookup_modes_vs_oracle(pa, oracle, force_partition, mode):
     """option bloom_lookup: 1 = pass 1 with perm / runinfo + k_bloom_gather + k_bloom_collect, 0 = keyed probes + k_bloom_test, 3 = the
-    insert's compact probes + a flag per tile that met a clear bit + k_bloom_flag_resolve (round 5); all against the oracle over hits, misses,
+    insert's compact probes + a flag per tile that met a clear bit + k_bloom_flag_resolve (round 5), 4 = lazy gathers (one key per lane, the next
+    probe only while every earlier bit was set: k_bloom_check_lazy); all against the oracle over hits, misses,
     k classes, table sizes, layouts, rounds and segment overflow"""
     force_partition.set_option("bloom_lookup", mode)
     try:
@@ -691,7 +692,11 @@ def test_bloom_lookup_auto_mode_follows_the_miss_rate_and_stays_exact(pa, oracle
     want_mixed = ob.check_keys(mixed)
     dk, df, dm = _dev(keys), _dev(fresh), _dev(mixed)
     for batch, want in [(dk, want_hit), (dk, want_hit), (df, want_miss), (df, want_miss), (df, want_miss), (dm, want_mixed), (dk, want_hit),
-                        (dk, want_hit), (dk, want_hit), (df, want_miss), (dm, want_mixed)]:
+                        (dk, want_hit), (dk, want_hit), (df, want_miss), (dm, want_mixed),
+                        # a run of all-miss batches: return trip, then lazy gathers (scheme 4: enough of them for it to be entered and kept),
+                        # a mixed batch through it (too many gathers per key: back to the return trip) and misses again (held off for a while)
+                        (df, want_miss), (df, want_miss), (df, want_miss), (df, want_miss), (df, want_miss), (dm, want_mixed), (dm, want_mixed),
+                        (df, want_miss), (df, want_miss), (dk, want_hit)]:
         got = blm.check_many(batch)
         torch.cuda.synchronize()   # the tally of this call is on the pinned page before the next call chooses
         assert np.array_equal(got.cpu().numpy().astype(np.uint8), want)
