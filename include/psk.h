@@ -115,7 +115,9 @@ int psk_device_count(int *count);
  * measured without gain), "remove_exact" (0: remove_many may tally violations instead of replaying order-dependent batches);
  * round 5: "ragged_sort" (default 1: pass 1 hands keys of different lengths to its lanes in order of length -- a counting sort per tile; 0 = batch
  * order, A/B), "update_window_tile" (keys per pass-1 tile of an update window: 0 (default) = 4096 where the table has ~900 slices and more,
- * 2048 otherwise; 2048 / 4096 = forced), "bloom_lookup" 3 = the tile-flag scheme for batches of present keys (2, the default, picks per call);
+ * 2048 otherwise; 2048 / 4096 = forced), "bloom_lookup" 3 = the tile-flag scheme for batches of present keys, 4 = lazy gathers for batches of absent keys (one key per lane, the
+ * next probe only while every earlier bit was set; 2, the default, picks per call: 4 while nearly every key is absent and a key costs fewer
+ * gathers than the return trip costs bytes);
  * per sketch, read-only: "window_pending_batches" (batches the update window still holds: PSK_DEVICE_BORROWED buffers among them must stay);
  * bench knobs: "lookup_split", "lookup_run_lanes", "tile_threads", "scatter_workgroups", "slice_bias" */
 int psk_set_option(const char *name, int64_t value);
