@@ -37,7 +37,9 @@ OUT = CSRC / "libpsk_hip.so"
 OBJ = CSRC / "build"
 OUT_KNOBS = CSRC / "libpsk_hip_knobs.so"
 OBJ_KNOBS = CSRC / "build_knobs"
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fvisibility-inlines-hidden"]
+# --offload-compress: every unit's gfx950 code object is zstd-compressed inside its bundle (the HIP runtime inflates it when the library is
+# loaded): the ~1000 k_part_scatter instantiations are near-copies of each other, so the library that travels to every GPU box shrinks several-fold
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fvisibility-inlines-hidden", "--offload-compress"]
 
 
 def hipcc() -> str:
@@ -97,10 +99,32 @@ def _compile(item, force: bool, verbose: bool, objdir: Path, extra: list) -> Pat
     return obj
 
 
+PYLIST_SRC = CSRC / "psk_pylist.c"
+PYLIST_OUT = CSRC.parent / "_pylist.so"
+
+
+def build_pylist(force: bool = False, verbose: bool = True) -> Path:
+    """the host-side packer of key LISTS (csrc/psk_pylist.c, a CPython extension: gcc, no GPU code) -> pyprobables_amd/_pylist.so"""
+    import sysconfig
+
+    if not force and PYLIST_OUT.exists() and PYLIST_OUT.stat().st_mtime >= PYLIST_SRC.stat().st_mtime:
+        return PYLIST_OUT
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        raise RuntimeError("gcc not found (needed for pyprobables_amd/_pylist.so)")
+    cmd = [cc, "-O2", "-fPIC", "-shared", "-Wall", "-I" + sysconfig.get_paths()["include"], str(PYLIST_SRC), "-o", str(PYLIST_OUT)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return PYLIST_OUT
+
+
 def build(force: bool = False, verbose: bool = True, knobs: bool = False) -> Path:
     """knobs=True: the bench-only build with the ablation / phase-profile bits compiled in (-DPSK_BENCH_KNOBS=1) ->
     csrc/libpsk_hip_knobs.so; never loaded unless PSK_LIB_PATH points at it (scripts/ablate.py, scripts/profile_sq.sh)"""
     out = OUT_KNOBS if knobs else OUT
+    if not knobs:
+        build_pylist(force, verbose)
     if not knobs and not force and not needs_build():
         return out
     objdir = OBJ_KNOBS if knobs else OBJ

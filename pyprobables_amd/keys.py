@@ -39,6 +39,12 @@ class KeyBatch:
         return (self.layout, self.data or None, self.offsets or None, self.n, self.key_len)
 
 
+try:  # the C packer of key lists (csrc/psk_pylist.c, built by build.py); without it the python packer below does the same job
+    from . import _pylist
+except Exception:  # pragma: no cover
+    _pylist = None
+
+
 def _np_ptr(a: np.ndarray) -> int:
     return a.ctypes.data
 
@@ -178,6 +184,16 @@ def pack_keys(keys) -> KeyBatch:
     n = len(keys)
     if n == 0:
         return KeyBatch(N.KEYS_FIXED, 0, 0, 0, 0, N.HOST)
+    if _pylist is not None:
+        packed = _pylist.pack(keys)  # None: an element that is neither str nor bytes / bytearray -- the python path decides
+        if packed is not None:
+            layout, blob, offs, n, key_len = packed
+            if layout == 0:
+                a = np.frombuffer(blob, dtype=np.uint8)[: n * key_len].reshape(n, key_len)
+                return KeyBatch(N.KEYS_FIXED, _np_ptr(a) if a.size else 0, 0, n, key_len, N.HOST, None, [a, blob])
+            b = np.frombuffer(blob, dtype=np.uint8 if layout == 1 else np.uint32)
+            o = np.frombuffer(offs, dtype=np.uint64)
+            return KeyBatch(N.KEYS_VARLEN8 if layout == 1 else N.KEYS_VARLEN32, _np_ptr(b), _np_ptr(o), n, 0, N.HOST, None, [b, o, blob, offs])
     fast = _pack_homogeneous(keys, n)
     if fast is not None:
         return fast

@@ -168,12 +168,22 @@ def test_vectorised_key_packing_equals_the_per_key_path(monkeypatch):
         [b"", b""],
         [bytearray(b"ab"), b"cd", memoryview(b"efg")],
     ]
+    cases += [
+        ["ab", b"cd", bytearray(b"ef")],                          # mixed str / bytes of one length
+        ["a", b"bcd", "\xe9\xff", b""],                           # mixed, ragged
+        ["x", b"\xfe\xff", "\u0100", "\U0001F600\ud800"],        # mixed with wide strings and a lone surrogate: everything widens
+        [("k%d" % i) * (i % 5) for i in range(500)] + ["\u20ac"],  # one wide key at the end widens 500 narrow ones
+    ]
+    assert K._pylist is not None, "pyprobables_amd/_pylist.so is not built (python -m pyprobables_amd.build)"
     for keys in cases:
-        fast = image(K.pack_keys(keys))
+        c_path = image(K.pack_keys(keys))                         # csrc/psk_pylist.c
         with monkeypatch.context() as m:
+            m.setattr(K, "_pylist", None)
+            fast = image(K.pack_keys(keys))                       # one join / one encode
             m.setattr(K, "_pack_homogeneous", lambda keys, n: None)
-            slow = image(K.pack_keys(keys))
+            slow = image(K.pack_keys(keys))                       # the per-key loop
         assert fast == slow, keys[:3]
+        assert c_path == slow, keys[:3]
     with pytest.raises(TypeError):
         K.pack_keys(["a", 3])
     mixed = K.pack_keys(["ab", b"cd"])   # mixed str / bytes still works (careful path)
