@@ -650,6 +650,12 @@ def side_measurements(ctx: Ctx, n, blm, keys):
     out["check_half_fresh_hits"] = int(res.sum().item())          # n/2 true members + the false positives among the fresh half
     out["check_half_fresh_members_found"] = bool(res[: n // 2].all().item())
     del fresh, mixed, res
+    # membership as a ballot bitmap + hit count (psk_bloom_check_bits): the partitioned lookup's bytes packed by one streaming pass
+    bits, hits = blm.check_many_bits(keys)
+    out["check_bits_all_found"] = bool(int(hits.item()) == n)
+    ms = timed_loop(torch, lambda: blm.check_many_bits(keys), 5, warm=4)
+    out["check_bits_Mkeys_s"] = n / ms / 1e3
+    del bits, hits
     # The reference's NATIVE key type: variable-length byte / str keys (hashes.py:98 walks the key element by element).  A ragged batch
     # handed over as (blob, offsets) on the device: lengths 4 + min(36, floor(Exp(12.6))) bytes (4 .. 40, mean ~15.4).
     import numpy as np

@@ -171,7 +171,8 @@ int psk_rescan_bound(psk_sketch *s, void *stream);
 /* ------------------------------------------------------------- BloomFilter
  * add:   for each key: for i<k: bit = h_i % m; table |= bit      (bloom.py:234-250 add/add_alt)
  * check: for each key: out = AND_i bit(h_i % m)                  (bloom.py:252-272 check/check_alt)
- * check_bits: same result ballot-packed, bit (i & 63) of out_bits[i >> 6]; *hits += popcount */
+ * check_bits: same result ballot-packed, bit (i & 63) of out_bits[i >> 6]; *hits += popcount (large batches: the partitioned lookup's
+ *             answers -- n bytes of the handle's scratch -- packed by one streaming pass) */
 int psk_bloom_add(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
                   uint32_t key_len, int where, void *stream);
 int psk_bloom_check(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,

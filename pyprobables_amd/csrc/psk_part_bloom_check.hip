@@ -345,7 +345,7 @@ static int choose_scheme(psk_sketch *s, hipStream_t st)
         // (scripts/ab_bloom_lookup_r05.py, profiles/r05_ab_bloom_lookup_lazy.txt: a gather costs ~17.4 ns of kernel time at any table
         // size, the return trip 28.5 ns per key at 256 slices and 54.7 at 2048 -- the bound is their ratio)
         const double kLazyStay = s->m <= (1ULL << 29) ? 1.6 : (s->m <= (1ULL << 30) ? 2.2 : 3.0);
-        const double kLazyEnter = s->m <= (1ULL << 29) ? 0.93 : (s->m <= (1ULL << 30) ? 0.88 : 0.80);
+        const double kLazyEnter = s->m <= (1ULL << 29) ? 0.93 : (s->m <= (1ULL << 30) ? 0.85 : 0.72);
         constexpr uint32_t kLazyBackoff = 32;
         volatile unsigned long long &lazy_seq = s->lk.pin[4], &lazy_wait = s->lk.pin[5];  // (host-only words of the pinned page)
         if (seq != lazy_seq) {

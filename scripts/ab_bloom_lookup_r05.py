@@ -32,6 +32,7 @@ for est, n, extra in ((28005615, 10_000_000, 0), (28005615, 10_000_000, 18_000_0
     p1e2 = keys.clone(); p1e2[:: 100] = fresh[: (n + 99) // 100]
     q25 = torch.cat([keys[: 3 * n // 4], fresh[: n - 3 * n // 4]])
     q90 = fresh.clone(); q90[:: 10] = keys[: (n + 9) // 10]
+    q75 = fresh.clone(); q75[:: 4] = keys[: (n + 3) // 4]
     blm = pa.BloomFilter(est_elements=est, false_positive_rate=0.01)
     blm.add_many(keys)
     if extra:
@@ -39,8 +40,8 @@ for est, n, extra in ((28005615, 10_000_000, 0), (28005615, 10_000_000, 18_000_0
     print(f"m = {blm.number_bits}, {n} keys per call, {n + extra} keys inserted", flush=True)
     for mode, name in ((0, "keyed"), (1, "return trip"), (3, "tile flags"), (4, "lazy gathers"), (2, "auto")):
         N.set_option("bloom_lookup", mode)
-        cases = [("all-hit", keys), ("1 absent", one), ("1e-4 absent", p1e4), ("1e-2 absent", p1e2), ("25% absent", q25), ("90% absent", q90), ("all absent", fresh)]
+        cases = [("all-hit", keys), ("1 absent", one), ("1e-4 absent", p1e4), ("1e-2 absent", p1e2), ("25% absent", q25), ("75% absent", q75), ("90% absent", q90), ("all absent", fresh)]
         print(f"  {name:12s}: " + "  ".join(f"{c} {tl(lambda: blm.check_many(k)):7.1f}" for c, k in cases), flush=True)
     N.set_option("bloom_lookup", 2)
-    del blm, keys, fresh, one, p1e4, p1e2, q25, q90
+    del blm, keys, fresh, one, p1e4, p1e2, q25, q75, q90
     torch.cuda.empty_cache()

@@ -188,9 +188,15 @@ def test_bloom_check_partitioned_vs_oracle(pa, oracle, force_partition):
     got = blm.check_many(keys).astype(np.uint8)  # host-staged
     exp = ob.check_keys(keys)
     assert np.array_equal(got, exp) and 0 < int(exp[250_000:].sum()) < 50_000
-    # bitmap variant still goes through the direct kernel and must agree
+    # bitmap variant (large batches: the partitioned lookup's bytes packed into ballot words by k_pack_answer_bits) must agree, word for word
     bits, hits = blm.check_many_bits(keys)
     assert hits == int(exp.sum())
+    assert np.array_equal(np.unpackbits(np.asarray(bits).view(np.uint8), bitorder="little")[: len(keys)], exp)
+    odd = keys[: len(keys) - 37]                                   # a last word with 27 live bits; device batch, hits accumulate on the device
+    dbits, dhits = blm.check_many_bits(_dev(odd))
+    assert int(dhits.item()) == int(exp[: len(odd)].sum())
+    got = np.unpackbits(dbits.cpu().numpy().view(np.uint8), bitorder="little")
+    assert np.array_equal(got[: len(odd)], exp[: len(odd)]) and not got[len(odd):].any()
 
 
 def test_bloom_check_partitioned_overflow_and_rounds(pa, oracle, force_partition):
