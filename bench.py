@@ -271,6 +271,13 @@ class EventTimer:
         p = self.pairs.get(name, [])
         return sum(a.elapsed_time(b) for a, b in p) / len(p) if p else float("nan")
 
+    def median_ms(self, name):
+        """the median pair: one sample that caught a host hiccup (the GPU idling inside the event window) does not move it"""
+        t = sorted(a.elapsed_time(b) for a, b in self.pairs.get(name, []))
+        if not t:
+            return float("nan")
+        return t[len(t) // 2] if len(t) % 2 else 0.5 * (t[len(t) // 2 - 1] + t[len(t) // 2])
+
 
 def timed_loop(torch, fn, iters, warm=2):
     for _ in range(warm):  # synchronised warm-up calls: scratch buffers exist and the engine's adaptive choices (Bloom lookup
@@ -585,8 +592,10 @@ class Cfg2:
             side, rl = side_measurements(ctx, n, blm, self.keys)
             detail.update(side)
             rooflines.update(rl)
-        step_ms = timer.mean_ms("step")
+        step_ms = timer.median_ms("step")
         detail["step_ms_events"] = step_ms
+        detail["step_ms_events_mean"] = timer.mean_ms("step")
+        detail["step_event_samples"] = len(timer.pairs.get("step", []))
         line = {
             "metric": METRIC_CFG2,
             "config": {
@@ -597,7 +606,7 @@ class Cfg2:
             },
             "roofline": step_roofline(
                 "one timed STEP = clear + Bloom insert (k_part_scatter + k_bloom_apply) + " + ("allreduce(OR) + " if ctx.distributed else "") +
-                "Bloom lookup (k_part_scatter + k_bloom_test_flag + k_bloom_flag_resolve); avg_kernel_ms = HIP events around whole steps of the timed region",
+                "Bloom lookup (k_part_scatter + k_bloom_test_flag + k_bloom_flag_resolve); avg_kernel_ms = HIP events around whole steps of the timed region (median pair; detail.step_ms_events_mean)",
                 n, step_ms, launches,
                 "both pass 1s are co-limited by VALU (the k FNV-1a chains, ~75 of ~130 us) and the LDS counting sort, not by HBM; the pass 2s "
                 "stream the probes back at 4-5 TB/s"),
@@ -973,7 +982,7 @@ class Cfg5:
                        "parallelism": f"key-range x{ctx.world}, replica per GPU, allreduce(OR) = all_to_all + OR kernel + all_gather"},
             "roofline": step_roofline(
                 "one timed STEP = clear + insert the shard (k_part_scatter + k_bloom_apply per 32M-key chunk) + " + ("allreduce(OR) + " if ctx.distributed else "") +
-                "check the shard; avg_kernel_ms = HIP events around whole steps of the timed region", self.n, self.timer.mean_ms("step"),
+                "check the shard; avg_kernel_ms = HIP events around whole steps of the timed region (median pair)", self.n, self.timer.median_ms("step"),
                 {"bloom_insert": roofline("bloom_insert", "Bloom insert, m=2^31 (2048 slices): k_part_scatter + k_bloom_apply per 32M-key chunk", self.n, ins,
                                           "short (tile, slice) runs at 2048 slices: pass 1 is write-out bound", "bloom31_insert"),
                  "bloom_check": roofline("bloom_check", "Bloom lookup, m=2^31", self.n, chk, "as the insert", "bloom31_check")},
@@ -1097,7 +1106,10 @@ def run_workload(ctx: Ctx, args, name: str, steps: int, warmup: int, spinup: flo
         ctx.fence()
         t0 = time.perf_counter()
         for it in range(steps):
-            wl.step(1 if it % sample_every == 0 else (2 if it % sample_every == sample_every // 2 else 0))
+            # (never the block's first step: it starts on an idle GPU right behind the fence, and an event pair around it times the host's
+            # enqueueing of the step -- tens of microseconds of Python -- on top of the kernels)
+            # (blocks of fewer than three steps have no other step to offer)
+            wl.step(0 if (it == 0 and steps >= 3) else (1 if it % sample_every == 0 else (2 if it % sample_every == sample_every // 2 else 0)))
         ctx.fence()
         blocks.append(ctx.max_over_ranks(time.perf_counter() - t0))
     srt = sorted(blocks)
