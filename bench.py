@@ -86,6 +86,7 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5, help="the block of --steps timed steps is run this many times, each between its own fences; "
                     "`ms_per_step` / `value` are the MEDIAN block's, min / max are reported next to it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--print-detail", action="store_true", help="also print the FULL result object (the one written to gpurun_out/bench_detail.json) on stderr")
     ap.add_argument("--no-detail", action="store_true", help="skip the CMS / CBF / GUPS side measurements")
     ap.add_argument("--no-combine", action="store_true", help="cfg4: apply every 1M-key batch at once (update windows off: psk_set_option update_window=0)")
     ap.add_argument("--legacy-combine", action="store_true", help="cfg4: the round-2/3 opt-in (combine_updates=True: removes are plain decrements applied after "
@@ -1143,6 +1144,155 @@ def extra_config(ctx: Ctx, args, name: str):
     return obj, fails
 
 
+# ----------------------------------------------------------------------------------------------- the result line
+# The driver keeps the last ~8 KB of stdout: the LAST line is a compact object (numbers and short names only, < 6 KB); everything
+# else the run measured (limiter notes, per-launch objects, per-rank diagnostics, the scaling model, the host legs) is the FULL object,
+# written to gpurun_out/bench_detail.json (PSK_BENCH_DETAIL overrides the path; --print-detail also sends it to stderr).
+LINE_LIMIT = 6000
+
+
+def _r(x, sig=6):
+    """floats to `sig` significant digits (the line is read by a parser with a length cap, not by a bit-exact consumer)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _short(text, n=80):
+    text = str(text)
+    return text if len(text) <= n else text[: n - 3] + "..."
+
+
+def compact_roofline(r, kernel=None):
+    if not r:
+        return None
+    l2 = r.get("l2_hit")
+    if isinstance(l2, dict):  # a whole step: the launches' rates, in launch order
+        l2 = [v for v in l2.values()]
+    return _r({"bound": r["bound"], "kernel": _short(kernel or r["kernel"]), "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
+               "frac": r["frac"], "traffic": r.get("traffic"), "l2_hit": l2, "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+               "avg_kernel_ms": r["avg_kernel_ms"]})
+
+
+def compact_cpu(c):
+    if not c:
+        return None
+    out = {k: c.get(k) for k in ("value", "unit", "cores", "kind", "seconds")}
+    out["sample"] = _short(c.get("sample", ""), 110)
+    for name, leg in (c.get("legs") or {}).items():
+        if name != "port_1core":
+            out[name] = {"value": leg["value"], "cores": leg["cores"]}
+    return _r(out)
+
+
+SHORT_KERNEL = {
+    "cfg2": "step = clear + 2 x k_part_scatter + k_bloom_apply + k_bloom_test_flag",
+    "cfg3": "CMS add: k_part_scatter<IdxCms,PayWeightSmall,5> + k_counter_apply",
+    "cfg4": "window: key copies + k_part_scatter<PayNonePhased> + k_win_fold (1 GiB)",
+    "cfg5": "step = clear + chunks of (k_part_scatter + k_bloom_apply | k_bloom_test_flag)",
+}
+SHORT_WORKLOAD = {
+    "cfg2": "cfg2 Bloom m=2^28 k=7: per rank per step clear + insert 10M 16B keys + (merge) + check them",
+    "cfg3": "cfg3 CMS 2^20x5: per step clear + 100M weighted updates (10 passes x 10M keys) + (merge)",
+    "cfg4": "cfg4 CBF m=2^28 (1 GiB) k=7: per step clear + 50 batches (add 1M, remove 0.5M of the previous)",
+    "cfg5": "cfg5 Bloom m=2^31 k=7: per step clear + insert the rank's key range + allreduce(OR) + check it",
+}
+DETAIL_KEEP = {
+    "cfg2": ("insert_Mkeys_s", "check_Mkeys_s", "check_all_fresh_Mkeys_s", "check_half_fresh_Mkeys_s", "check_bits_Mkeys_s", "clear_ms", "merge_ms",
+             "merge_plus_check_ms", "all_inserted_found", "merged_table_equals_single_stream", "bits_set", "step_ms_events", "step_event_samples",
+             "cms_add_Mupd_s", "cms_check_Mkeys_s", "cbf_add_Mops_s", "cbf_check_Mkeys_s", "cbf_check_unchanged_table_Mkeys_s", "cbf_remove_Mops_s",
+             "gups_atomic_or_32MiB_Gprobes_s", "gups_gather_32MiB_Gprobes_s", "gups_atomic_add_1GiB_Gprobes_s", "gups_gather_1GiB_Gprobes_s"),
+    "cfg3": ("add_Mupd_s", "check_Mkeys_s", "elements_added", "sum_bins_equals_depth_x_weights", "prefix_1M_equals_oracle", "merge_ms"),
+    "cfg4": ("elements_added", "expected_elements", "sum_counters_equals_k_x_live"),
+    "cfg5": ("insert_ms", "merge_ms", "check_ms", "insert_Mkeys_s_per_gpu", "check_Mkeys_s_per_gpu", "merge_GBs_per_gpu", "all_inserted_found",
+             "merged_prefix_equals_single_stream"),
+}
+
+
+def compact_config(name, cfg):
+    keep = ("keys_per_rank", "keys_total", "key_bytes", "m_bits", "k", "width", "depth", "updates_per_step", "ops_per_step", "batch", "batches", "parallelism", "api")
+    out = {"workload": SHORT_WORKLOAD[name]}
+    out.update({k: (_short(v, 70) if isinstance(v, str) else v) for k, v in cfg.items() if k in keep})
+    return out
+
+
+def compact_line(full: dict, name: str, detail_path) -> dict:
+    """the driver's line: the contract's fields, the dominant launch's roofline, one short object per other operation / configuration"""
+    head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "repeats", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "rc")
+    out = {k: full.get(k) for k in head}
+    out["config"] = compact_config(name, full["config"])
+    out["roofline"] = compact_roofline(full.get("roofline"), SHORT_KERNEL[name])
+    lau = (full.get("roofline") or {}).get("launches") or {}
+    ops = {**lau, **(full.get("rooflines") or {})}
+    if ops:  # per operation: fraction of the 8 TB/s roofline, launch time, counter traffic over algorithmic bytes
+        out["rooflines"] = {k: {"frac": v["frac"], "ms": v["avg_kernel_ms"], "traffic_x": (v["traffic"] / v["algorithmic_bytes_per_launch"]) if v.get("traffic") else None,
+                                "l2_hit": v.get("l2_hit")} for k, v in ops.items()}
+    det = full.get("detail") or {}
+    out["detail"] = {k: det[k] for k in DETAIL_KEEP[name] if det.get(k) is not None}
+    rag = det.get("bloom_ragged_keys_Mkeys_s")
+    if rag:
+        out["detail"]["ragged_insert_Mkeys_s"], out["detail"]["ragged_check_Mkeys_s"] = rag["insert"], rag["check"]
+    hb = det.get("bloom_host_buffers_Mkeys_s")
+    if hb:
+        out["detail"]["pcie_inclusive_insert_Mkeys_s"], out["detail"]["pcie_inclusive_check_Mkeys_s"] = hb["insert"], hb["check"]
+    if full.get("multi_gpu"):
+        mg = full["multi_gpu"]
+        out["multi_gpu"] = {"ranks_seen_by_rccl": mg["ranks_seen_by_rccl"], "backend": mg["backend"], "merge_GBs_per_gpu": mg.get("merge_GBs_per_gpu"),
+                            "insert_ms_max": max(p["insert_ms"] for p in mg["per_rank"]), "merge_ms_max": max(p["merge_ms"] for p in mg["per_rank"]),
+                            "check_ms_max": max(p["check_ms"] for p in mg["per_rank"])}
+    if full.get("predicted"):
+        out["predicted_value_by_n"] = {n: v["value_Mkeys_s"] for n, v in full["predicted"]["per_N"].items()}
+    if full.get("configs"):
+        out["configs"] = {}
+        for cname, c in full["configs"].items():
+            o = {"value": c["value"], "unit": c["unit"], "ms_per_step": c["ms_per_step"], "steps": c["steps"], "parity_ok": c["parity_ok"],
+                 "frac": (c.get("roofline") or {}).get("frac"), "traffic": (c.get("roofline") or {}).get("traffic"),
+                 "avg_kernel_ms": (c.get("roofline") or {}).get("avg_kernel_ms")}
+            if c.get("cpu_baseline"):
+                o["cpu_baseline"] = {k: c["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "seconds")}
+            if c.get("with_borrow_keys"):
+                o["with_borrow_keys"] = {k: c["with_borrow_keys"][k] for k in ("value", "ms_per_step", "parity_ok", "roofline_frac")}
+            for k in ("check_Mkeys_s", "insert_Mkeys_s_per_gpu", "check_Mkeys_s_per_gpu"):
+                if (c.get("detail") or {}).get(k) is not None:
+                    o[k] = c["detail"][k]
+            out["configs"][cname] = o
+    if full.get("cms"):
+        out["cms"] = {k: full["cms"][k] for k in ("insert_Mupdates_s", "lookup_Mkeys_s")}
+    out["cpu_baseline"] = compact_cpu(full.get("cpu_baseline"))
+    if full.get("error"):
+        out["error"] = _short(full["error"], 600)
+    out["detail_file"] = str(detail_path) if detail_path else None
+    out = _r(out)
+    text = json.dumps(out, separators=(",", ":"))
+    for drop in ("predicted_value_by_n", "rooflines", "detail"):  # never over the cap, whatever a future field adds
+        if len(text) <= LINE_LIMIT:
+            break
+        out.pop(drop, None)
+        text = json.dumps(out, separators=(",", ":"))
+    return out
+
+
+def write_detail(full: dict):
+    """the full object -> gpurun_out/bench_detail.json (scratch on the GPU box; copies judged live under profiles/); returns the path or None"""
+    path = Path(os.environ.get("PSK_BENCH_DETAIL", ROOT / "gpurun_out" / "bench_detail.json"))
+    try:
+        path.parent.mkdir(parents=True, exist_ok=True)
+        path.write_text(json.dumps(full) + "\n")
+        try:
+            return path.relative_to(ROOT)
+        except ValueError:
+            return path
+    except OSError:
+        return None
+
+
 def main():
     args = parse()
     self_launch(args)
@@ -1257,7 +1407,10 @@ def run(args):
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(line), flush=True)
+        where = write_detail(line)
+        if args.print_detail:
+            print(json.dumps(line), file=sys.stderr, flush=True)
+        print(json.dumps(compact_line(line, args.config, where), separators=(",", ":")), flush=True)
     if fails:
         print("; ".join(fails), file=sys.stderr)
         return 2

@@ -74,6 +74,27 @@ class CountingBloomFilter(BloomFilter):
         inst._borrowed = []
         return inst
 
+    def _release_borrowed(self, keep_last: int = 0) -> None:
+        """let go of lent key tensors whose batches the engine has hashed (all but the newest ``keep_last``).  The kernels that read them
+        were enqueued on the sketch's stream -- torch's CURRENT stream of the device (``_base.py`` ``stream``) --, so every tensor is
+        first recorded on that stream: the caching allocator then keeps its memory until those kernels have run, even when the tensor
+        was allocated on another stream.  (The sketch must be driven from the stream the key tensors are ready on; see ``borrow_keys``.)"""
+        lent = getattr(self, "_borrowed", None)
+        if not lent:
+            return
+        gone = lent[: len(lent) - keep_last] if keep_last else lent[:]
+        try:
+            import torch
+
+            cur = torch.cuda.current_stream(self._tab.device) if self._tab is not None else None
+            for keep in gone:
+                for t in keep if isinstance(keep, (list, tuple)) else (keep,):
+                    if cur is not None and isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(cur)
+        except ImportError:  # pragma: no cover
+            pass
+        del lent[: len(gone)]
+
     @staticmethod
     def _insufficient_msg() -> str:
         return "Insufecient parameters to set up the Counting Bloom Filter"  # (sic) countingbloom.py:73
@@ -82,8 +103,7 @@ class CountingBloomFilter(BloomFilter):
         super()._flush()
         if self._tab is not None:  # write-combined updates (automatic for small add batches into big tables) reach the table
             self._tab.flush()
-            if getattr(self, "_borrowed", None):
-                self._borrowed.clear()  # (the flush has hashed the borrowed key tensors: they may go)
+            self._release_borrowed()  # (the flush has hashed the borrowed key tensors: they may go)
 
     def _table_len(self, n_bits: int) -> int:
         return int(n_bits)  # one uint32 per position (countingbloom.py:77)
@@ -94,8 +114,7 @@ class CountingBloomFilter(BloomFilter):
         if self._tab is None or not getattr(self, "_dirty", False):
             return
         c = self._tab.counters()  # (flushes the engine's write-combined updates)
-        if getattr(self, "_borrowed", None):
-            self._borrowed.clear()
+        self._release_borrowed()
         self._els_added = min(self._els_added + c[N.CTR_ADDED], _U64_MAX) - c[N.CTR_REMOVED]
         self._diag = [a + b for a, b in zip(getattr(self, "_diag", [0, 0]), (c[N.CTR_VIOLATIONS], c[N.CTR_SATURATED]))]
         self._tab.reset_counters()
@@ -122,8 +141,7 @@ class CountingBloomFilter(BloomFilter):
     def clear(self) -> None:
         super().clear()
         self._dirty, self._diag = False, [0, 0]
-        if getattr(self, "_borrowed", None):
-            self._borrowed.clear()
+        self._release_borrowed()
 
     # -------------------------------------------------------------- single-key ops (ordered kernel)
     def _ordered(self, b: KeyBatch, num_els, opmode: int) -> np.ndarray:
@@ -169,8 +187,7 @@ class CountingBloomFilter(BloomFilter):
     def _check_batch(self, b: KeyBatch):
         addr, fin = self._tab.out_buffer(b, b.n, np.uint32, _torch_dtype("int32"))
         N.check(N.lib().psk_cbf_check(self._tab.handle, *b.args(), b.where, addr, self._tab.stream))
-        if getattr(self, "_borrowed", None):
-            self._borrowed.clear()  # (the engine applied what was waiting before it looked anything up)
+        self._release_borrowed()  # (the engine applied what was waiting before it looked anything up)
         return fin()
 
     def _update_batch(self, remove: bool, b: KeyBatch, num_els) -> None:
@@ -203,7 +220,7 @@ class CountingBloomFilter(BloomFilter):
                 # (asked every 128 lent batches, not every call: the question is a ctypes round trip on a path that is enqueue-bound)
                 pending = self._tab.get_option("window_pending_batches")
                 if pending < len(self._borrowed):
-                    del self._borrowed[: len(self._borrowed) - pending]
+                    self._release_borrowed(keep_last=pending)
         self._dirty = True
 
     def _add_batch(self, b: KeyBatch, num_els=None) -> None:  # type: ignore[override]

@@ -1220,11 +1220,26 @@ static int win_reserve(psk_sketch *s, uint64_t want, uint64_t cap, hipStream_t s
         return PSK_OK;
     }
     if (s->win.copied) {
-        PSK_TRY(comb_order(s, st));
-        HIP_TRY(hipMemcpyAsync(p, s->win.keys.p, s->win.copied * 16, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));  // (the old list is freed below)
+        // (the new list is ours until it is stored below: every failure on the way frees it)
+        auto moved = [&]() -> int {
+            PSK_TRY(comb_order(s, st));
+            HIP_TRY(hipMemcpyAsync(p, s->win.keys.p, s->win.copied * 16, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));  // (the old list is freed below)
+            return PSK_OK;
+        };
+        const int rc = moved();
+        if (rc != PSK_OK) {
+            (void)hipFree(p);
+            return rc;
+        }
     }
-    if (s->win.keys.p) HIP_TRY(hipFree(s->win.keys.p));
+    if (s->win.keys.p) {
+        const hipError_t e = hipFree(s->win.keys.p);
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return fail(PSK_EHIP, "hipFree of the window's key list failed: %s", hipGetErrorString(e));
+        }
+    }
     s->win.keys.p = p;
     s->win.keys.cap = keys * 16;
     return PSK_OK;

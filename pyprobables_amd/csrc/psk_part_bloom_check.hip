@@ -35,16 +35,30 @@ static int check_round_test(psk_sketch *s, const PartGeom &g, uint8_t *out, hipS
     return PSK_OK;
 }
 
-static bool check_geometry(psk_sketch *s, uint64_t n, PartGeom *g, uint64_t *round_keys)
+static bool check_geometry(psk_sketch *s, const Batch &b, PartGeom *g, uint64_t *round_keys)
 {
+    const uint64_t n = b.n;
     if (!part_wanted(n, s->k, 4)) return false;
     if (!part_slices(s->m, 20, 7, g)) return false;
     g->k = s->k;
     uint64_t rk = part_round_keys_big_table(n, s->k, PayKeyId::group, s->padded_bytes);
     // a keyed group spells the tile's ordinal inside its workgroup in 4 bits: at most 16 tiles per workgroup and round
     // (256 workgroups x 16 x 2048-key tiles for k <= 8; 512-key tiles beyond)
-    const uint64_t cap = (uint64_t)PayKeyId::max_tiles_per_wg * (g_part_wgs > 0 ? (uint64_t)(g_part_wgs < 1024 ? g_part_wgs : 1024) : (keyed_wgs(*g) ? keyed_wgs(*g) : 256u)) *
-                         (s->k <= 8 ? (g_part_tile_threads == 512 ? 1024 : 2048) : 512);  // (forced 512-thread tiles hold 1024 keys at k = 7, 8)
+    uint64_t cap = (uint64_t)PayKeyId::max_tiles_per_wg * (g_part_wgs > 0 ? (uint64_t)(g_part_wgs < 1024 ? g_part_wgs : 1024) : (keyed_wgs(*g) ? keyed_wgs(*g) : 256u)) *
+                   (s->k <= 8 ? (g_part_tile_threads == 512 ? 1024 : 2048) : 512);  // (forced 512-thread tiles hold 1024 keys at k = 7, 8)
+    // ... of the tile launch_scatter_nt will really run: it cuts the tile where the LDS stage -- plus the per-tile length sort of ragged keys --
+    // would not fit (e.g. 1280 keys at 2048 slices), and a round sized for 2048-key tiles would then need more than 16 tiles per workgroup
+    bool handled = false;
+    uint64_t cap_layout = cap;
+    (void)with_part_source(b, &handled, [&](auto src) {
+        using Src = decltype(src);
+        return with_kt<Src>(s->k, [&](auto kt) {
+            constexpr int KT = decltype(kt)::value;
+            cap_layout = scatter_round_cap<PayKeyId, KT, src_fat512<Src>::value, src_sorted<Src>::value>(g, keyed_wgs(*g), PayKeyId::max_tiles_per_wg);
+            return (int)PSK_OK;
+        });
+    });
+    if (handled && cap_layout < cap) cap = cap_layout;
     if (rk > cap) rk = cap;
     *round_keys = rk;
     return true;
@@ -396,7 +410,7 @@ int PSK_VARIANT(bloom_check_partitioned)(psk_sketch *s, const Batch &b, uint8_t 
     *done = false;
     PartGeom g;
     uint64_t round_keys;
-    if (!check_geometry(s, b.n, &g, &round_keys)) return PSK_OK;
+    if (!check_geometry(s, b, &g, &round_keys)) return PSK_OK;
     HIP_TRY(hipMemsetAsync(out_dev, 1, b.n, st));  // once for every round (a fill launch is ~5 us whatever it fills)
     for (uint64_t start = 0; start < b.n; start += round_keys) {
         const uint64_t cnt = b.n - start < round_keys ? b.n - start : round_keys;
@@ -434,7 +448,7 @@ int PSK_VARIANT(bloom_check_begin_partitioned)(psk_sketch *s, const Batch &b, hi
             return PSK_OK;
         }
     }
-    if (!check_geometry(s, b.n, &s->pend.g, &s->pend.round_keys)) return PSK_OK;
+    if (!check_geometry(s, b, &s->pend.g, &s->pend.round_keys)) return PSK_OK;
     PSK_TRY(ensure(s->s_flag, 8));
     uint32_t *flag = (uint32_t *)s->s_flag.p;
     HIP_TRY(hipMemsetAsync(flag, 0, 4, st));

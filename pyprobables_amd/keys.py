@@ -12,6 +12,7 @@ The reference hashes one python object at a time (``fnv_1a`` walks ``list(key)``
 
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -101,6 +102,10 @@ def _pack_homogeneous(keys: list, n: int):
     return KeyBatch(N.KEYS_VARLEN8, _np_ptr(blob), _np_ptr(offs), n, 0, N.HOST, None, [blob, offs, blob8])
 
 
+# device (blob, offsets) pairs are validated only on request (see _pack_ragged)
+VALIDATE_DEVICE_OFFSETS = os.environ.get("PSK_VALIDATE_OFFSETS", "0") not in ("", "0")
+
+
 def _is_array(x) -> bool:
     return isinstance(x, np.ndarray) or (torch is not None and isinstance(x, torch.Tensor))
 
@@ -108,7 +113,12 @@ def _is_array(x) -> bool:
 def _pack_ragged(blob, offsets) -> KeyBatch:
     """a ragged batch handed over as it lies in memory: ``blob`` = the keys' elements end to end (uint8 bytes, or 4-byte code points
     for str keys -- hashes.py:98 XORs whole code points), ``offsets`` = n + 1 ascending 8-byte positions, key i = blob[offsets[i]:offsets[i+1]].
-    Both on the host, or both on one device (zero-copy: the C ABI takes ``offsets`` from either side)."""
+    Both on the host, or both on one device (zero-copy: the C ABI takes ``offsets`` from either side).
+
+    CONTRACT for device pairs: the offsets ascend and stay inside the blob.  Host pairs are validated here; a device pair is handed to the
+    kernels as it is (checking it would cost a reduction over the offsets and a synchronisation on every batch) -- a descending or
+    out-of-range offset makes a lane walk memory far outside the blob, which can fault the GPU.  ``PSK_VALIDATE_OFFSETS=1`` in the
+    environment (or ``keys.VALIDATE_DEVICE_OFFSETS = True``) turns the same two checks on for device pairs (debugging a producer)."""
     is_t = [torch is not None and isinstance(x, torch.Tensor) for x in (blob, offsets)]
     cuda = [t and x.is_cuda for t, x in zip(is_t, (blob, offsets))]
     if cuda[0] != cuda[1]:
@@ -127,6 +137,12 @@ def _pack_ragged(blob, offsets) -> KeyBatch:
         else:
             raise TypeError("(blob, offsets): blob must be uint8 bytes or 4-byte code points")
         b, o = blob.contiguous(), offsets.contiguous()
+        if VALIDATE_DEVICE_OFFSETS:
+            oi = o.view(torch.int64)
+            if oi.numel() > 1 and bool((oi[1:] < oi[:-1]).any().item()):
+                raise ValueError("(blob, offsets): offsets must ascend")
+            if int(oi[0].item()) < 0 or int(oi[-1].item()) > b.numel():
+                raise ValueError("(blob, offsets): offsets reach past the blob")
         if b.numel() == 0:
             b = torch.zeros(1, dtype=blob.dtype, device=blob.device)  # (all keys empty: the engine still wants an address)
         return KeyBatch(layout, b.data_ptr(), o.data_ptr(), o.numel() - 1, 0, N.DEVICE, b.device.index, [b, o])

@@ -30,7 +30,7 @@ for c in tot:
     for f in glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].replace("psk::", "").replace("void ", "")
-            if not k.startswith(("k_part", "k_bloom", "k_counter", "k_lookup", "k_weight_sum", "k_apply", "k_cbf", "k_nib", "k_tally")):
+            if not k.startswith(("k_part", "k_bloom", "k_counter", "k_lookup", "k_weight_sum", "k_apply", "k_cbf", "k_nib", "k_tally", "k_win", "k_pack", "__amd_rocclr")):
                 continue
             short = re.sub(r"\(.*", "", k)
             short = re.sub(r"KeysFixed16, |Spill\w+(<\w+>)?, ", "", short)

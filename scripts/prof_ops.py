@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Run one engine operation repeatedly (for rocprofv3 --kernel-trace --stats / --pmc):  prof_ops.py <op> [n] [iters]
 ops: bloom_add bloom_check bloom_check_fresh bloom31_add bloom31_check cms_add cms_add_unit cms_check cbf_add cbf_check cbf_check_kept cbf_remove cbf25_check cbf25_add
-     cfg4_stream (n = keys per batch, 50 batches: BASELINE cfg 4's add / remove stream, write-combined, flush included)"""
+     cfg4_stream (n = keys per batch, 50 batches: BASELINE cfg 4's add / remove stream through the DEFAULT API -- update windows, k_win_fold --,
+                  flush included; PSK_CFG4_MODE = window (default) | borrow_window (borrow_keys=True) | combine | combine_borrow (the round-2/3 opt-ins))
+The Bloom lookups are PINNED to the scheme the timed step of bench.py settles on for that kind of batch (the per-call automatic choice starts on
+keyed probes and needs up to four calls to move: a profile of the first calls measures kernels the step does not run):
+     bloom_check / bloom31_check (all keys present) -> tile flags (bloom_lookup = 3);  bloom_check_fresh (all absent) -> lazy gathers (4);
+     bloom_check_half (every other key absent) -> the automatic choice, warmed over 8 calls before the profiled ones.
+PSK_OPTS (e.g. PSK_OPTS=bloom_lookup=0) overrides the pin."""
 import sys
 from pathlib import Path
 
@@ -31,8 +37,9 @@ def gen(n, start):
 if op == "cfg4_stream":
     B, NB = n, 50
     allk = gen(B * NB, 0)
-    mode = os.environ.get("PSK_CFG4_MODE", "copy")  # "copy" (bench.py's default) or "borrow"
-    s = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, combine_updates="borrow" if mode == "borrow" else True)
+    mode = os.environ.get("PSK_CFG4_MODE", "window")
+    kw = {"window": {}, "borrow_window": {"borrow_keys": True}, "combine": {"combine_updates": True}, "combine_borrow": {"combine_updates": "borrow"}}[mode]
+    s = pa.CountingBloomFilter(est_elements=28005615, false_positive_rate=0.01, **kw)  # "window" = bench.py --config cfg4 as it runs by default
 
     def fn():
         s.clear()
@@ -53,7 +60,7 @@ if op == "cfg4_stream":
     torch.cuda.synchronize()
     ms = a.elapsed_time(b_) / iters
     ops = B * NB + (NB - 1) * (B // 2)
-    print(f"{op}: {ms * 1e3:.1f} us per {ops} ops -> {ops / ms / 1e3:.0f} M/s  launches={2 + iters} n={ops}")
+    print(f"{op} ({mode}): {ms * 1e3:.1f} us per {ops} ops -> {ops / ms / 1e3:.0f} M/s  launches={2 + iters} n={ops}")
     sys.exit(0)
 keys = gen(n, 0)
 w = torch.empty(n, dtype=torch.int32, device="cuda")
@@ -79,7 +86,20 @@ elif op.startswith("bloom"):
     s = pa.BloomFilter(est_elements=224044920 if op.startswith("bloom31") else 28005615, false_positive_rate=0.01)  # 2^31 / 2^28 bits
     s.add_many(keys)
     fresh = gen(n, 7 * n)
-    fn = {"add": lambda: s.add_many(keys), "check": lambda: s.check_many(keys), "check_fresh": lambda: s.check_many(fresh)}[op.split("_", 1)[1]]
+    kind = op.split("_", 1)[1]
+    pinned = "bloom_lookup=" in os.environ.get("PSK_OPTS", "")
+    if kind == "check" and not pinned:
+        s.set_engine_option("bloom_lookup", 3)   # tile flags: what the timed step runs on batches of present keys
+    if kind == "check_fresh" and not pinned:
+        s.set_engine_option("bloom_lookup", 4)   # lazy gathers: what the automatic choice settles on for batches of absent keys
+    if kind == "check_half":
+        half = keys.clone()
+        half[1::2] = fresh[1::2]
+        for _ in range(8):                       # the automatic choice settles (the profiled launches = 2 + iters come after)
+            s.check_many(half)
+        torch.cuda.synchronize()
+    fn = {"add": lambda: s.add_many(keys), "check": lambda: s.check_many(keys), "check_fresh": lambda: s.check_many(fresh),
+          "check_half": lambda: s.check_many(half)}[kind]
 elif op.startswith("cms"):
     s = pa.CountMinSketch(width=2**20, depth=5)
     s.add_many(keys, w)

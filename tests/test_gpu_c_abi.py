@@ -1,6 +1,7 @@
 """The drop-in boundary is a C ABI: build examples/psk_demo.c with the system C compiler, link it against
 libpsk_hip.so + the ROCm HIP runtime (no Python, no torch in the process) and run it on the GPU."""
 
+import json
 import shutil
 import subprocess
 from pathlib import Path
@@ -10,6 +11,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = Path(__file__).resolve().parent.parent
+# what the REAL reference held after the C programs' workloads (tests/golden/gen_golden_cdemo.py, imported pyprobables)
+GOLDEN = json.loads((ROOT / "tests" / "golden" / "golden_cdemo.json").read_text())
+
+
+def _printed(stdout: str) -> dict:
+    return dict(x.split("=", 1) for x in stdout.splitlines() if "=" in x and " " not in x.split("=", 1)[0])
 
 
 def test_plain_c_program_drives_the_engine(tmp_path):
@@ -28,6 +35,10 @@ def test_plain_c_program_drives_the_engine(tmp_path):
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "PSK C ABI OK" in run.stdout
+    got, g = _printed(run.stdout), GOLDEN["psk_demo"]
+    assert got["table_sha256"] == g["sha256_table"] == "1e9bfcfc3ad261a36f218553a905d142a95295333e2b6ec63d9710543db83d7c"
+    assert got["membership_sha256"] == g["sha256_membership_bytes"] and int(got["elements_added"]) == g["elements_added"]
+    assert f"false positives {g['false_positives']} of" in run.stdout
 
 
 def test_plain_c_program_merges_replicas_over_rccl(tmp_path):
@@ -68,3 +79,7 @@ def test_plain_c_program_two_threads_two_handles(tmp_path):
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "PSK THREADS OK" in run.stdout
+    got = _printed(run.stdout)
+    assert got["bloom_table_sha256"] == GOLDEN["threads_bloom"]["sha256_table"] and int(got["bloom_elements_added"]) == GOLDEN["threads_bloom"]["elements_added"]
+    assert got["cbf_table_sha256"] == GOLDEN["threads_cbf"]["sha256_table"] and int(got["cbf_elements_added"]) == GOLDEN["threads_cbf"]["elements_added"]
+    assert got["cbf_mins_sha256"] == GOLDEN["threads_cbf"]["sha256_last_round_mins_u32"]
