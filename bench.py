@@ -67,8 +67,8 @@ SEED = 0x5EED
 BYTES = {"bloom_insert": 72, "bloom_check": 45, "cms_add": 60, "cms_check": 40, "cbf_add": 76, "cbf_remove": 76, "cbf_check": 48,
          "bloom_step": 72 + 45}  # one key inserted AND looked up: what one unit of cfg 2 / cfg 5's `value` moves
 DEFAULT_STEPS = {"cfg2": (200, 20), "cfg3": (20, 3), "cfg4": (10, 2), "cfg5": (5, 1)}
-PMC_FILE = next((f for f in (ROOT / "profiles" / f"r0{r}_pmc_traffic.json" for r in (5, 4, 3)) if f.exists()), ROOT / "profiles" / "r05_pmc_traffic.json")
-L2_FILE = next((f for f in (ROOT / "profiles" / f"r0{r}_l2_hit.json" for r in (5, 4, 3)) if f.exists()), ROOT / "profiles" / "r05_l2_hit.json")
+PMC_FILE = next((f for f in (ROOT / "profiles" / f"r0{r}_pmc_traffic.json" for r in (6, 5, 4, 3)) if f.exists()), ROOT / "profiles" / "r06_pmc_traffic.json")
+L2_FILE = next((f for f in (ROOT / "profiles" / f"r0{r}_l2_hit.json" for r in (6, 5, 4, 3)) if f.exists()), ROOT / "profiles" / "r06_l2_hit.json")
 METRIC_CFG2 = "million keys/sec insert+lookup (Bloom m=2^28 k=7, CMS 2^20x5)"
 
 
@@ -297,7 +297,7 @@ def timed_loop(torch, fn, iters, warm=2):
 
 def pmc_traffic(op: str, n: int):
     """HBM-side bytes per launch of `op` from the committed PMC profile of the same workload and kernels
-    (scripts/profile_r05.sh -> profiles/r05_pmc_traffic.json); None when there is no matching record.  A record measured
+    (scripts/profile_r06_pmc.sh -> profiles/r06_pmc_traffic.json); None when there is no matching record.  A record measured
     on chunks of the same kernels (`per_key_scalable`: cfg 5 inserts its shard in 2^25-key calls) is scaled by the key count."""
     try:
         pmc = json.loads(PMC_FILE.read_text())
@@ -890,7 +890,8 @@ class Cfg4:
                                "--no-combine: update windows off, every batch at once"},
             "roofline": roofline("cbf_add", "CBF stream = per window: key copies + k_part_scatter<PayNonePhased> + k_win_fold over the 1 GiB table",
                                  self.ops_per_step, ms, "the fold read-modify-writes the whole 1 GiB table; batches are combined before it",
-                                 {True: "cfg4_stream", "borrow": "cfg4_stream_borrow", "off": "cfg4_stream_nocombine", "window": "cfg4_stream_window", "window_borrow": "cfg4_stream_window"}[self.mode]),
+                                 # (profiles/r06_pmc_traffic.json: "cfg4_stream" = the default API's update windows -- key copies + pass 1 + k_win_fold --, "..._borrow_keys" = the same without copies)
+                                 {True: "cfg4_stream_combine", "borrow": "cfg4_stream_combine_borrow", "off": "cfg4_stream_nocombine", "window": "cfg4_stream", "window_borrow": "cfg4_stream_borrow_keys"}[self.mode]),
             "rooflines": {},
             "detail": {"elements_added": els, "expected_elements": expect, "sum_counters_equals_k_x_live": total == 7 * expect, "diagnostics": diag,
                        "update_window_folds": self._opt("update_window_folds"), "update_window_replays": self._opt("update_window_replays")},

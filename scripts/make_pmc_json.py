@@ -8,7 +8,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r03"
 src = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / TAG
-names = {"bloom_add": "bloom_insert", "bloom_check": "bloom_check", "bloom_check_fresh": "bloom_check_all_fresh", "cms_add": "cms_add_weighted",
+names = {"bloom_add": "bloom_insert", "bloom_check": "bloom_check", "bloom_check_fresh": "bloom_check_all_fresh", "bloom_check_half": "bloom_check_half_fresh", "cms_add": "cms_add_weighted",
          "cms_check": "cms_check", "cbf_add": "cbf_add", "cbf_check": "cbf_check", "cbf_check_kept": "cbf_check_unchanged_table", "cbf_remove": "cbf_remove", "cfg4_stream": "cfg4_stream",
          "bloom31_add": "bloom31_insert", "bloom31_check": "bloom31_check"}
 SCALABLE = {"bloom31_add", "bloom31_check"}  # measured on one 2^25-key call; cfg 5 makes ceil(n / 2^25) such calls per step
@@ -32,10 +32,18 @@ def factor(kernel: str) -> int:
 
 for f in sorted(src.glob("pmc_*.json")):
     d = json.loads(f.read_text())
+    if f.stem == "pmc_cfg4_stream_borrow":
+        d["op"] = "cfg4_stream_borrow_keys"
     if d["keys"] == 10_000_000:
         out["keys"] = d["keys"]
+    # kernels of the SET-UP (prof_ops.py fills the filter once before the profiled lookups: 1 dispatch against `launches` profiled
+    # calls) are not part of the operation: listed aside, not counted
+    setup = {k: v for k, v in d["kernels"].items() if v["dispatches_per_launch"] < 0.3 and not k.startswith("__amd_rocclr")}
+    d["kernels"] = {k: v for k, v in d["kernels"].items() if k not in setup}
     hbm = int(sum(factor(k) * v["fetch_KiB_per_launch"] + v["write_KiB_per_launch"] for k, v in d["kernels"].items()) * 1024)
     rec = {"keys": d["keys"], "kernels": d["kernels"], "hbm_bytes_per_launch": hbm, "bytes_per_key": round(hbm / d["keys"], 1), "l2_hit": d.get("l2_hit")}
+    if setup:
+        rec["setup_kernels_not_counted"] = sorted(setup)
     if d["op"] in SCALABLE:
         rec["per_key_scalable"] = True
     out[names.get(d["op"], d["op"])] = rec

@@ -95,7 +95,7 @@ elif op.startswith("bloom"):
     if kind == "check_half":
         half = keys.clone()
         half[1::2] = fresh[1::2]
-        for _ in range(8):                       # the automatic choice settles (the profiled launches = 2 + iters come after)
+        for _ in range(8):                       # the automatic choice settles (counted: launches = 8 + 2 + iters)
             s.check_many(half)
         torch.cuda.synchronize()
     fn = {"add": lambda: s.add_many(keys), "check": lambda: s.check_many(keys), "check_fresh": lambda: s.check_many(fresh),
@@ -114,7 +114,7 @@ else:
         N.set_option("cbf_lookup_shadow", 0)
     fn = {"add": lambda: s.add_many(keys), "check": lambda: s.check_many(keys), "check_kept": lambda: s.check_many(keys),
           "remove": lambda: (s.add_many(keys), s.remove_many(keys))}[op.split("_", 1)[1]]  # (remove: the keys go back in first, so that every remove finds its key)
-launches = 2 + iters + (1 if op in ("bloomvar_add", "bloom_add", "bloom31_add", "cms_add", "cbf_add", "cbf25_add") else 0)  # the set-up insert runs the same kernels
+launches = 2 + iters + (8 if op == "bloom_check_half" else 0) + (1 if op in ("bloomvar_add", "bloom_add", "bloom31_add", "cms_add", "cbf_add", "cbf25_add") else 0)  # the set-up insert runs the same kernels
 for _ in range(2):
     fn()
 torch.cuda.synchronize()
