@@ -33,7 +33,7 @@ partition scratch per 2^25-key chunk (bucket buffer ~1.1 GB insert / ~1.9 GB loo
 buffers: < 6 GB of the 288 GB.  At N = 1 the 10^9 keys are 16 GB.
 
 Every line carries
-  roofline      the dominant kernel of the configuration (cfg2: the Bloom insert launch = k_part_scatter + k_bloom_apply):
+  roofline      the dominant kernel of the configuration (cfg2: the Bloom insert launch = k_part_bins + k_bloom_apply):
                 ALGORITHMIC bytes (72 B per inserted key, 45 per Bloom lookup, 60 per CMS update, ...) divided
                 by the launch time measured with HIP events on the launch stream, against the 8 TB/s HBM peak.
   rooflines     the same object for the other operations of the metric (Bloom check, CMS add, CMS / CBF lookups ...).
@@ -579,12 +579,12 @@ class Cfg2:
             "all_inserted_found": ok, "merged_table_equals_single_stream": merged_ok, "bits_set": bits_set,
         }
         launches = {"bloom_insert": roofline(
-            "bloom_insert", "Bloom insert = k_part_scatter<KeysFixed16,IdxBloom<pow2>,PayNone,SpillBloomOr,7> + k_bloom_apply "
+            "bloom_insert", "Bloom insert = k_part_bins<KeysFixed16,IdxBloom<pow2>,PayNone,SpillBloomOr,7> + k_bloom_apply "
             "(one insert launch = both kernels; avg_kernel_ms is their sum between two HIP events)", n, ins_ms,
-            "pass 1 is co-limited by VALU (the k FNV-1a chains) and the LDS counting sort, not by HBM; pass 2 streams at ~5.5 TB/s")}
+            "pass 1 is VALU bound (SQ counters: a VALU instruction issued in ~96 % of the SIMD cycles, 2 of 3 of them the k FNV-1a chains), not HBM bound; pass 2 streams at ~5 TB/s")}
         if not overlapped:
             launches["bloom_check"] = roofline(
-                "bloom_check", "Bloom lookup of present keys = k_part_scatter<KeysFixed16,IdxBloom<pow2>,PayTileTag,SpillBloomFlag,7> + k_bloom_test_flag + "
+                "bloom_check", "Bloom lookup of present keys = k_part_bins<KeysFixed16,IdxBloom<pow2>,PayTileTag,SpillBloomFlag,7> + k_bloom_test_flag + "
                 "k_bloom_flag_resolve (tile flags; keyed probes / return trip for batches with absent keys: detail.check_*_fresh)",
                 n, chk_ms, "pass 1 is the insert's (hash + LDS counting sort, 2.67-byte probes); pass 2 streams the probes back "
                 "from the Infinity Cache against an LDS-resident slice")
@@ -606,10 +606,10 @@ class Cfg2:
                 "parallelism": f"key-range x{ctx.world}, replica per GPU, allreduce(OR)" if ctx.world > 1 else "single GPU",
             },
             "roofline": step_roofline(
-                "one timed STEP = clear + Bloom insert (k_part_scatter + k_bloom_apply) + " + ("allreduce(OR) + " if ctx.distributed else "") +
-                "Bloom lookup (k_part_scatter + k_bloom_test_flag + k_bloom_flag_resolve); avg_kernel_ms = HIP events around whole steps of the timed region (median pair; detail.step_ms_events_mean)",
+                "one timed STEP = clear + Bloom insert (k_part_bins + k_bloom_apply) + " + ("allreduce(OR) + " if ctx.distributed else "") +
+                "Bloom lookup (k_part_bins + k_bloom_test_flag + k_bloom_flag_resolve); avg_kernel_ms = HIP events around whole steps of the timed region (median pair; detail.step_ms_events_mean)",
                 n, step_ms, launches,
-                "both pass 1s are co-limited by VALU (the k FNV-1a chains, ~75 of ~130 us) and the LDS counting sort, not by HBM; the pass 2s "
+                "both pass 1s are VALU bound (the k FNV-1a chains are 2 of 3 of their instructions: profiles/r06_sq_pass1.txt), not HBM bound; the pass 2s "
                 "stream the probes back at 4-5 TB/s"),
             "rooflines": rooflines, "detail": detail,
         }
@@ -689,7 +689,7 @@ def side_measurements(ctx: Ctx, n, blm, keys):
     cms = pa.CountMinSketch(width=2**20, depth=5, device=dev)
     ms = timed_loop(torch, lambda: cms.add_many(keys, w), 5)
     out["cms_add_Mupd_s"] = n / ms / 1e3
-    rl["cms_add"] = roofline("cms_add", "CMS weighted add = k_part_scatter<...,IdxCms<pow2>,PayWeightSmall (weights 0..15 as 20-bit fields; PayWeight otherwise),...,5> (sums the weights) + k_tally_fold + k_counter_apply",
+    rl["cms_add"] = roofline("cms_add", "CMS weighted add = k_part_bins<...,IdxCms<pow2>,PayWeightSmall,...,5> (weights 0..15 as 20-bit fields; k_part_scatter<PayWeight> otherwise) (sums the weights) + k_tally_fold + k_counter_apply",
                              n, ms, "pass 1 (5 FNV-1a chains + LDS counting sort), pass 2 folds 2^15-cell slices", "cms_add_weighted")
     ms = timed_loop(torch, lambda: cms.check_many(keys), 5)
     out["cms_check_Mkeys_s"] = n / ms / 1e3
@@ -804,7 +804,7 @@ class Cfg3:
                                    "(10 passes over 10M 16-byte keys, weights 1..7) + (SUM merge)",
                        "keys_per_rank": n, "passes": self.PASSES, "width": 2**20, "depth": 5,
                        "parallelism": f"key-range x{ctx.world}, replica per GPU, allreduce(SUM)" if ctx.world > 1 else "single GPU"},
-            "roofline": roofline("cms_add", "CMS weighted add = k_part_scatter<...,IdxCms<pow2>,PayWeightSmall (weights 0..15 as 20-bit fields; PayWeight otherwise),...,5> (sums the weights) + k_tally_fold + k_counter_apply "
+            "roofline": roofline("cms_add", "CMS weighted add = k_part_bins<...,IdxCms<pow2>,PayWeightSmall,...,5> (weights 0..15 as 20-bit fields; k_part_scatter<PayWeight> otherwise) (sums the weights) + k_tally_fold + k_counter_apply "
                                  "(one pass of 10M updates between two HIP events)", n, add_ms,
                                  "pass 1 (5 FNV-1a chains + LDS counting sort), pass 2 folds 2^15-cell slices", "cms_add_weighted"),
             "rooflines": {"cms_check": roofline("cms_check", "CMS lookup (min over 5 rows)", n, chk_ms, "see DESIGN.md 3.2")},
@@ -1193,8 +1193,8 @@ def compact_cpu(c):
 
 
 SHORT_KERNEL = {
-    "cfg2": "step = clear + 2 x k_part_scatter + k_bloom_apply + k_bloom_test_flag",
-    "cfg3": "CMS add: k_part_scatter<IdxCms,PayWeightSmall,5> + k_counter_apply",
+    "cfg2": "step = clear + 2 x k_part_bins + k_bloom_apply + k_bloom_test_flag",
+    "cfg3": "CMS add: k_part_bins<IdxCms,PayWeightSmall,5> + k_counter_apply",
     "cfg4": "window: key copies + k_part_scatter<PayNonePhased> + k_win_fold (1 GiB)",
     "cfg5": "step = clear + chunks of (k_part_scatter + k_bloom_apply | k_bloom_test_flag)",
 }

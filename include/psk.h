@@ -88,38 +88,38 @@ enum psk_counter {
 const char *psk_last_error(void);         /* thread-local text of the last failure */
 int psk_version(void);
 int psk_device_count(int *count);
-/* process-wide tunables: "partition" (0 = direct kernels only, 1 = auto), "partition_min_keys" (Bloom inserts with
- * at least this many keys -- 4x as many for lookups and counter adds -- take the partitioned path), "partition_max_keys" (keys per partition round, default 2^26), "partition_cache_bytes" (bucket-buffer budget per round, default
- * 240 MiB: batches whose buffer would exceed 1.5x this are cut into equal rounds so that pass 2 reads pass 1's output from
- * the 256 MB Infinity Cache instead of HBM; 0 disables), "partition_two_level_slices" (default 2048: tables cut into more
- * LDS-sized slices than this are partitioned in two levels -- coarse buckets, then slices; 0 = such tables use the direct
- * kernels), "combine_keys" (keys per write-combining list of psk_cbf_update_combined, default 2^26), "bloom_lookup" (large Bloom
- * lookups: 0 = keyed probes + one store per missing probe, 1 = return trip with a cost independent of the answers, 2 (default) =
- * chosen per call from the miss tally of the previous lookups on the handle), "merge_single_rank" (1: psk_merge_* run the
- * collective path on a one-rank communicator), "even_tiles" (default 1: pass 1 gives every workgroup the same number of equally
- * sized tiles), "dense_walk_groups" (default 40: pass 2 walks a wave's segments end to end -- every lane of a load busy -- when a
- * (slice, workgroup) segment holds fewer 16-byte groups than this on average, e.g. small batches into 2048-slice tables), "lookup_half_slices" (default 1: CMS / CBF lookups into tables of 2^26 .. 2^27
- * counters run partitioned over slices of 2^16 counters held as 16-bit values; 0 = such tables use the direct kernels);
- * round 3: "auto_combine" / "auto_combine_keys", "remove_optimistic", "lookup_nibble_slices", "update_nibble_slices", "nibble_min_lg_lookup",
- * "nibble_min_lg_update", "cbf_lookup_shadow" (all described with psk_cbf_add below), "scratch_budget_bytes" (cap on the partition scratch of a
- * round; 0 = none), "cms_small_weights" (weighted psk_cms_add: 1 (default) = weights 0 .. 15 travel as 20-bit fields once the previous batches
- * brought no other weight, 0 = never, 2 = always -- exact either way, a weight outside the range goes to the table directly); read-only
- * counters for tests: "cbf_lookup_shadow_hits", "cms_small_weights_used";
- * round 4: "update_window" / "update_window_keys" (described with psk_cbf_add below), "update_window_nt" (default 1: nontemporal table accesses
- * in the windows' fold), "update_window_wide" (default 1: tables of few slices take the fold with five probe groups per lane and phase),
- * "update_window_shadow" (default 0: 1 = a fold leaves the lookups' kept 4-bit images up to date; measured without gain),
- * "update_window_image" (the fold's LDS image of the counters: 4 (default) = four bits per counter, one workgroup per
- * 2^18-counter slice; 8 = a byte per counter, two workgroups per slice -- exact either way), "nibble_update_pipe" (unit adds / decrements into tables of more than 2^24 counters: 1 (default) = the pipelined pass
- * over the table -- persistent workgroups, the fold of one slice under the probe groups of the next, nontemporal table accesses; 3 = the same
- * with plain accesses; 0 = the two-phase kernel of round 3), "nibble_lookup_pipe" (default 0: 1 = the pipelined form of the lookups' table pass,
- * measured without gain), "remove_exact" (0: remove_many may tally violations instead of replaying order-dependent batches);
- * round 5: "ragged_sort" (default 1: pass 1 hands keys of different lengths to its lanes in order of length -- a counting sort per tile; 0 = batch
- * order, A/B), "update_window_tile" (keys per pass-1 tile of an update window: 0 (default) = 4096 where the table has ~900 slices and more,
- * 2048 otherwise; 2048 / 4096 = forced), "bloom_lookup" 3 = the tile-flag scheme for batches of present keys, 4 = lazy gathers for batches of absent keys (one key per lane, the
- * next probe only while every earlier bit was set; 2, the default, picks per call: 4 while nearly every key is absent and a key costs fewer
- * gathers than the return trip costs bytes);
- * per sketch, read-only: "window_pending_batches" (batches the update window still holds: PSK_DEVICE_BORROWED buffers among them must stay);
- * bench knobs: "lookup_split", "lookup_run_lanes", "tile_threads", "scatter_workgroups", "slice_bias" */
+/* Options (tunables of this engine: no reference counterpart).  psk_set_option keeps the PROCESS value; the names marked (s) can also be
+ * overridden for one handle with psk_sketch_set_option (value INT64_MIN: follow the process value again).
+ *
+ *   name                        default  meaning
+ *   "partition"                 1        0 = direct kernels only (one fabric transaction per probe), 1 = large batches take the partitioned passes
+ *   "partition_min_keys" (s)    65536    Bloom inserts of at least this many keys are partitioned (4 x as many for lookups / counter updates)
+ *   "partition_max_keys"        2^26     keys per partition round (bounds the scratch: ~2 GB per round at k = 7)
+ *   "partition_cache_bytes"     240 MiB  cache-sized tables: a batch whose probe buffer exceeds 1.5 x this is cut into equal rounds (0 = never)
+ *   "scratch_budget_bytes" (s)  0        cap on a handle's partition scratch (more, smaller rounds); 0 = none
+ *   "pass1_bins"                1        pass 1 of Bloom inserts / tile-flag lookups through fixed-capacity LDS bins (psk_part_bins.hpp); 0 = the
+ *                                        counting-sort form everywhere (same probes, same results)
+ *   "bloom_lookup" (s)          2        large Bloom lookups: 0 keyed probes, 1 return trip, 3 tile flags (batches of present keys), 4 lazy gathers
+ *                                        (batches of absent keys), 2 = chosen per call from the previous lookups' miss tally
+ *   "cms_small_weights"         1        weighted psk_cms_add: weights 0 .. 15 travel as 20-bit fields once the previous batches brought no
+ *                                        other weight; 0 = never, 2 = always (exact either way)
+ *   "cbf_lookup_shadow" (s)     1        psk_cbf_check keeps 4-bit images of an unchanged big table between lookups (cells / 2 bytes)
+ *   "remove_exact" (s)          1        psk_cbf_remove replays order-dependent batches in order; 0 = tallies them as violations instead
+ *   "update_window" (s)         1        small unit psk_cbf_add / _remove batches into big tables share one proven pass (psk_cbf_add below)
+ *   "update_window_keys" (s)    2^27     most keys such a window holds
+ *   "auto_combine" (s)          1        (update windows off) small unit add batches wait as scattered probes
+ *   "combine_keys"              2^26     keys per list of psk_cbf_update_combined
+ *   "merge_single_rank"         0        1: psk_merge_* run the collective path on a one-rank communicator (tests)
+ *   per sketch only: "table_private" (below), read-only "window_pending_batches" (batches an update window still holds: PSK_DEVICE_BORROWED
+ *   buffers among them must stay as they are).
+ *
+ * Also accepted -- where the engine switches between its kernel families, and test hooks (the tests steer small inputs onto the big-table paths
+ * with them; not for callers): "partition_two_level_slices", "auto_combine_keys", "tile_threads", "even_tiles", "dense_walk_groups",
+ * "lookup_half_slices", "remove_optimistic", "lookup_nibble_slices", "update_nibble_slices", "nibble_min_lg_lookup", "nibble_min_lg_update",
+ * "update_window_tile", "update_window_wide", "update_window_force_fail", "ragged_sort"; read-only counters "cbf_ordered_replays",
+ * "update_window_folds", "update_window_replays", "cms_small_weights_used", "cbf_lookup_shadow_hits".
+ * The A/B switches of experiments that were measured and dropped (NOTES.md) exist only in the bench build (-DPSK_BENCH_KNOBS=1,
+ * libpsk_hip_knobs.so); this library answers "unknown option" to them. */
 int psk_set_option(const char *name, int64_t value);
 int psk_get_option(const char *name, int64_t *value);
 /* Per-sketch options (round 4): "partition_min_keys", "cbf_lookup_shadow", "auto_combine", "update_window", "update_window_keys",

@@ -546,8 +546,84 @@ int64_t g_nib_gather_pipe = 0;   // 1 = k_nib_gather_pipe (psk_nibble_pipe.hpp: 
 int64_t g_nib_update_pipe = 1;   // 1 = k_nib_apply_pipe (psk_nibble_pipe.hpp: persistent workgroups, fold of slice s under the probes of slice s + 1; nontemporal
                                  // table accesses: 551 -> 514 us per 10 M adds), 3 = the same with plain accesses (A/B), 0 = k_nib_apply
 int64_t g_update_nibble = 1;   // CBF unit-weight adds / decrements into 2^26 .. 2^29 counters: 4-bit delta images, one level; 0 = two-level 32-bit path
+int64_t g_part_bins = 1;   // pass 1 through fixed-capacity bins wherever eligible (psk_part_bins.hpp); option "pass1_bins"
 int64_t g_part_dense_groups = 40;   // pass 2: segments of fewer groups (mean) are walked end to end (for_each_batch_at); 0 = never
 extern PSK_HIDDEN int64_t g_merge_single_rank;  // psk_merge.hip
+
+// ---- process-wide options: ONE table.  Three classes (include/psk.h lists the first by name):
+//   supported   tunables of the shipped library a caller may have a reason to touch;
+//   threshold   where the engine switches between its kernel families, and test hooks -- tests steer small inputs onto the big-table paths with them;
+//   knob        A/B switches of experiments that were measured and dropped: compiled in only with -DPSK_BENCH_KNOBS=1
+//               (python -m pyprobables_amd.build --knobs -> libpsk_hip_knobs.so), the shipped library answers "unknown option";
+//   read-only   counters tests read back.
+// (the per-sketch options -- kHoNames -- are handled in front of the table: their process defaults live in d_opt)
+namespace {
+enum OptClass { kOptSupported, kOptThreshold, kOptKnob, kOptReadOnly };
+struct OptDesc {
+    const char *name;
+    int64_t *var;
+    OptClass cls;
+    int64_t lo;  // smallest value accepted (smaller ones are raised to it)
+};
+constexpr int64_t kAny = INT64_MIN;
+const OptDesc kOptions[] = {
+    // supported
+    {"partition", &g_part_mode, kOptSupported, kAny},
+    {"partition_max_keys", &g_part_max_keys, kOptSupported, 1024},
+    {"partition_cache_bytes", &g_part_cache_bytes, kOptSupported, kAny},
+    {"combine_keys", &g_combine_keys, kOptSupported, kAny},
+    {"cms_small_weights", &g_small_weights, kOptSupported, kAny},
+    {"pass1_bins", &g_part_bins, kOptSupported, kAny},
+    {"merge_single_rank", &g_merge_single_rank, kOptSupported, kAny},
+    // thresholds of the path choice, test hooks
+    {"partition_two_level_slices", &g_part_two_level_slices, kOptThreshold, kAny},
+    {"auto_combine_keys", &g_auto_combine_keys, kOptThreshold, kAny},
+    {"tile_threads", &g_part_tile_threads, kOptThreshold, kAny},
+    {"even_tiles", &g_part_even_tiles, kOptThreshold, kAny},
+    {"dense_walk_groups", &g_part_dense_groups, kOptThreshold, kAny},
+    {"lookup_half_slices", &g_lookup_half, kOptThreshold, kAny},
+    {"remove_optimistic", &g_remove_dryrun, kOptThreshold, kAny},
+    {"lookup_nibble_slices", &g_lookup_nibble, kOptThreshold, kAny},
+    {"update_nibble_slices", &g_update_nibble, kOptThreshold, kAny},
+    {"nibble_min_lg_lookup", &g_nib_min_lg_lookup, kOptThreshold, 20},
+    {"nibble_min_lg_update", &g_nib_min_lg_update, kOptThreshold, 20},
+    {"update_window_tile", &g_window_tile, kOptThreshold, kAny},
+    {"update_window_wide", &g_window_wide, kOptThreshold, kAny},
+    {"update_window_force_fail", &g_window_force_fail, kOptThreshold, kAny},
+    {"ragged_sort", &g_ragged_sort, kOptThreshold, kAny},
+    // read-only counters
+    {"cbf_ordered_replays", &g_cbf_ordered_replays, kOptReadOnly, kAny},
+    {"update_window_folds", &g_window_folds, kOptReadOnly, kAny},
+    {"update_window_replays", &g_window_replays, kOptReadOnly, kAny},
+    {"cms_small_weights_used", &g_small_weights_used, kOptReadOnly, kAny},
+    {"cbf_lookup_shadow_hits", &g_cbf_shadow_hits, kOptReadOnly, kAny},
+    // retired experiments (bench builds only)
+    {"part_debug", &g_part_debug, kOptKnob, kAny},
+    {"combine_scatter", &g_combine_scatter, kOptKnob, kAny},
+    {"combine_fused_flush", &g_fused_flush, kOptKnob, kAny},
+    {"lookup_run_lanes", &g_lookup_run_lanes, kOptKnob, kAny},
+    {"lookup_split", &g_lookup_split, kOptKnob, kAny},
+    {"lookup_collect_threads", &g_lookup_collect_threads, kOptKnob, kAny},
+    {"slice_bias", &g_part_slice_bias, kOptKnob, kAny},
+    {"scatter_workgroups", &g_part_wgs, kOptKnob, kAny},
+    {"nibble_update_layout", &g_nib_update_layout, kOptKnob, kAny},
+    {"nibble_update_parts", &g_nib_update_parts, kOptKnob, kAny},
+    {"nibble_update_pipe", &g_nib_update_pipe, kOptKnob, kAny},
+    {"nibble_lookup_pipe", &g_nib_gather_pipe, kOptKnob, kAny},
+    {"nibble_nt_loads", &g_nib_nt, kOptKnob, kAny},
+    {"update_window_nt", &g_window_nt, kOptKnob, kAny},
+    {"update_window_image", &g_window_image, kOptKnob, kAny},
+    {"update_window_shadow", &g_window_shadow, kOptKnob, kAny},
+    {"update_window_shadow_writes", &g_window_shadow_writes, kOptKnob, kAny},
+    {"big_table_nt", &g_big_table_nt, kOptKnob, kAny},
+};
+const OptDesc *opt_find(const char *name)
+{
+    for (const OptDesc &d : kOptions)
+        if (!strcmp(name, d.name)) return (d.cls == kOptKnob && !kBenchKnobs) ? nullptr : &d;
+    return nullptr;
+}
+}  // namespace
 
 extern "C" int psk_set_option(const char *name, int64_t value)
 {
@@ -558,53 +634,10 @@ extern "C" int psk_set_option(const char *name, int64_t value)
         *ho_var(i) = value;
         return PSK_OK;
     }
-    if (!strcmp(name, "partition")) g_part_mode = value;
-    else if (!strcmp(name, "partition_min_keys")) g_part_min_keys = value;
-    else if (!strcmp(name, "partition_max_keys")) g_part_max_keys = value < 1024 ? 1024 : value;
-    else if (!strcmp(name, "partition_cache_bytes")) g_part_cache_bytes = value;
-    else if (!strcmp(name, "partition_two_level_slices")) g_part_two_level_slices = value;
-    else if (!strcmp(name, "part_debug")) g_part_debug = value;
-    else if (!strcmp(name, "merge_single_rank")) g_merge_single_rank = value;
-    else if (!strcmp(name, "combine_keys")) g_combine_keys = value;
-    else if (!strcmp(name, "auto_combine")) g_auto_combine = value;
-    else if (!strcmp(name, "combine_scatter")) g_combine_scatter = value;
-    else if (!strcmp(name, "combine_fused_flush")) g_fused_flush = value;
-    else if (!strcmp(name, "auto_combine_keys")) g_auto_combine_keys = value;
-    else if (!strcmp(name, "lookup_run_lanes")) g_lookup_run_lanes = value;
-    else if (!strcmp(name, "bloom_lookup")) g_bloom_lookup = value;
-    else if (!strcmp(name, "lookup_split")) g_lookup_split = value;
-    else if (!strcmp(name, "tile_threads")) g_part_tile_threads = value;
-    else if (!strcmp(name, "slice_bias")) g_part_slice_bias = value;
-    else if (!strcmp(name, "scatter_workgroups")) g_part_wgs = value;
-    else if (!strcmp(name, "even_tiles")) g_part_even_tiles = value;
-    else if (!strcmp(name, "dense_walk_groups")) g_part_dense_groups = value;
-    else if (!strcmp(name, "lookup_half_slices")) g_lookup_half = value;
-    else if (!strcmp(name, "lookup_collect_threads")) g_lookup_collect_threads = value;
-    else if (!strcmp(name, "scratch_budget_bytes")) g_scratch_budget = value;
-    else if (!strcmp(name, "remove_optimistic")) g_remove_dryrun = value;
-    else if (!strcmp(name, "lookup_nibble_slices")) g_lookup_nibble = value;
-    else if (!strcmp(name, "update_nibble_slices")) g_update_nibble = value;
-    else if (!strcmp(name, "nibble_update_layout")) g_nib_update_layout = value;
-    else if (!strcmp(name, "nibble_update_parts")) g_nib_update_parts = value;
-    else if (!strcmp(name, "nibble_update_pipe")) g_nib_update_pipe = value;
-    else if (!strcmp(name, "nibble_lookup_pipe")) g_nib_gather_pipe = value;
-    else if (!strcmp(name, "update_window_nt")) g_window_nt = value;
-    else if (!strcmp(name, "update_window_image")) g_window_image = value;
-    else if (!strcmp(name, "update_window_wide")) g_window_wide = value;
-    else if (!strcmp(name, "update_window_shadow")) g_window_shadow = value;
-    else if (!strcmp(name, "big_table_nt")) g_big_table_nt = value;
-    else if (!strcmp(name, "ragged_sort")) g_ragged_sort = value;
-    else if (!strcmp(name, "update_window_tile")) g_window_tile = value;
-    else if (!strcmp(name, "nibble_min_lg_lookup")) g_nib_min_lg_lookup = value < 20 ? 20 : value;
-    else if (!strcmp(name, "nibble_min_lg_update")) g_nib_min_lg_update = value < 20 ? 20 : value;
-    else if (!strcmp(name, "nibble_nt_loads")) g_nib_nt = value;
-    else if (!strcmp(name, "cbf_lookup_shadow")) g_cbf_shadow = value;
-    else if (!strcmp(name, "cms_small_weights")) g_small_weights = value;
-    else if (!strcmp(name, "remove_exact")) g_remove_exact = value;
-    else if (!strcmp(name, "update_window")) g_window = value;
-    else if (!strcmp(name, "update_window_keys")) g_window_keys = value;
-    else if (!strcmp(name, "update_window_force_fail")) g_window_force_fail = value;
-    else return fail(PSK_EINVAL, "unknown option %s", name);
+    const OptDesc *d = opt_find(name);
+    if (!d || d->cls == kOptReadOnly) return fail(PSK_EINVAL, d ? "option %s is read-only" : "unknown option %s", name);
+    if (value < d->lo) value = d->lo;
+    *d->var = value;
     return PSK_OK;
 }
 
@@ -661,57 +694,9 @@ extern "C" int psk_get_option(const char *name, int64_t *value)
         *value = __atomic_load_n(&d_opt[i], __ATOMIC_RELAXED);
         return PSK_OK;
     }
-    if (!strcmp(name, "partition")) *value = g_part_mode;
-    else if (!strcmp(name, "partition_min_keys")) *value = g_part_min_keys;
-    else if (!strcmp(name, "partition_max_keys")) *value = g_part_max_keys;
-    else if (!strcmp(name, "partition_cache_bytes")) *value = g_part_cache_bytes;
-    else if (!strcmp(name, "partition_two_level_slices")) *value = g_part_two_level_slices;
-    else if (!strcmp(name, "combine_keys")) *value = g_combine_keys;
-    else if (!strcmp(name, "auto_combine")) *value = g_auto_combine;
-    else if (!strcmp(name, "combine_scatter")) *value = g_combine_scatter;
-    else if (!strcmp(name, "combine_fused_flush")) *value = g_fused_flush;
-    else if (!strcmp(name, "auto_combine_keys")) *value = g_auto_combine_keys;
-    else if (!strcmp(name, "bloom_lookup")) *value = g_bloom_lookup;
-    else if (!strcmp(name, "lookup_split")) *value = g_lookup_split;
-    else if (!strcmp(name, "tile_threads")) *value = g_part_tile_threads;
-    else if (!strcmp(name, "lookup_run_lanes")) *value = g_lookup_run_lanes;
-    else if (!strcmp(name, "even_tiles")) *value = g_part_even_tiles;
-    else if (!strcmp(name, "dense_walk_groups")) *value = g_part_dense_groups;
-    else if (!strcmp(name, "lookup_half_slices")) *value = g_lookup_half;
-    else if (!strcmp(name, "lookup_collect_threads")) *value = g_lookup_collect_threads;
-    else if (!strcmp(name, "scratch_budget_bytes")) *value = g_scratch_budget;
-    else if (!strcmp(name, "remove_optimistic")) *value = g_remove_dryrun;
-    else if (!strcmp(name, "lookup_nibble_slices")) *value = g_lookup_nibble;
-    else if (!strcmp(name, "update_nibble_slices")) *value = g_update_nibble;
-    else if (!strcmp(name, "nibble_update_layout")) *value = g_nib_update_layout;
-    else if (!strcmp(name, "nibble_update_parts")) *value = g_nib_update_parts;
-    else if (!strcmp(name, "nibble_update_pipe")) *value = g_nib_update_pipe;
-    else if (!strcmp(name, "nibble_lookup_pipe")) *value = g_nib_gather_pipe;
-    else if (!strcmp(name, "update_window_nt")) *value = g_window_nt;
-    else if (!strcmp(name, "update_window_image")) *value = g_window_image;
-    else if (!strcmp(name, "update_window_wide")) *value = g_window_wide;
-    else if (!strcmp(name, "update_window_shadow")) *value = g_window_shadow;
-    else if (!strcmp(name, "update_window_shadow_writes")) *value = g_window_shadow_writes;
-    else if (!strcmp(name, "big_table_nt")) *value = g_big_table_nt;
-    else if (!strcmp(name, "ragged_sort")) *value = g_ragged_sort;
-    else if (!strcmp(name, "update_window_tile")) *value = g_window_tile;
-    else if (!strcmp(name, "nibble_min_lg_lookup")) *value = g_nib_min_lg_lookup;
-    else if (!strcmp(name, "nibble_min_lg_update")) *value = g_nib_min_lg_update;
-    else if (!strcmp(name, "nibble_nt_loads")) *value = g_nib_nt;
-    else if (!strcmp(name, "cbf_lookup_shadow")) *value = g_cbf_shadow;
-    else if (!strcmp(name, "cms_small_weights")) *value = g_small_weights;
-    else if (!strcmp(name, "remove_exact")) *value = g_remove_exact;
-    else if (!strcmp(name, "cbf_ordered_replays")) *value = g_cbf_ordered_replays;
-    else if (!strcmp(name, "update_window")) *value = g_window;
-    else if (!strcmp(name, "update_window_keys")) *value = g_window_keys;
-    else if (!strcmp(name, "update_window_force_fail")) *value = g_window_force_fail;
-    else if (!strcmp(name, "update_window_folds")) *value = g_window_folds;
-    else if (!strcmp(name, "update_window_replays")) *value = g_window_replays;
-    else if (!strcmp(name, "cms_small_weights_used")) *value = g_small_weights_used;
-    else if (!strcmp(name, "cbf_lookup_shadow_hits")) *value = g_cbf_shadow_hits;
-    else if (!strcmp(name, "scatter_workgroups")) *value = g_part_wgs;
-    else if (!strcmp(name, "slice_bias")) *value = g_part_slice_bias;
-    else return fail(PSK_EINVAL, "unknown option %s", name);
+    const OptDesc *d = opt_find(name);
+    if (!d) return fail(PSK_EINVAL, "unknown option %s", name);
+    *value = *d->var;
     return PSK_OK;
 }
 

@@ -4,11 +4,13 @@
 #pragma once
 #include "psk_device.hpp"
 #include "psk_partition.hpp"
+#include "psk_part_bins.hpp"
 
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <type_traits>
@@ -353,10 +355,95 @@ struct ScatterTarget {
 
 constexpr size_t kScatterLdsBudget = 160 * 1024;
 constexpr size_t kScatterLdsTwoPerCu = 78 * 1024;  // two workgroups' dynamic LDS per CU
+
+template <class Src>
+struct src_fat512 { static constexpr bool value = std::is_same<Src, KeysFixed16>::value || std::is_same<Src, KeysFixed16Multi>::value || std::is_same<Src, KeysFixed8>::value; };
+
+// ---- pass 1 through fixed-capacity bins (psk_part_bins.hpp, round 6): which (layout, payload, k) may take it, and its geometry
+// option "pass1_bins": 1 (default) = wherever eligible, 0 = k_part_scatter everywhere (A/B, tests)
+extern PSK_HIDDEN int64_t g_part_bins;
+template <class Src, class Pay, int KT>
+struct bins_eligible {
+    static constexpr bool value = pay_bins_ok<Pay>::value && KT <= 8 && src_fat512<Src>::value;  // (the 16- and 8-byte layouts)
+};
+struct BinsPlan {
+    uint32_t tile, cap, stride, per_cu;
+    size_t lds;
+};
+// false: the geometry does not fit (too many slices for the write-out's lanes, or a bin table beyond the LDS)
+template <int KT>
+static bool bins_plan(const PartGeom *g, BinsPlan *p)
+{
+    if (g_part_bins == 0 || g->nbuckets > (uint32_t)kBinThreads * kBinSlicesPerLane || g->nbuckets < 2) return false;
+    constexpr double kSigmas = 3.5;  // bin capacity = mean + 3.5 sigma of a tile's load: ~1e-3 of the bins of a tile fill up (2.8 measured the same)
+    const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
+    p->tile = (uint32_t)kBinThreads * kBinKpt;
+    const double mean = (double)p->tile * kk / (double)g->nbuckets;
+    uint32_t cap = (uint32_t)(mean + kSigmas * __builtin_sqrt(mean) + 2.0);
+    cap = (cap + 5) / 6 * 6;            // whole groups
+    p->cap = cap;
+    // words between bins: 2 in front of the probes (word 1 = the counter), the probes, the slot a full bin's stores land on -- rounded up to
+    // 2 (mod 4), so that neighbouring bins start two banks apart (slot r of ALL bins is what the lanes of a wave write at about the same time)
+    uint32_t stride = kBinHead + cap + 1;
+    while (stride % 4 != 2) ++stride;
+    p->stride = stride;
+    p->lds = ((size_t)g->nbuckets * stride + 8) * 4;
+    if (p->lds > kScatterLdsBudget / 2) return false;   // (at least two workgroups per CU, or the old shape does better)
+    uint32_t per_cu = (uint32_t)(kScatterLdsBudget / p->lds);
+    const uint32_t by_waves = 2048u / (uint32_t)kBinThreads;   // (32 wave slots per CU)
+    p->per_cu = per_cu > by_waves ? by_waves : per_cu;
+    return true;
+}
+
+template <class Src, class IdxFn, class Pay, class Spill, int KT>
+static int launch_scatter_bins(psk_sketch *s, const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, PartGeom *g, uint64_t n,
+                               hipStream_t st, uint32_t want_wgs, const BinsPlan &bp)
+{
+    const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
+    const uint64_t tile_full = bp.tile;
+    const uint64_t ntiles = (n + tile_full - 1) / tile_full;
+    // (32-bit key indices inside the kernel: n < 2^31, the caller checked; the prefetch of the tile behind the last one stays below 2^32)
+    uint64_t nwg = 256ULL * bp.per_cu;
+    if (want_wgs) nwg = want_wgs;
+    if (g_part_wgs > 0) nwg = (uint64_t)g_part_wgs;
+    if (nwg > 64u * kApplyWaves) nwg = 64u * kApplyWaves;  // pass 2: a wave walks at most one segment per lane (for_each_batch_at)
+    if (nwg > ntiles) nwg = ntiles;
+    if (nwg == 0) nwg = 1;
+    const uint64_t tiles_per_wg = (ntiles + nwg - 1) / nwg;
+    uint64_t tk = tile_full;
+    if (g_part_even_tiles != 0 && nwg * tiles_per_wg > ntiles) {  // (see launch_scatter_nt)
+        tk = ((n + nwg * tiles_per_wg - 1) / (nwg * tiles_per_wg) + 63) & ~63ULL;
+        if (tk > tile_full) tk = tile_full;
+    }
+    const double mean = (double)tiles_per_wg * (double)tk * kk / (double)g->nbuckets;  // probes per segment
+    uint64_t segcap = (uint64_t)(mean / 6.0 + 0.5 * (double)tiles_per_wg + 8.0 * __builtin_sqrt(mean) / 6.0 + 16.0);
+    if constexpr (pay_tile_tag<Pay>::value) {
+        if (tiles_per_wg > 16) return fail(PSK_EINVAL, "lookup round of %llu keys needs %llu tiles per workgroup (max 16)",
+                                           (unsigned long long)n, (unsigned long long)tiles_per_wg);
+    }
+    if (segcap >= (1u << 24) || (uint64_t)g->nbuckets * segcap >= (1ULL << 32))
+        return fail(PSK_EINVAL, "partition round of %llu keys is too large (segments of %llu groups)", (unsigned long long)n, (unsigned long long)segcap);
+    g->nwg = (uint32_t)nwg;
+    g->segcap = (uint32_t)segcap;
+    g->tile = (uint32_t)tk;
+    g->dense = (mean / 6.0 + 0.5 * (double)tiles_per_wg) < (double)g_part_dense_groups ? 1u : 0u;
+    PSK_TRY(ensure(s->s_part, (uint64_t)g->nbuckets * nwg * segcap * 16 + 256));
+    PSK_TRY(ensure(s->s_cnt, (uint64_t)g->nbuckets * nwg * 4 + 128));
+    auto kern = k_part_bins<Src, IdxFn, Pay, Spill, KT, kBinKpt>;
+    PSK_TRY(set_dyn_lds(kern, bp.lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kBinThreads), bp.lds, st, src, idxfn, pay, spill, *g, (uint32_t)n, bp.cap, bp.stride,
+                       (uint32_t *)s->s_cnt.p, (uint4 *)s->s_part.p);
+    HIP_TRY(hipGetLastError());
+    return PSK_OK;
+}
 template <class Src, class IdxFn, class Pay, class Spill, int KT, int NT>
 static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, const Pay &pay, const Spill &spill, PartGeom *g,
                              uint64_t n, hipStream_t st, uint32_t want_wgs, const ScatterTarget *fixed = nullptr)
 {
+    if constexpr (bins_eligible<Src, Pay, KT>::value) {  // pass 1 through fixed-capacity bins where the geometry admits it (psk_part_bins.hpp)
+        BinsPlan bp;
+        if (!fixed && n < (1ULL << 31) && bins_plan<KT>(g, &bp)) return launch_scatter_bins<Src, IdxFn, Pay, Spill, KT>(s, src, idxfn, pay, spill, g, n, st, want_wgs, bp);
+    }
     using Tile = PartTile<Pay, KT, NT>;
     constexpr bool kSorted = src_sorted<Src>::value;  // (keys of different lengths: + the LDS of the tile's length sort)
     const uint32_t kk = g->k < (uint32_t)KT ? g->k : (uint32_t)KT;
@@ -431,8 +518,6 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
 // the two-per-CU twin (Pay::fat512) exists for the 16-byte fast layouts only: the other layouts take the one 1024-thread shape (keys of
 // different lengths hold a descriptor and a window per key in registers -- four keys per thread spill --, and the rare layouts are not worth
 // a second copy of every kernel)
-template <class Src>
-struct src_fat512 { static constexpr bool value = std::is_same<Src, KeysFixed16>::value || std::is_same<Src, KeysFixed16Multi>::value || std::is_same<Src, KeysFixed8>::value; };
 
 template <class Pay, int KT, bool FAT = true>
 static int scatter_threads(const PartGeom *g)
@@ -458,6 +543,16 @@ template <class Pay, int KT, bool FAT = true, bool SORTED = false>
 static uint64_t scatter_round_cap(const PartGeom *g, uint32_t want_wgs, uint32_t max_tiles)
 {
     if constexpr (!FAT && (pay_fat512<Pay>::value || pay_fat1024<Pay>::value)) return scatter_round_cap<PaySlim<Pay>, KT, false, SORTED>(g, want_wgs, max_tiles);
+    if constexpr (pay_bins_ok<Pay>::value && KT <= 8 && FAT) {  // (FAT = src_fat512: the layouts whose pass 1 goes through the bins, launch_scatter_bins)
+        BinsPlan bp;
+        if (bins_plan<KT>(g, &bp)) {
+            uint64_t nwg = 256ULL * bp.per_cu;
+            if (want_wgs) nwg = want_wgs;
+            if (g_part_wgs > 0) nwg = (uint64_t)g_part_wgs;
+            if (nwg > 64u * kApplyWaves) nwg = 64u * kApplyWaves;
+            return nwg * max_tiles * bp.tile;
+        }
+    }
     const bool big = scatter_threads<Pay, KT, FAT>(g) == 1024;
     const size_t lds = big ? scatter_lds_bytes<Pay, KT, 1024>(g) : scatter_lds_bytes<Pay, KT, kPartThreads>(g);
     uint64_t tile = big ? (uint64_t)PartTile<Pay, KT, 1024>::TILE : (uint64_t)PartTile<Pay, KT, kPartThreads>::TILE;

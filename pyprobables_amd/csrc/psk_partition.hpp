@@ -48,6 +48,14 @@ constexpr uint32_t kGeomNoSortBit = 0x40000000u;  // PartGeom::dbg bit 30 (a pro
 constexpr int kSortSub = 16;                 // pass 1's length sort of ragged keys: counters per length class (one per lane mod 16)
 constexpr int kSortBins = 64 * kSortSub;
 constexpr uint32_t kPadProbe = 0xFFFFFFFFu;  // filler that pads every run to whole groups; pass 2 skips it
+// Wave priorities inside pass 1 (s_setprio; -DPSK_EXP_PRIO=n for A/B builds, scripts/build_variant.sh): 1 (default) = the hash phase runs at
+// priority 0 and everything behind barrier 1 (scan, sort, write-out: short dependent VALU sequences between LDS round trips) at priority 3,
+// so that a workgroup in its LDS phases is never queued behind the other workgroup's hash chains (same-box A/B, profiles/r06_ab_pass1.txt:
+// cfg 2 step 369 -> 362-366 us with k_part_scatter, 350 -> 346 with k_part_bins); 0 = all waves equal, 2 = the reverse (no gain), 3 = only the
+// scanning wave raised (no gain)
+#ifndef PSK_EXP_PRIO
+#define PSK_EXP_PRIO 1
+#endif
 
 enum PartMode { kModePlain = 0, kModeInline = 1, kModeKeyed = 2 };
 
@@ -726,6 +734,8 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         uint32_t *hist_next = hist0 + (size_t)(parity ? 0 : B);
         parity ^= 1u;
         PSK_TICK(1);
+        if constexpr (PSK_EXP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if constexpr (PSK_EXP_PRIO == 2) __builtin_amdgcn_s_setprio(3);
 
         // ---- hash + histogram: rank = my position among this tile's probes of the same slice
         uint32_t idx[KPT][KT], rank[KPT][KT], payload[KPT];
@@ -843,6 +853,9 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
         PSK_TICK(9);
         lds_barrier();
         PSK_TICK(2);
+        if constexpr (PSK_EXP_PRIO == 1) __builtin_amdgcn_s_setprio(3);
+        if constexpr (PSK_EXP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+        if constexpr (PSK_EXP_PRIO == 3) { if (threadIdx.x < 64) __builtin_amdgcn_s_setprio(3); }
 
         // ---- prefetch the next tile's keys (consumed -- pinned -- before the write-out below)
         uint64_t nbase = 0;
@@ -897,6 +910,7 @@ __global__ __launch_bounds__(NTHREADS, (KT <= 8 ? 4 : 1)) void k_part_scatter(Sr
             }
         }
         PSK_TICK(8);
+        if constexpr (PSK_EXP_PRIO == 3) { if (threadIdx.x < 64) __builtin_amdgcn_s_setprio(0); }
         lds_barrier();
         if (B <= 64 * kPartScanPerThread) tile_probes = wave_tot[0];
         PSK_TICK(3);

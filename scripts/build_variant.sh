@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B helper: scripts/build_variant.sh NAME "-DFOO=1 ..." -> ab/libpsk_NAME.so
-# Recompiles only the power-of-two Bloom launcher units (insert + lookup: the bench path of cfg 2 / cfg 5) with the extra
+# Recompiles only the power-of-two Bloom launcher units (insert + lookup: the bench path of cfg 2 / cfg 5; UNITS="psk_part_cms ..." names others) with the extra
 # flags and links them with the shipped build's other objects (python -m pyprobables_amd.build first).  Load the result
 # through PSK_LIB_PATH (scripts/ab.sh).
 set -e
@@ -12,7 +12,7 @@ OUT=$ROOT/ab/$NAME
 mkdir -p "$OUT"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -fvisibility-inlines-hidden"
 pids=()
-for u in psk_part_bloom_add psk_part_bloom_check; do
+for u in ${UNITS:-psk_part_bloom_add psk_part_bloom_check}; do
   /opt/rocm/bin/hipcc $FLAGS $EXTRA -DPSK_TU_POW2=1 -c $CSRC/$u.hip -o $OUT/${u}_v1.o &
   pids+=($!)
 done

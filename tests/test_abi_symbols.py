@@ -68,3 +68,35 @@ def test_fails_loudly_without_a_device():
         pa.CountMinSketch(width=100, depth=3)
     with pytest.raises(pa.NativeLibraryError):
         pa.CountingBloomFilter(est_elements=10, false_positive_rate=0.05)
+
+
+# include/psk.h's option table: the names a caller may rely on
+SUPPORTED_OPTIONS = ["partition", "partition_min_keys", "partition_max_keys", "partition_cache_bytes", "scratch_budget_bytes", "pass1_bins", "bloom_lookup",
+                     "cms_small_weights", "cbf_lookup_shadow", "remove_exact", "update_window", "update_window_keys", "auto_combine", "combine_keys",
+                     "merge_single_rank"]
+# A/B switches of experiments that were measured and dropped: bench build (-DPSK_BENCH_KNOBS=1) only
+RETIRED_OPTIONS = ["update_window_shadow", "update_window_image", "update_window_nt", "nibble_lookup_pipe", "nibble_update_pipe", "nibble_update_parts",
+                   "nibble_update_layout", "nibble_nt_loads", "big_table_nt", "lookup_split", "lookup_run_lanes", "lookup_collect_threads", "slice_bias",
+                   "scatter_workgroups", "combine_scatter", "combine_fused_flush", "part_debug"]
+
+
+def test_option_table_supported_names_work_and_retired_ones_are_rejected():
+    """psk_set_option / psk_get_option are host-only: the shipped library knows every name of include/psk.h's table, gives each back what was
+    set, and answers "unknown option" to the retired bench knobs"""
+    from pyprobables_amd import _native as N
+
+    L = N.lib()
+    header = (ROOT / "include" / "psk.h").read_text()
+    assert len(SUPPORTED_OPTIONS) <= 15
+    for name in SUPPORTED_OPTIONS:
+        assert f'"{name}"' in header, f"{name} missing from include/psk.h's option table"
+        old = N.get_option(name)
+        N.set_option(name, old)
+        assert N.get_option(name) == old
+    if N.LIB_PATH.name != "libpsk_hip.so":
+        return  # (a bench build loaded through PSK_LIB_PATH knows the retired names by design)
+    for name in RETIRED_OPTIONS:
+        assert L.psk_set_option(name.encode(), 0) != 0 and "unknown option" in N.last_error(), name
+        v = C.c_int64(0)
+        assert L.psk_get_option(name.encode(), C.byref(v)) != 0, name
+    assert L.psk_set_option(b"update_window_folds", 1) != 0 and "read-only" in N.last_error()  # counters are read-only

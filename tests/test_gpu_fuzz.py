@@ -28,7 +28,7 @@ def engine_options():
     from pyprobables_amd import _native as N
 
     old = {k: N.get_option(k) for k in ("partition", "partition_min_keys", "partition_max_keys", "partition_cache_bytes", "partition_two_level_slices",
-                                        "bloom_lookup", "lookup_split", "even_tiles", "dense_walk_groups", "cms_small_weights")}
+                                        "bloom_lookup", "even_tiles", "dense_walk_groups", "cms_small_weights", "pass1_bins")}
     yield N
     for k, v in old.items():
         N.set_option(k, v)
@@ -69,6 +69,7 @@ def test_fuzz_bloom(pa, oracle, engine_options, seed):
     engine_options.set_option("bloom_lookup", int(seed % 5))   # keyed probes / return trip / chosen per call / tile flags / lazy gathers
     engine_options.set_option("even_tiles", int(seed // 3 % 2))
     engine_options.set_option("dense_walk_groups", (0, 40, 1 << 30)[seed // 2 % 3])  # pass 2: chunked walk / by segment length / end-to-end walk
+    engine_options.set_option("pass1_bins", int(seed // 2 % 2))  # pass 1 through fixed-capacity bins / the counting sort (16- and 8-byte keys)
     est = int(rng.choice([50, 3000, 40_000, 200_000, 1_000_000]))
     fpr = float(rng.choice([0.3, 0.05, 0.01, 0.001, 1e-6]))
     blm = pa.BloomFilter(est_elements=est, false_positive_rate=fpr)
@@ -97,7 +98,6 @@ def test_fuzz_cms(pa, oracle, engine_options, seed):
     engine_options.set_option("partition", int(rng.integers(0, 2)))
     engine_options.set_option("partition_min_keys", int(rng.choice([1, 1, 4096])))
     engine_options.set_option("partition_two_level_slices", int(rng.choice([0, 2, 512])))
-    engine_options.set_option("lookup_split", int(seed % 2))
     engine_options.set_option("dense_walk_groups", (0, 40, 1 << 30)[seed // 2 % 3])
     engine_options.set_option("cms_small_weights", (1, 2, 1, 0)[seed // 3 % 4])  # weighted adds: compact probe format by the hint / always / never
     width = int(rng.choice([7, 1000, 4096, 65_536, 100_003, 1 << 18]))

@@ -194,11 +194,8 @@ def test_lookup_value_formats_and_shared_slices(pa, oracle, force_partition):
     ocm.remove_keys(keys[:5000], np.full(5000, 100_000, dtype=np.int32))
     wantc = ocm.check_keys(keys).astype(np.int32)
     assert int(wantc.min()) < 0
-    for split in (1, 0):
-        force_partition.set_option("lookup_split", split)
-        assert np.array_equal(cbf.check_many(_dev(keys)).cpu().numpy().view(np.uint32), want)
-        assert np.array_equal(cms.check_many(_dev(keys)).cpu().numpy(), wantc)
-    force_partition.set_option("lookup_split", 1)
+    assert np.array_equal(cbf.check_many(_dev(keys)).cpu().numpy().view(np.uint32), want)
+    assert np.array_equal(cms.check_many(_dev(keys)).cpu().numpy(), wantc)
 
 
 # ------------------------------------------------------------------ 2^26 .. 2^27 counters: slices of 2^16 counters held as 16-bit values
