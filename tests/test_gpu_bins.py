@@ -180,3 +180,77 @@ def test_weighted_cms_adds_through_the_bins(pa, oracle, N, width, depth):
             assert np.array_equal(tab, oc.bins) and els == oc.els_added
     finally:
         N.set_option("cms_small_weights", old)
+
+
+@pytest.mark.parametrize("width,depth", [(2**20, 5), (2**18, 7), (100_003, 4), (2**16, 8)])
+def test_cms_lookups_with_bin_table_positions(pa, oracle, N, width, depth):
+    """return-trip lookups (countminsketch.py:332-340, 429-453) of tables the bins FILLED: pass 1 of the lookups themselves keeps the counting
+    sort (the bins measured slower there, profiles/r06_ab_lookup_bins.txt), so the option must not change an answer -- min, mean and mean-min
+    queries against the oracle, with keys that repeat 400 times inside a tile"""
+    n = 500_009
+    keys = oracle.gen_keys16(31, n)
+    w = oracle.gen_weights(31, n).astype(np.int32)
+    probe = np.concatenate([keys[: n // 2], oracle.gen_keys16(800_000_000, n // 2)])
+    hot = probe.copy()
+    hot[1000:1400] = hot[3]                                    # 400 copies of one key in a tile
+    for query in ("min", "mean", "mean-min"):
+        cls = {"min": pa.CountMinSketch, "mean": pa.CountMeanSketch, "mean-min": pa.CountMeanMinSketch}[query]
+        oc = oracle.OracleCMS(width, depth, query=query)
+        oc.add_keys(keys, w)
+        for bins in (1, 0):
+            N.set_option("pass1_bins", bins)
+            cms = cls(width=width, depth=depth)
+            cms.add_many(_dev(keys), _dev(w))
+            for p in (probe, hot):
+                got = cms.check_many(_dev(p)).cpu().numpy()
+                assert np.array_equal(got.astype(np.int64), oc.check_keys(p).astype(np.int64)), (query, bins)
+            del cms
+
+
+@pytest.mark.parametrize("est,fpr", [(28005615, 0.01), (10_000_000, 0.01), (28005615, 0.05)])
+def test_bloom_return_trip_lookups_with_bin_table_positions(pa, oracle, N, est, fpr):
+    """bloom_lookup = 1 (the return trip: one byte per group of six probes comes back, bloom.py:261-272) on filters the bins / the counting
+    sort filled"""
+    n = 900_001
+    keys = oracle.gen_keys16(41, n)
+    probe = np.concatenate([keys[: n // 2], oracle.gen_keys16(600_000_000, n // 2)])
+    probe[2000:2300] = probe[n - 5]                            # an absent key 300 times in one tile
+    for bins in (1, 0):
+        N.set_option("pass1_bins", bins)
+        blm = pa.BloomFilter(est_elements=est, false_positive_rate=fpr)
+        blm.add_many(_dev(keys))
+        if bins:
+            ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+            ob.add_keys(keys)
+            want = ob.check_keys(probe).astype(np.uint8)
+        blm.set_engine_option("bloom_lookup", 1)
+        assert np.array_equal(blm.check_many(_dev(probe)).cpu().numpy().astype(np.uint8), want)
+        assert bool(blm.check_many(_dev(keys)).all())
+        del blm
+
+
+@pytest.mark.parametrize("est", [2_000_000, 7_000_000])
+def test_cbf_lookups_with_bin_table_positions(pa, oracle, N, est):
+    """CountingBloomFilter.check (countingbloom.py:166-174) through 32-bit slices (1.9e7 counters) and 4-bit slice images (6.7e7) of tables
+    whose unit adds went through the bins (k <= 8, slices that fit) and through the counting sort"""
+    n = 600_000
+    keys = oracle.gen_keys16(51, n)
+    probe = np.concatenate([keys[: n // 2], oracle.gen_keys16(700_000_000, n // 2)])
+    old = N.get_option("lookup_nibble_slices")
+    try:
+        N.set_option("lookup_nibble_slices", 2)                # (the 4-bit images whatever the batch size, where the table is big enough)
+        want = None
+        for bins in (1, 0):
+            N.set_option("pass1_bins", bins)
+            cbf = pa.CountingBloomFilter(est_elements=est, false_positive_rate=0.01)
+            cbf.add_many(_dev(keys))
+            cbf.add_many(_dev(keys[: n // 3]))
+            if want is None:
+                oc = oracle.OracleCBF(cbf.number_bits, cbf.number_hashes)
+                oc.update_keys(keys)
+                oc.update_keys(keys[: n // 3])
+                want = oc.check_keys(probe)
+            assert np.array_equal(cbf.check_many(_dev(probe)).cpu().numpy().astype(np.uint32), want)
+            del cbf
+    finally:
+        N.set_option("lookup_nibble_slices", old)
