@@ -97,8 +97,8 @@ int psk_device_count(int *count);
  *   "partition_max_keys"        2^26     keys per partition round (bounds the scratch: ~2 GB per round at k = 7)
  *   "partition_cache_bytes"     240 MiB  cache-sized tables: a batch whose probe buffer exceeds 1.5 x this is cut into equal rounds (0 = never)
  *   "scratch_budget_bytes" (s)  0        cap on a handle's partition scratch (more, smaller rounds); 0 = none
- *   "pass1_bins"                1        pass 1 of Bloom inserts / tile-flag lookups through fixed-capacity LDS bins (psk_part_bins.hpp); 0 = the
- *                                        counting-sort form everywhere (same probes, same results)
+ *   "pass1_bins"                1        pass 1 of Bloom inserts / tile-flag lookups, CBF unit updates and weighted CMS adds through fixed-capacity
+ *                                        LDS bins where they fit (psk_part_bins.hpp); 0 = the counting sort everywhere (same probes, same results)
  *   "bloom_lookup" (s)          2        large Bloom lookups: 0 keyed probes, 1 return trip, 3 tile flags (batches of present keys), 4 lazy gathers
  *                                        (batches of absent keys), 2 = chosen per call from the previous lookups' miss tally
  *   "cms_small_weights"         1        weighted psk_cms_add: weights 0 .. 15 travel as 20-bit fields once the previous batches brought no

@@ -353,6 +353,10 @@ struct ScatterTarget {
     uint4 *part;
 };
 
+#ifndef PSK_LOOKUP_FAT_SLICES
+#define PSK_LOOKUP_FAT_SLICES 900
+#endif
+constexpr uint32_t kLookupFatSlices = PSK_LOOKUP_FAT_SLICES;  // return-trip lookups: 4096-key pass-1 tiles from this many slices on
 constexpr size_t kScatterLdsBudget = 160 * 1024;
 constexpr size_t kScatterLdsTwoPerCu = 78 * 1024;  // two workgroups' dynamic LDS per CU
 
@@ -450,6 +454,10 @@ static int launch_scatter_nt(psk_sketch *s, const Src &src, const IdxFn &idxfn, 
     // keys per tile: the shape's, cut down (whole waves) where its LDS stage would not fit -- 8-probe groups at 2048 slices carry 7 pad
     // slots per slice: 1984-key tiles instead of 2048 (the kernel sizes its stage by PartGeom::tile)
     uint64_t tile_full = Tile::TILE;
+    // lookups with the 4096-key shape (PayBloomLookup): only where the slices are many (pass 3's run copies halve); 2048 keys below that
+    if constexpr (pay_is_lookup<Pay>::value && pay_fat1024<Pay>::value) {
+        if (g->nbuckets < kLookupFatSlices && tile_full > 2048) tile_full = 2048;
+    }
     while (tile_full > 64 && scatter_lds_bytes<Pay, KT, NT>(g, tile_full, kSorted) > kScatterLdsBudget) tile_full -= 64;
     if (scatter_lds_bytes<Pay, KT, NT>(g, tile_full, kSorted) > kScatterLdsBudget) return fail(PSK_EINVAL, "pass 1: %u slices do not fit the LDS stage", g->nbuckets);
     const uint64_t ntiles = (n + tile_full - 1) / tile_full;

@@ -38,6 +38,10 @@ struct PayBloomLookup {  // as PayNone (6 x 20-bit bit indices per group) + the 
     static constexpr int mode = kModePlain;
     static constexpr int group = 6;
     static constexpr bool lookup = true;
+    // 4096-key tiles (32 probes per thread) for tables of ~900 slices and more -- the 1 GiB CountingBloomFilter's 1024 nibble slices, Bloom tables of
+    // 2^30 bits and more: a 2048-key tile brings 14 probes = 2.3 groups per slice there, and pass 3 copies every (tile, slice) run of values on
+    // its own (launch_scatter_nt keeps 2048-key tiles below that: kLookupFatSlices)
+    static constexpr bool fat1024 = true;
     uint32_t *perm;
     uint2 *runinfo;
     __device__ __forceinline__ uint32_t operator()(uint64_t, uint64_t) const { return 0; }

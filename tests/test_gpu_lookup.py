@@ -272,3 +272,22 @@ def test_wide_device_weights_are_range_checked(pa, oracle):
     oc.add_keys(keys, np.full(1000, 3, dtype=np.int32))
     assert np.array_equal(cms.table_tensor.cpu().numpy()[: oc.bins.size], oc.bins)
     assert cms.elements_added == 3000
+
+
+# ------------------------------------------------------------------ return-trip lookups into tables of ~900 slices and more: 4096-key pass-1 tiles
+@pytest.mark.parametrize("est", [112_000_000, 224_044_920])
+def test_bloom_return_trip_with_4096_key_tiles(pa, oracle, force_partition, est):
+    """m = 2^30 / 2^31 bits (1024 / 2048 slices): pass 1 of the return trip runs 4096-key tiles there (PayBloomLookup::fat1024 -- cut to what the
+    LDS stage holds at 2048 slices), perm[] positions reach past 2^15, pass 3 prefetches four perm records per thread.  A batch that ends inside a
+    tile, keys that repeat, half of the keys absent.  bloom.py:261-272."""
+    n = 2_600_003
+    keys = oracle.gen_keys16(61, n)
+    keys[5000:5200] = keys[4]
+    probe = np.concatenate([keys[: n // 2], oracle.gen_keys16(3_000_000_000, n // 2 + 1)])
+    blm = pa.BloomFilter(est_elements=est, false_positive_rate=0.01)
+    blm.add_many(_dev(keys))
+    ob = oracle.OracleBloom(blm.number_bits, blm.number_hashes)
+    ob.add_keys(keys)
+    blm.set_engine_option("bloom_lookup", 1)
+    assert np.array_equal(blm.check_many(_dev(probe)).cpu().numpy().astype(np.uint8), ob.check_keys(probe).astype(np.uint8))
+    assert bool(blm.check_many(_dev(keys)).all())
