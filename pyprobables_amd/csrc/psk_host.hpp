@@ -370,6 +370,7 @@ template <class Src, class Pay, int KT>
 struct bins_eligible {
     static constexpr bool value = pay_bins_ok<Pay>::value && KT <= 8 && src_fat512<Src>::value;  // (the 16- and 8-byte layouts)
 };
+constexpr size_t kBinSlackWords = 8 + 16;  // behind the last bin: what the write-out's last group may read past a bin's end + the bench build's phase-profile slots
 struct BinsPlan {
     uint32_t tile, cap, stride, per_cu;
     size_t lds;
@@ -391,7 +392,7 @@ static bool bins_plan(const PartGeom *g, BinsPlan *p)
     uint32_t stride = kBinHead + cap + 1;
     while (stride % 4 != 2) ++stride;
     p->stride = stride;
-    p->lds = ((size_t)g->nbuckets * stride + 8) * 4;
+    p->lds = ((size_t)g->nbuckets * stride + kBinSlackWords) * 4;
     if (p->lds > kScatterLdsBudget / 2) return false;   // (at least two workgroups per CU, or the old shape does better)
     uint32_t per_cu = (uint32_t)(kScatterLdsBudget / p->lds);
     const uint32_t by_waves = 2048u / (uint32_t)kBinThreads;   // (32 wave slots per CU)

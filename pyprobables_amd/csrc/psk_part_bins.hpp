@@ -95,6 +95,22 @@ __global__ __launch_bounds__(kBinThreads, kBinMinWaves) void k_part_bins(Src src
     }
     for (uint32_t b = threadIdx.x; b < B; b += NT) *reinterpret_cast<uint32_t *>(lds + b * stride4 + kCnt) = kBinHead * 4u;
 
+    // bench-only (a -DPSK_BENCH_KNOBS=1 build, scripts/ablate.py; every test below folds to false in the shipped library): PartGeom::dbg bit 1 =
+    // no segment stores, 2 = hashing only, 4 = no hashing (a cheap stand-in for the chains), 32 = phase profile -- lane 0 of the FIRST and of the
+    // LAST wave accumulate cycle-counter deltas per phase (hash + slots, wait at barrier 1, write-out, wait at barrier 2) in the LDS slack
+    const uint32_t dbg = kBenchKnobs ? g.dbg : 0u;
+    unsigned long long *t_acc = reinterpret_cast<unsigned long long *>(lds + (size_t)B * stride4 + 32);  // 8 slots (host: kBinSlackWords)
+    unsigned long long t_prev = 0;
+    const bool t_lane = (dbg & 32) && (threadIdx.x == 0 || threadIdx.x == NT - 64);
+    const uint32_t t_base = threadIdx.x == 0 ? 0u : 4u;
+    if ((dbg & 32) && threadIdx.x < 8) t_acc[threadIdx.x] = 0;
+#define PSK_BIN_TICK(ph)                                                 \
+    if (t_lane) {                                                        \
+        const unsigned long long t_now = __builtin_readcyclecounter();   \
+        t_acc[t_base + (ph)] += t_now - t_prev;                          \
+        t_prev = t_now;                                                  \
+    }
+    uint32_t fold = 0;  // (dbg & 2: keeps the hashes alive)
     constexpr bool WP = pay_weighted_plain<Pay>::value;  // PayWeightSmall: every probe carries its key's weight (prefetched with the key)
     typename Src::Key kcur[KPT];
     uint32_t wcur[WP ? KPT : 1];
@@ -111,6 +127,7 @@ __global__ __launch_bounds__(kBinThreads, kBinMinWaves) void k_part_bins(Src src
         }
     }
     lds_barrier();
+    if (t_lane) t_prev = __builtin_readcyclecounter();
 
     uint32_t ordinal = ~0u;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -140,7 +157,12 @@ __global__ __launch_bounds__(kBinThreads, kBinMinWaves) void k_part_bins(Src src
                 }
                 if constexpr (IdxFn::lo32) {
                     uint32_t h[KT];
-                    src.template hash32<KT>(kcur[q], i, 0u, h);
+                    if (dbg & 4) {
+#pragma unroll
+                        for (int j = 0; j < KT; ++j) h[j] = (uint32_t)(((uint64_t)(i * 2654435761u + (uint32_t)j * 40503u) * 0x9E3779B97F4A7C15ULL) >> 13);
+                    } else {
+                        src.template hash32<KT>(kcur[q], i, 0u, h);
+                    }
 #pragma unroll
                     for (int j = 0; j < KT; ++j) {
                         if constexpr (std::is_same<IdxFn, IdxBloom<true>>::value || std::is_same<IdxFn, IdxBloomWide<true>>::value) {
@@ -161,6 +183,11 @@ __global__ __launch_bounds__(kBinThreads, kBinMinWaves) void k_part_bins(Src src
                         val[j] = x & mask;
                         bin[j] = x >> g.shift;
                     }
+                }
+                if (dbg & 2) {  // bench-only: hashing alone
+#pragma unroll
+                    for (int j = 0; j < KT; ++j) fold ^= val[j] + bin[j];
+                    continue;
                 }
                 uint32_t at[KT], r4[KT], worst = 0;
 #pragma unroll
@@ -207,7 +234,13 @@ __global__ __launch_bounds__(kBinThreads, kBinMinWaves) void k_part_bins(Src src
                 if constexpr (WP) wcur[q] = pay(i < last ? i : last, 0);
             }
         }
+        if (dbg & 2) {  // bench-only: hashing alone -- no barrier, no write-out (uniform)
+            if (fold == 0x12345u) segcnt[0] = fold;
+            continue;
+        }
+        PSK_BIN_TICK(0);
         lds_barrier();
+        PSK_BIN_TICK(1);
         if constexpr (PSK_EXP_PRIO == 1) __builtin_amdgcn_s_setprio(3);
 
         // ---- write-out: my slices' bins as 16-byte groups behind my segments' cursors
@@ -231,7 +264,7 @@ __global__ __launch_bounds__(kBinThreads, kBinMinWaves) void k_part_bins(Src src
                     o.y = (a0.y >> 12) | (a1.x << 8) | hi0;
                     o.z = a1.y | (a2.x << 20);
                     o.w = (a2.x >> 12) | (a2.y << 8) | hi1;
-                    out[gq] = o;
+                    if (!(dbg & 1)) out[gq] = o;
                 }
                 if (rem && sub == (whole & (L - 1))) {  // the run's last group: the slots past the count read as pads (all ones in the field, as k_part_scatter leaves them)
                     const uint2 a0 = e[3 * whole], a1 = e[3 * whole + 1], a2 = e[3 * whole + 2];
@@ -245,7 +278,7 @@ __global__ __launch_bounds__(kBinThreads, kBinMinWaves) void k_part_bins(Src src
                     o.y = (f[1] >> 12) | (f[2] << 8) | ((n0 | t0) << 28);
                     o.z = f[3] | (f[4] << 20);
                     o.w = (f[4] >> 12) | (f[5] << 8) | ((n1 | t1) << 28);
-                    out[whole] = o;
+                    if (!(dbg & 1)) out[whole] = o;
                 }
             } else {  // the segment fills up: group by group, what does not fit takes the exact fallback probe by probe
                 for (uint32_t gq = sub; gq < ngroups; gq += L) {
@@ -286,8 +319,16 @@ __global__ __launch_bounds__(kBinThreads, kBinMinWaves) void k_part_bins(Src src
             Src::pin(kcur[q]);
             if constexpr (WP) asm volatile("" : "+v"(wcur[q]));
         }
+        PSK_BIN_TICK(2);
         lds_barrier();
+        PSK_BIN_TICK(3);
     }
+    if (t_lane) {  // (bench-only) behind the segment counts, where scripts/ablate.py reads them (psk_debug_phase_profile)
+        unsigned long long *prof = reinterpret_cast<unsigned long long *>(segcnt + (size_t)g.nbuckets * g.nwg);
+        for (int ph = 0; ph < 4; ++ph) atomicAdd(prof + 1 + t_base + ph, t_acc[t_base + ph]);
+        if (threadIdx.x == 0) atomicAdd(prof, 1ULL);
+    }
+#undef PSK_BIN_TICK
     if constexpr (WP) {  // (sum w, sum |w|, weights outside 0 .. 15) of my keys -> my slot: plain stores, folded by pass 2 / k_tally_fold
         if (pay.tally) {
             for (int o = 32; o > 0; o >>= 1) {
