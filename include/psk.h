@@ -116,7 +116,8 @@ int psk_device_count(int *count);
  * Also accepted -- where the engine switches between its kernel families, and test hooks (the tests steer small inputs onto the big-table paths
  * with them; not for callers): "partition_two_level_slices", "auto_combine_keys", "tile_threads", "even_tiles", "dense_walk_groups",
  * "lookup_half_slices", "remove_optimistic", "lookup_nibble_slices", "update_nibble_slices", "nibble_min_lg_lookup", "nibble_min_lg_update",
- * "update_window_tile", "update_window_wide", "update_window_force_fail", "ragged_sort"; read-only counters "cbf_ordered_replays",
+ * "update_window_tile", "update_window_wide", "update_window_force_fail", "ragged_sort", "host_poll_us" (how long a tiny PSK_HOST call
+ * polls its completion mailbox before it waits for the stream; 0 = never poll); read-only counters "cbf_ordered_replays",
  * "update_window_folds", "update_window_replays", "cms_small_weights_used", "cbf_lookup_shadow_hits".
  * The A/B switches of experiments that were measured and dropped (NOTES.md) exist only in the bench build (-DPSK_BENCH_KNOBS=1,
  * libpsk_hip_knobs.so); this library answers "unknown option" to them. */

@@ -33,6 +33,25 @@ def _resolve_device(device) -> int:
     return int(device)
 
 
+_raw_stream = getattr(getattr(torch, "_C", None), "_cuda_getCurrentRawStream", None) if torch is not None else None
+
+
+class OneKey:
+    """Argument and result words of the value-returning single-key calls (``key in blm``, ``cms.add(key)`` ...), allocated once per
+    sketch: the reference's whole interface is per key (bloom.py:252, countminsketch.py:257, countingbloom.py:125), and a call that is one
+    kernel launch + one wait should not spend more time building numpy arrays around its 16 bytes than on the device.  A handle is used
+    by one thread at a time (include/psk.h), so is this."""
+
+    __slots__ = ("w", "w_addr", "o", "o_addr", "o_u8", "o_i32", "o_u32")
+
+    def __init__(self):
+        self.w = np.zeros(1, dtype=np.int64)       # num_els of an ordered update
+        self.w_addr = self.w.ctypes.data
+        self.o = np.zeros(2, dtype=np.int64)       # the result (+ elements_added behind a CountMinSketch update)
+        self.o_addr = self.o.ctypes.data
+        self.o_u8, self.o_i32, self.o_u32 = self.o.view(np.uint8), self.o.view(np.int32), self.o.view(np.uint32)
+
+
 class DeviceTable:
     """owns the psk handle and the table tensor"""
 
@@ -40,6 +59,8 @@ class DeviceTable:
         L = N.lib()  # raises NativeLibraryError when the engine is missing
         self.kind, self.m, self.k = kind, int(m), int(k)
         self.device = _resolve_device(device)
+        self.one = OneKey()
+        self._cuda = torch is not None and torch.cuda.is_available()
         if N.device_count() == 0:
             raise NativeLibraryError(
                 "no HIP device available: the sketch table lives in GPU memory and there is no CPU fallback"
@@ -82,7 +103,9 @@ class DeviceTable:
     # -- helpers
     @property
     def stream(self):
-        if torch is not None and torch.cuda.is_available():
+        if self._cuda:  # torch's CURRENT stream of the sketch's device, looked up per call (callers switch streams)
+            if _raw_stream is not None:
+                return _raw_stream(self.device) or None
             return torch.cuda.current_stream(self.device).cuda_stream or None
         return None
 

@@ -24,7 +24,7 @@ from . import _native as N
 from ._base import DeviceTable
 from .exceptions import InitializationError, SimilarityError
 from .hashes import HashFuncT, HashResultsT, KeyT, default_fnv_1a, device_digest, is_fused_fnv
-from .keys import KeyBatch, digest_batch, pack_hashes, pack_keys
+from .keys import KeyBatch, digest_batch, one_key_bytes, pack_hashes, pack_keys
 
 _LN2_SQUARED = 0.4804530139182   # bloom.py:477 (the literal the reference and its C sibling use)
 _LN2 = 0.6931471805599453        # bloom.py:478
@@ -254,9 +254,21 @@ class BloomFilter:
         """bloom.py:241-250: insert the element represented by its hashes"""
         self._add_batch(pack_hashes(hashes, self._number_hashes))
 
+    def _one_key(self, key):
+        """a single key for the value-returning per-key calls: its bytes when the engine hashes it itself (``_base.OneKey``), else None"""
+        return one_key_bytes(key) if self._is_fused else None
+
     def check(self, key: KeyT) -> bool:
         """bloom.py:252-259"""
-        return bool(self._check_batch(self._batch(key))[0])
+        raw = self._one_key(key)
+        if raw is None:
+            return bool(self._check_batch(self._batch(key))[0])
+        if self._pending:
+            self._flush()
+        t = self._tab
+        one = t.one
+        N.check(N.lib().psk_bloom_check(t.handle, N.KEYS_FIXED, raw or None, None, 1, len(raw), N.HOST, one.o_addr, t.stream))
+        return bool(one.o_u8[0])
 
     def check_alt(self, hashes: HashResultsT) -> bool:
         """bloom.py:261-272"""

@@ -154,9 +154,23 @@ class CountingBloomFilter(BloomFilter):
         self._dirty = True
         return out
 
+    def _ordered_one(self, key, num_els, opmode: int):
+        """one ordered update of one key through the preallocated words (``_base.OneKey``); None: take the general path"""
+        raw = self._one_key(key)
+        if raw is None or type(num_els) is not int or not 0 <= num_els < 1 << 62:
+            return None
+        t = self._tab
+        one = t.one
+        one.w[0] = num_els
+        N.check(N.lib().psk_cbf_update_ordered(t.handle, N.KEYS_FIXED, raw or None, None, 1, len(raw), one.w_addr, opmode, N.HOST,
+                                               one.o_addr, t.stream))
+        self._dirty = True
+        return int(one.o_u32[0])
+
     def add(self, key: KeyT, num_els: int = 1) -> int:
         """countingbloom.py:125-133"""
-        return int(self._ordered(self._batch(key), num_els, N.OP_ADD)[0])
+        res = self._ordered_one(key, num_els, N.OP_ADD)
+        return res if res is not None else int(self._ordered(self._batch(key), num_els, N.OP_ADD)[0])
 
     def add_alt(self, hashes: HashResultsT, num_els: int = 1) -> int:
         """countingbloom.py:135-155"""
@@ -164,7 +178,8 @@ class CountingBloomFilter(BloomFilter):
 
     def remove(self, key: KeyT, num_els: int = 1) -> int:
         """countingbloom.py:176-184"""
-        return int(self._ordered(self._batch(key), num_els, N.OP_REMOVE)[0])
+        res = self._ordered_one(key, num_els, N.OP_REMOVE)
+        return res if res is not None else int(self._ordered(self._batch(key), num_els, N.OP_REMOVE)[0])
 
     def remove_alt(self, hashes: HashResultsT, num_els: int = 1) -> int:
         """countingbloom.py:186-208"""
@@ -177,7 +192,14 @@ class CountingBloomFilter(BloomFilter):
 
     def check(self, key: KeyT) -> int:  # type: ignore[override]
         """countingbloom.py:157-164"""
-        return int(self._check_batch(self._batch(key))[0])
+        raw = self._one_key(key)
+        if raw is None:
+            return int(self._check_batch(self._batch(key))[0])
+        t = self._tab
+        one = t.one
+        N.check(N.lib().psk_cbf_check(t.handle, N.KEYS_FIXED, raw or None, None, 1, len(raw), N.HOST, one.o_addr, t.stream))
+        self._release_borrowed()
+        return int(one.o_u32[0])
 
     def check_alt(self, hashes: HashResultsT) -> int:  # type: ignore[override]
         """countingbloom.py:166-174 (min over ALL supplied hashes)"""

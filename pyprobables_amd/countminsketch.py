@@ -23,7 +23,7 @@ from ._base import DeviceTable, weights_arg
 from .bloom import _existing_file, _torch_dtype
 from .exceptions import CountMinSketchError, InitializationError
 from .hashes import HashFuncT, HashResultsT, KeyT, default_fnv_1a, device_digest, is_fused_fnv
-from .keys import KeyBatch, digest_batch, pack_hashes, pack_keys
+from .keys import KeyBatch, digest_batch, one_key_bytes, pack_hashes, pack_keys
 
 _I32_MAX, _I32_MIN = 2**31 - 1, -(2**31)
 _I64_MAX, _I64_MIN = 2**63 - 1, -(2**63)
@@ -243,9 +243,23 @@ class CountMinSketch:
         self._els_added = int(out[b.n])
         return out[: b.n]
 
+    def _ordered_one(self, key, num_els, opmode: int):
+        """one ordered update of one key through the preallocated words (``_base.OneKey``); None: take the general path"""
+        raw = one_key_bytes(key) if self._is_fused else None
+        if raw is None or type(num_els) is not int or not -(1 << 62) < num_els < 1 << 62:
+            return None
+        t = self._tab
+        one = t.one
+        one.w[0] = num_els
+        N.check(N.lib().psk_cms_update_ordered(t.handle, N.KEYS_FIXED, raw or None, None, 1, len(raw), one.w_addr, opmode,
+                                               _QUERIES[self._query], self.elements_added, N.HOST, one.o_addr, t.stream))
+        self._els_added = int(one.o[1])
+        return int(one.o[0])
+
     def add(self, key: KeyT, num_els: int = 1) -> int:
         """countminsketch.py:257-265"""
-        return int(self._ordered(self._batch(key), num_els, N.OP_ADD)[0])
+        res = self._ordered_one(key, num_els, N.OP_ADD)
+        return res if res is not None else int(self._ordered(self._batch(key), num_els, N.OP_ADD)[0])
 
     def add_alt(self, hashes: HashResultsT, num_els: int = 1) -> int:
         """countminsketch.py:267-288"""
@@ -253,7 +267,8 @@ class CountMinSketch:
 
     def remove(self, key: KeyT, num_els: int = 1) -> int:
         """countminsketch.py:290-298"""
-        return int(self._ordered(self._batch(key), num_els, N.OP_REMOVE)[0])
+        res = self._ordered_one(key, num_els, N.OP_REMOVE)
+        return res if res is not None else int(self._ordered(self._batch(key), num_els, N.OP_REMOVE)[0])
 
     def remove_alt(self, hashes: HashResultsT, num_els: int = 1) -> int:
         """countminsketch.py:300-321"""
@@ -276,7 +291,18 @@ class CountMinSketch:
 
     def check(self, key: KeyT) -> int:
         """countminsketch.py:323-330"""
-        return int(self._check_batch(self._batch(key))[0])
+        raw = one_key_bytes(key) if self._is_fused else None
+        if raw is None:
+            return int(self._check_batch(self._batch(key))[0])
+        t = self._tab
+        one = t.one
+        if self._query == "mean-min":
+            N.check(N.lib().psk_cms_check_meanmin(t.handle, N.KEYS_FIXED, raw or None, None, 1, len(raw), N.HOST, self.elements_added,
+                                                  one.o_addr, t.stream))
+            return int(one.o[0])
+        N.check(N.lib().psk_cms_check(t.handle, N.KEYS_FIXED, raw or None, None, 1, len(raw), N.HOST, _QUERIES[self._query], one.o_addr,
+                                      t.stream))
+        return int(one.o_i32[0])
 
     def check_alt(self, hashes: HashResultsT) -> int:
         """countminsketch.py:332-340"""

@@ -5,6 +5,7 @@
 #include "psk_nibble.hpp"
 #include "psk_window.hpp"
 
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -164,6 +165,7 @@ extern "C" int psk_destroy(psk_sketch *s)
         if (b->pin) hipHostFree(b->pin);
     }
     if (s->win.pin) hipHostFree(s->win.pin);
+    if (s->mbox) hipHostFree((void *)s->mbox);
     if (s->scat.ev) hipEventDestroy(s->scat.ev);
     delete s;
     return PSK_OK;
@@ -359,6 +361,45 @@ int raise_dyn_lds(const void *kernel, size_t bytes)
     return PSK_OK;
 }
 
+// ---- completion mailbox of tiny PSK_HOST batches (mailbox_post, psk_device.hpp): the kernel stores the call's sequence number into a
+// pinned word behind its results (which it wrote into a pinned page) and the host polls that word -- a value-returning single-key call
+// ends when its answer is in host memory; the stream wait (a barrier packet, its signal, the runtime's bookkeeping: ~5 us of a ~15 us
+// call) is what the reference's per-key callers would otherwise pay on every `key in blm`.  The poll gives up after host_poll_us
+// microseconds (option; 0 = never poll) and falls back to the stream wait, which also reports a kernel that died.
+int64_t g_host_poll_us = 200;
+struct Mailbox {
+    volatile uint32_t *word = nullptr;  // nullptr: not armed -- finish() waits for the stream
+    uint32_t seq = 0;
+    uint32_t *dev() const { return const_cast<uint32_t *>(word); }
+};
+static void mailbox_disarm(Mailbox *mb) { mb->word = nullptr; }
+static int mailbox_arm(psk_sketch *s, int where, uint64_t n, bool out_pinned, Mailbox *mb)
+{
+    mb->word = nullptr;
+    if (where != PSK_HOST || n == 0 || n > kBlock || !out_pinned || g_host_poll_us <= 0) return PSK_OK;
+    if (!s->mbox) {
+        void *pp = nullptr;
+        HIP_TRY(hipHostMalloc(&pp, 64, hipHostMallocDefault));
+        *(volatile uint32_t *)pp = 0;
+        s->mbox = (volatile uint32_t *)pp;
+    }
+    if (++s->mbox_seq == 0) ++s->mbox_seq;  // (never the word's initial 0)
+    mb->word = s->mbox;
+    mb->seq = s->mbox_seq;
+    return PSK_OK;
+}
+static bool mailbox_wait(const Mailbox *mb)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 1;; ++spins) {
+        if (__atomic_load_n(mb->word, __ATOMIC_ACQUIRE) == mb->seq) return true;
+        __builtin_ia32_pause();
+        if ((spins & 1023) == 0 &&
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > g_host_poll_us)
+            return false;
+    }
+}
+
 // small-transfer fast path: lazily allocated pinned (host-coherent, device-visible) page per scratch buffer
 static int pinned(DevBuf &b, void **out)
 {
@@ -435,10 +476,12 @@ static int with_source(const Batch &b, F &&f)
 }
 
 template <class Src, class Op>
-static int launch_apply(const Src &src, const Op &op, uint64_t n, hipStream_t st)
+static int launch_apply(const Src &src, const Op &op, uint64_t n, hipStream_t st, Mailbox *mb = nullptr)
 {
     if (n == 0) return PSK_OK;
-    hipLaunchKernelGGL((k_apply<Src, Op>), dim3(grid_for(n)), dim3(kBlock), 0, st, src, op, n);
+    const uint32_t grid = grid_for(n);
+    if (mb && grid != 1) mailbox_disarm(mb);  // (the kernel's one workgroup posts it: see mailbox_post, psk_device.hpp)
+    hipLaunchKernelGGL((k_apply<Src, Op>), dim3(grid), dim3(kBlock), 0, st, src, op, n, mb ? mb->dev() : nullptr, mb ? mb->seq : 0u);
     HIP_TRY(hipGetLastError());
     return PSK_OK;
 }
@@ -495,12 +538,12 @@ static int stage_out(DevBuf &buf, void *out, uint64_t bytes, int where, OutBuf *
     return PSK_OK;
 }
 
-static int finish(int where, const OutBuf *o, hipStream_t st)
+static int finish(int where, const OutBuf *o, hipStream_t st, const Mailbox *mb = nullptr)
 {
     if (where == PSK_HOST) {
         const bool copy = o && o->host && o->bytes;
         if (copy && !o->is_pinned) HIP_TRY(hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        if (!(mb && mb->word && mailbox_wait(mb))) HIP_TRY(hipStreamSynchronize(st));
         if (copy && o->is_pinned) memcpy(o->host, o->dev, o->bytes);
     }
     return PSK_OK;
@@ -591,6 +634,7 @@ const OptDesc kOptions[] = {
     {"update_window_wide", &g_window_wide, kOptThreshold, kAny},
     {"update_window_force_fail", &g_window_force_fail, kOptThreshold, kAny},
     {"ragged_sort", &g_ragged_sort, kOptThreshold, kAny},
+    {"host_poll_us", &g_host_poll_us, kOptThreshold, kAny},
     // read-only counters
     {"cbf_ordered_replays", &g_cbf_ordered_replays, kOptReadOnly, kAny},
     {"update_window_folds", &g_window_folds, kOptReadOnly, kAny},
@@ -735,11 +779,13 @@ extern "C" int psk_bloom_check(psk_sketch *s, int layout, const void *data, cons
         if (!s->pend.active) PSK_TRY(bloom_check_partitioned(s, b, (uint8_t *)o.dev, st, &done));
         if (done) return finish(where, &o, st);
     }
+    Mailbox mb;
+    PSK_TRY(mailbox_arm(s, where, n, o.is_pinned, &mb));
     PSK_TRY(with_source(b, [&](auto src) {
-        if (s->pow2) return launch_apply(src, BloomCheck<true>{(const uint32_t *)s->table, s->md, s->k, (uint8_t *)o.dev}, n, st);
-        return launch_apply(src, BloomCheck<false>{(const uint32_t *)s->table, s->md, s->k, (uint8_t *)o.dev}, n, st);
+        if (s->pow2) return launch_apply(src, BloomCheck<true>{(const uint32_t *)s->table, s->md, s->k, (uint8_t *)o.dev}, n, st, &mb);
+        return launch_apply(src, BloomCheck<false>{(const uint32_t *)s->table, s->md, s->k, (uint8_t *)o.dev}, n, st, &mb);
     }));
-    return finish(where, &o, st);
+    return finish(where, &o, st, &mb);
 }
 
 extern "C" int psk_bloom_indices(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
@@ -1612,10 +1658,10 @@ static int cbf_remove_exact(psk_sketch *s, const Batch &b, const uint32_t *w, hi
         using Src = decltype(src);
         if (s->pow2)
             hipLaunchKernelGGL((k_cbf_ordered<Src, true>), dim3(1), dim3(64), 0, st, src, (uint32_t *)s->table, s->md, s->k, w64, (int)PSK_OP_REMOVE, b.n,
-                               (uint32_t *)nullptr, (unsigned long long *)s->ctr, wide);
+                               (uint32_t *)nullptr, (unsigned long long *)s->ctr, wide, (uint32_t *)nullptr, 0u);
         else
             hipLaunchKernelGGL((k_cbf_ordered<Src, false>), dim3(1), dim3(64), 0, st, src, (uint32_t *)s->table, s->md, s->k, w64, (int)PSK_OP_REMOVE, b.n,
-                               (uint32_t *)nullptr, (unsigned long long *)s->ctr, wide);
+                               (uint32_t *)nullptr, (unsigned long long *)s->ctr, wide, (uint32_t *)nullptr, 0u);
         HIP_TRY(hipGetLastError());
         return (int)PSK_OK;
     });
@@ -1689,11 +1735,13 @@ extern "C" int psk_cbf_check(psk_sketch *s, int layout, const void *data, const 
         PSK_TRY(rc);
         if (done) return finish(where, &o, st);
     }
+    Mailbox mb;
+    PSK_TRY(mailbox_arm(s, where, n, o.is_pinned, &mb));
     PSK_TRY(with_source(b, [&](auto src) {
-        if (s->pow2) return launch_apply(src, CbfCheck<true>{(const uint32_t *)s->table, s->md, kk, (uint32_t *)o.dev}, n, st);
-        return launch_apply(src, CbfCheck<false>{(const uint32_t *)s->table, s->md, kk, (uint32_t *)o.dev}, n, st);
+        if (s->pow2) return launch_apply(src, CbfCheck<true>{(const uint32_t *)s->table, s->md, kk, (uint32_t *)o.dev}, n, st, &mb);
+        return launch_apply(src, CbfCheck<false>{(const uint32_t *)s->table, s->md, kk, (uint32_t *)o.dev}, n, st, &mb);
     }));
-    return finish(where, &o, st);
+    return finish(where, &o, st, &mb);
 }
 
 extern "C" int psk_cbf_update_ordered(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
@@ -1716,20 +1764,22 @@ extern "C" int psk_cbf_update_ordered(psk_sketch *s, int layout, const void *dat
         PSK_TRY(ensure(s->s_aux, 16ULL * s->k));
         wide = (uint64_t *)s->s_aux.p;
     }
+    Mailbox mb;
+    PSK_TRY(mailbox_arm(s, where, n, out && o.is_pinned, &mb));
     if (n) {
         PSK_TRY(with_source(b, [&](auto src) {
             using Src = decltype(src);
             if (s->pow2)
                 hipLaunchKernelGGL((k_cbf_ordered<Src, true>), dim3(1), dim3(64), 0, st, src, (uint32_t *)s->table, s->md,
-                                   s->k, w, opmode, n, (uint32_t *)(out ? o.dev : nullptr), (unsigned long long *)s->ctr, wide);
+                                   s->k, w, opmode, n, (uint32_t *)(out ? o.dev : nullptr), (unsigned long long *)s->ctr, wide, mb.dev(), mb.seq);
             else
                 hipLaunchKernelGGL((k_cbf_ordered<Src, false>), dim3(1), dim3(64), 0, st, src, (uint32_t *)s->table, s->md,
-                                   s->k, w, opmode, n, (uint32_t *)(out ? o.dev : nullptr), (unsigned long long *)s->ctr, wide);
+                                   s->k, w, opmode, n, (uint32_t *)(out ? o.dev : nullptr), (unsigned long long *)s->ctr, wide, mb.dev(), mb.seq);
             HIP_TRY(hipGetLastError());
             return (int)PSK_OK;
         }));
     }
-    return finish(where, &o, st);
+    return finish(where, &o, st, &mb);
 }
 
 // ---------------------------------------------------------- CountMinSketch
@@ -1790,11 +1840,13 @@ extern "C" int psk_cms_check(psk_sketch *s, int layout, const void *data, const 
         PSK_TRY(cms_check_partitioned(s, b, query, 0, o.dev, st, &done));
         if (done) return finish(where, &o, st);
     }
+    Mailbox mb;
+    PSK_TRY(mailbox_arm(s, where, n, o.is_pinned, &mb));
     PSK_TRY(with_source(b, [&](auto src) {
-        if (s->pow2) return launch_apply(src, CmsCheck<true>{(const int32_t *)s->table, s->md, s->k, (int32_t *)o.dev, mean}, n, st);
-        return launch_apply(src, CmsCheck<false>{(const int32_t *)s->table, s->md, s->k, (int32_t *)o.dev, mean}, n, st);
+        if (s->pow2) return launch_apply(src, CmsCheck<true>{(const int32_t *)s->table, s->md, s->k, (int32_t *)o.dev, mean}, n, st, &mb);
+        return launch_apply(src, CmsCheck<false>{(const int32_t *)s->table, s->md, s->k, (int32_t *)o.dev, mean}, n, st, &mb);
     }));
-    return finish(where, &o, st);
+    return finish(where, &o, st, &mb);
 }
 
 extern "C" int psk_cms_check_meanmin(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
@@ -1817,10 +1869,12 @@ extern "C" int psk_cms_check_meanmin(psk_sketch *s, int layout, const void *data
                 using Src = decltype(src);
                 if (s->pow2)
                     hipLaunchKernelGGL((k_cms_ordered<Src, true>), dim3(1), dim3(64), 0, st, src, (int32_t *)s->table, s->md, s->k,
-                                       (const int64_t *)nullptr, 3, (int)PSK_Q_MEANMIN, elements_added, n, (int64_t *)o.dev, s->ctr, (int64_t *)s->s_aux.p);
+                                       (const int64_t *)nullptr, 3, (int)PSK_Q_MEANMIN, elements_added, n, (int64_t *)o.dev, s->ctr, (int64_t *)s->s_aux.p,
+                                       (uint32_t *)nullptr, 0u);
                 else
                     hipLaunchKernelGGL((k_cms_ordered<Src, false>), dim3(1), dim3(64), 0, st, src, (int32_t *)s->table, s->md, s->k,
-                                       (const int64_t *)nullptr, 3, (int)PSK_Q_MEANMIN, elements_added, n, (int64_t *)o.dev, s->ctr, (int64_t *)s->s_aux.p);
+                                       (const int64_t *)nullptr, 3, (int)PSK_Q_MEANMIN, elements_added, n, (int64_t *)o.dev, s->ctr, (int64_t *)s->s_aux.p,
+                                       (uint32_t *)nullptr, 0u);
                 HIP_TRY(hipGetLastError());
                 return (int)PSK_OK;
             }));
@@ -1832,12 +1886,14 @@ extern "C" int psk_cms_check_meanmin(psk_sketch *s, int layout, const void *data
         PSK_TRY(cms_check_partitioned(s, b, PSK_Q_MEANMIN, elements_added, o.dev, st, &done));
         if (done) return finish(where, &o, st);
     }
+    Mailbox mb;
+    PSK_TRY(mailbox_arm(s, where, n, o.is_pinned, &mb));
     PSK_TRY(with_source(b, [&](auto src) {
         if (s->pow2)
-            return launch_apply(src, CmsCheckMeanMin<true>{(const int32_t *)s->table, s->md, s->k, elements_added, (int64_t *)o.dev}, n, st);
-        return launch_apply(src, CmsCheckMeanMin<false>{(const int32_t *)s->table, s->md, s->k, elements_added, (int64_t *)o.dev}, n, st);
+            return launch_apply(src, CmsCheckMeanMin<true>{(const int32_t *)s->table, s->md, s->k, elements_added, (int64_t *)o.dev}, n, st, &mb);
+        return launch_apply(src, CmsCheckMeanMin<false>{(const int32_t *)s->table, s->md, s->k, elements_added, (int64_t *)o.dev}, n, st, &mb);
     }));
-    return finish(where, &o, st);
+    return finish(where, &o, st, &mb);
 }
 
 extern "C" int psk_cms_update_ordered(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
@@ -1861,18 +1917,20 @@ extern "C" int psk_cms_update_ordered(psk_sketch *s, int layout, const void *dat
         PSK_TRY(ensure(s->s_aux, 8ULL * s->k));
         wide = (int64_t *)s->s_aux.p;
     }
+    Mailbox mb;
+    PSK_TRY(mailbox_arm(s, where, n, out && o.is_pinned, &mb));
     PSK_TRY(with_source(b, [&](auto src) {
         using Src = decltype(src);
         if (s->pow2)
             hipLaunchKernelGGL((k_cms_ordered<Src, true>), dim3(1), dim3(64), 0, st, src, (int32_t *)s->table, s->md, s->k, w,
-                               opmode, query, elements_added_in, n, (int64_t *)(out ? o.dev : nullptr), s->ctr, wide);
+                               opmode, query, elements_added_in, n, (int64_t *)(out ? o.dev : nullptr), s->ctr, wide, mb.dev(), mb.seq);
         else
             hipLaunchKernelGGL((k_cms_ordered<Src, false>), dim3(1), dim3(64), 0, st, src, (int32_t *)s->table, s->md, s->k, w,
-                               opmode, query, elements_added_in, n, (int64_t *)(out ? o.dev : nullptr), s->ctr, wide);
+                               opmode, query, elements_added_in, n, (int64_t *)(out ? o.dev : nullptr), s->ctr, wide, mb.dev(), mb.seq);
         HIP_TRY(hipGetLastError());
         return (int)PSK_OK;
     }));
-    return finish(where, &o, st);
+    return finish(where, &o, st, &mb);
 }
 
 // ------------------------------------------------------------------ hashing

@@ -486,9 +486,19 @@ __device__ __forceinline__ void for_each_hash(const Src &src, const typename Src
     }
 }
 
+// Completion mailbox of the value-returning single-key calls (`key in blm`, `cms.add(key)`: the reference's whole interface is per key).
+// The results of a tiny PSK_HOST batch are written straight into a pinned host page; behind them the ONE workgroup of the launch stores the
+// call's sequence number into a pinned word, and the host polls that word instead of waiting for the stream (psk_capi.hip finish()): the
+// call ends when the answer is in host memory, not when the command processor has retired the kernel and a barrier packet behind it.
+__device__ __forceinline__ void mailbox_post(uint32_t *mbox, uint32_t seq)  // by ONE lane, behind a system-scope fence of every writer
+{
+    __hip_atomic_store(mbox, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Op interface:  uint32_t k;  void prepare();  State begin(i);  void apply(State&, j, hash);  void end(State&, i)
+// `mbox`: only with a one-workgroup grid (see mailbox_post), else nullptr
 template <class Src, class Op>
-__global__ __launch_bounds__(kBlock) void k_apply(Src src, Op op, uint64_t n)
+__global__ __launch_bounds__(kBlock) void k_apply(Src src, Op op, uint64_t n, uint32_t *mbox, uint32_t seq)
 {
     op.prepare();
     const uint32_t k = op.k;
@@ -498,6 +508,11 @@ __global__ __launch_bounds__(kBlock) void k_apply(Src src, Op op, uint64_t n)
         typename Op::State st = op.begin(i);
         for_each_hash(src, key, i, k, [&](uint32_t j, uint64_t h) { op.apply(st, j, h); });
         op.end(st, i);
+    }
+    if (mbox) {  // (uniform)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) mailbox_post(mbox, seq);
     }
 }
 
@@ -868,15 +883,75 @@ __global__ __launch_bounds__(kBlock) void k_cbf_remove(Src src, uint32_t *tab, M
 // One lane walks the batch in order and applies the reference semantics literally, including every
 // op's return value: exact for ANY stream (ill-formed removes, saturation, mixed signs).
 // `wide`: device scratch of 2 * k uint64 for k > kMaxKOrdered (the reference has no limit on k), else nullptr
+// ONE op (the per-key API) with k <= 64: lane s takes probe s, so the k hash chains and the k table round trips overlap instead of
+// queueing up behind one lane; a key whose probes collide (two probes, one counter -- the sequential semantics matter) and every longer
+// batch walk the literal loop below.  `mbox`: see mailbox_post.
 template <class Src, bool POW2>
 __global__ void k_cbf_ordered(Src src, uint32_t *tab, Mod md, uint32_t k, const int64_t *weights, int opmode,
-                              uint64_t n, uint32_t *out, unsigned long long *ctr, uint64_t *wide)
+                              uint64_t n, uint32_t *out, unsigned long long *ctr, uint64_t *wide, uint32_t *mbox, uint32_t seq)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
     unsigned long long added = 0, removed = 0, sat = 0, abs_sum = 0;
+    bool one_done = false;
+    if (n == 1 && !wide && blockDim.x == 64) {
+        const uint32_t s = threadIdx.x;
+        const typename Src::Key key = src.load(0);
+        int64_t w = weights ? weights[0] : 1;
+        bool rem = opmode == 1;
+        if (opmode == 2 && w < 0) { rem = true; w = -w; }
+        uint64_t my = ~0ULL;  // (no counter)
+        if (s < k) {
+            uint64_t h[1];
+            src.template hash<1>(key, 0, s, h);
+            my = reduce<POW2>(md, h[0]);
+        }
+        bool dup = false;
+        for (uint32_t q = 0; q < k; ++q) {
+            const uint64_t other = __shfl((unsigned long long)my, (int)q);
+            dup |= s < k && q != s && other == my;
+        }
+        if (__ballot(dup) == 0) {  // k different counters: the k read-modify-writes are independent
+            uint32_t ret;
+            if (!rem) {  // countingbloom.py:135-155
+                uint64_t v = ~0ULL;
+                bool s1 = false;
+                if (s < k) {
+                    v = (uint64_t)tab[my] + (uint64_t)w;
+                    if (v > 0xFFFFFFFFULL) { v = 0xFFFFFFFFULL; s1 = true; }
+                    tab[my] = (uint32_t)v;
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const uint64_t u = __shfl_xor((unsigned long long)v, o);
+                    v = u < v ? u : v;
+                }
+                sat = (unsigned long long)__popcll(__ballot(s1));
+                added = (uint64_t)w;
+                ret = (uint32_t)v;
+            } else {  // countingbloom.py:186-208
+                const uint32_t t = s < k ? tab[my] : 0xFFFFFFFFu;
+                uint32_t mn = t;
+                for (int o = 32; o > 0; o >>= 1) {
+                    const uint32_t u = __shfl_xor(mn, o);
+                    mn = u < mn ? u : mn;
+                }
+                if (mn == 0xFFFFFFFFu) ret = 0xFFFFFFFFu;
+                else if (mn == 0) ret = 0;
+                else {
+                    const uint32_t tr = (uint64_t)mn > (uint64_t)w ? (uint32_t)w : mn;
+                    if (s < k && t < 0xFFFFFFFFu) tab[my] = t - tr;
+                    removed = tr;
+                    ret = mn - tr;
+                }
+            }
+            abs_sum = (unsigned long long)(w < 0 ? -w : w);
+            if (s == 0 && out) out[0] = ret;
+            one_done = true;
+        }
+    }
+    if (threadIdx.x != 0) return;  // (out[0] is lane 0's own store: the fence in front of the mailbox below covers it)
     uint64_t idx_r[kMaxKOrdered], vals_r[kMaxKOrdered];
     uint64_t *idx = wide ? wide : idx_r, *vals = wide ? wide + k : vals_r;
-    for (uint64_t i = 0; i < n; ++i) {
+    for (uint64_t i = 0; i < (one_done ? 0 : n); ++i) {
         const typename Src::Key key = src.load(i);
         int64_t w = weights ? weights[i] : 1;
         bool rem = opmode == 1;
@@ -919,15 +994,23 @@ __global__ void k_cbf_ordered(Src src, uint32_t *tab, Mod md, uint32_t k, const 
     // every op moved a counter by at most k*|w|: keep the wrap-free bound an upper bound
     const unsigned long long nb = ctr[4] + abs_sum * (unsigned long long)k;
     ctr[4] = (nb < ctr[4] || nb > (1ULL << 62)) ? (1ULL << 62) : nb;
+    if (mbox) {
+        __threadfence_system();
+        mailbox_post(mbox, seq);
+    }
 }
 
 // opmode 3 (internal): query only -- every op adds 0, i.e. returns check()'s value under `query` and changes nothing
 // `wide`: device scratch of `depth` int64 for depth > kMaxDepthMeanMin, else nullptr
+// ONE op (the per-key API) with depth <= 64: lane s takes row s -- the rows are disjoint, so the depth hash chains and read-modify-writes
+// overlap -- and lane 0 finishes the op (query, elements_added, tallies) from the values it collects.  `mbox`: see mailbox_post.
 template <class Src, bool POW2>
 __global__ void k_cms_ordered(Src src, int32_t *bins, Mod md, uint32_t depth, const int64_t *weights, int opmode,
-                              int query, int64_t els, uint64_t n, int64_t *out, long long *ctr, int64_t *wide)
+                              int query, int64_t els, uint64_t n, int64_t *out, long long *ctr, int64_t *wide, uint32_t *mbox, uint32_t seq)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
+    const bool lanes = n == 1 && !wide && blockDim.x == 64;  // (!wide: depth <= kMaxDepthMeanMin = 64)
+    if (!lanes && threadIdx.x != 0) return;
     unsigned long long sat = 0, abs_sum = 0;
     int64_t vals_r[kMaxDepthMeanMin];
     int64_t *vals = wide ? wide : vals_r;
@@ -937,6 +1020,23 @@ __global__ void k_cms_ordered(Src src, int32_t *bins, Mod md, uint32_t depth, co
         bool rem = opmode == 1;
         if (opmode == 2 && w < 0) { rem = true; w = -w; }
         abs_sum += (unsigned long long)(w < 0 ? -w : w);
+        if (lanes) {
+            const uint32_t s = threadIdx.x;
+            int64_t v = 0;
+            bool s1 = false;
+            if (s < depth) {
+                uint64_t h[1];
+                src.template hash<1>(key, i, s, h);
+                int32_t *p = bins + reduce<POW2>(md, h[0]) + (uint64_t)s * md.m;
+                v = (int64_t)*p + (rem ? -w : w);   // :276 / :309
+                if (v > INT32_MAX) { v = INT32_MAX; s1 = true; }
+                if (v < INT32_MIN) { v = INT32_MIN; s1 = true; }
+                if (opmode != 3) *p = (int32_t)v;
+            }
+            sat += (unsigned long long)__popcll(__ballot(s1));
+            for (uint32_t q = 0; q < depth; ++q) vals[q] = (int64_t)__shfl((long long)v, (int)q);
+            if (threadIdx.x != 0) return;
+        } else
         for (uint32_t s = 0; s < depth; ++s) {
             uint64_t h[1];
             src.template hash<1>(key, i, s, h);
@@ -969,12 +1069,17 @@ __global__ void k_cms_ordered(Src src, int32_t *bins, Mod md, uint32_t depth, co
         } else r = vals[0];
         if (out) out[i] = r;
     }
-    if (opmode == 3) return;
-    ctr[5] = els;
-    if (out) out[n] = els;  // out is int64[n + 1]: the caller gets elements_added with the results, no second read-back
-    ctr[3] += (long long)sat;
-    const unsigned long long nb = (unsigned long long)ctr[4] + abs_sum;
-    ctr[4] = (nb < (unsigned long long)ctr[4] || nb > (1ULL << 62)) ? (1LL << 62) : (long long)nb;
+    if (opmode != 3) {
+        ctr[5] = els;
+        if (out) out[n] = els;  // out is int64[n + 1]: the caller gets elements_added with the results, no second read-back
+        ctr[3] += (long long)sat;
+        const unsigned long long nb = (unsigned long long)ctr[4] + abs_sum;
+        ctr[4] = (nb < (unsigned long long)ctr[4] || nb > (1ULL << 62)) ? (1LL << 62) : (long long)nb;
+    }
+    if (mbox) {
+        __threadfence_system();
+        mailbox_post(mbox, seq);
+    }
 }
 
 // ------------------------------------------------------------- hash only

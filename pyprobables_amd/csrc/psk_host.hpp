@@ -103,6 +103,8 @@ struct psk_sketch {
     uint64_t padded_bytes, logical_bytes;
     long long *ctr;    // device int64[PSK_CTR_COUNT]
     DevBuf s_keys, s_offs, s_w, s_out, s_aux;  // staging for PSK_HOST buffers
+    volatile uint32_t *mbox = nullptr;         // completion mailbox of tiny PSK_HOST batches (psk_capi.hip Mailbox): a pinned word the
+    uint32_t mbox_seq = 0;                     // kernel stores the call's sequence number into, behind its results
     DevBuf s_part, s_cnt;                      // partitioned path: bucket buffer + per-bucket fill counts
     DevBuf s_flag;                             // split lookup: "a segment overflowed" flag
     DevBuf s_tflag;                            // tile-flag Bloom lookups: one uint32 per pass-1 tile of a round; "flagged" = holds the round's

@@ -173,6 +173,18 @@ def _pack_ragged(blob, offsets) -> KeyBatch:
     return KeyBatch(layout, _np_ptr(b), _np_ptr(o), o.size - 1, 0, N.HOST, None, [b, o])
 
 
+def one_key_bytes(key):
+    """ONE ``str`` / ``bytes`` key as the bytes the engine hashes -- a ``str`` by code point, so code points <= 255 travel as byte values
+    (hashes.py:98 of the reference: ``ord`` per character) -- or None when the key needs the general packer (wider code points,
+    ``bytearray`` / ``memoryview``, anything else: ``pack_keys`` also raises the TypeError)."""
+    if type(key) is str:
+        try:
+            return key.encode("latin-1")
+        except UnicodeEncodeError:
+            return None
+    return key if type(key) is bytes else None
+
+
 def pack_keys(keys) -> KeyBatch:
     """one key, a sequence of keys, a (n, L) uint8 array or a (n, L) uint8 torch tensor, or a ragged ``(blob, offsets)`` pair of
     arrays / tensors (host or device) -> KeyBatch"""

@@ -679,3 +679,69 @@ def test_exports_match_the_reference_text_for_text(pa, tmp_path):
         assert same(bytes(back).hex(), c["bytes_hex"]) and all(back.check(kx) for kx in c["keys"] if kx != c["keys"][1] or c["kind"] == "bloom")
         again = cls.frombytes(f.read_bytes())
         assert same(again.export_hex(), c["export_hex"])
+
+
+def _plain(k):
+    return bytes(k) if isinstance(k, (bytearray, memoryview)) else k
+
+
+@pytest.mark.parametrize("poll_us", [200, 0])
+def test_single_key_calls_equal_the_batch_calls_for_every_kind_of_key(pa, poll_us):
+    """`key in blm`, `cms.add(key)`, `cbf.remove(key)` ... go through preallocated argument / result words (`_base.OneKey`) when the engine
+    hashes the key itself; keys that need the general packer (wide code points, bytearray, memoryview) take it.  On the device a one-op
+    call spreads its probes over the lanes of a wave (k_cbf_ordered / k_cms_ordered, psk_device.hpp) and posts a completion mailbox the
+    host polls (`host_poll_us`; 0 = wait for the stream).  Either way the answers, the tables and elements_added are those of the SAME
+    ops run as one ordered batch -- the literal one-lane loop -- for every kind of key the reference accepts (hashes.py:98: a str by code
+    point, anything else by byte value), for probes that collide (tiny tables) and at the counters' rails."""
+    from pyprobables_amd import _native as N
+
+    kinds = ["plain ascii", "café ÿ", "wide € \U0001f600", b"raw \x00 bytes \xff", bytearray(b"byte array"),
+             memoryview(b"memory view"), "", b"", "x" * 300]
+    N.set_option("host_poll_us", poll_us)
+    try:
+        blm, ref = pa.BloomFilter(est_elements=1000, false_positive_rate=0.01), pa.BloomFilter(est_elements=1000, false_positive_rate=0.01)
+        for k in kinds[::2]:
+            blm.add(k)
+        ref.add_many([_plain(k) for k in kinds[::2]])
+        assert blm.export_hex() == ref.export_hex()
+        for k in kinds:
+            assert blm.check(k) is bool(ref.check_many([_plain(k), "other"])[0]) and (k in blm) is blm.check(k)
+        assert blm.check("never added") is False
+
+        for query in ("min", "mean", "mean-min"):
+            for width in (1000, 2):
+                cms, ref = pa.CountMinSketch(width=width, depth=5), pa.CountMinSketch(width=width, depth=5)
+                cms.query_type = ref.query_type = query
+                ops, got = [], []
+                for i, k in enumerate(kinds):
+                    for w in (i + 1, 1, -2):
+                        got.append(cms.add(k, w) if w > 0 else cms.remove(k, -w))
+                        ops.append((_plain(k), w))
+                for w in ((1 << 31) - 5, 7, -(1 << 40), 1 << 40):  # (the int32 rails: countminsketch.py:276-283)
+                    got.append(cms.add("rail", w) if w > 0 else cms.remove("rail", -w))
+                    ops.append(("rail", w))
+                want = ref.update_ordered([k for k, _ in ops], [w for _, w in ops])
+                assert got == [int(v) for v in want]
+                assert bytes(cms._tab.read()) == bytes(ref._tab.read()) and cms.elements_added == ref.elements_added
+                assert [cms.check(k) for k in kinds] == [int(v) for v in ref.check_many([_plain(k) for k in kinds])]
+
+        for est in (1000, 2):  # (est_elements = 2: a handful of counters, so the k probes of a key collide)
+            cbf, ref = (pa.CountingBloomFilter(est_elements=est, false_positive_rate=0.05) for _ in range(2))
+            ops, got = [], []
+            for i, k in enumerate(kinds):
+                for w in (i + 1, 1, -1, -3):
+                    got.append(cbf.add(k, w) if w > 0 else cbf.remove(k, -w))
+                    ops.append((_plain(k), w))
+            for w in ((1 << 32) - 3, 5, -1, 2):  # (saturation: countingbloom.py:148-152, and the frozen counters of :198)
+                got.append(cbf.add("rail", w) if w > 0 else cbf.remove("rail", -w))
+                ops.append(("rail", w))
+            want = ref.update_ordered([k for k, _ in ops], [w for _, w in ops])
+            assert got == [int(v) for v in want]
+            assert cbf.export_hex() == ref.export_hex() and cbf.elements_added == ref.elements_added
+            assert [cbf.check(k) for k in kinds] == [int(v) for v in ref.check_many([_plain(k) for k in kinds])]
+        with pytest.raises(TypeError):
+            blm.check(17)
+        with pytest.raises(TypeError):
+            cms.add(17)
+    finally:
+        N.set_option("host_poll_us", 200)
