@@ -725,6 +725,23 @@ def side_measurements(ctx: Ctx, n, blm, keys):
     rl["cbf_remove"] = roofline("cbf_remove", "validated CBF remove of present keys, 1 GiB table: k_part_scatter + k_nib_apply_pipe<3> (optimistic decrement, one pipelined pass over the table)",
                                 ncbf, ms, "the pass over the table (2 GiB read + written) whatever the batch brings")
     del cbf
+    # The reference's own interface -- one key per call, the value back at once (bloom.py:252, countminsketch.py:257, countingbloom.py:125):
+    # microseconds per call in a python loop, one launch + a polled completion mailbox each (NOTES.md 3.5); latency, not part of `value`
+    def per_call_us(fn, calls=2000):
+        for _ in range(200):
+            fn()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            fn()
+        return (time.perf_counter() - t0) / calls * 1e6
+
+    key1 = "0123456789abcdef"
+    cms1 = pa.CountMinSketch(width=2**20, depth=5, device=dev)
+    cbf1 = pa.CountingBloomFilter(est_elements=1_000_000, false_positive_rate=0.01, device=dev)
+    out["per_key_call_us"] = {"bloom_check": per_call_us(lambda: key1 in blm), "cms_add": per_call_us(lambda: cms1.add(key1)),
+                              "cms_check": per_call_us(lambda: cms1.check(key1)), "cbf_add": per_call_us(lambda: cbf1.add(key1)),
+                              "cbf_check": per_call_us(lambda: cbf1.check(key1)), "key": "16 characters"}
+    del cms1, cbf1
     # random-access ceilings at the headline table size (2^23 words = 32 MiB) and at 1 GiB
     sink = torch.zeros(1, dtype=torch.int64, device=f"cuda:{dev}")
     nprobe = 7 * n
@@ -1240,6 +1257,9 @@ def compact_line(full: dict, name: str, detail_path) -> dict:
     rag = det.get("bloom_ragged_keys_Mkeys_s")
     if rag:
         out["detail"]["ragged_insert_Mkeys_s"], out["detail"]["ragged_check_Mkeys_s"] = rag["insert"], rag["check"]
+    pk = det.get("per_key_call_us")
+    if pk:
+        out["detail"]["per_key_call_us"] = {k: _r(v, 3) for k, v in pk.items() if k != "key"}
     hb = det.get("bloom_host_buffers_Mkeys_s")
     if hb:
         out["detail"]["pcie_inclusive_insert_Mkeys_s"], out["detail"]["pcie_inclusive_check_Mkeys_s"] = hb["insert"], hb["check"]
