@@ -756,11 +756,13 @@ extern "C" int psk_bloom_add(psk_sketch *s, int layout, const void *data, const 
     bool done = false;
     if (!s->pend.active) PSK_TRY(bloom_add_partitioned(s, b, st, &done));  // (a pending split lookup owns the bucket buffer)
     if (done) return finish(where, nullptr, st);
+    Mailbox mb;  // (an update returns nothing, but a PSK_HOST call ends when the kernel has read the caller's keys: the same mailbox says so)
+    PSK_TRY(mailbox_arm(s, where, n, true, &mb));
     PSK_TRY(with_source(b, [&](auto src) {
-        if (s->pow2) return launch_apply(src, BloomAdd<true>{(uint32_t *)s->table, s->md, s->k}, n, st);
-        return launch_apply(src, BloomAdd<false>{(uint32_t *)s->table, s->md, s->k}, n, st);
+        if (s->pow2) return launch_apply(src, BloomAdd<true>{(uint32_t *)s->table, s->md, s->k}, n, st, &mb);
+        return launch_apply(src, BloomAdd<false>{(uint32_t *)s->table, s->md, s->k}, n, st, &mb);
     }));
-    return finish(where, nullptr, st);
+    return finish(where, nullptr, st, &mb);
 }
 
 extern "C" int psk_bloom_check(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,
@@ -1520,11 +1522,13 @@ extern "C" int psk_cbf_add(psk_sketch *s, int layout, const void *data, const ui
         PSK_TRY(settle_acct(s, w, n, st));
         if (done) return finish(where, nullptr, st);
     }
+    Mailbox mb;
+    PSK_TRY(mailbox_arm(s, where, n, true, &mb));
     PSK_TRY(with_source(b, [&](auto src) {
-        if (s->pow2) return launch_apply(src, CbfAdd<true>{(uint32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st);
-        return launch_apply(src, CbfAdd<false>{(uint32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st);
+        if (s->pow2) return launch_apply(src, CbfAdd<true>{(uint32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st, &mb);
+        return launch_apply(src, CbfAdd<false>{(uint32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st, &mb);
     }));
-    return finish(where, nullptr, st);
+    return finish(where, nullptr, st, &mb);
 }
 
 // countingbloom.py:198-203 for a whole batch: from the min over the key's counters (a lookup) to the amount actually removed
@@ -1802,12 +1806,14 @@ static int cms_update(psk_sketch *s, int layout, const void *data, const uint64_
         PSK_TRY(settle_acct(s, w, n, st));
         if (done) return finish(where, nullptr, st);
     }
+    Mailbox mb;
+    PSK_TRY(mailbox_arm(s, where, n, true, &mb));
     PSK_TRY(with_source(b, [&](auto src) {
         if (s->pow2)
-            return launch_apply(src, CmsAdd<true, NEG>{(int32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st);
-        return launch_apply(src, CmsAdd<false, NEG>{(int32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st);
+            return launch_apply(src, CmsAdd<true, NEG>{(int32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st, &mb);
+        return launch_apply(src, CmsAdd<false, NEG>{(int32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st, &mb);
     }));
-    return finish(where, nullptr, st);
+    return finish(where, nullptr, st, &mb);
 }
 
 extern "C" int psk_cms_add(psk_sketch *s, int layout, const void *data, const uint64_t *offsets, uint64_t n,

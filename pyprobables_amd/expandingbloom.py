@@ -279,9 +279,43 @@ class ExpandingBloomFilter:
         for b in self._batches(hashes, True):
             self._add_batch(b, force)
 
+    # Single-key calls (the reference's interface: expandingbloom.py:132-158) on a shallow stack go filter by filter through the engine's
+    # one-key path -- one launch and a polled completion mailbox each (NOTES.md 3.5) -- instead of the batch machinery (hash once, test every
+    # filter, read the verdict back: three launches and two stream waits for one key); deeper stacks hash once for all filters.
+    _ONE_KEY_FILTERS = 4
+
+    def _one(self, key):
+        """the bytes of ONE key the engine hashes itself (``BloomFilter._one_key``), or None: take the batch path"""
+        return self._blooms[-1]._one_key(key) if len(self._blooms) <= self._ONE_KEY_FILTERS else None
+
+    def _reported(self, raw: bytes) -> bool:
+        """expandingbloom.py:140-147 for one key: does ANY filter report it"""
+        L = N.lib()
+        for f in self._blooms:
+            t = f._tab
+            N.check(L.psk_bloom_check(t.handle, N.KEYS_FIXED, raw or None, None, 1, len(raw), N.HOST, t.one.o_addr, t.stream))
+            if t.one.o_u8[0]:
+                return True
+        return False
+
     def add(self, key: KeyT, force: bool = False) -> None:
         """expandingbloom.py:149-158"""
-        self.add_many([key], force)
+        raw = self._one(key)
+        if raw is None:
+            self.add_many([key], force)
+            return
+        self.last_batch_stats = {"chunks": 0}
+        if not force and self._reported(raw):  # :154: counted, not inserted
+            self._added_elements += 1
+            return
+        last = self._blooms[-1]
+        if self._room(last) == 0:
+            self._grow()  # (a rotation may drop the oldest filter: the key is still absent afterwards)
+            last = self._blooms[-1]
+        t = last._tab
+        N.check(N.lib().psk_bloom_add(t.handle, N.KEYS_FIXED, raw or None, None, 1, len(raw), N.HOST, t.stream))
+        last._els_added += 1
+        self._added_elements += 1
 
     def add_alt(self, hashes: HashResultsT, force: bool = False) -> None:
         """expandingbloom.py:160-170"""
@@ -308,7 +342,8 @@ class ExpandingBloomFilter:
 
     def check(self, key: KeyT) -> bool:
         """expandingbloom.py:132-138"""
-        return bool(self.check_many([key])[0])
+        raw = self._one(key)
+        return self._reported(raw) if raw is not None else bool(self.check_many([key])[0])
 
     def check_alt(self, hashes: HashResultsT) -> bool:
         """expandingbloom.py:140-147"""

@@ -50,3 +50,17 @@ cbf = CountingBloomFilter(est_elements=1_000_000, false_positive_rate=0.01)
 print(f"CountingBloomFilter.add(key)      {loop(lambda: cbf.add(key)):7.2f} us")
 print(f"CountingBloomFilter.check(key)    {loop(lambda: cbf.check(key)):7.2f} us")
 print(f"CountingBloomFilter.remove(key)   {loop(lambda: (cbf.add(key), cbf.remove(key))) / 2:7.2f} us   (half of an add + remove pair)")
+from pyprobables_amd import ExpandingBloomFilter
+
+ebf = ExpandingBloomFilter(est_elements=1_000_000, false_positive_rate=0.01)
+ctr = [0]
+
+
+def fresh_add():
+    ctr[0] += 1
+    ebf.add(f"fresh-{ctr[0]}")
+
+
+print(f"ExpandingBloomFilter.add(fresh)   {loop(fresh_add):7.2f} us   (one filter: a check, then an insert)")
+print(f"ExpandingBloomFilter.add(seen)    {loop(lambda: ebf.add('fresh-1')):7.2f} us")
+print(f"ExpandingBloomFilter.check(key)   {loop(lambda: ebf.check('fresh-1')):7.2f} us")
