@@ -475,13 +475,31 @@ static int with_source(const Batch &b, F &&f)
     return fail(PSK_EINVAL, "unknown key layout");
 }
 
+// ONE fixed-layout key of a PSK_HOST call that ends on the mailbox travels in the kernel arguments (KeysInline64, psk_device.hpp), not
+// through the pinned page stage_batch filled; `data` is the caller's pointer.  -> the source to launch with, or nullptr (the batch's own)
+static const KeysInline64 *inline_key(int layout, const void *data, uint64_t n, uint32_t key_len, const Mailbox &mb, KeysInline64 *k)
+{
+    if (!mb.word || n != 1 || layout != PSK_KEYS_FIXED || key_len > sizeof k->w) return nullptr;
+    memset(k->w, 0, sizeof k->w);
+    if (key_len) memcpy(k->w, data, key_len);
+    k->L = key_len;
+    return k;
+}
+template <class F>
+static int with_source_one(const Batch &b, const KeysInline64 *one, F &&f)
+{
+    if (one) return f(*one);
+    return with_source(b, f);
+}
+
 template <class Src, class Op>
 static int launch_apply(const Src &src, const Op &op, uint64_t n, hipStream_t st, Mailbox *mb = nullptr)
 {
     if (n == 0) return PSK_OK;
     const uint32_t grid = grid_for(n);
     if (mb && grid != 1) mailbox_disarm(mb);  // (the kernel's one workgroup posts it: see mailbox_post, psk_device.hpp)
-    hipLaunchKernelGGL((k_apply<Src, Op>), dim3(grid), dim3(kBlock), 0, st, src, op, n, mb ? mb->dev() : nullptr, mb ? mb->seq : 0u);
+    // (thread t of workgroup 0 takes keys t, t + kBlock ...: a batch of up to 64 keys needs one wave)
+    hipLaunchKernelGGL((k_apply<Src, Op>), dim3(grid), dim3(n <= 64 ? 64 : kBlock), 0, st, src, op, n, mb ? mb->dev() : nullptr, mb ? mb->seq : 0u);
     HIP_TRY(hipGetLastError());
     return PSK_OK;
 }
@@ -758,7 +776,8 @@ extern "C" int psk_bloom_add(psk_sketch *s, int layout, const void *data, const 
     if (done) return finish(where, nullptr, st);
     Mailbox mb;  // (an update returns nothing, but a PSK_HOST call ends when the kernel has read the caller's keys: the same mailbox says so)
     PSK_TRY(mailbox_arm(s, where, n, true, &mb));
-    PSK_TRY(with_source(b, [&](auto src) {
+    KeysInline64 ik;
+    PSK_TRY(with_source_one(b, inline_key(layout, data, n, key_len, mb, &ik), [&](auto src) {
         if (s->pow2) return launch_apply(src, BloomAdd<true>{(uint32_t *)s->table, s->md, s->k}, n, st, &mb);
         return launch_apply(src, BloomAdd<false>{(uint32_t *)s->table, s->md, s->k}, n, st, &mb);
     }));
@@ -783,7 +802,8 @@ extern "C" int psk_bloom_check(psk_sketch *s, int layout, const void *data, cons
     }
     Mailbox mb;
     PSK_TRY(mailbox_arm(s, where, n, o.is_pinned, &mb));
-    PSK_TRY(with_source(b, [&](auto src) {
+    KeysInline64 ik;
+    PSK_TRY(with_source_one(b, inline_key(layout, data, n, key_len, mb, &ik), [&](auto src) {
         if (s->pow2) return launch_apply(src, BloomCheck<true>{(const uint32_t *)s->table, s->md, s->k, (uint8_t *)o.dev}, n, st, &mb);
         return launch_apply(src, BloomCheck<false>{(const uint32_t *)s->table, s->md, s->k, (uint8_t *)o.dev}, n, st, &mb);
     }));
@@ -1524,7 +1544,8 @@ extern "C" int psk_cbf_add(psk_sketch *s, int layout, const void *data, const ui
     }
     Mailbox mb;
     PSK_TRY(mailbox_arm(s, where, n, true, &mb));
-    PSK_TRY(with_source(b, [&](auto src) {
+    KeysInline64 ik;
+    PSK_TRY(with_source_one(b, inline_key(layout, data, n, key_len, mb, &ik), [&](auto src) {
         if (s->pow2) return launch_apply(src, CbfAdd<true>{(uint32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st, &mb);
         return launch_apply(src, CbfAdd<false>{(uint32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st, &mb);
     }));
@@ -1741,7 +1762,8 @@ extern "C" int psk_cbf_check(psk_sketch *s, int layout, const void *data, const 
     }
     Mailbox mb;
     PSK_TRY(mailbox_arm(s, where, n, o.is_pinned, &mb));
-    PSK_TRY(with_source(b, [&](auto src) {
+    KeysInline64 ik;
+    PSK_TRY(with_source_one(b, inline_key(layout, data, n, key_len, mb, &ik), [&](auto src) {
         if (s->pow2) return launch_apply(src, CbfCheck<true>{(const uint32_t *)s->table, s->md, kk, (uint32_t *)o.dev}, n, st, &mb);
         return launch_apply(src, CbfCheck<false>{(const uint32_t *)s->table, s->md, kk, (uint32_t *)o.dev}, n, st, &mb);
     }));
@@ -1770,8 +1792,10 @@ extern "C" int psk_cbf_update_ordered(psk_sketch *s, int layout, const void *dat
     }
     Mailbox mb;
     PSK_TRY(mailbox_arm(s, where, n, out && o.is_pinned, &mb));
+    if (mb.word && n == 1 && weights && weights[0] == 1) w = nullptr;  // (a null weight list means 1: no read of the pinned page for `cbf.add(key)`)
+    KeysInline64 ik;
     if (n) {
-        PSK_TRY(with_source(b, [&](auto src) {
+        PSK_TRY(with_source_one(b, inline_key(layout, data, n, key_len, mb, &ik), [&](auto src) {
             using Src = decltype(src);
             if (s->pow2)
                 hipLaunchKernelGGL((k_cbf_ordered<Src, true>), dim3(1), dim3(64), 0, st, src, (uint32_t *)s->table, s->md,
@@ -1808,7 +1832,8 @@ static int cms_update(psk_sketch *s, int layout, const void *data, const uint64_
     }
     Mailbox mb;
     PSK_TRY(mailbox_arm(s, where, n, true, &mb));
-    PSK_TRY(with_source(b, [&](auto src) {
+    KeysInline64 ik;
+    PSK_TRY(with_source_one(b, inline_key(layout, data, n, key_len, mb, &ik), [&](auto src) {
         if (s->pow2)
             return launch_apply(src, CmsAdd<true, NEG>{(int32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st, &mb);
         return launch_apply(src, CmsAdd<false, NEG>{(int32_t *)s->table, s->md, s->k, w, s->ctr, sat, false}, n, st, &mb);
@@ -1848,7 +1873,8 @@ extern "C" int psk_cms_check(psk_sketch *s, int layout, const void *data, const 
     }
     Mailbox mb;
     PSK_TRY(mailbox_arm(s, where, n, o.is_pinned, &mb));
-    PSK_TRY(with_source(b, [&](auto src) {
+    KeysInline64 ik;
+    PSK_TRY(with_source_one(b, inline_key(layout, data, n, key_len, mb, &ik), [&](auto src) {
         if (s->pow2) return launch_apply(src, CmsCheck<true>{(const int32_t *)s->table, s->md, s->k, (int32_t *)o.dev, mean}, n, st, &mb);
         return launch_apply(src, CmsCheck<false>{(const int32_t *)s->table, s->md, s->k, (int32_t *)o.dev, mean}, n, st, &mb);
     }));
@@ -1894,7 +1920,8 @@ extern "C" int psk_cms_check_meanmin(psk_sketch *s, int layout, const void *data
     }
     Mailbox mb;
     PSK_TRY(mailbox_arm(s, where, n, o.is_pinned, &mb));
-    PSK_TRY(with_source(b, [&](auto src) {
+    KeysInline64 ik;
+    PSK_TRY(with_source_one(b, inline_key(layout, data, n, key_len, mb, &ik), [&](auto src) {
         if (s->pow2)
             return launch_apply(src, CmsCheckMeanMin<true>{(const int32_t *)s->table, s->md, s->k, elements_added, (int64_t *)o.dev}, n, st, &mb);
         return launch_apply(src, CmsCheckMeanMin<false>{(const int32_t *)s->table, s->md, s->k, elements_added, (int64_t *)o.dev}, n, st, &mb);
@@ -1925,7 +1952,9 @@ extern "C" int psk_cms_update_ordered(psk_sketch *s, int layout, const void *dat
     }
     Mailbox mb;
     PSK_TRY(mailbox_arm(s, where, n, out && o.is_pinned, &mb));
-    PSK_TRY(with_source(b, [&](auto src) {
+    if (mb.word && n == 1 && weights && weights[0] == 1) w = nullptr;  // (a null weight list means 1: no read of the pinned page for `cms.add(key)`)
+    KeysInline64 ik;
+    PSK_TRY(with_source_one(b, inline_key(layout, data, n, key_len, mb, &ik), [&](auto src) {
         using Src = decltype(src);
         if (s->pow2)
             hipLaunchKernelGGL((k_cms_ordered<Src, true>), dim3(1), dim3(64), 0, st, src, (int32_t *)s->table, s->md, s->k, w,

@@ -334,6 +334,45 @@ struct KeysFixed {  // uint8[n][L]; DWORDS: L % 4 == 0 and base 4-byte aligned
     }
 };
 
+// ONE key of at most 64 bytes passed BY VALUE in the kernel arguments: the value-returning single-key calls (`key in blm`, `cms.add(key)`;
+// psk_capi.hip inline_key).  A kernel that reads its key from the pinned staging page pays a PCIe round trip before it can hash (~1.7 us of
+// a ~10 us call, scripts/ubench/latency.hip); the kernel arguments are where the kernel's other operands already come from.  Every lane
+// sees the same key (scalar loads); never part of with_source's layouts -- only the one-key launches are built for it.
+struct KeysInline64 {
+    uint32_t w[16];
+    uint32_t L;  // bytes, <= 64
+    struct Key {};
+    __device__ __forceinline__ Key load(uint64_t) const { return {}; }
+    static __device__ __forceinline__ void pin(Key &) {}
+    template <int G>
+    __device__ __forceinline__ void hash(const Key &, uint64_t, uint32_t s0, uint64_t (&h)[G]) const
+    {
+        fnv_init<G>(h, s0);
+        FnvPairs<G> pr;
+        const uint32_t nw = L >> 2;
+        for (uint32_t j = 0; j < nw; ++j) fnv_word<G>(h, pr, w[j]);
+        const uint32_t tail = w[nw < 16u ? nw : 15u];
+        for (uint32_t b = 0; b < (L & 3u); ++b) {
+            const uint32_t e = (tail >> (8u * b)) & 0xFFu;
+#pragma unroll
+            for (int g = 0; g < G; ++g) h[g] = fnv_step(h[g], e, pr.p[g]);
+        }
+    }
+    template <int G>
+    __device__ __forceinline__ void hash32(const Key &, uint64_t, uint32_t s0, uint32_t (&h)[G]) const
+    {
+        fnv_init32<G>(h, s0);
+        const uint32_t nw = L >> 2;
+        for (uint32_t j = 0; j < nw; ++j) fnv_word32<G>(h, w[j]);
+        const uint32_t tail = w[nw < 16u ? nw : 15u];
+        for (uint32_t b = 0; b < (L & 3u); ++b) {
+            const uint32_t e = (tail >> (8u * b)) & 0xFFu;
+#pragma unroll
+            for (int g = 0; g < G; ++g) h[g] = fnv_step32(h[g], e);
+        }
+    }
+};
+
 template <class T>
 struct KeysVarlen {  // elements T (uint8 bytes, or uint32 code points for str keys: hashes.py:98)
     const T *p;
