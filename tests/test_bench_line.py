@@ -43,3 +43,16 @@ def test_an_oversized_object_still_fits():
     full = json.loads((ROOT / "profiles" / "r05_bench_cfg2_default.json").read_text().strip().splitlines()[-1])
     full["rooflines"] = {f"op{i}": dict(full["rooflines"]["cms_add"]) for i in range(200)}
     assert len(json.dumps(bench.compact_line(full, "cfg2", None), separators=(",", ":"))) < bench.LINE_LIMIT
+
+
+def test_the_round_6_detail_object_keeps_the_per_key_latencies_on_the_line():
+    """the FULL object of a default run (profiles/r06_bench_cfg2_default_detail.json, as bench.py wrote it on the GPU box) -> the compact line:
+    the per-key call latencies travel on it, rounded, and it still fits"""
+    import bench
+
+    full = json.loads((ROOT / "profiles" / "r06_bench_cfg2_default_detail.json").read_text())
+    line = bench.compact_line(full, "cfg2", "gpurun_out/bench_detail.json")
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < bench.LINE_LIMIT
+    pk = json.loads(text)["detail"]["per_key_call_us"]
+    assert set(pk) == {"bloom_check", "cms_add", "cms_check", "cbf_add", "cbf_check"} and all(0 < v < 100 for v in pk.values())

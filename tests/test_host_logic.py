@@ -257,3 +257,24 @@ def test_pack_keys_ragged_pairs_on_the_host():
         pack_keys((blob, np.array([0, 30], dtype=np.int64)))
     with pytest.raises(ValueError):
         pack_keys((blob, np.array([0, 5, 4], dtype=np.int64)))
+
+
+def test_single_key_bytes_are_the_packers_bytes():
+    """`one_key_bytes` (the value-returning per-key calls) hands the engine the same bytes `pack_keys` would, or defers to it: a str by code
+    point (hashes.py:98) -- so only code points <= 255 fit one byte each -- bytes as they are, everything else through the general packer"""
+    from pyprobables_amd._base import OneKey
+    from pyprobables_amd.keys import one_key_bytes
+
+    for key in ("plain ascii", "café ÿ", "", b"", b"raw \x00 bytes \xff", "x" * 300):
+        raw = one_key_bytes(key)
+        b = pack_keys([key])
+        assert b.layout == N.KEYS_FIXED and b.n == 1 and b.key_len == len(raw)
+        assert raw == (b.keep[0].tobytes() if b.key_len else b"")
+    for key in ("wide € \U0001f600", bytearray(b"ba"), memoryview(b"mv"), 17, None, ["k"]):
+        assert one_key_bytes(key) is None      # (pack_keys packs the first three and raises TypeError for the rest)
+    with pytest.raises(TypeError):
+        pack_keys([17])
+    one = OneKey()                             # preallocated words: the views alias ONE buffer, the addresses are its
+    one.o[0] = -1
+    assert one.o_addr == one.o.ctypes.data and one.w_addr == one.w.ctypes.data
+    assert int(one.o_u8[0]) == 255 and int(one.o_u32[1]) == 0xFFFFFFFF and int(one.o_i32[0]) == -1
