@@ -117,7 +117,7 @@ else:
 launches = 2 + iters + (8 if op == "bloom_check_half" else 0) + (1 if op in ("bloomvar_add", "bloom_add", "bloom31_add", "cms_add", "cbf_add", "cbf25_add") else 0)  # the set-up insert runs the same kernels
 for _ in range(2):
     fn()
-torch.cuda.synchronize()
+    torch.cuda.synchronize()  # (formats chosen from the PREVIOUS call's published tally -- PayWeightSmall, the lookup scheme -- settle before the profiled calls)
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
 for _ in range(iters):
