@@ -7,7 +7,10 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 from _common import gen_keys, gen_weights, timed_loop, use_knobs_build  # noqa: E402
 
-use_knobs_build()  # the part_debug bits exist only in the -DPSK_BENCH_KNOBS=1 build
+import os
+
+if not os.environ.get("PSK_LIB_PATH"):  # (a bench build handed over explicitly: PSK_LIB_PATH=ab/libpsk_knobs.so -- the in-tree one does not travel to the GPU box)
+    use_knobs_build()  # the part_debug bits exist only in the -DPSK_BENCH_KNOBS=1 build
 import torch
 
 import bench
