@@ -18,6 +18,11 @@
  *   - `where` says where the caller's buffers (keys, offsets, weights, outputs) live:
  *     PSK_HOST  -> pageable/pinned host memory; the call stages through device
  *                  scratch and returns after the result is back on the host.
+ *                  (That is what it promises -- not hipStreamSynchronize: a tiny batch, e.g. the
+ *                  one-key calls of a per-key loop, ends as soon as its kernel has posted a
+ *                  completion word in pinned memory, a few microseconds before the runtime sees
+ *                  the stream idle.  Work the caller queued on `stream` EARLIER has completed by
+ *                  then: the kernel ran behind it.  Option "host_poll_us" = 0 restores the wait.)
  *     PSK_DEVICE-> device memory of the sketch's GPU; the call only enqueues work on
  *                  `stream` (a hipStream_t passed as void*, NULL = default stream)
  *                  and returns immediately.
