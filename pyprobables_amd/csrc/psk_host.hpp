@@ -105,6 +105,7 @@ struct psk_sketch {
     DevBuf s_keys, s_offs, s_w, s_out, s_aux;  // staging for PSK_HOST buffers
     volatile uint32_t *mbox = nullptr;         // completion mailbox of tiny PSK_HOST batches (psk_capi.hip Mailbox): a pinned word the
     uint32_t mbox_seq = 0;                     // kernel stores the call's sequence number into, behind its results
+    uint32_t mbox_timeouts = 0, mbox_skipped = 0;  // polls in a row that gave up / calls since the handle stopped polling (mailbox_arm)
     DevBuf s_part, s_cnt;                      // partitioned path: bucket buffer + per-bucket fill counts
     DevBuf s_flag;                             // split lookup: "a segment overflowed" flag
     DevBuf s_tflag;                            // tile-flag Bloom lookups: one uint32 per pass-1 tile of a round; "flagged" = holds the round's

@@ -685,7 +685,7 @@ def _plain(k):
     return bytes(k) if isinstance(k, (bytearray, memoryview)) else k
 
 
-@pytest.mark.parametrize("poll_us", [200, 0])
+@pytest.mark.parametrize("poll_us", [200, 0, 1])  # (1 us: every poll gives up -- the stream wait takes over, and after eight in a row the handle stops polling)
 def test_single_key_calls_equal_the_batch_calls_for_every_kind_of_key(pa, poll_us):
     """`key in blm`, `cms.add(key)`, `cbf.remove(key)` ... go through preallocated argument / result words (`_base.OneKey`) when the engine
     hashes the key itself; keys that need the general packer (wide code points, bytearray, memoryview) take it.  On the device a one-op
