@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace psk {
 
@@ -535,14 +536,53 @@ __device__ __forceinline__ void mailbox_post(uint32_t *mbox, uint32_t seq)  // b
 }
 
 // Op interface:  uint32_t k;  void prepare();  State begin(i);  void apply(State&, j, hash);  void end(State&, i)
+//                optional: void merge(State &a, const State &b) -- folds what two lanes gathered for the SAME key (begin() is its identity)
 // `mbox`: only with a one-workgroup grid (see mailbox_post), else nullptr
+template <class Op, class = void>
+struct op_has_merge : std::false_type {};
+template <class Op>
+struct op_has_merge<Op, std::void_t<decltype(&Op::merge)>> : std::true_type {};
+template <class T>
+__device__ __forceinline__ T shfl_xor_words(const T &v, int o)  // a State of 32-bit words from lane ^ o
+{
+    static_assert(sizeof(T) % 4 == 0, "State: whole 32-bit words");
+    T r;
+    uint32_t w[sizeof(T) / 4];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (unsigned e = 0; e < sizeof(T) / 4; ++e) w[e] = (uint32_t)__shfl_xor((int)w[e], o);
+    __builtin_memcpy(&r, w, sizeof(T));
+    return r;
+}
 template <class Src, class Op>
 __global__ __launch_bounds__(kBlock) void k_apply(Src src, Op op, uint64_t n, uint32_t *mbox, uint32_t seq)
 {
     op.prepare();
     const uint32_t k = op.k;
+    bool one_done = false;
+    if constexpr (op_has_merge<Op>::value) {
+        // ONE key on one wave (the reference's per-key calls: `key in blm`): lane j runs hash chain j and its probe -- the k chains of a key
+        // on one lane are ~450 dependent-issue VALU instructions for a 16-byte key, 1.5 us of a 3.6 us kernel -- and a butterfly folds the answers
+        if (n == 1 && gridDim.x == 1 && blockDim.x == 64 && k <= 64) {
+            const typename Src::Key key = src.load(0);
+            typename Op::State st = op.begin(0);
+            if (threadIdx.x < k) {
+                uint64_t h[1];
+                src.template hash<1>(key, 0, threadIdx.x, h);
+                op.apply(st, threadIdx.x, h[0]);
+            }
+            if constexpr (!std::is_empty<typename Op::State>::value) {
+                for (int o = 32; o > 0; o >>= 1) {
+                    const typename Op::State other = shfl_xor_words(st, o);
+                    op.merge(st, other);
+                }
+            }
+            if (threadIdx.x == 0) op.end(st, 0);
+            one_done = true;
+        }
+    }
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < (one_done ? 0 : n); i += stride) {
         const typename Src::Key key = src.load(i);
         typename Op::State st = op.begin(i);
         for_each_hash(src, key, i, k, [&](uint32_t j, uint64_t h) { op.apply(st, j, h); });
@@ -588,6 +628,7 @@ struct BloomAdd {  // bloom.py:241-250 add_alt: bloom[k//8] |= 1 << (k%8)  == ui
         atomicOr(tab + (b >> 5), 1u << (uint32_t)(b & 31));  // result unused -> no-return global_atomic_or
     }
     __device__ __forceinline__ void end(State &, uint64_t) const {}
+    __device__ __forceinline__ void merge(State &, const State &) const {}
 };
 
 template <bool POW2>
@@ -605,6 +646,7 @@ struct BloomCheck {  // bloom.py:261-272 check_alt (AND of the k bits; early exi
         st.ok &= (tab[b >> 5] >> (uint32_t)(b & 31)) & 1u;
     }
     __device__ __forceinline__ void end(State &st, uint64_t i) const { out[i] = (uint8_t)st.ok; }
+    __device__ __forceinline__ void merge(State &a, const State &b) const { a.ok &= b.ok; }
 };
 
 // the k bit positions of every key, for index-only follow-up kernels (psk_index_ops.hip); m <= 2^32
@@ -731,6 +773,11 @@ struct CmsCheck {  // countminsketch.py:332-340 check_alt with the min (:429-432
     __device__ __forceinline__ void end(State &st, uint64_t i) const
     {
         out[i] = mean ? (int32_t)floordiv(st.sum, (int64_t)k) : st.mn;
+    }
+    __device__ __forceinline__ void merge(State &a, const State &b) const
+    {
+        a.mn = b.mn < a.mn ? b.mn : a.mn;
+        a.sum += b.sum;
     }
 };
 
@@ -870,6 +917,7 @@ struct CbfCheck {  // countingbloom.py:166-174 check_alt: min over the hashes
         st.mn = v < st.mn ? v : st.mn;
     }
     __device__ __forceinline__ void end(State &st, uint64_t i) const { out[i] = st.mn; }
+    __device__ __forceinline__ void merge(State &a, const State &b) const { a.mn = b.mn < a.mn ? b.mn : a.mn; }
 };
 
 constexpr int kMaxKOrdered = 64;  // ordered kernels keep the k indices of one key in registers

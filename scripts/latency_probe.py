@@ -4,7 +4,10 @@ Three layers per operation: the Python mirror method, the bare C-ABI call throug
 empty-batch call (n = 0: argument checks only, no launch) as the ctypes floor."""
 import ctypes as C, time, sys
 import numpy as np
-sys.path.insert(0, ".")
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
 from pyprobables_amd import BloomFilter, CountingBloomFilter, CountMinSketch, _native as N
 from pyprobables_amd.keys import pack_keys
 
@@ -22,7 +25,7 @@ blm = BloomFilter(est_elements=1_000_000, false_positive_rate=0.01)
 blm.add_many([f"k{i}" for i in range(1000)])
 key = sys.argv[1] if len(sys.argv) > 1 else "k17"
 print(f"key = {key!r} ({len(key)} characters)")
-sys.path.insert(0, "oracle")
+sys.path.insert(0, str(ROOT / "oracle"))
 import pymirror  # the interpreted per-key loop of the reference, restated (oracle/pymirror.py): the same host's figure to compare with
 
 mb = pymirror.MirrorBloom(blm.number_bits, blm.number_hashes)
